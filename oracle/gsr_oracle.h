@@ -1,0 +1,163 @@
+/*
+ * gsr_oracle.h — CPU restatement (plain C) of the reference's differentiable
+ * Gaussian-splat rasterizer. TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product path (gsorb-slam_amd/) never links, imports
+ * or falls back to it.
+ *
+ * PARITY PINNING: the reference path is CUDA-only (Thirdparty/
+ * diff_gaussian_rasterization/cuda_rasterizer/ .cu files need nvcc, CUB,
+ * cooperative_groups) and is unbuildable in this image; it ships no tests or
+ * golden vectors. This restatement is therefore pinned only (a) on the
+ * sub-functions the reference also ships as importable Python
+ * (utils/sh_utils.py eval_sh, utils/graphics_utils.py getProjectionMatrix /
+ * geom_transform_points — fixtures under tests/golden/ref_utils.npz) and
+ * (b) against an independent fp64 autograd restatement (tests/spec_fp64.py).
+ * Whole-pipeline parity with the CUDA binary is "parity unpinned".
+ *
+ * Every function cites the reference file:line it follows. Paths are
+ * relative to /root/reference; DGR = Thirdparty/diff_gaussian_rasterization.
+ */
+#ifndef GSR_ORACLE_H
+#define GSR_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* DGR/cuda_rasterizer/config.h:15-17 */
+#define GSRO_CHANNELS 3
+#define GSRO_BLOCK_X 16
+#define GSRO_BLOCK_Y 16
+
+/* DGR/cuda_rasterizer/rasterizer_impl.cu:36-51 (getHigherMsb) */
+uint32_t gsro_higher_msb(uint32_t n);
+
+/* DGR/cuda_rasterizer/rasterizer_impl.cu:55-67 + auxiliary.h:139-164 */
+void gsro_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                       const float* projmatrix, uint8_t* present);
+
+/* DGR/cuda_rasterizer/forward.cu:155-256 (preprocessCUDA, forward).
+ * Outputs are written only where the reference writes them; the caller
+ * zero-fills them first (src/Rasterizer.cu:127-134 zero-fills the blobs). */
+void gsro_preprocess(int P, int D, int M,
+                     const float* means3D, const float* scales, float scale_modifier,
+                     const float* rotations, const float* opacities, const float* shs,
+                     const float* cov3D_precomp, const float* colors_precomp,
+                     const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                     int W, int H, float tan_fovx, float tan_fovy,
+                     int* radii, float* means2D, float* depths, float* cov3Ds,
+                     float* rgb, uint8_t* clamped, float* conic_opacity,
+                     uint32_t* tiles_touched);
+
+/* DGR/cuda_rasterizer/forward.cu:404-473 (preprocessfilterCUDA, GSORB's visible_filter) */
+void gsro_filter_preprocess(int P, const float* means3D, const float* scales,
+                            float scale_modifier, const float* rotations,
+                            const float* viewmatrix, const float* projmatrix,
+                            int W, int H, float tan_fovx, float tan_fovy, int* radii);
+
+/* cub::DeviceScan::InclusiveSum as used at DGR/cuda_rasterizer/rasterizer_impl.cu:280-281 */
+void gsro_inclusive_sum(int P, const uint32_t* in, uint32_t* out);
+
+/* DGR/cuda_rasterizer/rasterizer_impl.cu:71-112 (duplicateWithKeys) */
+void gsro_duplicate_with_keys(int P, const float* means2D, const float* depths,
+                              const uint32_t* offsets, const int* radii, int W, int H,
+                              uint64_t* keys_unsorted, uint32_t* values_unsorted);
+
+/* cub::DeviceRadixSort::SortPairs(…, begin_bit=0, end_bit) as used at
+ * DGR/cuda_rasterizer/rasterizer_impl.cu:310-315: stable ascending sort on the
+ * low end_bit bits of the key. */
+void gsro_sort_pairs(size_t n, const uint64_t* keys_in, const uint32_t* vals_in,
+                     uint64_t* keys_out, uint32_t* vals_out, int end_bit);
+
+/* DGR/cuda_rasterizer/rasterizer_impl.cu:117-139 (identifyTileRanges); ranges
+ * (uint2 per tile) must be zeroed by the caller (:317). */
+void gsro_identify_tile_ranges(size_t L, const uint64_t* keys_sorted, uint32_t* ranges);
+
+/* DGR/cuda_rasterizer/forward.cu:261-401 (renderCUDA, forward) */
+void gsro_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                         const float* means2D, const float* features,
+                         const float* conic_opacity, const float* depths, const float* bg,
+                         float* final_T, uint32_t* n_contrib, float* out_color,
+                         float* out_depth);
+
+/* DGR/cuda_rasterizer/backward.cu:399-557 (renderCUDA, backward).
+ * accum_double != 0 accumulates the per-splat sums in fp64 (deterministic,
+ * order-insensitive checker); 0 restates the fp32 atomicAdd arithmetic in a
+ * fixed sequential order. dL_d* are accumulated into (caller zero-fills). */
+void gsro_render_backward(int W, int H, int P, const uint32_t* ranges,
+                          const uint32_t* point_list, const float* bg,
+                          const float* means2D, const float* conic_opacity,
+                          const float* colors, const float* final_T,
+                          const uint32_t* n_contrib, const float* dL_dpix,
+                          int accum_double,
+                          float* dL_dmean2D /*[P,3]*/, float* dL_dconic /*[P,4]*/,
+                          float* dL_dopacity /*[P]*/, float* dL_dcolor /*[P,3]*/);
+
+/* DGR/cuda_rasterizer/backward.cu:144-274 (computeCov2DCUDA) */
+void gsro_cov2d_backward(int P, const float* means3D, const int* radii, const float* cov3Ds,
+                         float focal_x, float focal_y, float tan_fovx, float tan_fovy,
+                         const float* viewmatrix, const float* dL_dconic,
+                         float* dL_dmean3D, float* dL_dcov3D);
+
+/* DGR/cuda_rasterizer/backward.cu:346-396 (preprocessCUDA, backward), incl.
+ * SH backward :20-139 and cov3D backward :278-341 */
+void gsro_preprocess_backward(int P, int D, int M, const float* means3D, const int* radii,
+                              const float* shs, const uint8_t* clamped, const float* scales,
+                              const float* rotations, float scale_modifier,
+                              const float* projmatrix, const float* cam_pos,
+                              const float* dL_dmean2D, float* dL_dmean3D, float* dL_dcolor,
+                              const float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                              float* dL_drot);
+
+/* Whole forward as DGR/cuda_rasterizer/rasterizer_impl.cu:199-345 orders it.
+ * Scratch and stage outputs live in a handle so tests can inspect each stage. */
+typedef struct gsro_state gsro_state;
+
+typedef struct {
+    int P, D, M, W, H;
+    const float* background;
+    const float* means3D;
+    const float* shs;            /* NULL if colours are precomputed */
+    const float* colors_precomp; /* NULL if SH */
+    const float* opacities;
+    const float* scales;         /* NULL if cov3D_precomp */
+    float scale_modifier;
+    const float* rotations;
+    const float* cov3D_precomp;
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* cam_pos;
+    float tan_fovx, tan_fovy;
+} gsro_scene;
+
+gsro_state* gsro_state_new(void);
+void gsro_state_free(gsro_state*);
+
+/* returns num_rendered; out_color [3,H,W], out_depth [H,W], radii [P] */
+int gsro_forward(gsro_state*, const gsro_scene*, float* out_color, float* out_depth, int* radii);
+
+/* DGR/cuda_rasterizer/rasterizer_impl.cu:405-498; needs the state of the
+ * matching gsro_forward. All outputs caller-zeroed (src/Rasterizer.cu:253-261). */
+void gsro_backward(gsro_state*, const gsro_scene*, const int* radii, const float* dL_dpix,
+                   int accum_double,
+                   float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                   float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                   float* dL_drot);
+
+/* stage accessors (pointers stay valid until the next gsro_forward / free) */
+enum {
+    GSRO_MEANS2D = 0, GSRO_DEPTHS, GSRO_COV3D, GSRO_CONIC_OPACITY, GSRO_RGB, GSRO_CLAMPED,
+    GSRO_TILES_TOUCHED, GSRO_POINT_OFFSETS, GSRO_KEYS_UNSORTED, GSRO_VALUES_UNSORTED,
+    GSRO_KEYS_SORTED, GSRO_POINT_LIST, GSRO_RANGES, GSRO_FINAL_T, GSRO_N_CONTRIB
+};
+const void* gsro_stage(const gsro_state*, int which, size_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

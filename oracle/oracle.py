@@ -1,0 +1,202 @@
+"""ctypes front end of the CPU oracle (oracle/gsr_oracle.c). TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg; never by the product package. See oracle/gsr_oracle.h for the
+parity-pinning statement.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build(force: bool = False) -> None:
+    """Compile both oracle libraries with the committed Makefile."""
+    libs = [os.path.join(_HERE, n) for n in ("libgsr_oracle.so", "libgsr_oracle_omp.so")]
+    src = [os.path.join(_HERE, n) for n in ("gsr_oracle.c", "gsr_oracle.h", "Makefile")]
+    if not force and all(os.path.exists(l) for l in libs):
+        newest = max(os.path.getmtime(s) for s in src)
+        if all(os.path.getmtime(l) >= newest for l in libs):
+            return
+    subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+
+
+class _Scene(C.Structure):
+    _fields_ = [("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("W", C.c_int), ("H", C.c_int),
+                ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p),
+                ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
+                ("scale_modifier", C.c_float), ("rotations", C.c_void_p),
+                ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p),
+                ("projmatrix", C.c_void_p), ("cam_pos", C.c_void_p),
+                ("tan_fovx", C.c_float), ("tan_fovy", C.c_float)]
+
+
+_STAGES = dict(means2D=(0, np.float32), depths=(1, np.float32), cov3D=(2, np.float32),
+               conic_opacity=(3, np.float32), rgb=(4, np.float32), clamped=(5, np.uint8),
+               tiles_touched=(6, np.uint32), point_offsets=(7, np.uint32),
+               keys_unsorted=(8, np.uint64), values_unsorted=(9, np.uint32),
+               keys_sorted=(10, np.uint64), point_list=(11, np.uint32), ranges=(12, np.uint32),
+               final_T=(13, np.float32), n_contrib=(14, np.uint32))
+
+
+def _load(omp: bool):
+    build()
+    lib = C.CDLL(os.path.join(_HERE, "libgsr_oracle_omp.so" if omp else "libgsr_oracle.so"))
+    lib.gsro_state_new.restype = C.c_void_p
+    lib.gsro_state_free.argtypes = [C.c_void_p]
+    lib.gsro_forward.restype = C.c_int
+    lib.gsro_forward.argtypes = [C.c_void_p, C.POINTER(_Scene), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gsro_backward.restype = None
+    lib.gsro_backward.argtypes = [C.c_void_p, C.POINTER(_Scene), C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 9
+    lib.gsro_stage.restype = C.c_void_p
+    lib.gsro_stage.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
+    lib.gsro_mark_visible.restype = None
+    lib.gsro_mark_visible.argtypes = [C.c_int] + [C.c_void_p] * 4
+    lib.gsro_filter_preprocess.restype = None
+    lib.gsro_filter_preprocess.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                           C.c_float, C.c_void_p]
+    lib.gsro_higher_msb.restype = C.c_uint32
+    lib.gsro_higher_msb.argtypes = [C.c_uint32]
+    return lib
+
+
+_LIBS: dict = {}
+
+
+def lib(omp: bool = False):
+    if omp not in _LIBS:
+        _LIBS[omp] = _load(omp)
+    return _LIBS[omp]
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class Forward:
+    color: np.ndarray      # [3,H,W]
+    depth: np.ndarray      # [1,H,W]
+    radii: np.ndarray      # [P] int32
+    num_rendered: int
+    stages: dict           # name -> ndarray (copies)
+
+
+@dataclass
+class Backward:
+    dL_dmeans2D: np.ndarray   # [P,3]
+    dL_dconic: np.ndarray     # [P,2,2]
+    dL_dopacity: np.ndarray   # [P,1]
+    dL_dcolors: np.ndarray    # [P,3]
+    dL_dmeans3D: np.ndarray   # [P,3]
+    dL_dcov3D: np.ndarray     # [P,6]
+    dL_dsh: np.ndarray        # [P,M,3]
+    dL_dscales: np.ndarray    # [P,3]
+    dL_drotations: np.ndarray  # [P,4]
+
+
+class Oracle:
+    """One forward (+ optional backward) of the restated reference pipeline."""
+
+    def __init__(self, omp: bool = False):
+        self.lib = lib(omp)
+        self.state = C.c_void_p(self.lib.gsro_state_new())
+        self._keep = None
+
+    def __del__(self):
+        try:
+            self.lib.gsro_state_free(self.state)
+        except Exception:
+            pass
+
+    def _scene(self, *, means3D, opacities, cam, colors=None, shs=None, scales=None, rotations=None,
+               cov3D_precomp=None, sh_degree=None):
+        k = dict(means3D=_f32(means3D), opac=_f32(opacities), colors=_f32(colors), shs=_f32(shs),
+                 scales=_f32(scales), rot=_f32(rotations), cov=_f32(cov3D_precomp),
+                 bg=_f32(cam.bg), view=_f32(cam.viewmatrix), proj=_f32(cam.projmatrix),
+                 campos=_f32(cam.campos))
+        P = k["means3D"].shape[0]
+        M = 0 if k["shs"] is None or k["shs"].size == 0 else k["shs"].shape[1]
+        D = cam.sh_degree if sh_degree is None else sh_degree
+        s = _Scene(P, D, M, cam.width, cam.height, _ptr(k["bg"]), _ptr(k["means3D"]), _ptr(k["shs"]),
+                   _ptr(k["colors"]), _ptr(k["opac"]), _ptr(k["scales"]), cam.scale_modifier,
+                   _ptr(k["rot"]), _ptr(k["cov"]), _ptr(k["view"]), _ptr(k["proj"]),
+                   _ptr(k["campos"]), cam.tanfovx, cam.tanfovy)
+        self._keep = k
+        return s, P, M
+
+    def forward(self, copy_stages: bool = True, **kw) -> Forward:
+        s, P, M = self._scene(**kw)
+        self._s, self._P, self._M = s, P, M
+        W, H = s.W, s.H
+        color = np.zeros((3, H, W), np.float32)
+        depth = np.zeros((1, H, W), np.float32)
+        radii = np.zeros((max(P, 1),), np.int32)
+        R = self.lib.gsro_forward(self.state, C.byref(s), _ptr(color), _ptr(depth), _ptr(radii))
+        radii = radii[:P]
+        self._radii = radii
+        stages = {}
+        if copy_stages and P > 0:
+            for name, (idx, dt) in _STAGES.items():
+                n = C.c_size_t(0)
+                p = self.lib.gsro_stage(self.state, idx, C.byref(n))
+                if n.value == 0 or not p:
+                    stages[name] = np.zeros((0,), dt)
+                    continue
+                buf = (C.c_char * (n.value * np.dtype(dt).itemsize)).from_address(p)
+                stages[name] = np.frombuffer(buf, dtype=dt).copy()
+            stages["means2D"] = stages["means2D"].reshape(P, 2)
+            stages["conic_opacity"] = stages["conic_opacity"].reshape(P, 4)
+            stages["ranges"] = stages["ranges"].reshape(-1, 2)
+        return Forward(color, depth, radii, int(R), stages)
+
+    def backward(self, dL_dpix, accum_double: bool = True) -> Backward:
+        P, M = self._P, self._M
+        g = _f32(dL_dpix)
+        z = lambda *shape: np.zeros(shape, np.float32)
+        out = Backward(z(P, 3), z(P, 2, 2), z(P, 1), z(P, 3), z(P, 3), z(P, 6), z(P, M, 3), z(P, 3),
+                       z(P, 4))
+        radii = np.ascontiguousarray(self._radii if P > 0 else np.zeros(1, np.int32))
+        self.lib.gsro_backward(self.state, C.byref(self._s), _ptr(radii), _ptr(g), int(accum_double),
+                               _ptr(out.dL_dmeans2D), _ptr(out.dL_dconic), _ptr(out.dL_dopacity),
+                               _ptr(out.dL_dcolors), _ptr(out.dL_dmeans3D), _ptr(out.dL_dcov3D),
+                               _ptr(out.dL_dsh), _ptr(out.dL_dscales), _ptr(out.dL_drotations))
+        return out
+
+
+def forward_scene(scene, omp: bool = False, copy_stages: bool = True):
+    """Convenience: run a gsorb-slam_amd.synthetic.Scene through the oracle."""
+    o = Oracle(omp)
+    f = o.forward(copy_stages=copy_stages, means3D=scene.means3D, opacities=scene.opacities,
+                  cam=scene.cam, colors=scene.colors, shs=scene.shs, scales=scene.scales,
+                  rotations=scene.rotations)
+    return o, f
+
+
+def mark_visible(means3D, cam) -> np.ndarray:
+    m = _f32(means3D)
+    out = np.zeros(m.shape[0], np.uint8)
+    v, p = _f32(cam.viewmatrix), _f32(cam.projmatrix)
+    lib().gsro_mark_visible(m.shape[0], _ptr(m), _ptr(v), _ptr(p), _ptr(out))
+    return out.astype(bool)
+
+
+def filter_radii(means3D, scales, rotations, cam, width=None, height=None) -> np.ndarray:
+    m, s, r = _f32(means3D), _f32(scales), _f32(rotations)
+    out = np.zeros(m.shape[0], np.int32)
+    v, p = _f32(cam.viewmatrix), _f32(cam.projmatrix)
+    lib().gsro_filter_preprocess(m.shape[0], _ptr(m), _ptr(s), cam.scale_modifier, _ptr(r), _ptr(v),
+                                 _ptr(p), width or cam.width, height or cam.height, cam.tanfovx,
+                                 cam.tanfovy, _ptr(out))
+    return out
