@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — forward+backward rasterization throughput on MI355X.
+
+Metric (BASELINE.json): splats·pixels/s for fwd+bwd at 1 M Gaussians, 1200x680
+= P * W * H / t(fwd+bwd). One "step" = one forward + one backward of the hot path on one
+synthetic scene whose inputs are already resident in HBM, through the C ABI
+(gsr_forward_ws + gsr_backward: the sync-free workspace entry points).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: weak scaling. The path partitions by scene shard: every rank owns its own
+1 M-Gaussian shard (different seed) and renders it to its own layer; there is no data-path
+collective inside the timed region, only the barriers around it.
+
+The JSON line also carries
+  roofline     : the dominant kernel (backward blend) against the HBM roofline, timed live
+                 with HIP events recorded by the library on the launching stream
+  cpu_baseline : the CPU oracle ("port", OpenMP over all host cores) on a bounded sample
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def _hip():
+    h = C.CDLL("libamdhip64.so.7")  # already loaded by torch: same runtime instance
+    h.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+    h.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+    h.hipEventSynchronize.argtypes = [C.c_void_p]
+    return h
+
+
+def cpu_baseline(sc, P, W, H, budget_s=20.0):
+    """Oracle (OpenMP build) fwd+bwd on the same scene, bounded to ~budget_s of CPU work."""
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    o = oracle.Oracle(omp=True)
+    kw = dict(means3D=sc.means3D, opacities=sc.opacities, cam=sc.cam, colors=sc.colors, scales=sc.scales,
+              rotations=sc.rotations)
+    t0 = time.perf_counter()
+    o.forward(copy_stages=False, **kw)
+    o.backward(sc.dL_dpix, accum_double=False)
+    first = time.perf_counter() - t0
+    reps = int(max(1, min(5, (budget_s - first) // max(first, 1e-3))))
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        o.forward(copy_stages=False, **kw)
+        o.backward(sc.dL_dpix, accum_double=False)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts)) if ts else first
+    return {"value": P * W * H / t, "unit": "splats*pixels/s", "cores": cores, "kind": "port",
+            "sample": f"{len(ts) or 1} fwd+bwd of the same {P}-splat {W}x{H} scene (median), oracle/libgsr_oracle_omp.so, "
+                      f"{t * 1e3:.0f} ms each"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--splats", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = world > 1
+    if dist:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    gsr = entry.load_package()
+    gsr.lib()  # fails loudly if the HIP extension is missing
+    syn = gsr.synthetic
+    P = a.splats
+    cam = syn.make_camera(**syn.REPLICA)
+    W, H = cam.width, cam.height
+    sc = syn.make_scene(P, cam, seed=rank)  # each rank: its own scene shard
+    s = gsr.capi.Settings.from_camera(cam, device=dev)
+    t = lambda x: torch.as_tensor(x, dtype=torch.float32, device=dev).contiguous()
+    ins = dict(means3D=t(sc.means3D), opacities=t(sc.opacities), colors=t(sc.colors), shs=None,
+               scales=t(sc.scales), rotations=t(sc.rotations), cov3D=None)
+    grad_in = t(sc.dL_dpix)
+
+    # size the persistent workspace from one untimed callback-mode forward
+    st0 = gsr.forward(s, ins["means3D"], ins["opacities"], colors=ins["colors"], scales=ins["scales"],
+                      rotations=ins["rotations"])
+    R = st0.num_rendered
+    V = int((st0.radii > 0).sum())
+    del st0
+    ws = gsr.capi.Workspace(P, W, H, max_rendered=int(R * 1.25) + 1024, device=dev)
+    grads = gsr.capi.alloc_grads(P, 0, dev)
+
+    hip = _hip()
+    n_ev = max(a.steps, 1)
+    ev = []  # per timed step: (start, stop) around the backward blend kernel, and around the forward blend
+    for _ in range(n_ev):
+        e = [C.c_void_p() for _ in range(4)]
+        for x in e:
+            hip.hipEventCreate(C.byref(x))
+        ev.append(e)
+    NB, NF = 3, 5
+    def ev_arrays(e):
+        f = (C.c_void_p * (2 * NF))()
+        b = (C.c_void_p * (2 * NB))()
+        f[2 * 4], f[2 * 4 + 1] = e[2], e[3]     # GSR_FWD_BLEND
+        b[2 * 1], b[2 * 1 + 1] = e[0], e[1]     # GSR_BWD_BLEND
+        return f, b
+
+    def step(fe=None, be=None):
+        st = gsr.forward_ws(s, ws, ins, None, events=fe)
+        gsr.backward(st, grad_in, grads=grads, events=be)
+
+    for _ in range(a.warmup):
+        step()
+    n, ovf = ws.status()
+    assert not ovf and n == R, (n, R, ovf)
+
+    def barrier():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    arrays = [ev_arrays(e) for e in ev]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(*arrays[i])
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    ms_step = dt / max(a.steps, 1) * 1e3
+    value = world * P * W * H / (dt / max(a.steps, 1))
+
+    def avg_ms(i0, i1):
+        tot = 0.0
+        for e in ev[:a.steps]:
+            ms = C.c_float(0)
+            hip.hipEventSynchronize(e[i1])
+            hip.hipEventElapsedTime(C.byref(ms), e[i0], e[i1])
+            tot += ms.value
+        return tot / max(a.steps, 1)
+
+    if rank == 0:
+        bwd_blend_ms = avg_ms(0, 1)
+        fwd_blend_ms = avg_ms(2, 3)
+        N = W * H
+        # algorithmic bytes of the backward blend kernel per launch: 40R + 20N + 36V
+        alg_bytes = 40 * R + 20 * N + 36 * V
+        achieved = alg_bytes / (bwd_blend_ms * 1e-3) / 1e9
+        total_alg = 152 * P + 340 * V + 128 * R + 44 * N   # whole fwd+bwd
+        out = {
+            "metric": "splats*pixels/s (fwd+bwd) @1M Gaussians 1200x680",
+            "value": value, "unit": "splats*pixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{P} random-init Gaussians per GPU (SinglePixel scale init, camera frame), "
+                                   f"{W}x{H} Replica camera, RGB colours, fwd+bwd rasterize through the C ABI "
+                                   f"(gsr_forward_ws + gsr_backward), inputs resident in HBM",
+                       "splats": P, "width": W, "height": H, "visible": V, "tile_instances": R,
+                       "parallelism": f"scene-shard x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "K_blend_bwd", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes": alg_bytes, "avg_launch_ms": bwd_blend_ms,
+                         "fwd_blend_avg_launch_ms": fwd_blend_ms,
+                         "whole_step": {"algorithmic_bytes": total_alg,
+                                        "achieved": total_alg / (ms_step * 1e-3) / 1e9,
+                                        "frac": total_alg / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+        }
+        if world == 1 and not a.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(sc, P, W, H)
+        print(json.dumps(out), flush=True)
+    if dist:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

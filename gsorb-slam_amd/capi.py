@@ -1,0 +1,350 @@
+"""ctypes binding of the C ABI (include/gsr.h) on torch device tensors.
+
+torch is used only as the owner of device memory and of the HIP stream; every
+computation happens in csrc/libgsr_hip.so. Missing library => ImportError at
+first use (no fallback of any kind).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+EXPORTS = ["gsr_forward", "gsr_forward_ws", "gsr_ws_status", "gsr_backward", "gsr_mark_visible",
+           "gsr_visible_filter", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
+           "gsr_debug_export", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
+
+
+def library_path() -> str:
+    return os.environ.get("GSR_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "libgsr_hip.so")
+
+
+class GsrError(RuntimeError):
+    pass
+
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class ForwardArgs(C.Structure):
+    _fields_ = [("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("background", C.c_void_p),
+                ("width", C.c_int), ("height", C.c_int), ("means3D", C.c_void_p), ("shs", C.c_void_p),
+                ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
+                ("scale_modifier", C.c_float), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
+                ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("cam_pos", C.c_void_p),
+                ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int),
+                ("out_color", C.c_void_p), ("out_depth", C.c_void_p), ("radii", C.c_void_p),
+                ("profile_events", C.POINTER(C.c_void_p))]
+
+
+class BackwardArgs(C.Structure):
+    _fields_ = [("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("R", C.c_int),
+                ("background", C.c_void_p), ("width", C.c_int), ("height", C.c_int),
+                ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+                ("scales", C.c_void_p), ("scale_modifier", C.c_float), ("rotations", C.c_void_p),
+                ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p),
+                ("cam_pos", C.c_void_p), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
+                ("radii", C.c_void_p), ("geom_buffer", C.c_void_p), ("binning_buffer", C.c_void_p),
+                ("image_buffer", C.c_void_p), ("binning_bytes", C.c_size_t), ("dL_dpix", C.c_void_p),
+                ("dL_dmean2D", C.c_void_p), ("dL_dconic", C.c_void_p), ("dL_dopacity", C.c_void_p),
+                ("dL_dcolor", C.c_void_p), ("dL_dmean3D", C.c_void_p), ("dL_dcov3D", C.c_void_p),
+                ("dL_dsh", C.c_void_p), ("dL_dscale", C.c_void_p), ("dL_drot", C.c_void_p),
+                ("profile_events", C.POINTER(C.c_void_p))]
+
+
+class DebugArrays(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("means2D", "depths", "conic_opacity", "rgb", "tiles_touched",
+                                          "point_list", "point_list_keys", "ranges", "final_T",
+                                          "n_contrib")]
+
+
+def lib():
+    """Load csrc/libgsr_hip.so (built by __graft_entry__.build()); raises if absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "— there is no CPU fallback for the rasterizer")
+    L = C.CDLL(path)
+    L.gsr_forward.restype = C.c_int
+    L.gsr_forward.argtypes = [C.POINTER(ForwardArgs), ALLOC_FN, C.c_void_p, ALLOC_FN, C.c_void_p, ALLOC_FN,
+                              C.c_void_p, C.c_void_p]
+    L.gsr_forward_ws.restype = C.c_int
+    L.gsr_forward_ws.argtypes = [C.POINTER(ForwardArgs), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.gsr_ws_status.restype = C.c_int
+    L.gsr_ws_status.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.gsr_backward.restype = C.c_int
+    L.gsr_backward.argtypes = [C.POINTER(BackwardArgs), C.c_void_p]
+    L.gsr_mark_visible.restype = C.c_int
+    L.gsr_mark_visible.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gsr_visible_filter.restype = C.c_int
+    L.gsr_visible_filter.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    for n in ("gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes"):
+        getattr(L, n).restype = C.c_size_t
+    L.gsr_geom_bytes.argtypes = [C.c_int]
+    L.gsr_image_bytes.argtypes = [C.c_int, C.c_int]
+    L.gsr_binning_bytes.argtypes = [C.c_size_t]
+    L.gsr_debug_export.restype = C.c_int
+    L.gsr_debug_export.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(DebugArrays), C.c_void_p]
+    L.gsr_error_string.restype = C.c_char_p
+    L.gsr_error_string.argtypes = [C.c_int]
+    L.gsr_last_hip_error.restype = C.c_char_p
+    L.gsr_abi_version.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def _check(rc: int) -> int:
+    if rc < 0:
+        L = lib()
+        msg = L.gsr_error_string(rc).decode()
+        if rc == -3:
+            msg += ": " + L.gsr_last_hip_error().decode()
+        raise GsrError(f"gsr error {rc}: {msg}")
+    return rc
+
+
+def _p(t):
+    if t is None or t.numel() == 0:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensors only"
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32(t, dev):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t)
+    return t.to(device=dev, dtype=torch.float32).contiguous()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@dataclass
+class Settings:
+    """The 11 fields of GaussianRasterizationSettings (include/Rasterizer.cuh:79-91)."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool = False
+
+    @staticmethod
+    def from_camera(cam, device="cuda"):
+        t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=device).contiguous()
+        return Settings(cam.height, cam.width, cam.tanfovx, cam.tanfovy, t(cam.bg), cam.scale_modifier,
+                        t(cam.viewmatrix), t(cam.projmatrix), cam.sh_degree, t(cam.campos), False)
+
+
+@dataclass
+class ForwardState:
+    """What crosses forward -> backward (the reference saves the same things, include/Rasterizer.cuh:190-203)."""
+    settings: Settings
+    P: int
+    M: int
+    num_rendered: int
+    inputs: dict
+    color: torch.Tensor
+    depth: torch.Tensor
+    radii: torch.Tensor
+    geom: torch.Tensor
+    binning: torch.Tensor
+    image: torch.Tensor
+    ws_binning_bytes: int = 0
+    keep: list = field(default_factory=list)
+
+
+def _fwd_args(s: Settings, means3D, opacities, colors, shs, scales, rotations, cov3D, color, depth, radii,
+              events=None):
+    P = int(means3D.shape[0])
+    M = 0 if shs is None or shs.numel() == 0 else int(shs.shape[1])
+    a = ForwardArgs(P, s.sh_degree, M, _p(s.bg), s.image_width, s.image_height, _p(means3D), _p(shs), _p(colors),
+                    _p(opacities), _p(scales), s.scale_modifier, _p(rotations), _p(cov3D), _p(s.viewmatrix),
+                    _p(s.projmatrix), _p(s.campos), s.tanfovx, s.tanfovy, int(s.prefiltered), _p(color),
+                    _p(depth), _p(radii), events)
+    return a, P, M
+
+
+def _prep(s: Settings, means3D, opacities, colors, shs, scales, rotations, cov3D):
+    dev = s.viewmatrix.device
+    ins = dict(means3D=_f32(means3D, dev), opacities=_f32(opacities, dev), colors=_f32(colors, dev),
+               shs=_f32(shs, dev), scales=_f32(scales, dev), rotations=_f32(rotations, dev),
+               cov3D=_f32(cov3D, dev))
+    if ins["means3D"].dim() != 2 or ins["means3D"].shape[1] != 3:
+        raise ValueError("means3D must have dimensions (num_points, 3)")  # src/Rasterizer.cu:158-160
+    return dev, ins
+
+
+def forward(s: Settings, means3D, opacities, colors=None, shs=None, scales=None, rotations=None,
+            cov3D_precomp=None) -> ForwardState:
+    """gsr_forward with torch-owned blobs (the reference's resizeFunctional, src/Rasterizer.cu:127-134)."""
+    L = lib()
+    dev, ins = _prep(s, means3D, opacities, colors, shs, scales, rotations, cov3D_precomp)
+    H, W = s.image_height, s.image_width
+    P = int(ins["means3D"].shape[0])
+    color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((max(P, 1),), dtype=torch.int32, device=dev)
+    blobs = {}
+
+    def mk(name):
+        def cb(_user, nbytes):
+            t = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=dev)
+            blobs[name] = t
+            return t.data_ptr()
+        return ALLOC_FN(cb)
+
+    cbs = [mk("geom"), mk("binning"), mk("image")]
+    a, P, M = _fwd_args(s, ins["means3D"], ins["opacities"], ins["colors"], ins["shs"], ins["scales"],
+                        ins["rotations"], ins["cov3D"], color, depth, radii)
+    with torch.cuda.device(dev):
+        R = _check(L.gsr_forward(C.byref(a), cbs[0], None, cbs[1], None, cbs[2], None, _stream()))
+    return ForwardState(s, P, M, R, ins, color, depth, radii[:P], blobs["geom"], blobs["binning"],
+                        blobs["image"])
+
+
+class Workspace:
+    """Persistent blobs for the sync-free gsr_forward_ws / gsr_backward loop."""
+
+    def __init__(self, P: int, width: int, height: int, max_rendered: int, device="cuda"):
+        L = lib()
+        self.device = torch.device(device)
+        self.binning_bytes = int(L.gsr_binning_bytes(max_rendered))
+        mk = lambda n: torch.empty((int(n),), dtype=torch.uint8, device=self.device)
+        self.geom = mk(L.gsr_geom_bytes(P))
+        self.image = mk(L.gsr_image_bytes(width, height))
+        self.binning = mk(self.binning_bytes)
+        self.P, self.W, self.H = P, width, height
+        self.color = torch.empty((3, height, width), dtype=torch.float32, device=self.device)
+        self.depth = torch.empty((1, height, width), dtype=torch.float32, device=self.device)
+        self.radii = torch.empty((max(P, 1),), dtype=torch.int32, device=self.device)
+        self.grads = None
+
+    def status(self):
+        n, o = C.c_int(0), C.c_int(0)
+        _check(lib().gsr_ws_status(_p(self.geom), _stream(), C.byref(n), C.byref(o)))
+        return n.value, bool(o.value)
+
+
+def forward_ws(s: Settings, ws: Workspace, means3D, opacities, colors=None, shs=None, scales=None,
+               rotations=None, cov3D_precomp=None, events=None) -> ForwardState:
+    L = lib()
+    dev, ins = (s.viewmatrix.device, means3D) if isinstance(means3D, dict) else \
+        _prep(s, means3D, opacities, colors, shs, scales, rotations, cov3D_precomp)
+    a, P, M = _fwd_args(s, ins["means3D"], ins["opacities"], ins["colors"], ins["shs"], ins["scales"],
+                        ins["rotations"], ins["cov3D"], ws.color, ws.depth, ws.radii, events)
+    assert P == ws.P and s.image_width == ws.W and s.image_height == ws.H
+    _check(L.gsr_forward_ws(C.byref(a), _p(ws.geom), _p(ws.binning), ws.binning_bytes, _p(ws.image), _stream()))
+    return ForwardState(s, P, M, -1, ins, ws.color, ws.depth, ws.radii[:P], ws.geom, ws.binning, ws.image,
+                        ws_binning_bytes=ws.binning_bytes)
+
+
+@dataclass
+class Grads:
+    dL_dmeans2D: torch.Tensor
+    dL_dconic: torch.Tensor
+    dL_dopacity: torch.Tensor
+    dL_dcolors: torch.Tensor
+    dL_dmeans3D: torch.Tensor
+    dL_dcov3D: torch.Tensor
+    dL_dsh: torch.Tensor
+    dL_dscales: torch.Tensor
+    dL_drotations: torch.Tensor
+
+
+def alloc_grads(P: int, M: int, dev) -> Grads:
+    e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    return Grads(e(P, 3), e(P, 2, 2), e(P, 1), e(P, 3), e(P, 3), e(P, 6), e(P, M, 3), e(P, 3), e(P, 4))
+
+
+def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None) -> Grads:
+    """gsr_backward; output shapes follow src/Rasterizer.cu:253-261."""
+    L = lib()
+    s = st.settings
+    dev = s.viewmatrix.device
+    g = _f32(dL_dpix, dev)
+    P, M = st.P, st.M
+    out = grads if grads is not None else alloc_grads(P, M, dev)
+    if P == 0:
+        return out
+    i = st.inputs
+    has_sr = i["scales"] is not None and i["scales"].numel() > 0
+    a = BackwardArgs(P, s.sh_degree, M, st.num_rendered, _p(s.bg), s.image_width, s.image_height, _p(i["means3D"]),
+                     _p(i["shs"]), _p(i["colors"]), _p(i["scales"]), s.scale_modifier, _p(i["rotations"]),
+                     _p(i["cov3D"]), _p(s.viewmatrix), _p(s.projmatrix), _p(s.campos), s.tanfovx, s.tanfovy,
+                     _p(st.radii), _p(st.geom), _p(st.binning), _p(st.image), st.ws_binning_bytes, _p(g),
+                     _p(out.dL_dmeans2D), _p(out.dL_dconic), _p(out.dL_dopacity), _p(out.dL_dcolors),
+                     _p(out.dL_dmeans3D), _p(out.dL_dcov3D), _p(out.dL_dsh) if M > 0 else None,
+                     _p(out.dL_dscales) if has_sr else None, _p(out.dL_drotations) if has_sr else None, events)
+    with torch.cuda.device(dev):
+        _check(L.gsr_backward(C.byref(a), _stream()))
+    if not has_sr:
+        out.dL_dscales.zero_()
+        out.dL_drotations.zero_()
+    return out
+
+
+def mark_visible(positions, viewmatrix, projmatrix):
+    dev = viewmatrix.device
+    p = _f32(positions, dev)
+    P = int(p.shape[0])
+    out = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P:
+        _check(lib().gsr_mark_visible(P, _p(p), _p(_f32(viewmatrix, dev)), _p(_f32(projmatrix, dev)), _p(out), _stream()))
+    return out
+
+
+def visible_filter(s: Settings, means3D, scales, rotations, width=None, height=None):
+    dev = s.viewmatrix.device
+    m, sc, r = _f32(means3D, dev), _f32(scales, dev), _f32(rotations, dev)
+    P = int(m.shape[0])
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    if P:
+        _check(lib().gsr_visible_filter(P, width or s.image_width, height or s.image_height, _p(m), _p(sc),
+                                        s.scale_modifier, _p(r), _p(s.viewmatrix), _p(s.projmatrix), s.tanfovx,
+                                        s.tanfovy, int(s.prefiltered), _p(radii), _stream()))
+    return radii
+
+
+def debug_export(st: ForwardState) -> dict:
+    """Stage arrays in the reference's layout (tests only)."""
+    s = st.settings
+    dev = s.viewmatrix.device
+    P, R = st.P, max(st.num_rendered, 0)
+    W, H = s.image_width, s.image_height
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+    o = dict(means2D=z((max(P, 1), 2), torch.float32), depths=z((max(P, 1),), torch.float32),
+             conic_opacity=z((max(P, 1), 4), torch.float32), rgb=z((max(P, 1), 3), torch.float32),
+             tiles_touched=z((max(P, 1),), torch.int32), point_list=z((max(R, 1),), torch.int32),
+             point_list_keys=z((max(R, 1),), torch.int64), ranges=z((T, 2), torch.int32),
+             final_T=z((H * W,), torch.float32), n_contrib=z((H * W,), torch.int32))
+    d = DebugArrays(*[_p(o[n]) for n, _ in DebugArrays._fields_])
+    _check(lib().gsr_debug_export(P, W, H, R, _p(st.geom), _p(st.binning), _p(st.image), C.byref(d), _stream()))
+    out = {k: v.cpu().numpy() for k, v in o.items()}
+    for k in ("means2D", "depths", "conic_opacity", "rgb", "tiles_touched"):
+        out[k] = out[k][:P]
+    out["point_list"] = out["point_list"][:R].astype("uint32")
+    out["point_list_keys"] = out["point_list_keys"][:R].astype("uint64")
+    out["tiles_touched"] = out["tiles_touched"].astype("uint32")
+    out["ranges"] = out["ranges"].astype("uint32")
+    out["n_contrib"] = out["n_contrib"].astype("uint32")
+    return out

@@ -1,0 +1,310 @@
+// gsr_api.hip — host side of the C ABI declared in include/gsr.h: argument checks,
+// workspace carving and kernel launches. No global mutable state (only a
+// thread-local "last HIP error" string); everything runs on the caller's stream.
+#include "../../include/gsr.h"
+#include "gsr_kernels.hip"
+
+#include <string.h>
+
+namespace {
+
+thread_local hipError_t t_last_hip = hipSuccess;
+
+inline bool hip_ok(hipError_t e)
+{
+    if (e != hipSuccess) { t_last_hip = e; return false; }
+    return true;
+}
+#define GSR_HIP(x) do { if (!hip_ok(x)) return GSR_EHIP; } while (0)
+#define GSR_LAUNCHED() do { if (!hip_ok(hipGetLastError())) return GSR_EHIP; } while (0)
+
+inline int blocks256(int n) { return (n + 255) / 256; }
+
+// optional per-stage event pairs (profiling hook of the args structs)
+struct StageTimer {
+    void** ev; hipStream_t st;
+    void begin(int i) const { if (ev && ev[2 * i]) (void)hipEventRecord((hipEvent_t)ev[2 * i], st); }
+    void end(int i) const { if (ev && ev[2 * i + 1]) (void)hipEventRecord((hipEvent_t)ev[2 * i + 1], st); }
+};
+
+FrameParams frame_params(int P, int D, int M, int W, int H, float tfx, float tfy, float mod)
+{
+    FrameParams f;
+    f.P = P; f.D = D; f.M = M; f.W = W; f.H = H;
+    f.grid_x = (W + GSR_TILE - 1) / GSR_TILE;
+    f.grid_y = (H + GSR_TILE - 1) / GSR_TILE;
+    f.tan_fovx = tfx; f.tan_fovy = tfy;
+    f.focal_y = H / (2.0f * tfy); // rasterizer_impl.cu:227-228
+    f.focal_x = W / (2.0f * tfx);
+    f.scale_modifier = mod;
+    return f;
+}
+
+int check_forward(const gsr_forward_args* a)
+{
+    if (!a || a->P < 0 || a->width <= 0 || a->height <= 0) return GSR_EINVAL;
+    if (!a->out_color || !a->out_depth) return GSR_EINVAL;
+    if (a->P == 0) return GSR_OK;
+    if (!a->means3D || !a->opacities || !a->viewmatrix || !a->projmatrix || !a->background) return GSR_EINVAL;
+    const bool has_sh = a->shs != nullptr, has_col = a->colors_precomp != nullptr;
+    if (has_sh == has_col) return GSR_EINVAL; // exactly one (include/Rasterizer.cuh:310-312)
+    if (has_sh && (a->M <= 0 || a->D < 0 || a->D > 3 || (a->D + 1) * (a->D + 1) > a->M || !a->cam_pos)) return GSR_EINVAL;
+    const bool has_sr = a->scales != nullptr && a->rotations != nullptr, has_cov = a->cov3D_precomp != nullptr;
+    if (has_sr == has_cov) return GSR_EINVAL; // exactly one (:313-316)
+    return GSR_OK;
+}
+
+gsr::SplatInputs splat_inputs(const float* means3D, const float* scales, const float* rotations,
+                              const float* opacities, const float* shs, const float* cov3D,
+                              const float* colors, const float* view, const float* proj, const float* campos)
+{
+    gsr::SplatInputs in;
+    in.means3D = means3D; in.scales = scales; in.rotations = rotations; in.opacities = opacities;
+    in.shs = shs; in.cov3D_precomp = cov3D; in.colors_precomp = colors;
+    in.view = view; in.proj = proj; in.campos = campos;
+    return in;
+}
+
+int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView& iv, const BinView& bv,
+                 const FrameParams& f, hipStream_t st)
+{
+    const int P = a->P, T = f.grid_x * f.grid_y;
+    const StageTimer tm{a->profile_events, st};
+    tm.begin(GSR_FWD_FILL);
+    hipLaunchKernelGGL(gsr::K_fill, dim3(blocks256(P)), dim3(256), 0, st, P, f.grid_x, f.grid_y, gv, iv.tile_cursor, bv.pairs);
+    GSR_LAUNCHED();
+    tm.end(GSR_FWD_FILL);
+    tm.begin(GSR_FWD_SORT);
+    hipLaunchKernelGGL(gsr::K_tile_sort, dim3(T), dim3(256), 0, st, T, iv.ranges, gv.hdr, bv.pairs, bv.point_list);
+    GSR_LAUNCHED();
+    tm.end(GSR_FWD_SORT);
+    tm.begin(GSR_FWD_BLEND);
+    hipLaunchKernelGGL(gsr::K_blend_fwd, dim3(T), dim3(256), 0, st, iv, bv, gv, a->background, a->width, a->height,
+                       f.grid_x, T, a->out_color, a->out_depth);
+    GSR_LAUNCHED();
+    tm.end(GSR_FWD_BLEND);
+    return GSR_OK;
+}
+
+int forward_head(const gsr_forward_args* a, char* geom, char* image, hipStream_t st, uint32_t capacity,
+                 GeomView* gv, ImageView* iv, FrameParams* fo)
+{
+    const int P = a->P, W = a->width, H = a->height;
+    const FrameParams f = frame_params(P, a->D, a->M, W, H, a->tan_fovx, a->tan_fovy, a->scale_modifier);
+    const int T = f.grid_x * f.grid_y;
+    geom_layout(geom, P, gv);
+    image_layout(image, W, H, iv);
+    const gsr::SplatInputs in = splat_inputs(a->means3D, a->scales, a->rotations, a->opacities, a->shs,
+                                             a->cov3D_precomp, a->colors_precomp, a->viewmatrix,
+                                             a->projmatrix, a->cam_pos);
+    const StageTimer tm{a->profile_events, st};
+    tm.begin(GSR_FWD_PREPROCESS);
+    GSR_HIP(hipMemsetAsync(iv->tile_count, 0, (size_t)T * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(gsr::K_preprocess, dim3(blocks256(P)), dim3(256), 0, st, f, in, a->radii, *gv, iv->tile_count);
+    GSR_LAUNCHED();
+    tm.end(GSR_FWD_PREPROCESS);
+    tm.begin(GSR_FWD_SCAN);
+    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, T, iv->tile_count, iv->ranges, iv->tile_cursor, gv->hdr, capacity);
+    GSR_LAUNCHED();
+    tm.end(GSR_FWD_SCAN);
+    *fo = f;
+    return GSR_OK;
+}
+
+int forward_empty(const gsr_forward_args* a, char* geom, hipStream_t st)
+{
+    // the reference wrapper returns zero images without calling the core (src/Rasterizer.cu:183)
+    const size_t N = (size_t)a->width * a->height;
+    GSR_HIP(hipMemsetAsync(a->out_color, 0, N * 3 * sizeof(float), st));
+    GSR_HIP(hipMemsetAsync(a->out_depth, 0, N * sizeof(float), st));
+    if (geom) GSR_HIP(hipMemsetAsync(geom, 0, sizeof(GeomHeader), st));
+    return GSR_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+size_t gsr_geom_bytes(int P) { return geom_layout(nullptr, P, nullptr); }
+size_t gsr_image_bytes(int width, int height) { return image_layout(nullptr, width, height, nullptr); }
+size_t gsr_binning_bytes(size_t R) { return binning_layout(nullptr, R, nullptr); }
+int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+
+const char* gsr_error_string(int code)
+{
+    switch (code) {
+    case GSR_OK: return "ok";
+    case GSR_EINVAL: return "invalid argument";
+    case GSR_EALLOC: return "allocation callback returned NULL";
+    case GSR_EHIP: return "HIP runtime error";
+    case GSR_EOVERFLOW: return "binning workspace too small";
+    case GSR_ECHANNELS: return "only 3 colour channels are supported";
+    default: return code > 0 ? "ok" : "unknown error";
+    }
+}
+const char* gsr_last_hip_error(void) { return hipGetErrorString(t_last_hip); }
+
+int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geom_alloc, void* geom_user,
+                gsr_alloc_fn binning_alloc, void* binning_user, gsr_alloc_fn image_alloc,
+                void* image_user, void* stream)
+{
+    const int chk = check_forward(a);
+    if (chk != GSR_OK) return chk;
+    if (!geom_alloc || !binning_alloc || !image_alloc) return GSR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    char* geom = geom_alloc(geom_user, gsr_geom_bytes(a->P));
+    if (!geom) return GSR_EALLOC;
+    char* image = image_alloc(image_user, gsr_image_bytes(a->width, a->height));
+    if (!image) return GSR_EALLOC;
+    if (a->P == 0) {
+        if (!binning_alloc(binning_user, gsr_binning_bytes(0))) return GSR_EALLOC;
+        const int rc = forward_empty(a, geom, st);
+        return rc != GSR_OK ? rc : 0;
+    }
+    GeomView gv; ImageView iv; FrameParams f;
+    int rc = forward_head(a, geom, image, st, 0xFFFFFFFFu, &gv, &iv, &f);
+    if (rc != GSR_OK) return rc;
+    // the one device->host read of the forward (reference rasterizer_impl.cu:285)
+    uint32_t R = 0;
+    GSR_HIP(hipMemcpyAsync(&R, &gv.hdr->num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    GSR_HIP(hipStreamSynchronize(st));
+    if (R > 0x7FFFFFFFu) return GSR_EOVERFLOW;
+    char* binning = binning_alloc(binning_user, gsr_binning_bytes(R));
+    if (!binning) return GSR_EALLOC;
+    BinView bv;
+    binning_layout(binning, R, &bv);
+    rc = forward_tail(a, gv, iv, bv, f, st);
+    return rc != GSR_OK ? rc : (int)R;
+}
+
+int gsr_forward_ws(const gsr_forward_args* a, char* geom, char* binning, size_t binning_bytes,
+                   char* image, void* stream)
+{
+    const int chk = check_forward(a);
+    if (chk != GSR_OK) return chk;
+    if (!geom || !binning || !image) return GSR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (a->P == 0) return forward_empty(a, geom, st);
+    const size_t cap = binning_capacity(binning_bytes);
+    if (cap == 0) return GSR_EOVERFLOW;
+    GeomView gv; ImageView iv; FrameParams f;
+    int rc = forward_head(a, geom, image, st, (uint32_t)(cap > 0x7FFFFFFFu ? 0x7FFFFFFFu : cap), &gv, &iv, &f);
+    if (rc != GSR_OK) return rc;
+    BinView bv;
+    binning_layout(binning, cap, &bv); // layout fixed by the capacity, not by R
+    return forward_tail(a, gv, iv, bv, f, st);
+}
+
+int gsr_ws_status(const char* geom, void* stream, int* num_rendered, int* overflow)
+{
+    if (!geom) return GSR_EINVAL;
+    GeomHeader h;
+    GSR_HIP(hipMemcpyAsync(&h, geom, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GSR_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (num_rendered) *num_rendered = (int)h.num_rendered;
+    if (overflow) *overflow = (int)h.overflow;
+    return GSR_OK;
+}
+
+int gsr_backward(const gsr_backward_args* a, void* stream)
+{
+    if (!a || a->P < 0 || a->width <= 0 || a->height <= 0) return GSR_EINVAL;
+    if (a->P == 0) return GSR_OK; // src/Rasterizer.cu:263
+    if (!a->geom_buffer || !a->binning_buffer || !a->image_buffer || !a->dL_dpix || !a->means3D ||
+        !a->viewmatrix || !a->projmatrix || !a->background)
+        return GSR_EINVAL;
+    if ((a->scales != nullptr && a->rotations != nullptr) == (a->cov3D_precomp != nullptr)) return GSR_EINVAL;
+    if (a->shs && (!a->dL_dsh || a->M <= 0 || !a->cam_pos)) return GSR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int P = a->P, W = a->width, H = a->height;
+    const FrameParams f = frame_params(P, a->D, a->M, W, H, a->tan_fovx, a->tan_fovy, a->scale_modifier);
+    const int T = f.grid_x * f.grid_y;
+    GeomView gv; ImageView iv; BinView bv;
+    geom_layout(a->geom_buffer, P, &gv);
+    image_layout(a->image_buffer, W, H, &iv);
+    if (a->R >= 0) binning_layout(a->binning_buffer, (size_t)a->R, &bv);
+    else { // workspace mode: the layout was fixed by the capacity, which follows from the size
+        const size_t cap = binning_capacity(a->binning_bytes);
+        if (cap == 0) return GSR_EINVAL;
+        binning_layout(a->binning_buffer, cap, &bv);
+    }
+    const StageTimer tm{a->profile_events, st};
+    tm.begin(GSR_BWD_CLEAR);
+    GSR_HIP(hipMemsetAsync(gv.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
+    tm.end(GSR_BWD_CLEAR);
+    tm.begin(GSR_BWD_BLEND);
+    hipLaunchKernelGGL(gsr::K_blend_bwd, dim3(T), dim3(256), 0, st, iv, bv, gv, a->background, W, H, f.grid_x, T, a->dL_dpix);
+    GSR_LAUNCHED();
+    tm.end(GSR_BWD_BLEND);
+    const gsr::SplatInputs in = splat_inputs(a->means3D, a->scales, a->rotations, nullptr, a->shs, a->cov3D_precomp,
+                                             a->colors_precomp, a->viewmatrix, a->projmatrix, a->cam_pos);
+    gsr::SplatGrads o;
+    o.dL_dmean2D = a->dL_dmean2D; o.dL_dconic = a->dL_dconic; o.dL_dopacity = a->dL_dopacity;
+    o.dL_dcolor = a->dL_dcolor; o.dL_dmean3D = a->dL_dmean3D; o.dL_dcov3D = a->dL_dcov3D;
+    o.dL_dsh = a->dL_dsh; o.dL_dscale = a->dL_dscale; o.dL_drot = a->dL_drot;
+    tm.begin(GSR_BWD_SPLAT);
+    hipLaunchKernelGGL(gsr::K_splat_bwd, dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o);
+    GSR_LAUNCHED();
+    tm.end(GSR_BWD_SPLAT);
+    return GSR_OK;
+}
+
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream)
+{
+    (void)projmatrix; // the reference's test only uses the view-space depth (auxiliary.h:154)
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return GSR_EINVAL;
+    if (P == 0) return GSR_OK;
+    hipLaunchKernelGGL(gsr::K_mark_visible, dim3(blocks256(P)), dim3(256), 0, (hipStream_t)stream, P, means3D, viewmatrix, present);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_visible_filter(int P, int width, int height, const float* means3D, const float* scales,
+                       float scale_modifier, const float* rotations, const float* viewmatrix,
+                       const float* projmatrix, float tan_fovx, float tan_fovy, int prefiltered,
+                       int* radii, void* stream)
+{
+    (void)prefiltered;
+    if (P < 0 || width <= 0 || height <= 0) return GSR_EINVAL;
+    if (P == 0) return GSR_OK;
+    if (!means3D || !scales || !rotations || !viewmatrix || !projmatrix || !radii) return GSR_EINVAL;
+    const FrameParams f = frame_params(P, 0, 0, width, height, tan_fovx, tan_fovy, scale_modifier);
+    const gsr::SplatInputs in = splat_inputs(means3D, scales, rotations, nullptr, nullptr, nullptr, nullptr,
+                                             viewmatrix, projmatrix, nullptr);
+    hipLaunchKernelGGL(gsr::K_filter_radii, dim3(blocks256(P)), dim3(256), 0, (hipStream_t)stream, f, in, radii);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_debug_export(int P, int width, int height, int R, const char* geom, const char* binning,
+                     const char* image, const gsr_debug_arrays* out, void* stream)
+{
+    if (!out || !geom || !image || P < 0 || width <= 0 || height <= 0) return GSR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    GeomView gv; ImageView iv; BinView bv;
+    geom_layout(const_cast<char*>(geom), P, &gv);
+    image_layout(const_cast<char*>(image), width, height, &iv);
+    const int gx = (width + GSR_TILE - 1) / GSR_TILE, gy = (height + GSR_TILE - 1) / GSR_TILE, T = gx * gy;
+    const size_t N = (size_t)width * height;
+    if (P > 0) {
+        hipLaunchKernelGGL(gsr::K_export_splats, dim3(blocks256(P)), dim3(256), 0, st, P, gx, gy, gv, out->means2D,
+                           out->depths, out->conic_opacity, out->rgb, out->tiles_touched);
+        GSR_LAUNCHED();
+    }
+    if (out->ranges) GSR_HIP(hipMemcpyAsync(out->ranges, iv.ranges, (size_t)T * 8, hipMemcpyDeviceToDevice, st));
+    if (out->final_T) GSR_HIP(hipMemcpyAsync(out->final_T, iv.final_T, N * 4, hipMemcpyDeviceToDevice, st));
+    if (out->n_contrib) GSR_HIP(hipMemcpyAsync(out->n_contrib, iv.n_contrib, N * 4, hipMemcpyDeviceToDevice, st));
+    if (binning && R > 0) {
+        binning_layout(const_cast<char*>(binning), (size_t)R, &bv);
+        if (out->point_list) GSR_HIP(hipMemcpyAsync(out->point_list, bv.point_list, (size_t)R * 4, hipMemcpyDeviceToDevice, st));
+        if (out->point_list_keys) {
+            hipLaunchKernelGGL(gsr::K_export_keys, dim3(T), dim3(256), 0, st, T, iv.ranges, bv.point_list, gv, out->point_list_keys);
+            GSR_LAUNCHED();
+        }
+    }
+    GSR_HIP(hipStreamSynchronize(st));
+    return GSR_OK;
+}
+
+} // extern "C"

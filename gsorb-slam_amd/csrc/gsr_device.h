@@ -1,0 +1,156 @@
+// gsr_device.h — shared device-side definitions of the gfx950 rasterizer.
+//
+// Data layout in HBM (all sub-arrays 256-byte aligned inside caller-owned blobs):
+//
+//   geometry blob  (gsr_geom_bytes(P)):
+//     GeomHeader                         256 B   {num_rendered, overflow, capacity}
+//     g0   float4[P]  {x, y, conic_a, conic_b}           pixel centre + half of the conic
+//     g1   float4[P]  {conic_c, opacity, depth, radius}  radius stored as int bits
+//     col  float4[P]  {r, g, b, clamp-flags}             colour the blend uses (SH result or
+//                                                        copy of colors_precomp)
+//     acc  float[P][12]  backward accumulators {dmean2D.xy, dconic.xyw, dopacity, dcolor.rgb, pad}
+//   image blob     (gsr_image_bytes(W,H)):
+//     final_T f32[N], n_contrib u32[N], ranges uint2[T], tile_count u32[T], tile_cursor u32[T]
+//   binning blob   (gsr_binning_bytes(R)):
+//     pairs u64[R] (depth bits << 32 | splat id, grouped per tile), point_list u32[R]
+//
+// The reference keeps 79 B/splat + 24 B/instance (rasterizer_impl.h:21-65); this
+// layout is 48 B/splat (+48 scratch) and 12 B/instance, and every per-splat
+// gather of the blend kernels is a 16-byte aligned vector load.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GSR_TILE 16
+#define GSR_TILE_PIX 256
+#define GSR_ALIGN 256
+#define GSR_ACC_STRIDE 12
+
+struct GeomHeader {
+    uint32_t num_rendered;
+    uint32_t overflow;
+    uint32_t capacity;
+    uint32_t pad[61];
+};
+static_assert(sizeof(GeomHeader) == 256, "header is one aligned slot");
+
+struct GeomView {
+    GeomHeader* hdr;
+    float4* g0;
+    float4* g1;
+    float4* col;
+    float* acc;
+};
+struct ImageView {
+    float* final_T;
+    uint32_t* n_contrib;
+    uint2* ranges;
+    uint32_t* tile_count;
+    uint32_t* tile_cursor;
+};
+struct BinView {
+    uint64_t* pairs;
+    uint32_t* point_list;
+};
+
+__host__ __device__ inline size_t gsr_align_up(size_t x) { return (x + GSR_ALIGN - 1) & ~(size_t)(GSR_ALIGN - 1); }
+
+__host__ __device__ inline size_t geom_layout(char* base, int P, GeomView* v)
+{
+    size_t off = 0, Pz = P > 0 ? (size_t)P : 1;
+    GeomView g;
+    g.hdr = (GeomHeader*)(base + off); off = gsr_align_up(off + sizeof(GeomHeader));
+    g.g0 = (float4*)(base + off); off = gsr_align_up(off + Pz * 16);
+    g.g1 = (float4*)(base + off); off = gsr_align_up(off + Pz * 16);
+    g.col = (float4*)(base + off); off = gsr_align_up(off + Pz * 16);
+    g.acc = (float*)(base + off); off = gsr_align_up(off + Pz * GSR_ACC_STRIDE * 4);
+    if (v) *v = g;
+    return off;
+}
+__host__ __device__ inline size_t image_layout(char* base, int W, int H, ImageView* v)
+{
+    size_t off = 0, N = (size_t)W * H;
+    size_t T = (size_t)((W + GSR_TILE - 1) / GSR_TILE) * ((H + GSR_TILE - 1) / GSR_TILE);
+    if (N == 0) N = 1;
+    if (T == 0) T = 1;
+    ImageView g;
+    g.final_T = (float*)(base + off); off = gsr_align_up(off + N * 4);
+    g.n_contrib = (uint32_t*)(base + off); off = gsr_align_up(off + N * 4);
+    g.ranges = (uint2*)(base + off); off = gsr_align_up(off + T * 8);
+    g.tile_count = (uint32_t*)(base + off); off = gsr_align_up(off + T * 4);
+    g.tile_cursor = (uint32_t*)(base + off); off = gsr_align_up(off + T * 4);
+    if (v) *v = g;
+    return off;
+}
+__host__ __device__ inline size_t binning_layout(char* base, size_t R, BinView* v)
+{
+    size_t off = 0;
+    if (R == 0) R = 1;
+    BinView g;
+    g.pairs = (uint64_t*)(base + off); off = gsr_align_up(off + R * 8);
+    g.point_list = (uint32_t*)(base + off); off = gsr_align_up(off + R * 4);
+    if (v) *v = g;
+    return off;
+}
+// largest R such that binning_layout(R) <= bytes
+__host__ inline size_t binning_capacity(size_t bytes)
+{
+    if (bytes < 2 * GSR_ALIGN) return 0;
+    size_t r = (bytes - 2 * GSR_ALIGN) / 12;
+    while (r > 0 && binning_layout(nullptr, r, nullptr) > bytes) r--;
+    return r;
+}
+
+// Camera / frame constants shared by the per-splat kernels.
+struct FrameParams {
+    int P, D, M;
+    int W, H;
+    int grid_x, grid_y;
+    float tan_fovx, tan_fovy;
+    float focal_x, focal_y;
+    float scale_modifier;
+};
+
+// ---------------------------------------------------------------------------------
+// Pixel/splat pair evaluation shared by the forward and backward blend kernels.
+// The backward re-takes the forward's skip decisions, so both MUST produce the
+// same bits: the library is built with -ffp-contract=off and the contractions
+// below are explicit.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float pair_power(float dx, float dy, float ca, float cb, float cc)
+{
+    // -0.5*(a dx^2 + c dy^2) - b dx dy      (reference forward.cu:348, backward.cu:492)
+    const float q = fmaf(ca * dx, dx, (cc * dy) * dy);
+    return fmaf(-0.5f, q, -((cb * dx) * dy));
+}
+
+// wave64 all-lane sum; result valid in lane 63 (DPP row rotations + row broadcasts).
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false)); // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false)); // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false)); // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false)); // row_ror:1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false)); // row_bcast:15 -> rows 1,3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false)); // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = v > o ? v : o;
+    }
+    return v;
+}
+
+// XCD-aware block remap: consecutive block ids round-robin over the 8 XCDs, so give
+// XCD x the x-th contiguous band of tiles (neighbouring tiles share splats -> one L2).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nblocks)
+{
+    const uint32_t xcd = b & 7u, q = nblocks >> 3, r = nblocks & 7u;
+    const uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (b >> 3);
+}

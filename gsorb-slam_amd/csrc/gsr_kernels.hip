@@ -1,0 +1,688 @@
+// gsr_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the differentiable
+// Gaussian-splat rasterizer. Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off.
+//
+// Forward  (replaces rasterizer_impl.cu:199-345 of the reference's DGR tree):
+//   K_preprocess   per splat : project, cull, radius, tile rectangle, colour; counts the
+//                              splat into every tile it touches (tile_count atomics)
+//   K_scan_tiles   1 block   : tile_count -> ranges (start,end), cursors, num_rendered
+//   K_fill         per splat : (depth bits<<32 | id) into its tiles' segments (unordered)
+//   K_tile_sort    per tile  : bitonic sort of the tile's segment in LDS -> point_list
+//                              ((depth, id) ascending == the reference's stable radix order)
+//   K_blend_fwd    per tile  : front-to-back alpha blend, 4 waves = four 8x8 pixel quads,
+//                              per-wave ballot culling of splats that miss the quad
+// Backward (replaces rasterizer_impl.cu:405-498):
+//   K_blend_bwd    per tile  : back-to-front re-walk, DPP wave reduction, one 9-lane atomic
+//                              per (wave, splat) into a packed per-splat accumulator
+//   K_splat_bwd    per splat : conic/mean2D/colour gradients -> mean3D, cov3D, scale, rot, SH
+//
+// No global sort and no per-instance keys: per-tile counting replaces the
+// reference's 64-bit radix sort of R instances (6 passes over 24 B/instance) by
+// one 8 B/instance write and one LDS-resident sort per tile.
+#include "gsr_device.h"
+#include "gsr_splat_math.h"
+
+namespace gsr {
+
+// ===================================================================================
+// per-splat forward
+// ===================================================================================
+struct SplatInputs {
+    const float* means3D;
+    const float* scales;
+    const float* rotations;
+    const float* opacities;
+    const float* shs;
+    const float* cov3D_precomp;
+    const float* colors_precomp;
+    const float* view;
+    const float* proj;
+    const float* campos;
+};
+
+__device__ __forceinline__ void load_cov3d(const SplatInputs& in, const FrameParams& f, int idx, float cov[6])
+{
+    if (in.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cov[k] = in.cov3D_precomp[6 * (size_t)idx + k];
+    } else {
+        const float3 s = make_float3(in.scales[3 * (size_t)idx], in.scales[3 * (size_t)idx + 1], in.scales[3 * (size_t)idx + 2]);
+        const float4 q = reinterpret_cast<const float4*>(in.rotations)[idx];
+        cov3d_from_scale_rot(s, f.scale_modifier, q, cov);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomView g,
+             uint32_t* __restrict__ tile_count)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= f.P) return;
+    const float3 p = make_float3(in.means3D[3 * (size_t)idx], in.means3D[3 * (size_t)idx + 1], in.means3D[3 * (size_t)idx + 2]);
+    float cov[6];
+    load_cov3d(in, f, idx, cov);
+    Projected pr;
+    const bool vis = project_splat(p, cov, f, in.view, in.proj, pr);
+    if (!vis) {
+        g.g1[idx] = make_float4(0.f, 0.f, 0.f, 0.f); // radius 0 marks the splat invisible
+        if (radii_out) radii_out[idx] = 0;
+        return;
+    }
+    float4 c;
+    if (in.colors_precomp) {
+        c = make_float4(in.colors_precomp[3 * (size_t)idx], in.colors_precomp[3 * (size_t)idx + 1],
+                        in.colors_precomp[3 * (size_t)idx + 2], 0.f);
+    } else {
+        float3 raw;
+        const float3 d = unit_dir(p, in.campos, raw);
+        const float* sh = in.shs + (size_t)idx * f.M * 3;
+        const float r = sh_channel(f.D, sh, 0, d), gg = sh_channel(f.D, sh, 1, d), b = sh_channel(f.D, sh, 2, d);
+        const uint32_t flags = (r < 0 ? 1u : 0u) | (gg < 0 ? 2u : 0u) | (b < 0 ? 4u : 0u);
+        c = make_float4(fmaxf(r, 0.f), fmaxf(gg, 0.f), fmaxf(b, 0.f), __uint_as_float(flags));
+    }
+    g.g0[idx] = make_float4(pr.px, pr.py, pr.conic_a, pr.conic_b);
+    g.g1[idx] = make_float4(pr.conic_c, in.opacities[idx], pr.p_view.z, __int_as_float(pr.radius));
+    g.col[idx] = c;
+    if (radii_out) radii_out[idx] = pr.radius;
+    for (int y = pr.y0; y < pr.y1; y++)
+        for (int x = pr.x0; x < pr.x1; x++) atomicAdd(&tile_count[y * f.grid_x + x], 1u);
+}
+
+__global__ void __launch_bounds__(256)
+K_filter_radii(FrameParams f, SplatInputs in, int* __restrict__ radii_out)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= f.P) return;
+    const float3 p = make_float3(in.means3D[3 * (size_t)idx], in.means3D[3 * (size_t)idx + 1], in.means3D[3 * (size_t)idx + 2]);
+    float cov[6];
+    load_cov3d(in, f, idx, cov);
+    Projected pr;
+    radii_out[idx] = project_splat(p, cov, f, in.view, in.proj, pr) ? pr.radius : 0;
+}
+
+__global__ void __launch_bounds__(256)
+K_mark_visible(int P, const float* __restrict__ means3D, const float* __restrict__ view, uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float3 p = make_float3(means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]);
+    present[idx] = xform4x3(p, view).z <= 0.2f ? 0 : 1;
+}
+
+// ===================================================================================
+// tile binning
+// ===================================================================================
+__global__ void __launch_bounds__(1024)
+K_scan_tiles(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges,
+             uint32_t* __restrict__ cursor, GeomHeader* __restrict__ hdr, uint32_t capacity)
+{
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x;
+    const int per = (T + 1023) / 1024;
+    const int b = tid * per, e = min(T, b + per);
+    uint32_t s = 0;
+    for (int i = b; i < e; i++) s += tile_count[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
+        uint32_t v = tid >= off ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (int i = b; i < e; i++) {
+        const uint32_t c = tile_count[i];
+        ranges[i] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u); // empty tiles read (0,0) like the reference's memset
+        cursor[i] = run;
+        run += c;
+    }
+    if (tid == 1023) {
+        const uint32_t total = part[1023];
+        hdr->num_rendered = total;
+        hdr->overflow = total > capacity ? 1u : 0u;
+        hdr->capacity = capacity;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+K_fill(int P, int grid_x, int grid_y, GeomView g, uint32_t* __restrict__ cursor, uint64_t* __restrict__ pairs)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P || g.hdr->overflow) return;
+    const float4 b = g.g1[idx];
+    const int radius = __float_as_int(b.w);
+    if (radius <= 0) return;
+    const float4 a = g.g0[idx];
+    int x0, y0, x1, y1;
+    tile_rect(a.x, a.y, radius, grid_x, grid_y, x0, y0, x1, y1);
+    const uint64_t key = ((uint64_t)__float_as_uint(b.z) << 32) | (uint32_t)idx;
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) {
+            const uint32_t slot = atomicAdd(&cursor[y * grid_x + x], 1u);
+            pairs[slot] = key;
+        }
+}
+
+// All-ascending bitonic network ("flip" then "disperse" stages): every compare-exchange
+// keeps the smaller key at the lower index, so virtual +inf padding above n never moves.
+#define GSR_SORT_CAP 4096
+__device__ __forceinline__ void cex(uint64_t& a, uint64_t& b)
+{
+    if (a > b) { const uint64_t t = a; a = b; b = t; }
+}
+
+// runs the stages of block size k_from..k_to that fit inside one LDS chunk of `cap` keys
+__device__ __forceinline__ void lds_sort_stages(uint64_t* s, int cap, int k_from, int k_to, int j_first_override)
+{
+    for (int k = k_from; k <= k_to; k <<= 1) {
+        int j;
+        if (j_first_override > 0) j = j_first_override; // continue a global-stage merge: disperse only
+        else {
+            for (int i = threadIdx.x; i < cap / 2; i += blockDim.x) { // flip
+                const int blk = i / (k >> 1), off = i % (k >> 1);
+                const int lo = blk * k + off, hi = blk * k + (k - 1 - off);
+                cex(s[lo], s[hi]);
+            }
+            __syncthreads();
+            j = k >> 2;
+        }
+        for (; j > 0; j >>= 1) { // disperse
+            for (int i = threadIdx.x; i < cap / 2; i += blockDim.x) {
+                const int lo = (i / j) * 2 * j + (i % j);
+                cex(s[lo], s[lo + j]);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __restrict__ hdr,
+            uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list)
+{
+    __shared__ uint64_t s[GSR_SORT_CAP];
+    const uint32_t tile = xcd_remap(blockIdx.x, ntiles);
+    if (hdr->overflow) return;
+    const uint2 r = ranges[tile];
+    const int n = (int)(r.y - r.x);
+    if (n == 0) return;
+    uint64_t* seg = pairs + r.x;
+    if (n <= GSR_SORT_CAP) {
+        int n2 = 2;
+        while (n2 < n) n2 <<= 1;
+        for (int i = threadIdx.x; i < n2; i += 256) s[i] = i < n ? seg[i] : ~0ull;
+        __syncthreads();
+        lds_sort_stages(s, n2, 2, n2, 0);
+        for (int i = threadIdx.x; i < n; i += 256) point_list[r.x + i] = (uint32_t)s[i];
+        return;
+    }
+    // oversize tile: chunk-local stages in LDS, long-stride stages in global memory
+    long n2 = GSR_SORT_CAP;
+    while (n2 < n) n2 <<= 1;
+    const int nchunks = (int)(n2 / GSR_SORT_CAP);
+    for (int c = 0; c < nchunks; c++) {
+        const long base = (long)c * GSR_SORT_CAP;
+        if (base >= n) break;
+        for (int i = threadIdx.x; i < GSR_SORT_CAP; i += 256) s[i] = base + i < n ? seg[base + i] : ~0ull;
+        __syncthreads();
+        lds_sort_stages(s, GSR_SORT_CAP, 2, GSR_SORT_CAP, 0);
+        for (int i = threadIdx.x; i < GSR_SORT_CAP; i += 256) if (base + i < n) seg[base + i] = s[i];
+        __syncthreads();
+    }
+    for (long k = 2L * GSR_SORT_CAP; k <= n2; k <<= 1) {
+        for (long i = threadIdx.x; i < n2 / 2; i += 256) { // flip in global memory
+            const long blk = i / (k >> 1), off = i % (k >> 1);
+            const long lo = blk * k + off, hi = blk * k + (k - 1 - off);
+            if (hi < n) { uint64_t a = seg[lo], b = seg[hi]; if (a > b) { seg[lo] = b; seg[hi] = a; } }
+        }
+        __syncthreads();
+        long j = k >> 2;
+        for (; j >= GSR_SORT_CAP; j >>= 1) { // disperse with stride >= chunk: global memory
+            for (long i = threadIdx.x; i < n2 / 2; i += 256) {
+                const long lo = (i / j) * 2 * j + (i % j), hi = lo + j;
+                if (hi < n) { uint64_t a = seg[lo], b = seg[hi]; if (a > b) { seg[lo] = b; seg[hi] = a; } }
+            }
+            __syncthreads();
+        }
+        for (int c = 0; c < nchunks; c++) { // remaining strides are chunk-local
+            const long base = (long)c * GSR_SORT_CAP;
+            if (base >= n) break;
+            for (int i = threadIdx.x; i < GSR_SORT_CAP; i += 256) s[i] = base + i < n ? seg[base + i] : ~0ull;
+            __syncthreads();
+            lds_sort_stages(s, GSR_SORT_CAP, GSR_SORT_CAP, GSR_SORT_CAP, GSR_SORT_CAP / 2);
+            for (int i = threadIdx.x; i < GSR_SORT_CAP; i += 256) if (base + i < n) seg[base + i] = s[i];
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n; i += 256) point_list[r.x + i] = (uint32_t)seg[i];
+}
+
+// ===================================================================================
+// blending
+// ===================================================================================
+// Conservative test: can the splat reach alpha >= 1/255 at any pixel centre of the 8x8
+// quad centred at (qcx, qcy)? Uses the axis-aligned bounding box of the iso-alpha ellipse
+// 0.5*d^T*Conic*d <= ln(255*opacity). Never rejects a contributing splat (NaNs pass).
+__device__ __forceinline__ bool quad_hit(float x, float y, float ca, float cb, float cc, float op,
+                                         float qcx, float qcy)
+{
+#ifdef GSR_DISABLE_CULL
+    return true;
+#endif
+    if (op < 1.0f / 255.0f) return false; // alpha = op*exp(power<=0) can never reach 1/255
+    const float tau2 = 2.0f * (__logf(255.0f * op) + 0.01f);
+    const float det = ca * cc - cb * cb;
+    if (!(det > 0.f)) return true;
+    const float inv = tau2 / det;
+    const float hx = sqrtf(inv * cc) + 3.51f, hy = sqrtf(inv * ca) + 3.51f;
+    return !(fabsf(x - qcx) > hx) && !(fabsf(y - qcy) > hy);
+}
+
+__global__ void __launch_bounds__(256)
+K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
+            int grid_x, int ntiles, float* __restrict__ out_color, float* __restrict__ out_depth)
+{
+    __shared__ float4 s0[256], s1[256], s2[256];
+    const uint32_t tile = xcd_remap(blockIdx.x, ntiles);
+    const int tx = tile % grid_x, ty = tile / grid_x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int qx0 = tx * 16 + (wave & 1) * 8, qy0 = ty * 16 + (wave >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0 + 3.5f;
+    const uint2 range = im.ranges[tile];
+    const int n = g.hdr->overflow ? 0 : (int)(range.y - range.x);
+    const uint32_t* __restrict__ plist = bn.point_list + range.x;
+
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    for (int base = 0; base < n; base += 256) {
+        if (__syncthreads_count(done) == 256) break;
+        if (base + tid < n) {
+            const uint32_t id = plist[base + tid];
+            s0[tid] = g.g0[id];
+            s1[tid] = g.g1[id];
+            s2[tid] = g.col[id];
+        }
+        __syncthreads();
+        const int m = min(256, n - base);
+        if (__all(done)) continue;
+        for (int sb = 0; sb < m; sb += 64) {
+            const int j = sb + lane;
+            bool hit = false;
+            if (j < m) {
+                const float4 a = s0[j], b = s1[j];
+                hit = quad_hit(a.x, a.y, a.z, a.w, b.x, b.y, qcx, qcy);
+            }
+            unsigned long long mask = __ballot(hit);
+            while (mask) {
+                const int jj = sb + (int)__builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float4 a = s0[jj], b = s1[jj];
+                if (!done) {
+                    const float dx = a.x - pxf, dy = a.y - pyf;
+                    const float power = pair_power(dx, dy, a.z, a.w, b.x);
+                    if (power <= 0.0f) {
+                        const float alpha = fminf(0.99f, b.y * __expf(power));
+                        if (alpha >= 1.0f / 255.0f) {
+                            const float test_T = T * (1.f - alpha);
+                            if (test_T < 0.0001f) done = true;
+                            else {
+                                const float4 c = s2[jj];
+                                const float w = alpha * T;
+                                C0 = fmaf(c.x, w, C0);
+                                C1 = fmaf(c.y, w, C1);
+                                C2 = fmaf(c.z, w, C2);
+                                if (T > 0.5f) Dp = b.z;
+                                T = test_T;
+                                last = (uint32_t)(base + jj + 1);
+                            }
+                        }
+                    }
+                }
+                if (__all(done)) { mask = 0; sb = m; }
+            }
+        }
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+        im.final_T[pix] = T;
+        im.n_contrib[pix] = last;
+        out_color[pix] = C0 + T * bg[0];
+        out_color[HW + pix] = C1 + T * bg[1];
+        out_color[2 * HW + pix] = C2 + T * bg[2];
+        out_depth[pix] = Dp;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+K_blend_bwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
+            int grid_x, int ntiles, const float* __restrict__ dL_dpix)
+{
+    __shared__ float4 s0[256], s1[256], s2[256];
+    __shared__ uint32_t sid[256];
+    __shared__ uint32_t smax[4];
+    const uint32_t tile = xcd_remap(blockIdx.x, ntiles);
+    const int tx = tile % grid_x, ty = tile / grid_x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int qx0 = tx * 16 + (wave & 1) * 8, qy0 = ty * 16 + (wave >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0 + 3.5f;
+    const uint2 range = im.ranges[tile];
+    const int n = g.hdr->overflow ? 0 : (int)(range.y - range.x);
+    const uint32_t* __restrict__ plist = bn.point_list + range.x;
+    const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+
+    const float T_final = inside ? im.final_T[pix] : 0.f;
+    float T = T_final;
+    const uint32_t last = inside ? im.n_contrib[pix] : 0u;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (inside) { g0 = dL_dpix[pix]; g1 = dL_dpix[HW + pix]; g2 = dL_dpix[2 * HW + pix]; }
+    const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+
+    const uint32_t wmax = wave_max_u32(last); // nothing at list position >= wmax touches this wave
+    if (lane == 0) smax[wave] = wmax;
+    __syncthreads();
+    const int ntodo = min(n, (int)max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+
+    for (int base = 0; base < ntodo; base += 256) {
+        __syncthreads();
+        if (base + tid < ntodo) {
+            const uint32_t id = plist[ntodo - 1 - (base + tid)]; // back to front
+            s0[tid] = g.g0[id];
+            s1[tid] = g.g1[id];
+            s2[tid] = g.col[id];
+            sid[tid] = id;
+        }
+        __syncthreads();
+        const int m = min(256, ntodo - base);
+        for (int sb = 0; sb < m; sb += 64) {
+            const int j = sb + lane;
+            bool hit = false;
+            if (j < m && (uint32_t)(ntodo - 1 - (base + j)) < wmax) {
+                const float4 a = s0[j], b = s1[j];
+                hit = quad_hit(a.x, a.y, a.z, a.w, b.x, b.y, qcx, qcy);
+            }
+            unsigned long long mask = __ballot(hit);
+            while (mask) {
+                const int jj = sb + (int)__builtin_ctzll(mask);
+                mask &= mask - 1;
+                const uint32_t pos = (uint32_t)(ntodo - 1 - (base + jj));
+                const float4 a = s0[jj], b = s1[jj];
+                const float dx = a.x - pxf, dy = a.y - pyf;
+                float G = 0.f, alpha = 0.f;
+                bool contrib = false;
+                if (pos < last) {
+                    const float power = pair_power(dx, dy, a.z, a.w, b.x);
+                    if (power <= 0.0f) {
+                        G = __expf(power);
+                        alpha = fminf(0.99f, b.y * G);
+                        contrib = alpha >= 1.0f / 255.0f;
+                    }
+                }
+                if (!__any(contrib)) continue;
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
+                if (contrib) {
+                    const float4 c = s2[jj];
+                    const float ia = __builtin_amdgcn_rcpf(1.f - alpha);
+                    T = T * ia;
+                    const float dcol = alpha * T;
+                    ar0 = fmaf(last_alpha, lc0 - ar0, ar0); // last_alpha*lc + (1-last_alpha)*ar
+                    ar1 = fmaf(last_alpha, lc1 - ar1, ar1);
+                    ar2 = fmaf(last_alpha, lc2 - ar2, ar2);
+                    lc0 = c.x; lc1 = c.y; lc2 = c.z;
+                    float dL_dalpha = (c.x - ar0) * g0 + (c.y - ar1) * g1 + (c.z - ar2) * g2;
+                    v6 = dcol * g0; v7 = dcol * g1; v8 = dcol * g2;
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final * ia) * bg_dot;
+                    const float dL_dG = b.y * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                    const float dG_ddely = -gdy * b.x - gdx * a.w;
+                    v0 = dL_dG * dG_ddelx;          // scaled by 0.5*W in K_splat_bwd
+                    v1 = dL_dG * dG_ddely;          // scaled by 0.5*H in K_splat_bwd
+                    v2 = -0.5f * gdx * dx * dL_dG;
+                    v3 = -0.5f * gdx * dy * dL_dG;
+                    v4 = -0.5f * gdy * dy * dL_dG;
+                    v5 = G * dL_dalpha;
+                }
+                v0 = wave_sum_to_lane63(v0); v1 = wave_sum_to_lane63(v1); v2 = wave_sum_to_lane63(v2);
+                v3 = wave_sum_to_lane63(v3); v4 = wave_sum_to_lane63(v4); v5 = wave_sum_to_lane63(v5);
+                v6 = wave_sum_to_lane63(v6); v7 = wave_sum_to_lane63(v7); v8 = wave_sum_to_lane63(v8);
+                // lanes 55..63 each own one of the nine sums -> one 9-lane atomic, one cache line
+#define GSR_RL63(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63))
+                const float t0 = GSR_RL63(v0), t1 = GSR_RL63(v1), t2 = GSR_RL63(v2), t3 = GSR_RL63(v3),
+                            t4 = GSR_RL63(v4), t5 = GSR_RL63(v5), t6 = GSR_RL63(v6), t7 = GSR_RL63(v7);
+#undef GSR_RL63
+                float mine = v8;
+                mine = lane == 62 ? t7 : mine;
+                mine = lane == 61 ? t6 : mine;
+                mine = lane == 60 ? t5 : mine;
+                mine = lane == 59 ? t4 : mine;
+                mine = lane == 58 ? t3 : mine;
+                mine = lane == 57 ? t2 : mine;
+                mine = lane == 56 ? t1 : mine;
+                mine = lane == 55 ? t0 : mine;
+                if (lane >= 55) unsafeAtomicAdd(&g.acc[(size_t)sid[jj] * GSR_ACC_STRIDE + (lane - 55)], mine);
+            }
+        }
+    }
+}
+
+// ===================================================================================
+// per-splat backward (reference K11 + K12 fused; 3D covariance recomputed, not stored)
+// ===================================================================================
+struct SplatGrads {
+    float* dL_dmean2D;
+    float* dL_dconic;
+    float* dL_dopacity;
+    float* dL_dcolor;
+    float* dL_dmean3D;
+    float* dL_dcov3D;
+    float* dL_dsh;
+    float* dL_dscale;
+    float* dL_drot;
+};
+
+__device__ __forceinline__ void st3(float* p, size_t i, float a, float b, float c)
+{
+    if (p) { p[3 * i] = a; p[3 * i + 1] = b; p[3 * i + 2] = c; }
+}
+
+__global__ void __launch_bounds__(256)
+K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= f.P) return;
+    const size_t i = (size_t)idx;
+    const int radius = __float_as_int(g.g1[idx].w);
+    if (radius <= 0) { // invisible: every gradient is zero (the reference leaves its zero-fill)
+        st3(o.dL_dmean2D, i, 0.f, 0.f, 0.f);
+        if (o.dL_dconic) reinterpret_cast<float4*>(o.dL_dconic)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (o.dL_dopacity) o.dL_dopacity[i] = 0.f;
+        st3(o.dL_dcolor, i, 0.f, 0.f, 0.f);
+        st3(o.dL_dmean3D, i, 0.f, 0.f, 0.f);
+        if (o.dL_dcov3D) for (int k = 0; k < 6; k++) o.dL_dcov3D[6 * i + k] = 0.f;
+        if (o.dL_dsh) for (int k = 0; k < f.M * 3; k++) o.dL_dsh[i * f.M * 3 + k] = 0.f;
+        st3(o.dL_dscale, i, 0.f, 0.f, 0.f);
+        if (o.dL_drot) reinterpret_cast<float4*>(o.dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float* acc = g.acc + i * GSR_ACC_STRIDE;
+    const float4 q0 = reinterpret_cast<const float4*>(acc)[0], q1 = reinterpret_cast<const float4*>(acc)[1];
+    const float q8 = acc[8];
+    const float dmx = q0.x * (float)(0.5 * f.W), dmy = q0.y * (float)(0.5 * f.H);
+    const float dconx = q0.z, dcony = q0.w, dconw = q1.x;
+    float3 dcol = make_float3(q1.z, q1.w, q8);
+    st3(o.dL_dmean2D, i, dmx, dmy, 0.f);
+    if (o.dL_dconic) reinterpret_cast<float4*>(o.dL_dconic)[i] = make_float4(dconx, dcony, 0.f, dconw);
+    if (o.dL_dopacity) o.dL_dopacity[i] = q1.y;
+    st3(o.dL_dcolor, i, dcol.x, dcol.y, dcol.z);
+
+    const float3 mean = make_float3(in.means3D[3 * i], in.means3D[3 * i + 1], in.means3D[3 * i + 2]);
+    float cov3D[6];
+    load_cov3d(in, f, idx, cov3D);
+
+    // ---- conic -> 2D covariance -> 3D covariance and mean (backward.cu:144-274) ----
+    const Cov2D k = cov2d_forward(mean, f.focal_x, f.focal_y, f.tan_fovx, f.tan_fovy, cov3D, in.view);
+    const float x_grad_mul = (k.txtz < -k.limx || k.txtz > k.limx) ? 0.f : 1.f;
+    const float y_grad_mul = (k.tytz < -k.limy || k.tytz > k.limy) ? 0.f : 1.f;
+    const M3& T = k.T; const M3& Vrk = k.Vrk; const M3& Wm = k.W;
+    const float a = k.a, b = k.b, c = k.c;
+    const float denom = a * c - b * b;
+    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (denom2inv != 0.f) {
+        dL_da = denom2inv * (-c * c * dconx + 2 * b * c * dcony + (denom - a * c) * dconw);
+        dL_dc = denom2inv * (-a * a * dconw + 2 * a * b * dcony + (denom - a * c) * dconx);
+        dL_db = denom2inv * 2 * (b * c * dconx - (denom + 2 * b * b) * dcony + a * b * dconw);
+        dcov[0] = (T.m[0][0] * T.m[0][0] * dL_da + T.m[0][0] * T.m[1][0] * dL_db + T.m[1][0] * T.m[1][0] * dL_dc);
+        dcov[3] = (T.m[0][1] * T.m[0][1] * dL_da + T.m[0][1] * T.m[1][1] * dL_db + T.m[1][1] * T.m[1][1] * dL_dc);
+        dcov[5] = (T.m[0][2] * T.m[0][2] * dL_da + T.m[0][2] * T.m[1][2] * dL_db + T.m[1][2] * T.m[1][2] * dL_dc);
+        dcov[1] = 2 * T.m[0][0] * T.m[0][1] * dL_da + (T.m[0][0] * T.m[1][1] + T.m[0][1] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][1] * dL_dc;
+        dcov[2] = 2 * T.m[0][0] * T.m[0][2] * dL_da + (T.m[0][0] * T.m[1][2] + T.m[0][2] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][2] * dL_dc;
+        dcov[4] = 2 * T.m[0][2] * T.m[0][1] * dL_da + (T.m[0][1] * T.m[1][2] + T.m[0][2] * T.m[1][1]) * dL_db + 2 * T.m[1][1] * T.m[1][2] * dL_dc;
+    }
+    if (o.dL_dcov3D) for (int n = 0; n < 6; n++) o.dL_dcov3D[6 * i + n] = dcov[n];
+
+    // rows of (T * Vrk) for the two used columns of T
+    float tv0[3], tv1[3];
+#pragma unroll
+    for (int n = 0; n < 3; n++) {
+        tv0[n] = T.m[0][0] * Vrk.m[n][0] + T.m[0][1] * Vrk.m[n][1] + T.m[0][2] * Vrk.m[n][2];
+        tv1[n] = T.m[1][0] * Vrk.m[n][0] + T.m[1][1] * Vrk.m[n][1] + T.m[1][2] * Vrk.m[n][2];
+    }
+    const float dL_dT00 = 2 * tv0[0] * dL_da + tv1[0] * dL_db;
+    const float dL_dT01 = 2 * tv0[1] * dL_da + tv1[1] * dL_db;
+    const float dL_dT02 = 2 * tv0[2] * dL_da + tv1[2] * dL_db;
+    const float dL_dT10 = 2 * tv1[0] * dL_dc + tv0[0] * dL_db;
+    const float dL_dT11 = 2 * tv1[1] * dL_dc + tv0[1] * dL_db;
+    const float dL_dT12 = 2 * tv1[2] * dL_dc + tv0[2] * dL_db;
+    const float dL_dJ00 = Wm.m[0][0] * dL_dT00 + Wm.m[0][1] * dL_dT01 + Wm.m[0][2] * dL_dT02;
+    const float dL_dJ02 = Wm.m[2][0] * dL_dT00 + Wm.m[2][1] * dL_dT01 + Wm.m[2][2] * dL_dT02;
+    const float dL_dJ11 = Wm.m[1][0] * dL_dT10 + Wm.m[1][1] * dL_dT11 + Wm.m[1][2] * dL_dT12;
+    const float dL_dJ12 = Wm.m[2][0] * dL_dT10 + Wm.m[2][1] * dL_dT11 + Wm.m[2][2] * dL_dT12;
+    const float tz = 1.f / k.t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float hx = f.focal_x, hy = f.focal_y;
+    const float dL_dtx = x_grad_mul * -hx * tz2 * dL_dJ02;
+    const float dL_dty = y_grad_mul * -hy * tz2 * dL_dJ12;
+    const float dL_dtz = -hx * tz2 * dL_dJ00 - hy * tz2 * dL_dJ11 + (2 * hx * k.t.x) * tz3 * dL_dJ02 + (2 * hy * k.t.y) * tz3 * dL_dJ12;
+    const float* vm = in.view;
+    float3 dmean = make_float3(vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz,
+                               vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz,
+                               vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz);
+
+    // ---- screen-space mean -> 3D mean (backward.cu:366-387) ----
+    {
+        const float* pj = in.proj;
+        const float4 m_hom = xform4x4(mean, pj);
+        const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+        const float mul1 = (pj[0] * mean.x + pj[4] * mean.y + pj[8] * mean.z + pj[12]) * m_w * m_w;
+        const float mul2 = (pj[1] * mean.x + pj[5] * mean.y + pj[9] * mean.z + pj[13]) * m_w * m_w;
+        dmean.x += (pj[0] * m_w - pj[3] * mul1) * dmx + (pj[1] * m_w - pj[3] * mul2) * dmy;
+        dmean.y += (pj[4] * m_w - pj[7] * mul1) * dmx + (pj[5] * m_w - pj[7] * mul2) * dmy;
+        dmean.z += (pj[8] * m_w - pj[11] * mul1) * dmx + (pj[9] * m_w - pj[11] * mul2) * dmy;
+    }
+
+    // ---- colour -> SH and view direction -> mean (backward.cu:20-139) ----
+    if (in.shs && o.dL_dsh) {
+        const uint32_t flags = __float_as_uint(g.col[idx].w);
+        float3 raw;
+        const float3 d = unit_dir(mean, in.campos, raw);
+        const float gr = (flags & 1u) ? 0.f : dcol.x, gg = (flags & 2u) ? 0.f : dcol.y, gb = (flags & 4u) ? 0.f : dcol.z;
+        const float* sh = in.shs + i * f.M * 3;
+        float* dsh = o.dL_dsh + i * f.M * 3;
+        for (int n = (f.D + 1) * (f.D + 1); n < f.M; n++) { dsh[3 * n] = 0.f; dsh[3 * n + 1] = 0.f; dsh[3 * n + 2] = 0.f; }
+        const float3 d0 = sh_channel_backward(f.D, sh, dsh, 0, d, gr);
+        const float3 d1 = sh_channel_backward(f.D, sh, dsh, 1, d, gg);
+        const float3 d2 = sh_channel_backward(f.D, sh, dsh, 2, d, gb);
+        const float3 dL_ddir = make_float3(d0.x * gr + d1.x * gg + d2.x * gb, d0.y * gr + d1.y * gg + d2.y * gb,
+                                           d0.z * gr + d1.z * gg + d2.z * gb);
+        const float3 dm = dnormvdv(raw, dL_ddir);
+        dmean.x += dm.x; dmean.y += dm.y; dmean.z += dm.z;
+    }
+    st3(o.dL_dmean3D, i, dmean.x, dmean.y, dmean.z);
+
+    // ---- 3D covariance -> scale, rotation (backward.cu:278-341) ----
+    if (in.scales && o.dL_dscale && o.dL_drot) {
+        const float3 sc = make_float3(in.scales[3 * i], in.scales[3 * i + 1], in.scales[3 * i + 2]);
+        const float4 q = reinterpret_cast<const float4*>(in.rotations)[i];
+        const float r = q.x, x = q.y, y = q.z, z = q.w;
+        const M3 R = quat_R(q);
+        const float3 s = make_float3(f.scale_modifier * sc.x, f.scale_modifier * sc.y, f.scale_modifier * sc.z);
+        M3 M2 = scaled_R(s, R);
+#pragma unroll
+        for (int cc2 = 0; cc2 < 3; cc2++)
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++) M2.m[cc2][rr] = 2.0f * M2.m[cc2][rr];
+        M3 dS;
+        dS.m[0][0] = dcov[0]; dS.m[0][1] = 0.5f * dcov[1]; dS.m[0][2] = 0.5f * dcov[2];
+        dS.m[1][0] = 0.5f * dcov[1]; dS.m[1][1] = dcov[3]; dS.m[1][2] = 0.5f * dcov[4];
+        dS.m[2][0] = 0.5f * dcov[2]; dS.m[2][1] = 0.5f * dcov[4]; dS.m[2][2] = dcov[5];
+        const M3 dL_dM = m3_mul(M2, dS);
+        const M3 Rt = m3_t(R);
+        M3 dMt = m3_t(dL_dM);
+        const float dsx = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
+        const float dsy = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
+        const float dsz = Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2];
+        st3(o.dL_dscale, i, dsx, dsy, dsz);
+#pragma unroll
+        for (int n = 0; n < 3; n++) { dMt.m[0][n] *= s.x; dMt.m[1][n] *= s.y; dMt.m[2][n] *= s.z; }
+#define GSR_D(cc3, rr3) dMt.m[cc3][rr3]
+        float4 dq;
+        dq.x = 2 * z * (GSR_D(0, 1) - GSR_D(1, 0)) + 2 * y * (GSR_D(2, 0) - GSR_D(0, 2)) + 2 * x * (GSR_D(1, 2) - GSR_D(2, 1));
+        dq.y = 2 * y * (GSR_D(1, 0) + GSR_D(0, 1)) + 2 * z * (GSR_D(2, 0) + GSR_D(0, 2)) + 2 * r * (GSR_D(1, 2) - GSR_D(2, 1)) - 4 * x * (GSR_D(2, 2) + GSR_D(1, 1));
+        dq.z = 2 * x * (GSR_D(1, 0) + GSR_D(0, 1)) + 2 * r * (GSR_D(2, 0) - GSR_D(0, 2)) + 2 * z * (GSR_D(1, 2) + GSR_D(2, 1)) - 4 * y * (GSR_D(2, 2) + GSR_D(0, 0));
+        dq.w = 2 * r * (GSR_D(0, 1) - GSR_D(1, 0)) + 2 * x * (GSR_D(2, 0) + GSR_D(0, 2)) + 2 * y * (GSR_D(1, 2) + GSR_D(2, 1)) - 4 * z * (GSR_D(1, 1) + GSR_D(0, 0));
+#undef GSR_D
+        reinterpret_cast<float4*>(o.dL_drot)[i] = dq;
+    } else {
+        st3(o.dL_dscale, i, 0.f, 0.f, 0.f);
+        if (o.dL_drot) reinterpret_cast<float4*>(o.dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// ===================================================================================
+// inspection kernels (tests only): opaque blobs -> the reference's array layout
+// ===================================================================================
+__global__ void __launch_bounds__(256)
+K_export_splats(int P, int grid_x, int grid_y, GeomView g, float* means2D, float* depths,
+                float* conic_opacity, float* rgb, uint32_t* tiles_touched)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float4 b = g.g1[idx];
+    const int radius = __float_as_int(b.w);
+    const bool vis = radius > 0;
+    const float4 a = vis ? g.g0[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 c = vis ? g.col[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (means2D) { means2D[2 * idx] = a.x; means2D[2 * idx + 1] = a.y; }
+    if (depths) depths[idx] = vis ? b.z : 0.f;
+    if (conic_opacity) reinterpret_cast<float4*>(conic_opacity)[idx] = vis ? make_float4(a.z, a.w, b.x, b.y) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rgb) { rgb[3 * idx] = c.x; rgb[3 * idx + 1] = c.y; rgb[3 * idx + 2] = c.z; }
+    if (tiles_touched) {
+        uint32_t t = 0;
+        if (vis) { int x0, y0, x1, y1; tile_rect(a.x, a.y, radius, grid_x, grid_y, x0, y0, x1, y1); t = (uint32_t)((x1 - x0) * (y1 - y0)); }
+        tiles_touched[idx] = t;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+K_export_keys(int ntiles, const uint2* ranges, const uint32_t* point_list, GeomView g, uint64_t* keys)
+{
+    const int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const uint2 r = ranges[tile];
+    for (uint32_t k = r.x + threadIdx.x; k < r.y; k += 256)
+        keys[k] = ((uint64_t)tile << 32) | __float_as_uint(g.g1[point_list[k]].z);
+}
+
+} // namespace gsr

@@ -1,0 +1,180 @@
+/*
+ * gsr.h — C ABI of the MI355X (gfx950) differentiable Gaussian-splat rasterizer.
+ *
+ * This is the drop-in boundary for GSORB-SLAM's rasterizer core: each entry
+ * point replaces one member of `CudaRasterizer::Rasterizer`
+ * (Thirdparty/diff_gaussian_rasterization/cuda_rasterizer/rasterizer.h:24-99 in
+ * the reference tree). Plain pointers and sizes only: no torch, no C++ types.
+ * All pointers are DEVICE pointers unless stated; all floats fp32; matrices are
+ * 4x4 read column-major exactly like the reference (callers pass Tcw^T and
+ * (P·Tcw)^T, reference src/Camera.cc:33-36,46-47).
+ *
+ * Thread-safety: no global mutable state; every call works on the stream and
+ * buffers it is given, so two host threads may render concurrently on one
+ * device (the reference's viewer thread does, src/Viewer2.cc:256-263).
+ *
+ * Return value: >= 0 on success, a negative GSR_E* code otherwise.
+ */
+#ifndef GSR_H
+#define GSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_ABI_VERSION 1
+
+#define GSR_OK 0
+#define GSR_EINVAL (-1)    /* bad argument combination (NULL where data is required, sizes < 0 …) */
+#define GSR_EALLOC (-2)    /* an allocation callback returned NULL */
+#define GSR_EHIP (-3)      /* a HIP runtime call or kernel launch failed (see gsr_last_hip_error) */
+#define GSR_EOVERFLOW (-4) /* gsr_forward_ws: binning workspace too small for num_rendered */
+#define GSR_ECHANNELS (-5) /* only 3 colour channels are built (reference config.h:15) */
+
+/* Replaces std::function<char*(size_t)> (rasterizer.h:35-37): must return a
+ * device buffer of at least `bytes` bytes, 256-byte aligned, valid until the
+ * matching gsr_backward has run. Contents need not be zeroed. */
+typedef char* (*gsr_alloc_fn)(void* user, size_t bytes);
+
+/* Arguments of Rasterizer::forward (rasterizer.h:34-58), same meaning and order. */
+typedef struct gsr_forward_args {
+    int P;                       /* number of Gaussians */
+    int D;                       /* active SH degree (0..3) */
+    int M;                       /* SH coefficients per Gaussian (0 when colours are precomputed) */
+    const float* background;     /* [3] */
+    int width, height;
+    const float* means3D;        /* [P,3] */
+    const float* shs;            /* [P,M,3] or NULL */
+    const float* colors_precomp; /* [P,3] or NULL (exactly one of shs / colors_precomp) */
+    const float* opacities;      /* [P] */
+    const float* scales;         /* [P,3] or NULL */
+    float scale_modifier;
+    const float* rotations;      /* [P,4] (r,x,y,z), used un-normalised like forward.cu:127 */
+    const float* cov3D_precomp;  /* [P,6] or NULL (exactly one of scales+rotations / cov3D_precomp) */
+    const float* viewmatrix;     /* [16] */
+    const float* projmatrix;     /* [16] */
+    const float* cam_pos;        /* [3] */
+    float tan_fovx, tan_fovy;
+    int prefiltered;             /* accepted for signature parity; a culled splat is skipped, not trapped */
+    float* out_color;            /* [3,H,W] fully written */
+    float* out_depth;            /* [H,W]   fully written (median depth, forward.cu:374-379) */
+    int* radii;                  /* [P] fully written, or NULL */
+    /* Optional profiling hook (host array of 2*GSR_FWD_STAGES hipEvent_t, or NULL): events
+     * [2i] and [2i+1] are recorded on `stream` around stage i; NULL entries are skipped. */
+    void** profile_events;
+} gsr_forward_args;
+
+/* forward stages, in launch order */
+enum { GSR_FWD_PREPROCESS = 0, GSR_FWD_SCAN, GSR_FWD_FILL, GSR_FWD_SORT, GSR_FWD_BLEND, GSR_FWD_STAGES };
+/* backward stages */
+enum { GSR_BWD_CLEAR = 0, GSR_BWD_BLEND, GSR_BWD_SPLAT, GSR_BWD_STAGES };
+
+/* Rasterizer::forward (rasterizer_impl.cu:199-345). Calls each allocator exactly
+ * once (geometry and image before any kernel, binning once num_rendered is
+ * known — one 4-byte device→host read on `stream`, like :285). Returns
+ * num_rendered. `stream` is a hipStream_t (NULL = default stream). */
+int gsr_forward(const gsr_forward_args* args,
+                gsr_alloc_fn geom_alloc, void* geom_user,
+                gsr_alloc_fn binning_alloc, void* binning_user,
+                gsr_alloc_fn image_alloc, void* image_user,
+                void* stream);
+
+/* Sync-free variant for optimisation loops: the caller owns three persistent
+ * workspaces (sizes from gsr_*_bytes; `binning_bytes` fixes the capacity) and
+ * num_rendered never leaves the device. If the capacity is exceeded nothing is
+ * rendered and the overflow flag is raised: read it with gsr_ws_status. */
+int gsr_forward_ws(const gsr_forward_args* args, char* geom, char* binning, size_t binning_bytes,
+                   char* image, void* stream);
+
+/* Blocking: copies {num_rendered, overflow} of the last forward on `geom` to the host. */
+int gsr_ws_status(const char* geom, void* stream, int* num_rendered, int* overflow);
+
+/* Arguments of Rasterizer::backward (rasterizer.h:60-88). R is what gsr_forward
+ * returned; pass R < 0 and binning_bytes after gsr_forward_ws (num_rendered stays on the device). */
+typedef struct gsr_backward_args {
+    int P, D, M, R;
+    const float* background;
+    int width, height;
+    const float* means3D;
+    const float* shs;
+    const float* colors_precomp;
+    const float* scales;
+    float scale_modifier;
+    const float* rotations;
+    const float* cov3D_precomp;
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* cam_pos;
+    float tan_fovx, tan_fovy;
+    const int* radii;            /* as written by forward, or NULL */
+    char* geom_buffer;           /* the three blobs of the matching forward; geom is also scratch */
+    char* binning_buffer;
+    char* image_buffer;
+    size_t binning_bytes;        /* only read when R < 0: the size given to gsr_forward_ws */
+    const float* dL_dpix;        /* [3,H,W] */
+    /* Outputs. Unlike the reference (src/Rasterizer.cu:253-261 zero-fills nine
+     * tensors first) every non-NULL output is FULLY written, zeros included,
+     * so callers may pass uninitialised memory. */
+    float* dL_dmean2D;           /* [P,3]  (x,y in the reference's NDC-scaled units, z = 0) */
+    float* dL_dconic;            /* [P,4]  (x,y,·,w) or NULL */
+    float* dL_dopacity;          /* [P] */
+    float* dL_dcolor;            /* [P,3] */
+    float* dL_dmean3D;           /* [P,3] */
+    float* dL_dcov3D;            /* [P,6] */
+    float* dL_dsh;               /* [P,M,3] or NULL when M == 0 */
+    float* dL_dscale;            /* [P,3] or NULL when cov3D_precomp is used */
+    float* dL_drot;              /* [P,4] or NULL when cov3D_precomp is used */
+    void** profile_events;       /* like gsr_forward_args.profile_events, 2*GSR_BWD_STAGES entries */
+} gsr_backward_args;
+
+/* Rasterizer::backward (rasterizer_impl.cu:405-498). Never allocates, never syncs. */
+int gsr_backward(const gsr_backward_args* args, void* stream);
+
+/* Rasterizer::markVisible (rasterizer_impl.cu:142-154); present is bool[P] (1 byte each). */
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                     const float* projmatrix, uint8_t* present, void* stream);
+
+/* Rasterizer::visible_filter (rasterizer_impl.cu:348-401, GSORB's radii-only
+ * pass). The reference allocates geometry+image blobs it barely uses; this
+ * one needs no workspace. radii [P] fully written. */
+int gsr_visible_filter(int P, int width, int height, const float* means3D, const float* scales,
+                       float scale_modifier, const float* rotations, const float* viewmatrix,
+                       const float* projmatrix, float tan_fovx, float tan_fovy, int prefiltered,
+                       int* radii, void* stream);
+
+/* Workspace sizes: replace required<GeometryState/ImageState/BinningState>
+ * (rasterizer_impl.h:67-73). */
+size_t gsr_geom_bytes(int P);
+size_t gsr_image_bytes(int width, int height);
+size_t gsr_binning_bytes(size_t num_rendered);
+
+/* Test/inspection hook: re-expresses the opaque blobs in the reference's
+ * GeometryState/BinningState/ImageState array layout (rasterizer_impl.h:21-65).
+ * Every destination is a device pointer and may be NULL. Blocking. */
+typedef struct gsr_debug_arrays {
+    float* means2D;          /* [P,2] */
+    float* depths;           /* [P] */
+    float* conic_opacity;    /* [P,4] */
+    float* rgb;              /* [P,3] colours the blend used */
+    uint32_t* tiles_touched; /* [P] */
+    uint32_t* point_list;    /* [R] sorted splat ids */
+    uint64_t* point_list_keys; /* [R] (tile<<32 | depth bits), rebuilt */
+    uint32_t* ranges;        /* [tiles,2] */
+    float* final_T;          /* [H*W] */
+    uint32_t* n_contrib;     /* [H*W] */
+} gsr_debug_arrays;
+int gsr_debug_export(int P, int width, int height, int R, const char* geom, const char* binning,
+                     const char* image, const gsr_debug_arrays* out, void* stream);
+
+/* Text for a GSR_E* code; the HIP error string of the last failing HIP call on this thread. */
+const char* gsr_error_string(int code);
+const char* gsr_last_hip_error(void);
+int gsr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H */

@@ -215,6 +215,18 @@ static float sh_to_channel(int deg, const float* sh /* [M][3] */, int ch, float 
     return result + 0.5f;
 }
 
+/* direct access to the SH colour rule for the golden-vector test (forward.cu:20-71 incl.
+ * the +0.5 offset and the clamp at :63-70) */
+void gsro_eval_sh(int P, int deg, int M, const float* shs, const float* dirs, float* rgb, uint8_t* clamped)
+{
+    for (int i = 0; i < P; i++)
+        for (int ch = 0; ch < 3; ch++) {
+            float v = sh_to_channel(deg, shs + (size_t)i * M * 3, ch, dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+            clamped[3 * i + ch] = (v < 0);
+            rgb[3 * i + ch] = fmaxf(v, 0.0f);
+        }
+}
+
 static void view_dir(const float pos[3], const float campos[3], float dir_orig[3], float dir[3])
 {
     for (int k = 0; k < 3; k++) dir_orig[k] = pos[k] - campos[k];
@@ -446,6 +458,52 @@ void gsro_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* p
                     n_contrib[pix_id] = last_contributor;
                     for (int ch = 0; ch < 3; ch++) out_color[ch * H * W + pix_id] = C[ch] + T * bg[ch];
                     out_depth[pix_id] = Dp;
+                }
+        }
+}
+
+/* Test instrumentation (not in the reference): smallest relative distance of any
+ * data-dependent branch of forward.cu:346-379 from flipping, per pixel. exp() is not
+ * bit-reproducible across libm/CUDA/HIP, so a pixel whose margin is below the
+ * evaluation error of exp (~1e-6) may legitimately take the other branch; the parity
+ * tests mask such pixels instead of loosening the 1e-4 tolerance.
+ * margin_color covers power>0, alpha<1/255 and T(1-alpha)<1e-4; margin_depth adds T>0.5. */
+void gsro_render_margins(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                         const float* means2D, const float* conic_opacity, float* margin_color,
+                         float* margin_depth)
+{
+    const int gx = (W + GSRO_BLOCK_X - 1) / GSRO_BLOCK_X, gy = (H + GSRO_BLOCK_Y - 1) / GSRO_BLOCK_Y;
+    for (int ty = 0; ty < gy; ty++)
+        for (int tx = 0; tx < gx; tx++) {
+            const uint32_t r0 = ranges[2 * (ty * gx + tx)], r1 = ranges[2 * (ty * gx + tx) + 1];
+            for (int ly = 0; ly < GSRO_BLOCK_Y; ly++)
+                for (int lx = 0; lx < GSRO_BLOCK_X; lx++) {
+                    const int px = tx * GSRO_BLOCK_X + lx, py = ty * GSRO_BLOCK_Y + ly;
+                    if (!(px < W && py < H)) continue;
+                    const float pixf[2] = {(float)px, (float)py};
+                    float T = 1.0f, mc = 1e30f, md = 1e30f;
+                    for (uint32_t k = r0; k < r1; k++) {
+                        const uint32_t id = point_list[k];
+                        const float dx = means2D[2 * id] - pixf[0], dy = means2D[2 * id + 1] - pixf[1];
+                        const float* co = conic_opacity + 4 * id;
+                        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        /* power is a sum of terms of size ~|q|: its absolute error scales with them */
+                        const float pscale = 0.5f * (fabsf(co[0] * dx * dx) + fabsf(co[2] * dy * dy)) + fabsf(co[1] * dx * dy) + 1e-30f;
+                        mc = fminf(mc, fabsf(power) / pscale);
+                        if (power > 0.0f) continue;
+                        const float araw = co[3] * expf(power);
+                        /* d(alpha)/alpha = d(power): absolute power error matters, so weigh by max(1,|power|) */
+                        mc = fminf(mc, fabsf(araw * 255.0f - 1.0f) / fmaxf(1.0f, fabsf(power)));
+                        const float alpha = fminf(0.99f, araw);
+                        if (alpha < 1.0f / 255.0f) continue;
+                        const float test_T = T * (1 - alpha);
+                        mc = fminf(mc, fabsf(test_T * 10000.0f - 1.0f) * 0.1f); /* T is a product of many factors: 10x the error budget */
+                        if (test_T < 0.0001f) break;
+                        md = fminf(md, fabsf(T * 2.0f - 1.0f) * 0.1f);
+                        T = test_T;
+                    }
+                    margin_color[W * py + px] = mc;
+                    margin_depth[W * py + px] = fminf(mc, md);
                 }
         }
 }

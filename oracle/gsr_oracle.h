@@ -60,6 +60,9 @@ void gsro_filter_preprocess(int P, const float* means3D, const float* scales,
                             const float* viewmatrix, const float* projmatrix,
                             int W, int H, float tan_fovx, float tan_fovy, int* radii);
 
+/* DGR/cuda_rasterizer/forward.cu:20-71 on explicit unit directions (golden-vector hook) */
+void gsro_eval_sh(int P, int deg, int M, const float* shs, const float* dirs, float* rgb, uint8_t* clamped);
+
 /* cub::DeviceScan::InclusiveSum as used at DGR/cuda_rasterizer/rasterizer_impl.cu:280-281 */
 void gsro_inclusive_sum(int P, const uint32_t* in, uint32_t* out);
 
@@ -84,6 +87,12 @@ void gsro_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* p
                          const float* conic_opacity, const float* depths, const float* bg,
                          float* final_T, uint32_t* n_contrib, float* out_color,
                          float* out_depth);
+
+/* Test instrumentation, not in the reference: per-pixel smallest relative margin of the
+ * blend's data-dependent branches (see gsr_oracle.c). */
+void gsro_render_margins(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
+                         const float* means2D, const float* conic_opacity, float* margin_color,
+                         float* margin_depth);
 
 /* DGR/cuda_rasterizer/backward.cu:399-557 (renderCUDA, backward).
  * accum_double != 0 accumulates the per-splat sums in fp64 (deterministic,

@@ -62,6 +62,10 @@ def _load(omp: bool):
     lib.gsro_filter_preprocess.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                            C.c_float, C.c_void_p]
+    lib.gsro_render_margins.restype = None
+    lib.gsro_render_margins.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6
+    lib.gsro_eval_sh.restype = None
+    lib.gsro_eval_sh.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
     lib.gsro_higher_msb.restype = C.c_uint32
     lib.gsro_higher_msb.argtypes = [C.c_uint32]
     return lib
@@ -161,6 +165,22 @@ class Oracle:
             stages["ranges"] = stages["ranges"].reshape(-1, 2)
         return Forward(color, depth, radii, int(R), stages)
 
+    def margins(self, fwd: "Forward"):
+        """(margin_color, margin_depth) [H,W]: see gsro_render_margins. Needs copy_stages=True."""
+        s = self._s
+        mc = np.zeros((s.H, s.W), np.float32)
+        md = np.zeros((s.H, s.W), np.float32)
+        if self._P > 0:
+            st = fwd.stages
+            a = [np.ascontiguousarray(st[k]) for k in ("ranges", "point_list", "means2D", "conic_opacity")]
+            if a[1].size == 0:
+                a[1] = np.zeros(1, np.uint32)
+            self.lib.gsro_render_margins(s.W, s.H, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(mc), _ptr(md))
+        else:
+            mc[:] = 1e30
+            md[:] = 1e30
+        return mc, md
+
     def backward(self, dL_dpix, accum_double: bool = True) -> Backward:
         P, M = self._P, self._M
         g = _f32(dL_dpix)
@@ -200,3 +220,13 @@ def filter_radii(means3D, scales, rotations, cam, width=None, height=None) -> np
                                  _ptr(p), width or cam.width, height or cam.height, cam.tanfovx,
                                  cam.tanfovy, _ptr(out))
     return out
+
+
+def eval_sh(deg: int, shs, dirs):
+    """forward.cu:20-71 on explicit unit directions -> (rgb [P,3], clamped [P,3] bool)."""
+    sh, d = _f32(shs), _f32(dirs)
+    P, M = sh.shape[0], sh.shape[1]
+    rgb = np.zeros((P, 3), np.float32)
+    cl = np.zeros((P, 3), np.uint8)
+    lib().gsro_eval_sh(P, deg, M, _ptr(sh), _ptr(d), _ptr(rgb), _ptr(cl))
+    return rgb, cl.astype(bool)

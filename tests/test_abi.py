@@ -1,0 +1,72 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/gsr.h declares
+(no compute calls here: there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "gsr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsr_[a-z_0-9]+)\s*\(", src)) - {"gsr_alloc_fn"})
+
+
+def test_header_declares_the_reference_entry_points():
+    d = _declared()
+    for name in ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_visible_filter"):
+        assert name in d  # rasterizer.h:24-99 forward / backward / markVisible / visible_filter
+
+
+def test_library_exports_every_declared_symbol(gsr):
+    path = gsr.library_path()
+    if not os.path.exists(path):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(path)
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} declared in include/gsr.h but not exported"
+    assert set(gsr.capi.EXPORTS) == set(_declared())
+    assert gsr.lib().gsr_abi_version() == 1
+
+
+def test_workspace_sizes_are_sane(gsr):
+    L = gsr.lib()
+    assert L.gsr_geom_bytes(0) > 0 and L.gsr_geom_bytes(1000) >= 1000 * 96
+    assert L.gsr_geom_bytes(1_000_000) < 1_000_000 * 100 + 4096          # 96 B/splat (reference: 79 + scan temp)
+    assert L.gsr_binning_bytes(1_000_000) < 1_000_000 * 12 + 4096        # 12 B/instance (reference: 24 + sort temp)
+    assert L.gsr_image_bytes(1200, 680) >= 1200 * 680 * 8
+    assert L.gsr_error_string(-1).decode() == "invalid argument"
+
+
+def test_struct_layout_matches_header(gsr):
+    # field order of the ctypes mirrors must follow include/gsr.h
+    src = open(os.path.join(ROOT, "include", "gsr.h")).read()
+    def fields(struct):
+        body = src[src.index("typedef struct " + struct):]
+        body = body[body.index("{") + 1:body.index("} " + struct)]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                names.append(re.findall(r"([A-Za-z_0-9]+)\s*$", part.strip())[0])
+        return names
+    assert fields("gsr_forward_args") == [n for n, _ in gsr.capi.ForwardArgs._fields_]
+    assert fields("gsr_backward_args") == [n for n, _ in gsr.capi.BackwardArgs._fields_]
+    assert fields("gsr_debug_arrays") == [n for n, _ in gsr.capi.DebugArrays._fields_]
+
+
+def test_no_cpu_fallback_when_library_is_missing(gsr, monkeypatch):
+    monkeypatch.setenv("GSR_LIB_OVERRIDE", "/nonexistent/libgsr_hip.so")
+    monkeypatch.setattr(gsr.capi, "_LIB", None)
+    with pytest.raises(ImportError):
+        gsr.capi.lib()
+    monkeypatch.delenv("GSR_LIB_OVERRIDE")
+    monkeypatch.setattr(gsr.capi, "_LIB", None)
+    gsr.capi.lib()

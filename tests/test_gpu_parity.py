@@ -1,0 +1,210 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.
+
+Bars (BASELINE.json north_star): tile/sort indices BIT-EXACT (radii, tiles_touched,
+num_rendered, sorted point_list, keys, ranges); rendered RGB/depth and all gradients within
+1e-4 relative (fp32), relative to each output tensor's own scale (tests/util.py:rel_err).
+
+exp() is not bit-reproducible between glibc and the GPU, so a pixel that sits within ~1e-7
+of one of the blend's branch thresholds (alpha<1/255, power>0, T(1-alpha)<1e-4, T>0.5) may
+legitimately take the other branch — 1 pixel in 816 000 in the 300k-splat scene. The
+oracle reports each pixel's smallest branch margin (gsro_render_margins); pixels with margin
+< 1e-5 are excluded from the image comparison and their upstream gradient is zeroed for
+BOTH implementations, instead of loosening any tolerance. The fraction of such pixels is
+asserted to stay tiny.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from util import pose, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+EPS_MARGIN = 1e-5
+
+SMALL = dict(width=160, height=120, fx=120.0, fy=118.0)
+ODD = dict(width=203, height=149, fx=150.0, fy=152.0)   # not a multiple of 16: ragged edge tiles
+
+
+def _cases(syn):
+    return {
+        "small-rgb": dict(P=2000, cam=SMALL),
+        "tum-10k-rgb": dict(P=10000, cam=syn.TUM1),                                      # BASELINE configs[0] shape
+        "tum-10k-depth-fat": dict(P=10000, cam=syn.TUM1, mode="depth", mult=4.0),        # [z,1,0] colours, R/P ~ 8
+        "odd-sh3-pose-bg": dict(P=3000, cam=ODD, mode="sh", mult=3.0, Tcw=pose(), bg=(0.3, 0.5, 0.7),
+                                frac_behind=0.1, frac_offscreen=0.3),
+        "odd-sh1": dict(P=1500, cam=ODD, mode="sh", sh_degree=1, mult=2.0, bg=(0.2, 0.2, 0.2)),
+        "fat-clamped": dict(P=1500, cam=SMALL, mult=14.0, Tcw=pose(0.2), frac_offscreen=0.4),   # fov clamp, long lists
+        "dense-long-lists": dict(P=200000, cam=SMALL, mult=1.2),                           # > 256 and > 4096 entries per tile
+        "replica-300k": dict(P=300000, cam=syn.REPLICA),                                 # BASELINE configs[1]
+    }
+
+
+def _build(syn, P, cam, mode="rgb", mult=1.0, Tcw=None, bg=(0, 0, 0), seed=0, **kw):
+    c = syn.make_camera(**cam, Tcw=Tcw, bg=bg)
+    return syn.make_scene(P, c, seed=seed, scale_mult=mult, color_mode=mode, **kw)
+
+
+CASE_NAMES = ["small-rgb", "tum-10k-rgb", "tum-10k-depth-fat", "odd-sh3-pose-bg", "odd-sh1", "fat-clamped",
+              "dense-long-lists", "replica-300k"]
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_forward_backward_parity(gsr, syn, name):
+    sc = _build(syn, **_cases(syn)[name])
+    o, f = oracle.forward_scene(sc)
+    mc, md = o.margins(f)
+    ok_c, ok_d = mc >= EPS_MARGIN, md >= EPS_MARGIN
+    assert (~ok_c).mean() < 2e-3 and (~ok_d).mean() < 5e-3
+    g_in = sc.dL_dpix * ok_c[None]
+    b = o.backward(g_in)
+
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, shs=sc.shs, scales=sc.scales,
+                     rotations=sc.rotations)
+    d = gsr.debug_export(st)
+
+    # ---- integer stages: bit exact ----
+    assert st.num_rendered == f.num_rendered
+    np.testing.assert_array_equal(st.radii.cpu().numpy(), f.radii)
+    np.testing.assert_array_equal(d["tiles_touched"], f.stages["tiles_touched"])
+    np.testing.assert_array_equal(d["point_list"], f.stages["point_list"])
+    np.testing.assert_array_equal(d["point_list_keys"], f.stages["keys_sorted"])
+    np.testing.assert_array_equal(d["ranges"], f.stages["ranges"])
+    # per-splat projected geometry: same arithmetic, same bits
+    np.testing.assert_array_equal(d["means2D"], f.stages["means2D"])
+    np.testing.assert_array_equal(d["depths"], f.stages["depths"])
+    np.testing.assert_array_equal(d["conic_opacity"], f.stages["conic_opacity"])
+    if sc.shs is not None:
+        vis = f.radii > 0
+        np.testing.assert_allclose(d["rgb"][vis], f.stages["rgb"].reshape(-1, 3)[vis], atol=2e-6)
+
+    # ---- images ----
+    H, W = sc.cam.height, sc.cam.width
+    col = st.color.cpu().numpy()
+    scale = max(1.0, float(np.abs(f.color).max()))
+    assert np.abs(col - f.color)[:, ok_c].max() <= TOL * scale
+    dep = st.depth.cpu().numpy()[0]
+    assert np.array_equal(dep[ok_d], f.depth[0][ok_d])           # median depth is a copied input value
+    fT = d["final_T"].reshape(H, W)
+    assert np.abs(fT - f.stages["final_T"].reshape(H, W))[ok_c].max() <= TOL
+    assert np.array_equal(d["n_contrib"].reshape(H, W)[ok_c], f.stages["n_contrib"].reshape(H, W)[ok_c])
+
+    # ---- gradients ----
+    gr = gsr.backward(st, g_in)
+    torch.cuda.synchronize()
+    for n in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh",
+              "dL_dscales", "dL_drotations"):
+        e = rel_err(getattr(gr, n).cpu().numpy(), getattr(b, n))
+        assert e <= TOL, (n, e)
+
+
+def test_cov3d_precomp_path(gsr, syn):
+    sc = _build(syn, 3000, ODD, mult=2.0, bg=(0.1, 0.1, 0.4))
+    o0, f0 = oracle.forward_scene(sc)
+    cov = f0.stages["cov3D"].reshape(-1, 6)
+    o = oracle.Oracle()
+    f = o.forward(means3D=sc.means3D, opacities=sc.opacities, cam=sc.cam, colors=sc.colors, cov3D_precomp=cov)
+    mc, _ = o.margins(f)
+    g_in = sc.dL_dpix * (mc >= EPS_MARGIN)[None]
+    b = o.backward(g_in)
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, cov3D_precomp=cov)
+    np.testing.assert_array_equal(st.radii.cpu().numpy(), f.radii)
+    assert np.abs(st.color.cpu().numpy() - f.color)[:, mc >= EPS_MARGIN].max() <= TOL
+    gr = gsr.backward(st, g_in)
+    assert rel_err(gr.dL_dcov3D.cpu().numpy(), b.dL_dcov3D) <= TOL
+    assert rel_err(gr.dL_dmeans3D.cpu().numpy(), b.dL_dmeans3D) <= TOL
+    assert float(gr.dL_dscales.abs().max()) == 0.0 and float(gr.dL_drotations.abs().max()) == 0.0
+
+
+def test_edge_cases(gsr, syn):
+    cam = syn.make_camera(64, 48, 50.0, 50.0, bg=(0.1, 0.2, 0.3))
+    s = gsr.capi.Settings.from_camera(cam)
+    z = lambda *sh: torch.zeros(sh, device="cuda")
+    # P == 0: zero images, no background (src/Rasterizer.cu:183)
+    st = gsr.forward(s, z(0, 3), z(0, 1), colors=z(0, 3), scales=z(0, 3), rotations=z(0, 4))
+    assert st.num_rendered == 0 and float(st.color.abs().max()) == 0.0
+    gsr.backward(st, z(3, 48, 64))
+    # everything culled: background only, R == 0, zero gradients
+    P = 10
+    m = torch.tensor([[0, 0, -1.0]], device="cuda").repeat(P, 1)
+    q = torch.tensor([[1.0, 0, 0, 0]], device="cuda").repeat(P, 1)
+    st = gsr.forward(s, m, torch.full((P, 1), .5, device="cuda"), colors=z(P, 3), scales=torch.full((P, 3), .1, device="cuda"), rotations=q)
+    assert st.num_rendered == 0 and int(st.radii.abs().sum()) == 0
+    exp = torch.tensor(cam.bg, device="cuda")[:, None, None].expand(3, 48, 64)
+    assert torch.equal(st.color, exp)
+    gr = gsr.backward(st, torch.ones(3, 48, 64, device="cuda"))
+    assert float(gr.dL_dmeans3D.abs().max()) == 0.0 and float(gr.dL_dopacity.abs().max()) == 0.0
+    assert not gsr.mark_visible(m, s.viewmatrix, s.projmatrix).any()
+    # argument errors surface as GsrError / ValueError, not crashes
+    with pytest.raises(gsr.GsrError):
+        gsr.forward(s, m, torch.full((P, 1), .5, device="cuda"), colors=z(P, 3), shs=z(P, 16, 3), scales=z(P, 3), rotations=q)
+    with pytest.raises(gsr.GsrError):
+        gsr.forward(s, m, torch.full((P, 1), .5, device="cuda"), colors=z(P, 3))
+    with pytest.raises(ValueError):
+        gsr.forward(s, z(P, 4), torch.full((P, 1), .5, device="cuda"), colors=z(P, 3), scales=z(P, 3), rotations=q)
+
+
+def test_mark_visible_and_visible_filter(gsr, syn):
+    sc = _build(syn, 20000, syn.TUM1, mult=2.0, Tcw=pose(), frac_behind=0.3, frac_offscreen=0.3)
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    vis = gsr.mark_visible(sc.means3D, s.viewmatrix, s.projmatrix).cpu().numpy()
+    np.testing.assert_array_equal(vis, oracle.mark_visible(sc.means3D, sc.cam))
+    # GSORB renders the filter pass on a 1.2x enlarged image (src/Render.cc:794-795)
+    W2, H2 = int(sc.cam.width * 1.2), int(sc.cam.height * 1.2)
+    r = gsr.visible_filter(s, sc.means3D, sc.scales, sc.rotations, W2, H2).cpu().numpy()
+    np.testing.assert_array_equal(r, oracle.filter_radii(sc.means3D, sc.scales, sc.rotations, sc.cam, W2, H2))
+
+
+def test_workspace_path_matches_callback_path_and_flags_overflow(gsr, syn):
+    sc = _build(syn, 8000, SMALL, mult=2.0)
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    gr = gsr.backward(st, sc.dL_dpix)
+    ws = gsr.capi.Workspace(sc.P, sc.cam.width, sc.cam.height, max_rendered=st.num_rendered + 100)
+    st2 = gsr.forward_ws(s, ws, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    n, ovf = ws.status()
+    assert n == st.num_rendered and not ovf
+    assert torch.equal(st2.color, st.color) and torch.equal(st2.depth, st.depth) and torch.equal(st2.radii, st.radii)
+    gr2 = gsr.backward(st2, sc.dL_dpix)
+    assert rel_err(gr2.dL_dmeans3D.cpu().numpy(), gr.dL_dmeans3D.cpu().numpy()) < 1e-5   # atomic order only
+    small = gsr.capi.Workspace(sc.P, sc.cam.width, sc.cam.height, max_rendered=st.num_rendered // 2)
+    gsr.forward_ws(s, small, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    n, ovf = small.status()
+    assert n == st.num_rendered and ovf
+
+
+def test_properties_at_baseline_size(gsr, syn):
+    """BASELINE.json metric size (1M splats, 1200x680): size-independent properties only."""
+    sc = _build(syn, 1_000_000, syn.REPLICA)
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    d = gsr.debug_export(st)
+    assert st.num_rendered == int(d["tiles_touched"].sum())
+    keys = d["point_list_keys"]
+    assert np.all(np.diff(keys.astype(np.uint64)) >= 0) or np.all(keys[1:] >= keys[:-1])   # sorted by (tile, depth)
+    same = keys[1:] == keys[:-1]
+    assert np.all(d["point_list"][1:][same] > d["point_list"][:-1][same])                   # stable
+    r = d["ranges"].astype(np.int64)
+    assert int((r[:, 1] - r[:, 0]).sum()) == st.num_rendered
+    assert np.array_equal(np.sort(np.unique(d["point_list"])), np.nonzero(st.radii.cpu().numpy() > 0)[0])
+    T0 = d["final_T"].reshape(680, 1200)
+    assert np.isfinite(st.color.cpu().numpy()).all() and T0.min() >= 0 and T0.max() <= 1
+    # background linearity: C(bg) = C(0) + T_final * bg
+    bg = np.array([0.25, 0.5, 0.75], np.float32)
+    s2 = gsr.capi.Settings.from_camera(sc.cam)
+    s2.bg = torch.tensor(bg, device="cuda")
+    st2 = gsr.forward(s2, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    exp = st.color.cpu().numpy() + T0[None] * bg[:, None, None]
+    assert np.abs(st2.color.cpu().numpy() - exp).max() < 1e-5
+    # gradient linearity in the upstream gradient, and run-to-run agreement (atomics reorder only)
+    g1 = gsr.backward(st, sc.dL_dpix)
+    a = g1.dL_dmeans3D.clone()
+    g2 = gsr.backward(st, 2.0 * torch.tensor(sc.dL_dpix, device="cuda"))
+    assert rel_err(g2.dL_dmeans3D.cpu().numpy(), 2.0 * a.cpu().numpy()) < 1e-5
+    inv = st.radii == 0
+    assert float(g2.dL_dmeans3D[inv].abs().sum()) == 0.0
