@@ -8,11 +8,11 @@
 //   K_fill         per splat : (depth bits<<32 | id) into its tiles' segments (unordered)
 //   K_tile_sort    per tile  : bitonic sort of the tile's segment in LDS -> point_list
 //                              ((depth, id) ascending == the reference's stable radix order)
-//   K_blend_fwd    per tile  : front-to-back alpha blend, 4 waves = four 8x8 pixel quads,
-//                              per-wave ballot culling of splats that miss the quad
+//   K_blend_fwd    per tile  : front-to-back alpha blend, one wave per tile, 4 pixels per lane
+//                              (one per 8x8 quad), ballot culling + wave-uniform quad masks
 // Backward (replaces rasterizer_impl.cu:405-498):
 //   K_blend_bwd    per tile  : back-to-front re-walk, DPP wave reduction, one 9-lane atomic
-//                              per (wave, splat) into a packed per-splat accumulator
+//                              per (tile, splat) into a packed per-splat accumulator
 //   K_splat_bwd    per splat : conic/mean2D/colour gradients -> mean3D, cov3D, scale, rot, SH
 //
 // No global sort and no per-instance keys: per-tile counting replaces the
@@ -257,224 +257,10 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
     for (int i = threadIdx.x; i < n; i += 256) point_list[r.x + i] = (uint32_t)seg[i];
 }
 
-// ===================================================================================
-// blending
-// ===================================================================================
-// Conservative test: can the splat reach alpha >= 1/255 at any pixel centre of the 8x8
-// quad centred at (qcx, qcy)? Uses the axis-aligned bounding box of the iso-alpha ellipse
-// 0.5*d^T*Conic*d <= ln(255*opacity). Never rejects a contributing splat (NaNs pass).
-__device__ __forceinline__ bool quad_hit(float x, float y, float ca, float cb, float cc, float op,
-                                         float qcx, float qcy)
-{
-#ifdef GSR_DISABLE_CULL
-    return true;
-#endif
-    if (op < 1.0f / 255.0f) return false; // alpha = op*exp(power<=0) can never reach 1/255
-    const float tau2 = 2.0f * (__logf(255.0f * op) + 0.01f);
-    const float det = ca * cc - cb * cb;
-    if (!(det > 0.f)) return true;
-    const float inv = tau2 / det;
-    const float hx = sqrtf(inv * cc) + 3.51f, hy = sqrtf(inv * ca) + 3.51f;
-    return !(fabsf(x - qcx) > hx) && !(fabsf(y - qcy) > hy);
-}
-
-__global__ void __launch_bounds__(256)
-K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
-            int grid_x, int ntiles, float* __restrict__ out_color, float* __restrict__ out_depth)
-{
-    __shared__ float4 s0[256], s1[256], s2[256];
-    const uint32_t tile = xcd_remap(blockIdx.x, ntiles);
-    const int tx = tile % grid_x, ty = tile / grid_x;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int qx0 = tx * 16 + (wave & 1) * 8, qy0 = ty * 16 + (wave >> 1) * 8;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0 + 3.5f;
-    const uint2 range = im.ranges[tile];
-    const int n = g.hdr->overflow ? 0 : (int)(range.y - range.x);
-    const uint32_t* __restrict__ plist = bn.point_list + range.x;
-
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
-    uint32_t last = 0;
-    bool done = !inside;
-
-    for (int base = 0; base < n; base += 256) {
-        if (__syncthreads_count(done) == 256) break;
-        if (base + tid < n) {
-            const uint32_t id = plist[base + tid];
-            s0[tid] = g.g0[id];
-            s1[tid] = g.g1[id];
-            s2[tid] = g.col[id];
-        }
-        __syncthreads();
-        const int m = min(256, n - base);
-        if (__all(done)) continue;
-        for (int sb = 0; sb < m; sb += 64) {
-            const int j = sb + lane;
-            bool hit = false;
-            if (j < m) {
-                const float4 a = s0[j], b = s1[j];
-                hit = quad_hit(a.x, a.y, a.z, a.w, b.x, b.y, qcx, qcy);
-            }
-            unsigned long long mask = __ballot(hit);
-            while (mask) {
-                const int jj = sb + (int)__builtin_ctzll(mask);
-                mask &= mask - 1;
-                const float4 a = s0[jj], b = s1[jj];
-                if (!done) {
-                    const float dx = a.x - pxf, dy = a.y - pyf;
-                    const float power = pair_power(dx, dy, a.z, a.w, b.x);
-                    if (power <= 0.0f) {
-                        const float alpha = fminf(0.99f, b.y * __expf(power));
-                        if (alpha >= 1.0f / 255.0f) {
-                            const float test_T = T * (1.f - alpha);
-                            if (test_T < 0.0001f) done = true;
-                            else {
-                                const float4 c = s2[jj];
-                                const float w = alpha * T;
-                                C0 = fmaf(c.x, w, C0);
-                                C1 = fmaf(c.y, w, C1);
-                                C2 = fmaf(c.z, w, C2);
-                                if (T > 0.5f) Dp = b.z;
-                                T = test_T;
-                                last = (uint32_t)(base + jj + 1);
-                            }
-                        }
-                    }
-                }
-                if (__all(done)) { mask = 0; sb = m; }
-            }
-        }
-    }
-    if (inside) {
-        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-        im.final_T[pix] = T;
-        im.n_contrib[pix] = last;
-        out_color[pix] = C0 + T * bg[0];
-        out_color[HW + pix] = C1 + T * bg[1];
-        out_color[2 * HW + pix] = C2 + T * bg[2];
-        out_depth[pix] = Dp;
-    }
-}
-
-__global__ void __launch_bounds__(256)
-K_blend_bwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
-            int grid_x, int ntiles, const float* __restrict__ dL_dpix)
-{
-    __shared__ float4 s0[256], s1[256], s2[256];
-    __shared__ uint32_t sid[256];
-    __shared__ uint32_t smax[4];
-    const uint32_t tile = xcd_remap(blockIdx.x, ntiles);
-    const int tx = tile % grid_x, ty = tile / grid_x;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int qx0 = tx * 16 + (wave & 1) * 8, qy0 = ty * 16 + (wave >> 1) * 8;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float qcx = (float)qx0 + 3.5f, qcy = (float)qy0 + 3.5f;
-    const uint2 range = im.ranges[tile];
-    const int n = g.hdr->overflow ? 0 : (int)(range.y - range.x);
-    const uint32_t* __restrict__ plist = bn.point_list + range.x;
-    const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-
-    const float T_final = inside ? im.final_T[pix] : 0.f;
-    float T = T_final;
-    const uint32_t last = inside ? im.n_contrib[pix] : 0u;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    if (inside) { g0 = dL_dpix[pix]; g1 = dL_dpix[HW + pix]; g2 = dL_dpix[2 * HW + pix]; }
-    const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
-    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
-
-    const uint32_t wmax = wave_max_u32(last); // nothing at list position >= wmax touches this wave
-    if (lane == 0) smax[wave] = wmax;
-    __syncthreads();
-    const int ntodo = min(n, (int)max(max(smax[0], smax[1]), max(smax[2], smax[3])));
-
-    for (int base = 0; base < ntodo; base += 256) {
-        __syncthreads();
-        if (base + tid < ntodo) {
-            const uint32_t id = plist[ntodo - 1 - (base + tid)]; // back to front
-            s0[tid] = g.g0[id];
-            s1[tid] = g.g1[id];
-            s2[tid] = g.col[id];
-            sid[tid] = id;
-        }
-        __syncthreads();
-        const int m = min(256, ntodo - base);
-        for (int sb = 0; sb < m; sb += 64) {
-            const int j = sb + lane;
-            bool hit = false;
-            if (j < m && (uint32_t)(ntodo - 1 - (base + j)) < wmax) {
-                const float4 a = s0[j], b = s1[j];
-                hit = quad_hit(a.x, a.y, a.z, a.w, b.x, b.y, qcx, qcy);
-            }
-            unsigned long long mask = __ballot(hit);
-            while (mask) {
-                const int jj = sb + (int)__builtin_ctzll(mask);
-                mask &= mask - 1;
-                const uint32_t pos = (uint32_t)(ntodo - 1 - (base + jj));
-                const float4 a = s0[jj], b = s1[jj];
-                const float dx = a.x - pxf, dy = a.y - pyf;
-                float G = 0.f, alpha = 0.f;
-                bool contrib = false;
-                if (pos < last) {
-                    const float power = pair_power(dx, dy, a.z, a.w, b.x);
-                    if (power <= 0.0f) {
-                        G = __expf(power);
-                        alpha = fminf(0.99f, b.y * G);
-                        contrib = alpha >= 1.0f / 255.0f;
-                    }
-                }
-                if (!__any(contrib)) continue;
-                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
-                if (contrib) {
-                    const float4 c = s2[jj];
-                    const float ia = __builtin_amdgcn_rcpf(1.f - alpha);
-                    T = T * ia;
-                    const float dcol = alpha * T;
-                    ar0 = fmaf(last_alpha, lc0 - ar0, ar0); // last_alpha*lc + (1-last_alpha)*ar
-                    ar1 = fmaf(last_alpha, lc1 - ar1, ar1);
-                    ar2 = fmaf(last_alpha, lc2 - ar2, ar2);
-                    lc0 = c.x; lc1 = c.y; lc2 = c.z;
-                    float dL_dalpha = (c.x - ar0) * g0 + (c.y - ar1) * g1 + (c.z - ar2) * g2;
-                    v6 = dcol * g0; v7 = dcol * g1; v8 = dcol * g2;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final * ia) * bg_dot;
-                    const float dL_dG = b.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                    const float dG_ddely = -gdy * b.x - gdx * a.w;
-                    v0 = dL_dG * dG_ddelx;          // scaled by 0.5*W in K_splat_bwd
-                    v1 = dL_dG * dG_ddely;          // scaled by 0.5*H in K_splat_bwd
-                    v2 = -0.5f * gdx * dx * dL_dG;
-                    v3 = -0.5f * gdx * dy * dL_dG;
-                    v4 = -0.5f * gdy * dy * dL_dG;
-                    v5 = G * dL_dalpha;
-                }
-                v0 = wave_sum_to_lane63(v0); v1 = wave_sum_to_lane63(v1); v2 = wave_sum_to_lane63(v2);
-                v3 = wave_sum_to_lane63(v3); v4 = wave_sum_to_lane63(v4); v5 = wave_sum_to_lane63(v5);
-                v6 = wave_sum_to_lane63(v6); v7 = wave_sum_to_lane63(v7); v8 = wave_sum_to_lane63(v8);
-                // lanes 55..63 each own one of the nine sums -> one 9-lane atomic, one cache line
-#define GSR_RL63(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63))
-                const float t0 = GSR_RL63(v0), t1 = GSR_RL63(v1), t2 = GSR_RL63(v2), t3 = GSR_RL63(v3),
-                            t4 = GSR_RL63(v4), t5 = GSR_RL63(v5), t6 = GSR_RL63(v6), t7 = GSR_RL63(v7);
-#undef GSR_RL63
-                float mine = v8;
-                mine = lane == 62 ? t7 : mine;
-                mine = lane == 61 ? t6 : mine;
-                mine = lane == 60 ? t5 : mine;
-                mine = lane == 59 ? t4 : mine;
-                mine = lane == 58 ? t3 : mine;
-                mine = lane == 57 ? t2 : mine;
-                mine = lane == 56 ? t1 : mine;
-                mine = lane == 55 ? t0 : mine;
-                if (lane >= 55) unsafeAtomicAdd(&g.acc[(size_t)sid[jj] * GSR_ACC_STRIDE + (lane - 55)], mine);
-            }
-        }
-    }
-}
+// blending kernels (K_blend_fwd, K_blend_bwd)
+} // namespace gsr
+#include "gsr_blend.h"
+namespace gsr {
 
 // ===================================================================================
 // per-splat backward (reference K11 + K12 fused; 3D covariance recomputed, not stored)
