@@ -79,7 +79,7 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SORT);
     tm.begin(GSR_FWD_BLEND);
-    hipLaunchKernelGGL(gsr::K_blend_fwd, dim3(T), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
+    hipLaunchKernelGGL(gsr::K_blend_fwd, dim3(4 * T), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
                        f.grid_x, T, a->out_color, a->out_depth);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_BLEND);
@@ -233,7 +233,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
     GSR_HIP(hipMemsetAsync(gv.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
     tm.end(GSR_BWD_CLEAR);
     tm.begin(GSR_BWD_BLEND);
-    hipLaunchKernelGGL(gsr::K_blend_bwd, dim3(T), dim3(64), 0, st, iv, bv, gv, a->background, W, H, f.grid_x, T, a->dL_dpix);
+    hipLaunchKernelGGL(gsr::K_blend_bwd, dim3(4 * T), dim3(64), 0, st, iv, bv, gv, a->background, W, H, f.grid_x, T, a->dL_dpix);
     GSR_LAUNCHED();
     tm.end(GSR_BWD_BLEND);
     const gsr::SplatInputs in = splat_inputs(a->means3D, a->scales, a->rotations, nullptr, a->shs, a->cov3D_precomp,
