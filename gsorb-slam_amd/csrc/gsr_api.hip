@@ -71,7 +71,7 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     const int P = a->P, T = f.grid_x * f.grid_y;
     const StageTimer tm{a->profile_events, st};
     tm.begin(GSR_FWD_FILL);
-    hipLaunchKernelGGL(gsr::K_fill, dim3(blocks256(P)), dim3(256), 0, st, P, f.grid_x, f.grid_y, gv, iv.tile_cursor, bv.pairs);
+    hipLaunchKernelGGL(gsr::K_fill, dim3(blocks256(P)), dim3(256), 0, st, P, f.grid_x, f.grid_y, gv, iv.tiles, bv.pairs);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_FILL);
     tm.begin(GSR_FWD_SORT);
@@ -99,12 +99,12 @@ int forward_head(const gsr_forward_args* a, char* geom, char* image, hipStream_t
                                              a->projmatrix, a->cam_pos);
     const StageTimer tm{a->profile_events, st};
     tm.begin(GSR_FWD_PREPROCESS);
-    GSR_HIP(hipMemsetAsync(iv->tile_count, 0, (size_t)T * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(gsr::K_preprocess, dim3(blocks256(P)), dim3(256), 0, st, f, in, a->radii, *gv, iv->tile_count);
+    GSR_HIP(hipMemsetAsync(iv->tiles, 0, (size_t)T * sizeof(TileRec), st));
+    hipLaunchKernelGGL(gsr::K_preprocess, dim3(blocks256(P)), dim3(256), 0, st, f, in, a->radii, *gv, iv->tiles);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_PREPROCESS);
     tm.begin(GSR_FWD_SCAN);
-    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, T, iv->tile_count, iv->ranges, iv->tile_cursor, gv->hdr, capacity);
+    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, T, iv->tiles, iv->ranges, gv->hdr, capacity);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SCAN);
     *fo = f;

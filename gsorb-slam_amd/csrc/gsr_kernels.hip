@@ -53,7 +53,7 @@ __device__ __forceinline__ void load_cov3d(const SplatInputs& in, const FramePar
 
 __global__ void __launch_bounds__(256)
 K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomView g,
-             uint32_t* __restrict__ tile_count)
+             TileRec* __restrict__ tiles)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= f.P) return;
@@ -83,8 +83,18 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
     g.g1[idx] = make_float4(pr.conic_c, in.opacities[idx], pr.p_view.z, __int_as_float(pr.radius));
     g.col[idx] = c;
     if (radii_out) radii_out[idx] = pr.radius;
-    for (int y = pr.y0; y < pr.y1; y++)
-        for (int x = pr.x0; x < pr.x1; x++) atomicAdd(&tile_count[y * f.grid_x + x], 1u);
+    // count the splat into its tiles; a splat with few tiles keeps the slot each atomic returns
+    const int w = pr.x1 - pr.x0, ntl = w * (pr.y1 - pr.y0);
+    if (ntl <= GSR_SLOTS) {
+        uint32_t sl[GSR_SLOTS] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < GSR_SLOTS; k++)
+            if (k < ntl) sl[k] = atomicAdd(&tiles[(pr.y0 + k / w) * f.grid_x + pr.x0 + k % w].cnt_small, 1u);
+        g.slots[idx] = make_uint4(sl[0], sl[1], sl[2], sl[3]);
+    } else {
+        for (int y = pr.y0; y < pr.y1; y++)
+            for (int x = pr.x0; x < pr.x1; x++) atomicAdd(&tiles[y * f.grid_x + x].cnt_big, 1u);
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -112,15 +122,15 @@ K_mark_visible(int P, const float* __restrict__ means3D, const float* __restrict
 // tile binning
 // ===================================================================================
 __global__ void __launch_bounds__(1024)
-K_scan_tiles(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__ ranges,
-             uint32_t* __restrict__ cursor, GeomHeader* __restrict__ hdr, uint32_t capacity)
+K_scan_tiles(int T, TileRec* __restrict__ tiles, uint2* __restrict__ ranges,
+             GeomHeader* __restrict__ hdr, uint32_t capacity)
 {
     __shared__ uint32_t part[1024];
     const int tid = threadIdx.x;
     const int per = (T + 1023) / 1024;
     const int b = tid * per, e = min(T, b + per);
     uint32_t s = 0;
-    for (int i = b; i < e; i++) s += tile_count[i];
+    for (int i = b; i < e; i++) s += tiles[i].cnt_small + tiles[i].cnt_big;
     part[tid] = s;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
@@ -131,9 +141,10 @@ K_scan_tiles(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__
     }
     uint32_t run = part[tid] - s;
     for (int i = b; i < e; i++) {
-        const uint32_t c = tile_count[i];
+        const uint32_t cs = tiles[i].cnt_small, c = cs + tiles[i].cnt_big;
         ranges[i] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u); // empty tiles read (0,0) like the reference's memset
-        cursor[i] = run;
+        tiles[i].start = run;
+        tiles[i].cur_big = run + cs;
         run += c;
     }
     if (tid == 1023) {
@@ -145,7 +156,7 @@ K_scan_tiles(int T, const uint32_t* __restrict__ tile_count, uint2* __restrict__
 }
 
 __global__ void __launch_bounds__(256)
-K_fill(int P, int grid_x, int grid_y, GeomView g, uint32_t* __restrict__ cursor, uint64_t* __restrict__ pairs)
+K_fill(int P, int grid_x, int grid_y, GeomView g, TileRec* __restrict__ tiles, uint64_t* __restrict__ pairs)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P || g.hdr->overflow) return;
@@ -156,11 +167,17 @@ K_fill(int P, int grid_x, int grid_y, GeomView g, uint32_t* __restrict__ cursor,
     int x0, y0, x1, y1;
     tile_rect(a.x, a.y, radius, grid_x, grid_y, x0, y0, x1, y1);
     const uint64_t key = ((uint64_t)__float_as_uint(b.z) << 32) | (uint32_t)idx;
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            const uint32_t slot = atomicAdd(&cursor[y * grid_x + x], 1u);
-            pairs[slot] = key;
-        }
+    const int w = x1 - x0, ntl = w * (y1 - y0);
+    if (ntl <= GSR_SLOTS) { // slots were assigned when the splat was counted: no atomics
+        const uint4 s4 = g.slots[idx];
+        const uint32_t sl[GSR_SLOTS] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int k = 0; k < GSR_SLOTS; k++)
+            if (k < ntl) pairs[tiles[(y0 + k / w) * grid_x + x0 + k % w].start + sl[k]] = key;
+    } else {
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) pairs[atomicAdd(&tiles[y * grid_x + x].cur_big, 1u)] = key;
+    }
 }
 
 // All-ascending bitonic network ("flip" then "disperse" stages): every compare-exchange
