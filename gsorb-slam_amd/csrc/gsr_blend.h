@@ -151,7 +151,7 @@ K_blend_bwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
     const float g0 = inside ? dL_dpix[pix] : 0.f, g1 = inside ? dL_dpix[HW + pix] : 0.f,
                 g2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
     const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
-    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, la = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;
+    float S0 = 0.f, S1 = 0.f, S2 = 0.f;
     const int slot = reduce9_slot_of(lane); // which of the nine sums this lane commits (-1: none)
 
     const int ntodo = min(n, (int)wave_max_u32(last)); // nothing at list position >= this touches the quad
@@ -189,29 +189,26 @@ K_blend_bwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
             if (!__any(valid)) continue;
             const float alpha = valid ? araw : 0.f, G = valid ? Graw : 0.f;
             const float ia = __builtin_amdgcn_rcpf(1.f - alpha);
-            T = T * ia; // T <- T / (1 - alpha); unchanged where the pair did not blend
+            T = T * ia; // T <- T / (1 - alpha); unchanged where the pair did not blend (alpha = 0)
             const float dcol = alpha * T;
-            const float n0 = fmaf(la, lc0 - ar0, ar0); // last_alpha*last_color + (1-last_alpha)*accum_rec
-            const float n1 = fmaf(la, lc1 - ar1, ar1);
-            const float n2 = fmaf(la, lc2 - ar2, ar2);
-            float dL_dalpha = ((Cc.x - n0) * g0 + (Cc.y - n1) * g1 + (Cc.z - n2) * g2) * T;
-            dL_dalpha += (-T_final * ia) * bg_dot;
-            const float dL_dG = B.y * dL_dalpha;
-            const float gdx = G * dx, gdy = G * dy; // zero where the pair did not blend
-            const float h = -0.5f * dL_dG;
+            // S = colour accumulated behind this splat (the reference's accum_rec, updated eagerly:
+            // last_alpha*last_color + (1-last_alpha)*accum_rec == fma(alpha, c - S, S) one step later)
+            const float e0 = Cc.x - S0, e1 = Cc.y - S1, e2 = Cc.z - S2;
+            float dL_dalpha = (e0 * g0 + e1 * g1 + e2 * g2) * T;
+            dL_dalpha = fmaf(-T_final * ia, bg_dot, dL_dalpha);
+            S0 = fmaf(alpha, e0, S0); S1 = fmaf(alpha, e1, S1); S2 = fmaf(alpha, e2, S2);
+            // raw moments of u = G*dL/dalpha; conic, opacity and the NDC scale are applied per splat
+            const float u = G * dL_dalpha, udx = u * dx, udy = u * dy;
             float v[9];
-            v[0] = dL_dG * (-gdx * A.z - gdy * A.w); // scaled by 0.5*W in K_splat_bwd
-            v[1] = dL_dG * (-gdy * B.x - gdx * A.w); // scaled by 0.5*H in K_splat_bwd
-            v[2] = (h * gdx) * dx;
-            v[3] = (h * gdx) * dy;
-            v[4] = (h * gdy) * dy;
-            v[5] = G * dL_dalpha;
+            v[0] = u;
+            v[1] = udx;
+            v[2] = udy;
+            v[3] = udx * dx;
+            v[4] = udx * dy;
+            v[5] = udy * dy;
             v[6] = dcol * g0;
             v[7] = dcol * g1;
             v[8] = dcol * g2;
-            ar0 = valid ? n0 : ar0; ar1 = valid ? n1 : ar1; ar2 = valid ? n2 : ar2;
-            lc0 = valid ? Cc.x : lc0; lc1 = valid ? Cc.y : lc1; lc2 = valid ? Cc.z : lc2;
-            la = valid ? alpha : la;
             const float mine = reduce9(v, lane);
             const uint32_t sid = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(Cc.w));
             if (slot >= 0) unsafeAtomicAdd(&g.acc[(size_t)sid * GSR_ACC_STRIDE + slot], mine);

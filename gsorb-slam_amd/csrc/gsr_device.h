@@ -9,7 +9,8 @@
 //     col  float4[P]  {r, g, b, clamp-flags}             colour the blend uses (SH result or
 //                                                        copy of colors_precomp)
 //     slots uint4[P]     list slot the splat took in each of its (<= 4) tiles at count time
-//     acc  float[P][12]  backward accumulators {dmean2D.xy, dconic.xyw, dopacity, dcolor.rgb, pad}
+//     acc  float[P][12]  backward accumulators: moments of u = G*dL/dalpha over the splat's pixels
+//                        {sum u, u*dx, u*dy, u*dx^2, u*dx*dy, u*dy^2}, dcolor.rgb, pad
 //   image blob     (gsr_image_bytes(W,H)):
 //     final_T f32[N], n_contrib u32[N], ranges uint2[T], tiles TileRec[T] (one 64-B line each)
 //   binning blob   (gsr_binning_bytes(R)):
@@ -155,7 +156,7 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
 // Instead of nine independent 6-step butterflies (54 DPP adds + 9 readlanes + selects), each
 // exchange step halves the number of live registers: gfx950's v_permlane32_swap /
 // v_permlane16_swap move half a register between two values, so one add reduces two
-// values at once. 29 VALU instructions; on return lane reduce9_lane_of(k) holds sum_k.
+// values at once. ~25 VALU instructions; on return lane reduce9_lane_of(k) holds sum_k.
 //   v_permlane32_swap a,b : a[32:63] <-> b[0:31]
 //   v_permlane16_swap a,b : a.row1 <-> b.row0, a.row3 <-> b.row2   (row = 16 lanes)
 // ---------------------------------------------------------------------------------
@@ -177,12 +178,12 @@ __device__ __forceinline__ float swap16_add(float a, float b)
 // lane that ends up holding the total of value k (k = 0..8)
 __host__ __device__ constexpr int reduce9_lane_of(int k)
 {
-    return k == 0 ? 0 : k == 4 ? 8 : k == 2 ? 16 : k == 6 ? 24 : k == 1 ? 32 : k == 5 ? 40 : k == 3 ? 48 : k == 7 ? 56 : 1;
+    return k == 0 ? 0 : k == 4 ? 8 : k == 2 ? 16 : k == 6 ? 24 : k == 1 ? 32 : k == 5 ? 40 : k == 3 ? 48 : k == 7 ? 56 : 63;
 }
 // inverse: which value (0..8) this lane owns after reduce9, or -1
 __device__ __forceinline__ int reduce9_slot_of(int lane)
 {
-    if (lane == 1) return 8;
+    if (lane == 63) return 8;
     if (lane & 7) return -1;
     const int g = lane >> 3, r = g >> 1;          // 8-lane group, row
     const int base = (r == 0) ? 0 : (r == 1) ? 2 : (r == 2) ? 1 : 3; // rows hold values [0,2,1,3] (+4 in the upper half-row)
@@ -203,14 +204,9 @@ __device__ __forceinline__ float reduce9(const float (&v)[9], int lane)
     y += dpp_f<0x141>(y);                           // row_half_mirror: i <-> 7-i
     y += dpp_f<0xB1>(y);                            // quad_perm [1,0,3,2]
     y += dpp_f<0x4E>(y);                            // quad_perm [2,3,0,1]
-    // the ninth value: plain butterfly
-    float z = swap32_add(v[8], v[8]);
-    z = swap16_add(z, z);
-    z += dpp_f<0x128>(z);
-    z += dpp_f<0x141>(z);
-    z += dpp_f<0xB1>(z);
-    z += dpp_f<0x4E>(z);
-    return lane == 1 ? z : y;
+    // the ninth value: plain DPP butterfly, total lands in lane 63
+    const float z = wave_sum_to_lane63(v[8]);
+    return lane == 63 ? z : y;
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)

@@ -321,12 +321,19 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o)
     const float* acc = g.acc + i * GSR_ACC_STRIDE;
     const float4 q0 = reinterpret_cast<const float4*>(acc)[0], q1 = reinterpret_cast<const float4*>(acc)[1];
     const float q8 = acc[8];
-    const float dmx = q0.x * (float)(0.5 * f.W), dmy = q0.y * (float)(0.5 * f.H);
-    const float dconx = q0.z, dcony = q0.w, dconw = q1.x;
+    // K_blend_bwd accumulated the raw moments of u = G*dL/dalpha: {u, u dx, u dy, u dx^2, u dx dy, u dy^2};
+    // the reference's per-pixel terms (backward.cu:536-554) are these moments times conic / opacity:
+    const float4 ga = g.g0[idx], gb = g.g1[idx];
+    const float ca = ga.z, cb = ga.w, cc = gb.x, op = gb.y;
+    const float dmx = (op * -(ca * q0.y + cb * q0.z)) * (float)(0.5 * f.W);
+    const float dmy = (op * -(cc * q0.z + cb * q0.y)) * (float)(0.5 * f.H);
+    const float hop = -0.5f * op;
+    const float dconx = hop * q0.w, dcony = hop * q1.x, dconw = hop * q1.y;
+    const float dopac = q0.x;
     float3 dcol = make_float3(q1.z, q1.w, q8);
     st3(o.dL_dmean2D, i, dmx, dmy, 0.f);
     if (o.dL_dconic) reinterpret_cast<float4*>(o.dL_dconic)[i] = make_float4(dconx, dcony, 0.f, dconw);
-    if (o.dL_dopacity) o.dL_dopacity[i] = q1.y;
+    if (o.dL_dopacity) o.dL_dopacity[i] = dopac;
     st3(o.dL_dcolor, i, dcol.x, dcol.y, dcol.z);
 
     const float3 mean = make_float3(in.means3D[3 * i], in.means3D[3 * i + 1], in.means3D[3 * i + 2]);
