@@ -1,0 +1,87 @@
+// render_api_test.cpp — exercises the C++ drop-in API exactly the way the reference's
+// Render::StartSplatting does (src/Render.cc:711-781, default path useRadiusFilter=false):
+// means are moved into the camera frame with a bmm so that the pose receives its gradient
+// from autograd, activations are applied to the raw parameters, and
+// GaussianRasterizer::forward runs with viewmatrix = I. Reads a scene written by
+// tests/test_gpu_cpp_api.py, writes image/depth/radii and the gradients of a linear loss.
+#include <torch/torch.h>
+
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <vector>
+
+#include "../../gsorb-slam_amd/torch_ext/Rasterizer.h"
+
+using namespace ORB_SLAM2;
+
+static torch::Tensor read_f32(std::ifstream& f, std::vector<int64_t> shape)
+{
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    std::vector<float> buf(n);
+    f.read(reinterpret_cast<char*>(buf.data()), n * 4);
+    return torch::from_blob(buf.data(), shape, torch::kFloat32).clone();
+}
+static void write_t(std::ofstream& f, torch::Tensor t)
+{
+    t = t.detach().to(torch::kCPU).contiguous();
+    f.write(reinterpret_cast<const char*>(t.data_ptr()), t.numel() * t.element_size());
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin\n", argv[0]); return 2; }
+    std::ifstream in(argv[1], std::ios::binary);
+    int32_t hdr[4];
+    in.read(reinterpret_cast<char*>(hdr), sizeof(hdr));
+    const int64_t P = hdr[0], W = hdr[1], H = hdr[2];
+    float fl[4];
+    in.read(reinterpret_cast<char*>(fl), sizeof(fl)); // tanfovx, tanfovy, unused, unused
+    const auto dev = torch::Device(torch::kCUDA, 0);
+    auto xyz = read_f32(in, {P, 3}).to(dev).set_requires_grad(true);          // world-frame means
+    auto rgb = read_f32(in, {P, 3}).to(dev).set_requires_grad(true);
+    auto unnorm_quat = read_f32(in, {P, 4}).to(dev).set_requires_grad(true);
+    auto logit_opac = read_f32(in, {P, 1}).to(dev).set_requires_grad(true);
+    auto log_scales = read_f32(in, {P, 3}).to(dev).set_requires_grad(true);
+    auto Tcw = read_f32(in, {4, 4}).to(dev).set_requires_grad(true);
+    auto proj = read_f32(in, {4, 4}).to(dev);                                 // P^T (row-major tensor)
+    auto G = read_f32(in, {3, H, W}).to(dev);
+
+    GaussianRasterizationSettings s{(int)H, (int)W, fl[0], fl[1], torch::zeros({3}, dev), 1.0f,
+                                    torch::eye(4, dev), proj, 0, torch::zeros({3}, dev), false};
+    GaussianRasterizer rasterizer(s);
+
+    // src/Render.cc:750-752
+    auto Tb = Tcw.unsqueeze(0).repeat({P, 1, 1});
+    auto m4 = torch::cat({xyz, torch::ones({P, 1}, dev)}, 1).unsqueeze(-1);
+    auto mean3D = Tb.bmm(m4).squeeze(-1).index({torch::indexing::Slice(), torch::indexing::Slice(0, 3)});
+    // :756-760
+    auto mean2D = torch::zeros_like(mean3D).set_requires_grad(true);
+    auto opacities = torch::sigmoid(logit_opac);
+    auto norm_qua = torch::nn::functional::normalize(unnorm_quat);
+    auto scales = torch::exp(log_scales);
+    mean2D.retain_grad();
+
+    bool threw = false;
+    try { rasterizer.forward(mean3D, mean2D, opacities); } catch (const std::invalid_argument&) { threw = true; }
+
+    auto [image, radii, depth] = rasterizer.forward(mean3D, mean2D, opacities, torch::Tensor(), rgb, scales, norm_qua,
+                                                    torch::Tensor(), 0);
+    torch::cuda::synchronize();
+    auto loss = (image * G).sum();
+    loss.backward();
+    auto vis = rasterizer.mark_visible(mean3D.detach());
+    auto fr = std::get<0>(rasterizer.Visable(mean3D.detach(), opacities.detach(), scales.detach(), norm_qua.detach(), 0));
+
+    std::ofstream out(argv[2], std::ios::binary);
+    int32_t flags[4] = {threw ? 1 : 0, (int32_t)radii.scalar_type() == (int32_t)torch::kInt32 ? 1 : 0,
+                        depth.requires_grad() ? 1 : 0, (int32_t)torch::equal(fr, radii)};
+    out.write(reinterpret_cast<const char*>(flags), sizeof(flags));
+    write_t(out, image); write_t(out, depth); write_t(out, radii.to(torch::kInt32));
+    write_t(out, xyz.grad()); write_t(out, rgb.grad()); write_t(out, unnorm_quat.grad());
+    write_t(out, logit_opac.grad()); write_t(out, log_scales.grad()); write_t(out, Tcw.grad());
+    write_t(out, mean2D.grad()); write_t(out, vis.to(torch::kInt32));
+    std::printf("ok P=%ld loss=%f\n", (long)P, loss.item<float>());
+    return 0;
+}

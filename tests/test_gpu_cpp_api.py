@@ -1,0 +1,94 @@
+"""GPU (-m gpu): the C++ drop-in API (gsorb-slam_amd/torch_ext/Rasterizer.h, namespace
+ORB_SLAM2) driven by a C++ program that reproduces Render::StartSplatting
+(reference src/Render.cc:711-781): raw parameters + activations, camera-frame means via bmm,
+GaussianRasterizer::forward with viewmatrix = I, loss.backward() reaching the pose Tcw."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from util import pose, rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _binary():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "cpp"))
+    import build as cpp_build
+    return cpp_build.build()
+
+
+def test_render_start_splatting_pattern(syn):
+    exe = _binary()
+    W, H, fx, fy = 320, 240, 260.0, 258.0
+    Tcw = pose(0.15, (0.05, -0.02, 0.1)).astype(np.float32)
+    cam_world = syn.make_camera(W, H, fx, fy, Tcw=Tcw)           # only used to place the splats in view
+    sc = syn.make_scene(5000, cam_world, seed=7, scale_mult=2.0)
+    P = sc.P
+    xyz = sc.means3D.astype(np.float32)
+    rng = np.random.default_rng(0)
+    unq = (sc.rotations * rng.uniform(0.5, 2.0, (P, 1))).astype(np.float32)     # un-normalised quaternions
+    logit = np.log(sc.opacities / (1 - sc.opacities)).astype(np.float32)
+    logs = np.log(sc.scales).astype(np.float32)
+    cam = syn.make_camera(W, H, fx, fy)                                        # identity view: means arrive in camera frame
+    means_cam = (xyz.astype(np.float64) @ Tcw[:3, :3].T.astype(np.float64) + Tcw[:3, 3]).astype(np.float32)
+    q = unq / np.linalg.norm(unq, axis=1, keepdims=True)
+    opac = 1.0 / (1.0 + np.exp(-logit.astype(np.float64)))
+    scl = np.exp(logs.astype(np.float64))
+    o = oracle.Oracle()
+    f = o.forward(means3D=means_cam, opacities=opac.astype(np.float32), cam=cam, colors=sc.colors,
+                  scales=scl.astype(np.float32), rotations=q.astype(np.float32))
+    mc, md = o.margins(f)
+    ok = mc >= 1e-4          # wider margin: the C++ side computes means/activations with torch's own rounding
+    G = (sc.dL_dpix * ok[None]).astype(np.float32)
+    b = o.backward(G)
+
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "scene.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as fh:
+            np.array([P, W, H, 0], np.int32).tofile(fh)
+            np.array([cam.tanfovx, cam.tanfovy, 0, 0], np.float32).tofile(fh)
+            for a in (xyz, sc.colors, unq, logit, logs, Tcw, cam.projmatrix, G):
+                np.ascontiguousarray(a, np.float32).tofile(fh)
+        r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw = open(fout, "rb").read()
+    off = 0
+    def take(n, dt=np.float32):
+        nonlocal off
+        a = np.frombuffer(raw, dt, n, off)
+        off += n * 4
+        return a
+    flags = take(4, np.int32)
+    assert flags[0] == 1       # forward() without colours threw std::invalid_argument (include/Rasterizer.cuh:310-312)
+    assert flags[1] == 1       # radii are int32
+    assert flags[2] == 0       # depth carries no gradient
+    assert flags[3] == 1       # Visable() (radii-only pass) == radii of the full forward
+    image = take(3 * H * W).reshape(3, H, W); depth = take(H * W).reshape(H, W); radii = take(P, np.int32)
+    g_xyz = take(P * 3).reshape(P, 3); g_rgb = take(P * 3).reshape(P, 3); g_q = take(P * 4).reshape(P, 4)
+    g_lo = take(P).reshape(P, 1); g_ls = take(P * 3).reshape(P, 3); g_T = take(16).reshape(4, 4)
+    g_m2d = take(P * 3).reshape(P, 3); vis = take(P, np.int32)
+
+    assert (radii != f.radii).mean() < 2e-3                    # torch's bmm rounds differently from numpy: rare +-1
+    assert np.abs(image - f.color)[:, ok].max() <= 2e-4
+    assert (np.abs(depth - f.depth[0]) > 1e-5)[md >= 1e-4].mean() < 1e-3   # depth is a copied z: equal up to bmm rounding
+    np.testing.assert_array_equal(vis.astype(bool), oracle.mark_visible(means_cam, cam))
+
+    tol = 5e-4   # includes the activation / bmm rounding differences upstream of the rasterizer
+    R = Tcw[:3, :3].astype(np.float64)
+    gm = b.dL_dmeans3D.astype(np.float64)
+    assert rel_err(g_xyz, gm @ R) <= tol
+    gT = np.zeros((4, 4)); gT[:3, :3] = gm.T @ xyz.astype(np.float64); gT[:3, 3] = gm.sum(0)
+    assert rel_err(g_T, gT) <= tol                             # pose gradient (src/Render.cc:750-752 via autograd)
+    assert rel_err(g_rgb, b.dL_dcolors) <= tol
+    assert rel_err(g_lo, b.dL_dopacity * (opac * (1 - opac))) <= tol
+    assert rel_err(g_ls, b.dL_dscales * scl) <= tol
+    nq = np.linalg.norm(unq.astype(np.float64), axis=1, keepdims=True)
+    gq = b.dL_drotations.astype(np.float64)
+    assert rel_err(g_q, (gq - q * (q * gq).sum(1, keepdims=True)) / nq) <= tol
+    assert rel_err(g_m2d, b.dL_dmeans2D) <= tol

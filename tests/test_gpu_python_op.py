@@ -1,0 +1,103 @@
+"""GPU (-m gpu): the drop-in Python operator (gsorb-slam_amd/diff_gaussian_rasterization, the
+twin of the reference package) and its libtorch host layer, used the way the reference's
+only Python caller uses it (scripts/replay.py:122-161,299-330): camera-frame means, two
+renders per frame (RGB and depth colours), autograd backward."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from util import pose, rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gsorb-slam_amd"))
+
+
+def _settings(dgr, cam):
+    t = lambda a: torch.as_tensor(a, dtype=torch.float32, device="cuda")
+    return dgr.GaussianRasterizationSettings(
+        image_height=cam.height, image_width=cam.width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=t(cam.bg),
+        scale_modifier=1.0, viewmatrix=t(cam.viewmatrix), projmatrix=t(cam.projmatrix), sh_degree=cam.sh_degree,
+        campos=t(cam.campos), prefiltered=False)
+
+
+def test_module_surface():
+    import diff_gaussian_rasterization as dgr
+    assert {"rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible"} <= set(dir(dgr._C))
+    assert dgr.GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "sh_degree", "campos", "prefiltered")
+    r = dgr.GaussianRasterizer(None)
+    z = torch.zeros(4, 3, device="cuda")
+    with pytest.raises(Exception):      # exactly one of SHs / colours
+        r(means3D=z, means2D=z, opacities=z[:, :1])
+    with pytest.raises(Exception):      # exactly one of scale+rot / cov3D
+        r(means3D=z, means2D=z, opacities=z[:, :1], colors_precomp=z)
+
+
+@pytest.mark.parametrize("mode", ["rgb", "depth", "sh"])
+def test_replay_style_render_and_autograd(syn, mode):
+    import diff_gaussian_rasterization as dgr
+    cam = syn.make_camera(320, 240, 260.0, 258.0, bg=(0.0, 0.0, 0.0) if mode != "sh" else (0.2, 0.3, 0.1),
+                          Tcw=pose() if mode == "sh" else None)
+    sc = syn.make_scene(6000, cam, seed=2, scale_mult=2.0, color_mode=mode)
+    o, f = oracle.forward_scene(sc)
+    mc, md = o.margins(f)
+    ok = mc >= 1e-5
+    g_in = sc.dL_dpix * ok[None]
+    b = o.backward(g_in)
+
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True)
+    means3D, opac, scales, rots = t(sc.means3D), t(sc.opacities), t(sc.scales), t(sc.rotations)
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+    kw = dict(means3D=means3D, means2D=means2D, opacities=opac, scales=scales, rotations=rots)
+    if mode == "sh":
+        shs = t(sc.shs)
+        kw["shs"] = shs
+    else:
+        cols = t(sc.colors)
+        kw["colors_precomp"] = cols
+    im, radius, depth = dgr.GaussianRasterizer(raster_settings=_settings(dgr, cam))(**kw)
+    assert im.shape == (3, cam.height, cam.width) and depth.shape == (1, cam.height, cam.width)
+    assert radius.dtype == torch.int32 and not radius.requires_grad and not depth.requires_grad
+    np.testing.assert_array_equal(radius.cpu().numpy(), f.radii)
+    assert np.abs(im.detach().cpu().numpy() - f.color)[:, ok].max() <= 1e-4 * max(1.0, np.abs(f.color).max())
+    dok = md >= 1e-5
+    assert np.array_equal(depth[0].cpu().numpy()[dok], f.depth[0][dok])
+
+    (im * torch.tensor(g_in, device="cuda")).sum().backward()
+    assert rel_err(means3D.grad.cpu().numpy(), b.dL_dmeans3D) <= 1e-4
+    assert rel_err(means2D.grad.cpu().numpy(), b.dL_dmeans2D) <= 1e-4     # retained by GSORB (src/Render.cc:763)
+    assert rel_err(opac.grad.cpu().numpy(), b.dL_dopacity) <= 1e-4
+    assert rel_err(scales.grad.cpu().numpy(), b.dL_dscales) <= 1e-4
+    assert rel_err(rots.grad.cpu().numpy(), b.dL_drotations) <= 1e-4
+    if mode == "sh":
+        assert rel_err(shs.grad.cpu().numpy(), b.dL_dsh) <= 1e-4
+    else:
+        assert rel_err(cols.grad.cpu().numpy(), b.dL_dcolors) <= 1e-4
+
+    vis = dgr.GaussianRasterizer(raster_settings=_settings(dgr, cam)).markVisible(means3D.detach())
+    np.testing.assert_array_equal(vis.cpu().numpy(), oracle.mark_visible(sc.means3D, cam))
+
+
+def test_cov3d_precomp_and_no_grad_paths(syn):
+    import diff_gaussian_rasterization as dgr
+    cam = syn.make_camera(160, 120, 120.0, 118.0)
+    sc = syn.make_scene(1500, cam, seed=4, scale_mult=2.0)
+    _, f0 = oracle.forward_scene(sc)
+    cov = torch.tensor(f0.stages["cov3D"].reshape(-1, 6), device="cuda", requires_grad=True)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    r = dgr.GaussianRasterizer(raster_settings=_settings(dgr, cam))
+    im, radius, depth = r(means3D=t(sc.means3D), means2D=torch.zeros(sc.P, 3, device="cuda"), opacities=t(sc.opacities),
+                          colors_precomp=t(sc.colors), cov3D_precomp=cov)
+    np.testing.assert_array_equal(radius.cpu().numpy(), f0.radii)
+    im.sum().backward()
+    assert cov.grad is not None and torch.isfinite(cov.grad).all()
+    with torch.no_grad():
+        im2, _, _ = r(means3D=t(sc.means3D), means2D=torch.zeros(sc.P, 3, device="cuda"), opacities=t(sc.opacities),
+                      colors_precomp=t(sc.colors), scales=t(sc.scales), rotations=t(sc.rotations))
+    assert torch.allclose(im2, im.detach(), atol=1e-5)
