@@ -172,6 +172,13 @@ def main():
         alg_bytes = 40 * R + 20 * N + 36 * V
         achieved = alg_bytes / (bwd_blend_ms * 1e-3) / 1e9
         total_alg = 152 * P + 340 * V + 128 * R + 44 * N   # whole fwd+bwd
+        traffic = None   # HBM/fabric bytes per launch of the dominant kernel: PMC counters cannot be read live,
+        try:             # so the committed rocprofv3 --pmc summary of this same command is quoted
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if P == 1_000_000:
+                traffic = tj["kernels"]["K_blend_bwd"]["traffic_bytes"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "splats*pixels/s (fwd+bwd) @1M Gaussians 1200x680",
             "value": value, "unit": "splats*pixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -183,7 +190,7 @@ def main():
                        "splats": P, "width": W, "height": H, "visible": V, "tile_instances": R,
                        "parallelism": f"scene-shard x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "K_blend_bwd", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes": alg_bytes, "avg_launch_ms": bwd_blend_ms,
                          "fwd_blend_avg_launch_ms": fwd_blend_ms,
                          "whole_step": {"algorithmic_bytes": total_alg,
