@@ -75,7 +75,9 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     GSR_LAUNCHED();
     tm.end(GSR_FWD_FILL);
     tm.begin(GSR_FWD_SORT);
-    hipLaunchKernelGGL(gsr::K_tile_sort, dim3(T), dim3(256), 0, st, T, iv.ranges, gv.hdr, bv.pairs, bv.point_list);
+    hipLaunchKernelGGL(gsr::K_tile_sort<true>, dim3(T), dim3(256), 0, st, T, iv.ranges, gv.hdr, bv.pairs, bv.point_list);
+    GSR_LAUNCHED();
+    hipLaunchKernelGGL(gsr::K_tile_sort<false>, dim3(T), dim3(256), 0, st, T, iv.ranges, gv.hdr, bv.pairs, bv.point_list);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SORT);
     tm.begin(GSR_FWD_BLEND);

@@ -188,24 +188,27 @@ __device__ __forceinline__ void cex(uint64_t& a, uint64_t& b)
     if (a > b) { const uint64_t t = a; a = b; b = t; }
 }
 
-// runs the stages of block size k_from..k_to that fit inside one LDS chunk of `cap` keys
+// runs the stages of block size k_from..k_to that fit inside one LDS chunk of `cap` keys.
+// All strides are powers of two: indices are formed with shifts and masks (lk = log2 k).
 __device__ __forceinline__ void lds_sort_stages(uint64_t* s, int cap, int k_from, int k_to, int j_first_override)
 {
-    for (int k = k_from; k <= k_to; k <<= 1) {
-        int j;
-        if (j_first_override > 0) j = j_first_override; // continue a global-stage merge: disperse only
+    for (int k = k_from, lk = 31 - __builtin_clz(k_from); k <= k_to; k <<= 1, lk++) {
+        int lj;
+        if (j_first_override > 0) lj = 31 - __builtin_clz(j_first_override); // continue a global-stage merge: disperse only
         else {
-            for (int i = threadIdx.x; i < cap / 2; i += blockDim.x) { // flip
-                const int blk = i / (k >> 1), off = i % (k >> 1);
-                const int lo = blk * k + off, hi = blk * k + (k - 1 - off);
+            const int hm = (k >> 1) - 1; // flip: pair (blk*k + off, blk*k + k-1-off), off < k/2
+            for (int i = threadIdx.x; i < cap / 2; i += blockDim.x) {
+                const int off = i & hm, blk = i >> (lk - 1);
+                const int lo = (blk << lk) + off, hi = (blk << lk) + (k - 1 - off);
                 cex(s[lo], s[hi]);
             }
             __syncthreads();
-            j = k >> 2;
+            lj = lk - 2;
         }
-        for (; j > 0; j >>= 1) { // disperse
+        for (; lj >= 0; lj--) { // disperse: pair (lo, lo + j), j = 1 << lj
+            const int j = 1 << lj, jm = j - 1;
             for (int i = threadIdx.x; i < cap / 2; i += blockDim.x) {
-                const int lo = (i / j) * 2 * j + (i % j);
+                const int lo = ((i >> lj) << (lj + 1)) + (i & jm);
                 cex(s[lo], s[lo + j]);
             }
             __syncthreads();
@@ -213,16 +216,20 @@ __device__ __forceinline__ void lds_sort_stages(uint64_t* s, int cap, int k_from
     }
 }
 
+// Two instantiations share the tiles: SMALL sorts tiles of <= 1024 entries with 8 KB of LDS (many
+// blocks per CU), the other takes the longer lists with 32 KB; each skips the other's tiles.
+#define GSR_SORT_SMALL 1024
+template <bool SMALL>
 __global__ void __launch_bounds__(256)
 K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __restrict__ hdr,
             uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list)
 {
-    __shared__ uint64_t s[GSR_SORT_CAP];
+    __shared__ uint64_t s[SMALL ? GSR_SORT_SMALL : GSR_SORT_CAP];
     const uint32_t tile = xcd_remap(blockIdx.x, ntiles);
     if (hdr->overflow) return;
     const uint2 r = ranges[tile];
     const int n = (int)(r.y - r.x);
-    if (n == 0) return;
+    if (n == 0 || (n <= GSR_SORT_SMALL) != SMALL) return;
     uint64_t* seg = pairs + r.x;
     if (n <= GSR_SORT_CAP) {
         int n2 = 2;
