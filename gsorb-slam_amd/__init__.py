@@ -13,5 +13,5 @@ There is NO CPU fallback: every compute entry point goes to the HIP library
 and raises if it is missing.
 """
 from . import capi, synthetic  # noqa: F401
-from .capi import (GsrError, backward, debug_export, forward, forward_ws, lib, library_path,  # noqa: F401
+from .capi import (GsrError, backward, debug_export, dist2, forward, forward_ws, lib, library_path,  # noqa: F401
                    mark_visible, visible_filter)

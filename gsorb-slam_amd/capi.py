@@ -17,7 +17,7 @@ _LIB = None
 
 EXPORTS = ["gsr_forward", "gsr_forward_ws", "gsr_ws_status", "gsr_backward", "gsr_mark_visible",
            "gsr_visible_filter", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
-           "gsr_debug_export", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
+           "gsr_debug_export", "gsr_knn_bytes", "gsr_dist2", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
 
 
 def library_path() -> str:
@@ -95,6 +95,10 @@ def lib():
     L.gsr_debug_export.restype = C.c_int
     L.gsr_debug_export.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(DebugArrays), C.c_void_p]
+    L.gsr_knn_bytes.restype = C.c_size_t
+    L.gsr_knn_bytes.argtypes = [C.c_int]
+    L.gsr_dist2.restype = C.c_int
+    L.gsr_dist2.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.gsr_error_string.restype = C.c_char_p
     L.gsr_error_string.argtypes = [C.c_int]
     L.gsr_last_hip_error.restype = C.c_char_p
@@ -347,4 +351,21 @@ def debug_export(st: ForwardState) -> dict:
     out["tiles_touched"] = out["tiles_touched"].astype("uint32")
     out["ranges"] = out["ranges"].astype("uint32")
     out["n_contrib"] = out["n_contrib"].astype("uint32")
+    return out
+
+
+def dist2(points, workspace=None):
+    """distCUDA2 (reference include/spatial.h:13): mean squared distance to the 3 nearest neighbours, [P]."""
+    L = lib()
+    p = points if isinstance(points, torch.Tensor) else torch.as_tensor(points)
+    dev = p.device if p.is_cuda else torch.device("cuda")
+    p = _f32(p, dev)
+    P = int(p.shape[0])
+    out = torch.empty((P,), dtype=torch.float32, device=dev)
+    if P:
+        nbytes = int(L.gsr_knn_bytes(P))
+        ws = workspace if workspace is not None and workspace.numel() >= nbytes else \
+            torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _check(L.gsr_dist2(P, _p(p), _p(out), _p(ws), ws.numel(), _stream()))
     return out

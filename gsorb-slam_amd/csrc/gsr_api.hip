@@ -3,8 +3,10 @@
 // thread-local "last HIP error" string); everything runs on the caller's stream.
 #include "../../include/gsr.h"
 #include "gsr_kernels.hip"
+#include "gsr_knn.h"
 
 #include <string.h>
+#include <algorithm>
 
 namespace {
 
@@ -275,6 +277,40 @@ int gsr_visible_filter(int P, int width, int height, const float* means3D, const
     const gsr::SplatInputs in = splat_inputs(means3D, scales, rotations, nullptr, nullptr, nullptr, nullptr,
                                              viewmatrix, projmatrix, nullptr);
     hipLaunchKernelGGL(gsr::K_filter_radii, dim3(blocks256(P)), dim3(256), 0, (hipStream_t)stream, f, in, radii);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+size_t gsr_knn_bytes(int P) { return gsr::knn_layout(nullptr, P, nullptr); }
+
+int gsr_dist2(int P, const float* points, float* mean_dists, char* workspace, size_t workspace_bytes, void* stream)
+{
+    if (P < 0) return GSR_EINVAL;
+    if (P == 0) return GSR_OK;
+    if (!points || !mean_dists || !workspace || workspace_bytes < gsr_knn_bytes(P)) return GSR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    gsr::KnnView k;
+    gsr::knn_layout(workspace, P, &k);
+    const int bits = gsr::knn_bucket_bits(P), nb = 1 << bits, shift = 30 - bits;
+    const int nbox = (P + GSR_KNN_BOX - 1) / GSR_KNN_BOX;
+    GSR_HIP(hipMemsetAsync(k.buckets, 0, (size_t)nb * sizeof(TileRec), st));
+    hipLaunchKernelGGL(gsr::K_knn_init, dim3(1), dim3(64), 0, st, k.bbox);
+    GSR_LAUNCHED();
+    hipLaunchKernelGGL(gsr::K_knn_bbox, dim3(std::min(blocks256(P), 1024)), dim3(256), 0, st, P, points, k.bbox);
+    GSR_LAUNCHED();
+    hipLaunchKernelGGL(gsr::K_knn_code, dim3(blocks256(P)), dim3(256), 0, st, P, shift, points, k.bbox, k.buckets, k.code, k.slot);
+    GSR_LAUNCHED();
+    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, nb, k.buckets, k.ranges, k.hdr, 0xFFFFFFFFu);
+    GSR_LAUNCHED();
+    hipLaunchKernelGGL(gsr::K_knn_fill, dim3(blocks256(P)), dim3(256), 0, st, P, shift, k.code, k.slot, k.buckets, k.pairs);
+    GSR_LAUNCHED();
+    hipLaunchKernelGGL(gsr::K_tile_sort<true>, dim3(nb), dim3(256), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order);
+    GSR_LAUNCHED();
+    hipLaunchKernelGGL(gsr::K_tile_sort<false>, dim3(nb), dim3(256), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order);
+    GSR_LAUNCHED();
+    hipLaunchKernelGGL(gsr::K_knn_boxes, dim3(nbox), dim3(256), 0, st, P, points, k.order, k.spts, k.boxes);
+    GSR_LAUNCHED();
+    hipLaunchKernelGGL(gsr::K_knn_search, dim3(blocks256(P)), dim3(256), 0, st, P, nbox, k.spts, k.boxes, mean_dists);
     GSR_LAUNCHED();
     return GSR_OK;
 }

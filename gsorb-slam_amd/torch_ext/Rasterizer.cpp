@@ -285,3 +285,19 @@ torch::autograd::tensor_list _RasterizeGaussians::backward(torch::autograd::Auto
 }
 
 } // namespace ORB_SLAM2
+
+// reference src/spatial.cu:15-27
+torch::Tensor distCUDA2(const torch::Tensor& points, torch::Device device)
+{
+    const int P = (int)points.size(0);
+    c10::DeviceGuard guard(device);
+    const torch::Tensor pts = points.to(device, torch::kFloat32).contiguous();
+    torch::Tensor means = torch::empty({P}, torch::TensorOptions().device(device).dtype(torch::kFloat32));
+    if (P != 0) {
+        torch::Tensor ws = torch::empty({(int64_t)gsr_knn_bytes(P)}, torch::TensorOptions().device(device).dtype(torch::kByte));
+        const int rc = gsr_dist2(P, pts.data_ptr<float>(), means.data_ptr<float>(), reinterpret_cast<char*>(ws.data_ptr()),
+                                 (size_t)ws.numel(), (void*)c10::hip::getCurrentHIPStream(device.index()).stream());
+        if (rc < 0) throw std::runtime_error(std::string("distCUDA2: ") + gsr_error_string(rc));
+    }
+    return means;
+}

@@ -144,3 +144,7 @@ public:
 };
 
 } // namespace ORB_SLAM2
+
+// reference include/spatial.h:13 (global namespace there too): mean squared distance to the three
+// nearest neighbours, used for the initial scale of inserted Gaussians (src/Gaussian.cc:59-69)
+torch::Tensor distCUDA2(const torch::Tensor& points, torch::Device device);

@@ -145,6 +145,14 @@ int gsr_visible_filter(int P, int width, int height, const float* means3D, const
                        const float* projmatrix, float tan_fovx, float tan_fovy, int prefiltered,
                        int* radii, void* stream);
 
+/* SimpleKNN::knn / distCUDA2 (reference include/simple_knn.h:15-19, src/simple_knn.cu:185-219,
+ * src/spatial.cu:15-27): mean_dists[i] = mean of the three smallest squared distances from point i
+ * to the other points (exact 3-NN). `workspace` is caller-owned scratch of gsr_knn_bytes(P) bytes
+ * (the reference cudaMallocs its temporaries and syncs twice; this entry point does neither). */
+size_t gsr_knn_bytes(int P);
+int gsr_dist2(int P, const float* points /* [P,3] */, float* mean_dists /* [P] */, char* workspace,
+              size_t workspace_bytes, void* stream);
+
 /* Workspace sizes: replace required<GeometryState/ImageState/BinningState>
  * (rasterizer_impl.h:67-73). */
 size_t gsr_geom_bytes(int P);

@@ -932,3 +932,28 @@ const void* gsro_stage(const gsro_state* s, int which, size_t* count)
     if (count) *count = c;
     return p;
 }
+
+
+/* src/simple_knn.cu:131-183 reduced to its definition: for every point the three smallest squared
+ * distances to the other points (self excluded by index), kept ascending like updateKBest does, and
+ * their mean (best[0] + best[1] + best[2]) / 3.0f. Brute force O(P^2): the search structure of the
+ * reference (Morton boxes) only prunes, it does not change the result. */
+void gsro_dist2(int P, const float* pts, float* dists)
+{
+#ifdef GSRO_OMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int i = 0; i < P; i++) {
+        float best[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+        const float* p = pts + 3 * (size_t)i;
+        for (int j = 0; j < P; j++) {
+            if (j == i) continue;
+            const float* q = pts + 3 * (size_t)j;
+            const float dx = q[0] - p[0], dy = q[1] - p[1], dz = q[2] - p[2];
+            float dist = dx * dx + dy * dy + dz * dz;
+            for (int k = 0; k < 3; k++)
+                if (best[k] > dist) { float t = best[k]; best[k] = dist; dist = t; }
+        }
+        dists[i] = (best[0] + best[1] + best[2]) / 3.0f;
+    }
+}

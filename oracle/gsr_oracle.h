@@ -123,6 +123,9 @@ void gsro_preprocess_backward(int P, int D, int M, const float* means3D, const i
                               const float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                               float* dL_drot);
 
+/* src/simple_knn.cu:131-183 (boxMeanDist) as a brute-force definition; dists [P] */
+void gsro_dist2(int P, const float* pts, float* dists);
+
 /* Whole forward as DGR/cuda_rasterizer/rasterizer_impl.cu:199-345 orders it.
  * Scratch and stage outputs live in a handle so tests can inspect each stage. */
 typedef struct gsro_state gsro_state;

@@ -66,6 +66,8 @@ def _load(omp: bool):
     lib.gsro_render_margins.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6
     lib.gsro_eval_sh.restype = None
     lib.gsro_eval_sh.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
+    lib.gsro_dist2.restype = None
+    lib.gsro_dist2.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
     lib.gsro_higher_msb.restype = C.c_uint32
     lib.gsro_higher_msb.argtypes = [C.c_uint32]
     return lib
@@ -230,3 +232,11 @@ def eval_sh(deg: int, shs, dirs):
     cl = np.zeros((P, 3), np.uint8)
     lib().gsro_eval_sh(P, deg, M, _ptr(sh), _ptr(d), _ptr(rgb), _ptr(cl))
     return rgb, cl.astype(bool)
+
+
+def dist2(points, omp: bool = True) -> np.ndarray:
+    """simple_knn / distCUDA2 by brute force (src/simple_knn.cu:147-183)."""
+    p = _f32(points)
+    out = np.zeros(p.shape[0], np.float32)
+    lib(omp).gsro_dist2(p.shape[0], _ptr(p), _ptr(out))
+    return out

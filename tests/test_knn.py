@@ -1,0 +1,96 @@
+"""simple_knn / distCUDA2 (reference src/simple_knn.cu, src/spatial.cu).
+
+CPU: the oracle's brute-force restatement against scipy's cKDTree (independent exact k-NN).
+GPU: the HIP path (gsr_dist2 through the C ABI, and the libtorch/Python distCUDA2 wrappers)
+against the oracle. Squared distances are sums of three products: 1e-6 relative covers the
+contraction/association freedom; everything else is exact (it is a selection problem)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+
+def _cloud(kind, P, seed=0):
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        return rng.uniform(-3, 3, (P, 3)).astype(np.float32)
+    if kind == "surface":        # what a SLAM map looks like: points on a few surfaces, uneven density
+        u, v = rng.uniform(-2, 2, (2, P))
+        z = np.where(rng.random(P) < 0.5, 2.0 + 0.01 * rng.standard_normal(P), 0.5 * u + 4.0)
+        return np.stack([u * rng.choice([1.0, 0.1], P), v, z], 1).astype(np.float32)
+    if kind == "dupes":          # duplicates and a far outlier
+        p = rng.uniform(0, 1, (P, 3)).astype(np.float32)
+        p[1::7] = p[0::7][: len(p[1::7])]
+        p[-1] = [50, -40, 30]
+        return p
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "surface", "dupes"])
+def test_oracle_matches_kdtree(kind):
+    from scipy.spatial import cKDTree
+    pts = _cloud(kind, 3000, 1)
+    d = oracle.dist2(pts)
+    dd, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+    ref = (dd[:, 1:] ** 2).mean(1)
+    np.testing.assert_allclose(d, ref, rtol=2e-5, atol=1e-12)
+
+
+def test_oracle_small_counts():
+    big = np.float32(3.402823466e+38)
+    with np.errstate(over="ignore"):
+        assert np.isinf(oracle.dist2(np.zeros((1, 3), np.float32))[0])          # (FLT_MAX*3)/3 overflows like the reference
+        d = oracle.dist2(np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0]], np.float32))
+    assert np.isinf(d).all() or (d > big / 4).all()                              # fewer than 3 neighbours: FLT_MAX terms
+    d = oracle.dist2(np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0], [0, 0, 3]], np.float32))
+    np.testing.assert_allclose(d, [(1 + 4 + 9) / 3, (1 + 5 + 10) / 3, (4 + 5 + 13) / 3, (9 + 10 + 13) / 3], rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,P", [("uniform", 20000), ("surface", 30000), ("dupes", 5000), ("uniform", 700),
+                                      ("surface", 5)])
+def test_hip_dist2_matches_oracle(gsr, kind, P):
+    pts = _cloud(kind, P, 2)
+    d = gsr.dist2(pts).cpu().numpy()
+    np.testing.assert_allclose(d, oracle.dist2(pts), rtol=1e-6, atol=0)
+
+
+@pytest.mark.gpu
+def test_hip_dist2_edge_counts(gsr):
+    import torch
+    assert gsr.dist2(np.zeros((0, 3), np.float32)).numel() == 0
+    with np.errstate(over="ignore"):
+        for n in (1, 2, 3):
+            pts = _cloud("uniform", n, 3)
+            d = gsr.dist2(pts).cpu().numpy()
+            assert (d > 1e37).all()
+    pts = _cloud("uniform", 4, 3)
+    np.testing.assert_allclose(gsr.dist2(pts).cpu().numpy(), oracle.dist2(pts), rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_dist2_million_points_properties(gsr):
+    """1 M points (the BASELINE scale): properties only — every value is the mean of 3 real neighbour
+    distances: compare a random sample with an exact kd-tree."""
+    from scipy.spatial import cKDTree
+    pts = _cloud("surface", 1_000_000, 5)
+    d = gsr.dist2(pts).cpu().numpy()
+    assert np.isfinite(d).all() and (d >= 0).all()
+    sel = np.random.default_rng(0).choice(len(pts), 2000, replace=False)
+    dd, _ = cKDTree(pts.astype(np.float64)).query(pts[sel].astype(np.float64), k=4)
+    np.testing.assert_allclose(d[sel], (dd[:, 1:] ** 2).mean(1), rtol=5e-5, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_python_and_cpp_distCUDA2(syn):
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "gsorb-slam_amd"))
+    import diff_gaussian_rasterization as dgr
+    pts = _cloud("surface", 8000, 4)
+    out = dgr._C.distCUDA2(torch.tensor(pts, device="cuda"))
+    assert out.shape == (8000,) and out.dtype == torch.float32
+    np.testing.assert_allclose(out.cpu().numpy(), oracle.dist2(pts), rtol=1e-6)
