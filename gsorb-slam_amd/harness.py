@@ -1,0 +1,394 @@
+"""Optimisation harness around the operator: the build's counterpart of the
+reference's `Render` + `Gaussian` classes, i.e. everything that sits between the SLAM front end
+and the rasterizer — parameter store with two Adam optimisers, activations, camera-frame
+transform, the two colour modes, losses, the tracking and mapping loops, densification mask and
+pruning with optimiser-state surgery. Plain torch on top of the drop-in Python operator; nothing
+here is accelerated code. The ORB-SLAM2 side (features, covisibility, keyframes) is NOT here:
+candidate frames and optional feature matches are inputs.
+
+Reference behaviour reproduced (file:line under /root/reference/src unless noted):
+  * Render.cc:750-760   means -> camera frame by bmm (pose gradient via autograd), sigmoid / exp /
+                        normalize activations, viewmatrix = I in the rasterizer settings
+  * Render.cc:927-981   colour render (raw rgb) and depth render (colours [z_cam, 1, 0])
+  * Utils.cc:39-100     L1 losses (mean for mapping, sum for tracking) and SSIM with the 11x11
+                        window whose taps are exp(-floor((x-11)/2)^2 / (2*1.5^2)) (:68-75)
+  * Render.cc:420-483   mapping iteration: random candidate frame, image/depth/surface-depth
+                        losses, scale regularisers, Adam step   (surface-depth has no gradient)
+  * Render.cc:1054-1126 tracking iteration: pose-only Adam, best-pose bookkeeping with NaN guard,
+                        early stop when |loss - last| < 1e-3, optional reprojection term
+  * Gaussian.cc:50-95   insertion (logit opacity 1, identity quaternion, three scale inits)
+  * Gaussian.cc:144-175 Adam per group, eps 1e-15; the pose optimiser uses lrCamQuat for BOTH groups
+  * Gaussian.cc:180-258 pruning / concatenation with exp_avg / exp_avg_sq surgery
+  * Render.cc:557-594   densification mask from the rendered silhouette / depth error
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn.functional as F
+
+
+@dataclass
+class Config:
+    """Examples/RGB-D/replica.yaml:87-117 (Mapping / Tracking blocks)."""
+    mapping_iters: int = 60
+    im_weight_mapping: float = 1.0
+    depth_weight_mapping: float = 0.7
+    sur_depth_weight_mapping: float = 0.35
+    reg_long_weight: float = 5.0
+    reg_scalar_weight: float = 10.0
+    lam: float = 0.8
+    lr_mean3d: float = 0.0001
+    lr_rgb: float = 0.0025
+    lr_rotation: float = 0.001
+    lr_opacities: float = 0.05
+    lr_scales: float = 0.001
+    prune_opacities: float = 0.005
+    scale_modifier: float = 1.0
+    init_scalar_method: int = 2          # 0 Distance, 1 DistanceMean, 2 SinglePixel (Gaussian.cc:59-79)
+    radius_depth_ratio: float = 3.0
+    median_mul: float = 40.0
+    tracking_iters: int = 40
+    lr_cam_quat: float = 0.0004
+    lr_cam_trans: float = 0.002          # parsed by the reference but unused (Gaussian.cc:149-150)
+    im_weight_tracking: float = 0.7
+    feature_weight_tracking: float = 0.1
+    depth_weight_tracking: float = 1.0
+    use_sur_depth: bool = True
+
+
+def _dgr():
+    pkg = os.path.dirname(os.path.abspath(__file__))
+    if pkg not in sys.path:
+        sys.path.insert(0, pkg)
+    import diff_gaussian_rasterization as dgr
+    return dgr
+
+
+# ---- losses (Utils.cc:39-100) -----------------------------------------------------------
+def l1_mapping(a, b, mask=None):
+    d = torch.abs(a - b)
+    return d.mean() if mask is None else d.masked_select(mask).mean()
+
+
+def l1_tracking(a, b, mask=None):
+    d = torch.abs(a - b)
+    return d.sum() if mask is None else d.masked_select(mask).sum()
+
+
+def ssim_window(window_size=11, sigma=1.5, channel=3, device="cpu"):
+    g = torch.tensor([math.exp(-(math.floor((x - window_size) / 2.0) ** 2) / (2.0 * sigma * sigma))
+                      for x in range(window_size)], dtype=torch.float32)
+    g = (g / g.sum()).unsqueeze(1)
+    w = g.mm(g.t()).unsqueeze(0).unsqueeze(0)
+    return w.expand(channel, 1, window_size, window_size).contiguous().to(device)
+
+
+def ssim(img1, img2):
+    C1, C2 = 0.01 * 0.01, 0.03 * 0.03
+    ch = img1.shape[0]
+    w = ssim_window(11, 1.5, ch, img1.device)
+    conv = lambda x: F.conv2d(x.unsqueeze(0), w, padding=5, groups=ch).squeeze(0)
+    mu1, mu2 = conv(img1), conv(img2)
+    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1 = conv(img1 * img1) - mu1_sq
+    s2 = conv(img2 * img2) - mu2_sq
+    s12 = conv(img1 * img2) - mu12
+    m = ((2.0 * mu12 + C1) * (2.0 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+    return m.mean()
+
+
+# ---- pose parameterisation (include/Utils.h:56-77, Utils.cc:170-179) ----------------------------
+def rt2T(quat, trans):
+    """quat [4,1] un-normalised (r,x,y,z), trans [3,1] -> Tcw [4,4]."""
+    q = quat.reshape(4)
+    q = q / torch.sqrt((q * q).sum())
+    r, x, y, z = q[0], q[1], q[2], q[3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]).reshape(3, 3)
+    top = torch.cat([R, trans.reshape(3, 1)], 1)
+    return torch.cat([top, torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=top.device, dtype=top.dtype)], 0)
+
+
+def rot_to_quat(R):
+    """Rotation matrix -> (w,x,y,z), as cv::Quatd::createFromRotMat gives InitCameraPose (Gaussian.cc:97-128)."""
+    R = R.double()
+    t = R.trace()
+    if t > 0:
+        s = math.sqrt(t + 1.0) * 2
+        q = [0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s]
+    else:
+        i = int(torch.argmax(torch.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = math.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = [0.0] * 4
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    return torch.tensor([float(v) for v in q], dtype=torch.float32)
+
+
+@dataclass
+class Frame:
+    rgb: torch.Tensor      # [3,H,W] 0..1
+    depth: torch.Tensor    # [H,W] metres, 0 = invalid
+    Tcw: torch.Tensor      # [4,4]
+
+
+class GaussianMap:
+    """Parameter store + optimisers (reference class Gaussian)."""
+    NAMES = ("xyz", "rgb", "unnorm_quat", "logit_opacities", "log_scales")
+
+    def __init__(self, cfg: Config, fx: float, fy: float, device="cuda"):
+        self.cfg, self.fx, self.fy, self.device = cfg, fx, fy, torch.device(device)
+        self.xyz = self.rgb = self.unnorm_quat = self.logit_opacities = self.log_scales = None
+        self.opt = None
+        self.scene_radius = 1.0
+        self.cam_quat = self.cam_trans = self.opt_pose = None
+
+    def __len__(self):
+        return 0 if self.xyz is None else int(self.xyz.shape[0])
+
+    def _new_params(self, pts, cols):
+        n = pts.shape[0]
+        dev = self.device
+        quat = torch.zeros(n, 4, device=dev)
+        quat[:, 0] = 1.0
+        logit = torch.ones(n, 1, device=dev)
+        m = self.cfg.init_scalar_method
+        if m in (0, 1):
+            from . import capi
+            dis = torch.clamp_min(capi.dist2(pts), 1e-7)
+            s = torch.sqrt(dis)
+            if m == 1:
+                s = torch.clamp_max(s, 8 * s.mean())
+            logs = torch.log(s).unsqueeze(-1).repeat(1, 3)
+        elif m == 2:   # SinglePixel: one pixel wide at its depth
+            logs = torch.log(torch.sqrt((pts[:, 2] / ((self.fx + self.fy) * 0.5)) ** 2)).unsqueeze(-1).repeat(1, 3)
+        else:
+            raise ValueError("Unknown Init Scalar Method")
+        return [pts.clone(), cols.clone(), quat, logit, logs.contiguous()]
+
+    def _lrs(self):
+        c = self.cfg
+        return (c.lr_mean3d, c.lr_rgb, c.lr_rotation, c.lr_opacities, c.lr_scales)
+
+    def add_points(self, pts, cols):
+        """Gaussian.cc:50-95: first call creates the optimiser, later calls concatenate."""
+        pts, cols = pts.to(self.device, torch.float32), cols.to(self.device, torch.float32)
+        new = self._new_params(pts, cols)
+        if self.xyz is None:
+            for n, t in zip(self.NAMES, new):
+                setattr(self, n, t.requires_grad_(True))
+            groups = [{"params": [getattr(self, n)], "lr": lr} for n, lr in zip(self.NAMES, self._lrs())]
+            self.opt = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+            return
+        for gi, (n, t) in enumerate(zip(self.NAMES, new)):       # CatTensorToOptimizer, Gaussian.cc:236-258
+            old = getattr(self, n)
+            st = self.opt.state.pop(old, None)
+            merged = torch.cat([old.detach(), t], 0).requires_grad_(True)
+            if st is not None and "exp_avg" in st:
+                st["exp_avg"] = torch.cat([st["exp_avg"], torch.zeros_like(t)], 0)
+                st["exp_avg_sq"] = torch.cat([st["exp_avg_sq"], torch.zeros_like(t)], 0)
+                self.opt.state[merged] = st
+            self.opt.param_groups[gi]["params"][0] = merged
+            setattr(self, n, merged)
+
+    def prune(self, remove_mask):
+        """Gaussian.cc:196-234 (RemovePoints + PruneOptimizer)."""
+        keep = torch.nonzero(~remove_mask).squeeze(-1)
+        for gi, n in enumerate(self.NAMES):
+            old = getattr(self, n)
+            st = self.opt.state.pop(old, None)
+            new = old.detach().index_select(0, keep).requires_grad_(True)
+            if st is not None and "exp_avg" in st:
+                st["exp_avg"] = st["exp_avg"].index_select(0, keep)
+                st["exp_avg_sq"] = st["exp_avg_sq"].index_select(0, keep)
+                self.opt.state[new] = st
+            self.opt.param_groups[gi]["params"][0] = new
+            setattr(self, n, new)
+
+    def low_opacity_mask(self):
+        return (torch.sigmoid(self.logit_opacities) < self.cfg.prune_opacities).squeeze(-1)   # Gaussian.cc:180-185
+
+    def init_camera_pose(self, Tcw):
+        Tcw = Tcw.to(self.device, torch.float32)
+        self.cam_quat = rot_to_quat(Tcw[:3, :3].cpu()).reshape(4, 1).to(self.device).requires_grad_(True)
+        self.cam_trans = Tcw[:3, 3].clone().reshape(3, 1).requires_grad_(True)
+        # both groups use lrCamQuat, like the reference (Gaussian.cc:149-150)
+        self.opt_pose = torch.optim.Adam([{"params": [self.cam_quat], "lr": self.cfg.lr_cam_quat},
+                                          {"params": [self.cam_trans], "lr": self.cfg.lr_cam_quat}], lr=0.0, eps=1e-15)
+        return Tcw
+
+
+class SlamRenderer:
+    """Reference class Render reduced to its rasterizer-facing part."""
+
+    def __init__(self, gmap: GaussianMap, width: int, height: int, near=0.01, far=100.0, seed=0):
+        self.map, self.W, self.H = gmap, width, height
+        dgr = _dgr()
+        dev = gmap.device
+        tanfovx, tanfovy = width / (2 * gmap.fx), height / (2 * gmap.fy)
+        P = torch.tensor([[1 / tanfovx, 0, 0, 0], [0, 1 / tanfovy, 0, 0],
+                          [0, 0, far / (far - near), -(far * near) / (far - near)], [0, 0, 1, 0]], dtype=torch.float32, device=dev)
+        self.settings = dgr.GaussianRasterizationSettings(
+            image_height=height, image_width=width, tanfovx=tanfovx, tanfovy=tanfovy,
+            bg=torch.zeros(3, device=dev), scale_modifier=gmap.cfg.scale_modifier, viewmatrix=torch.eye(4, device=dev),
+            projmatrix=P.t().contiguous(), sh_degree=1, campos=torch.zeros(3, device=dev), prefiltered=False)
+        self.rasterizer = dgr.GaussianRasterizer(self.settings)
+        self.rng = torch.Generator().manual_seed(seed)
+        self.tracking_counts = self.mapping_counts = 0
+
+    # Render.cc:711-781 with useRadiusFilter = false
+    def splat(self, Tcw, mean3D, rgb, unnorm_quat, logit_opacities, log_scales):
+        n = mean3D.shape[0]
+        Tb = Tcw.unsqueeze(0).repeat(n, 1, 1)
+        m4 = torch.cat([mean3D, torch.ones(n, 1, device=mean3D.device)], 1).unsqueeze(-1)
+        mc = Tb.bmm(m4).squeeze(-1)[:, :3]
+        mean2D = torch.zeros_like(mc, requires_grad=True)
+        image, radii, depth = self.rasterizer(
+            means3D=mc, means2D=mean2D, opacities=torch.sigmoid(logit_opacities), colors_precomp=rgb,
+            scales=torch.exp(log_scales), rotations=F.normalize(unnorm_quat))
+        return image, depth, radii
+
+    def _params(self, tracking):
+        g = self.map
+        p = [g.xyz, g.rgb, g.unnorm_quat, g.logit_opacities, g.log_scales]
+        return [t.detach() for t in p] if tracking else p
+
+    def render_rgb(self, Tcw, tracking=False):               # GSParamRGBUpdata, Render.cc:927-946
+        xyz, rgb, q, o, s = self._params(tracking)
+        return self.splat(Tcw, xyz, rgb, q, o, s)
+
+    def render_depth(self, Tcw, tracking=False):             # GSParamDepthUpdata, Render.cc:949-981
+        xyz, _, q, o, s = self._params(tracking)
+        n = xyz.shape[0]
+        z = (Tcw.unsqueeze(0).repeat(n, 1, 1).bmm(torch.cat([xyz, torch.ones(n, 1, device=xyz.device)], 1).unsqueeze(-1))
+             .squeeze(-1)[:, 2:3])
+        col = torch.cat([z, torch.ones_like(z), torch.zeros_like(z)], 1)
+        if tracking:
+            col = col.detach()
+        return self.splat(Tcw, xyz, col, q, o, s)
+
+    # Render.cc:420-483
+    def mapping_iteration(self, frames):
+        g, c = self.map, self.map.cfg
+        k = int(torch.randint(0, len(frames), (1,), generator=self.rng))
+        fr = frames[k]
+        Tcw = fr.Tcw.to(g.device)
+        rdepth, _, _ = self.render_depth(Tcw)
+        rimage, rsur, _ = self.render_rgb(Tcw)
+        valid = fr.depth > 0
+        valid_sur = (fr.depth > 0) & (rdepth[1] > 0.99)
+        image_loss = c.lam * l1_mapping(rimage, fr.rgb) + (1 - c.lam) * (1.0 - ssim(rimage, fr.rgb))
+        depth_loss = l1_mapping(rdepth[0], fr.depth, valid.detach())
+        sur_loss = l1_mapping(rsur[0], fr.depth, valid_sur.detach()) if bool(valid_sur.any()) else rimage.sum() * 0
+        max_scalar = 0.1 * g.scene_radius
+        sc = torch.exp(g.log_scales)
+        big = torch.where(sc > max_scalar)[0]
+        sel = sc.index_select(0, big)
+        if sel.numel():
+            reg_scalar = (sel.max(1)[0] - max_scalar).sum()
+            reg_long = (sel.max(1)[0] - sel.min(1)[0]).mean()
+        else:
+            reg_scalar = reg_long = sc.sum() * 0
+        loss = (c.im_weight_mapping * image_loss + c.depth_weight_mapping * depth_loss + c.sur_depth_weight_mapping * sur_loss
+                + c.reg_long_weight * reg_long + c.reg_scalar_weight * reg_scalar)
+        loss.backward()
+        with torch.no_grad():
+            g.opt.step()
+            g.opt.zero_grad()
+            self.mapping_counts += 1
+        return float(loss.detach())
+
+    def map_frames(self, frames, iters=None):
+        return [self.mapping_iteration(frames) for _ in range(iters or self.map.cfg.mapping_iters)]
+
+    # Render.cc:985-1141
+    def track(self, frame: Frame, Tcw_init, iters=None, matches=None, K=None):
+        """matches = (obs [M,3,1] pixels (u,v,1), Xw4 [M,4,1], inv_sigma2 [M,1]) from the feature front end, or None."""
+        g, c = self.map, self.map.cfg
+        g.init_camera_pose(Tcw_init)
+        best_q, best_t = g.cam_quat.detach().clone(), g.cam_trans.detach().clone()
+        min_loss, last_loss = float("inf"), 0.0
+        iters = iters or c.tracking_iters
+        inline = None
+        history = []
+        for it in range(iters):
+            Tcw = rt2T(g.cam_quat.clone(), g.cam_trans.clone())
+            lrpj = Tcw.sum() * 0
+            if matches is not None:
+                obs, Xw4, inv_s2 = matches
+                M = obs.shape[0]
+                Xc = Tcw.unsqueeze(0).repeat(M, 1, 1).bmm(Xw4).transpose(1, 2)[..., :3]
+                Xc = Xc / Xc[..., 0, 2].reshape(M, 1, 1)
+                uv = K.unsqueeze(0).repeat(M, 1, 1).bmm(Xc.transpose(1, 2))
+                e = (uv - obs)[:, 0:2, 0]
+                werr = (e * e * inv_s2).sum(1, keepdim=True)
+                if inline is None:
+                    inline = torch.ones_like(werr, dtype=torch.bool)
+                if it == int(iters / 2.0):
+                    inline = werr < 5.991
+                lrpj = werr.masked_select(inline).sum()
+            rimage, rsur, _ = self.render_rgb(Tcw, tracking=True)
+            rdepth, _, _ = self.render_depth(Tcw, tracking=True)
+            certain = (rdepth[1] > 0.99) & ~torch.isnan(frame.depth)
+            image_l1 = l1_tracking(rimage, frame.rgb, certain.unsqueeze(0).repeat(3, 1, 1).detach())
+            depth_l1 = l1_tracking(rsur[0] if c.use_sur_depth else rdepth[0], frame.depth, certain.detach())
+            loss = c.im_weight_tracking * image_l1 + c.depth_weight_tracking * depth_l1 + c.feature_weight_tracking * lrpj
+            loss.backward()
+            with torch.no_grad():
+                lv = float(loss.detach())
+                history.append(lv)
+                if not math.isnan(lv) and lv < min_loss:
+                    best_q, best_t, min_loss = g.cam_quat.detach().clone(), g.cam_trans.detach().clone(), lv
+                if abs(last_loss - lv) < 10e-4:
+                    break
+                last_loss = lv
+                g.opt_pose.step()
+                g.opt_pose.zero_grad()
+                self.tracking_counts += 1
+        return rt2T(best_q, best_t).detach(), history
+
+    # Render.cc:557-594 + ProjectPixel :618-700 (back-projection of the masked pixels)
+    def densify(self, frame: Frame):
+        g, c = self.map, self.map.cfg
+        with torch.no_grad():
+            Tcw = frame.Tcw.to(g.device)
+            rim, _, _ = self.render_rgb(Tcw, tracking=True)
+            rdep, _, _ = self.render_depth(Tcw, tracking=True)
+            gray = (rim[0] * 299 + rim[1] * 587 + rim[2] * 114) / 1000
+            black = gray < 50 / 255.0
+            diff = torch.abs(frame.depth - rdep[0])
+            dmask = (diff < 0.05) & (frame.depth > 0) & (rdep[0] > 0)
+            if bool(dmask.any()):
+                vals = diff.masked_select(dmask)
+                th = float(vals.sum() / dmask.sum()) + c.median_mul * float(vals.median())
+            else:
+                th = 0.0
+            th = max(th, 0.01)
+            add = (~(rdep[1] > 0.99) & black & (diff > th)) | (rdep[1] < 0.8)
+            add = add & (frame.depth > 0)
+            v, u = torch.nonzero(add, as_tuple=True)
+            if v.numel() == 0:
+                return 0
+            z = frame.depth[v, u]
+            cx, cy = (self.W - 1) / 2.0, (self.H - 1) / 2.0
+            pc = torch.stack([(u.float() - cx) * z / g.fx, (v.float() - cy) * z / g.fy, z], 1)
+            Twc = torch.inverse(Tcw)
+            pw = pc @ Twc[:3, :3].t() + Twc[:3, 3]
+            g.add_points(pw, frame.rgb[:, v, u].t().contiguous())
+            return int(v.numel())
+
+    def remove_low_opacity(self):                              # Render.cc:598-616
+        m = self.map.low_opacity_mask()
+        n = int(m.sum())
+        if n > 0:
+            self.map.prune(m)
+        return n

@@ -1,0 +1,123 @@
+"""Optimisation harness: losses / pose parameterisation / optimiser surgery on CPU,
+tracking and mapping loops on the GPU through the drop-in operator."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from util import pose
+
+
+@pytest.fixture(scope="module")
+def hz(gsr):
+    return __import__("gsorb_slam_amd.harness", fromlist=["x"])
+
+
+def test_ssim_window_is_the_references_odd_formula(hz):
+    w = hz.ssim_window(11, 1.5, 3)
+    taps = np.array([math.exp(-(math.floor((x - 11) / 2.0) ** 2) / (2 * 1.5 * 1.5)) for x in range(11)])   # Utils.cc:68-75
+    taps /= taps.sum()
+    np.testing.assert_allclose(w[0, 0].numpy(), np.outer(taps, taps), rtol=1e-6)
+    assert w.shape == (3, 1, 11, 11) and abs(float(w[1].sum()) - 1.0) < 1e-6
+    assert taps[0] < taps[-1]                      # the window is NOT symmetric: floor((x-11)/2)
+    a = torch.rand(3, 40, 48)
+    assert abs(float(hz.ssim(a, a)) - 1.0) < 1e-5
+    assert float(hz.ssim(a, 1 - a)) < 0.5
+    m = torch.rand(3, 40, 48) > 0.5
+    assert torch.allclose(hz.l1_tracking(a, 1 - a, m), torch.abs(2 * a - 1)[m].sum())
+    assert torch.allclose(hz.l1_mapping(a, 1 - a), torch.abs(2 * a - 1).mean())
+
+
+def test_pose_parameterisation_round_trip(hz):
+    for th, t in ((0.3, (0.1, -0.2, 0.3)), (2.9, (1, 2, 3)), (-1.2, (0, 0, 0))):
+        T = torch.tensor(pose(th, t), dtype=torch.float32)
+        q = hz.rot_to_quat(T[:3, :3]).reshape(4, 1)
+        T2 = hz.rt2T(q * 3.0, T[:3, 3].reshape(3, 1))        # un-normalised quaternion is normalised inside
+        assert torch.allclose(T, T2, atol=1e-6)
+    q = torch.tensor([[1.0], [0.1], [0.2], [0.3]], requires_grad=True)
+    hz.rt2T(q, torch.zeros(3, 1)).sum().backward()
+    assert q.grad is not None and torch.isfinite(q.grad).all()
+
+
+def test_adam_state_surgery_on_insert_and_prune(hz):
+    cfg = hz.Config()
+    g = hz.GaussianMap(cfg, 600.0, 600.0, device="cpu")
+    pts = torch.rand(50, 3) + torch.tensor([0.0, 0.0, 1.0])
+    g.add_points(pts, torch.rand(50, 3))
+    assert len(g) == 50 and [pg["lr"] for pg in g.opt.param_groups] == [1e-4, 2.5e-3, 1e-3, 5e-2, 1e-3]
+    assert all(pg["eps"] == 1e-15 for pg in g.opt.param_groups)                      # Gaussian.cc:166-170
+    np.testing.assert_allclose(g.log_scales[:, 0].detach().numpy(), np.log(pts[:, 2].numpy() / 600.0), rtol=1e-5)  # SinglePixel
+    assert torch.all(g.logit_opacities == 1) and torch.all(g.unnorm_quat[:, 0] == 1)
+    (g.xyz.sum() + g.rgb.sum() + g.unnorm_quat.sum() + g.logit_opacities.sum() + g.log_scales.sum()).backward()
+    g.opt.step(); g.opt.zero_grad()
+    before = g.opt.state[g.rgb]["exp_avg"].clone()
+    g.add_points(torch.rand(7, 3) + 1, torch.rand(7, 3))
+    assert len(g) == 57 and g.opt.state[g.rgb]["exp_avg"].shape == (57, 3)
+    assert torch.equal(g.opt.state[g.rgb]["exp_avg"][:50], before) and torch.all(g.opt.state[g.rgb]["exp_avg"][50:] == 0)
+    with torch.no_grad():
+        g.logit_opacities[::3] = -10.0                                                # sigmoid < 0.005
+    m = g.low_opacity_mask()
+    g.prune(m)
+    assert len(g) == 57 - int(m.sum()) and g.opt.state[g.xyz]["exp_avg_sq"].shape[0] == len(g)
+    assert g.opt.param_groups[3]["params"][0] is g.logit_opacities
+    g.init_camera_pose(torch.tensor(pose(), dtype=torch.float32))
+    assert [pg["lr"] for pg in g.opt_pose.param_groups] == [cfg.lr_cam_quat, cfg.lr_cam_quat]   # Gaussian.cc:149-150
+
+
+def _world(syn, hz, P=6000, seed=5):
+    W, H, fx, fy = 320, 240, 260.0, 258.0
+    cam = syn.make_camera(W, H, fx, fy)
+    sc = syn.make_scene(P, cam, seed=seed, scale_mult=3.0)
+    cfg = hz.Config()
+    g = hz.GaussianMap(cfg, fx, fy)
+    g.add_points(torch.tensor(sc.means3D), torch.tensor(sc.colors))
+    with torch.no_grad():     # the "true" map: the synthetic scene's own shapes
+        g.log_scales.copy_(torch.log(torch.tensor(sc.scales)).cuda())
+        g.unnorm_quat.copy_(torch.tensor(sc.rotations).cuda())
+        g.logit_opacities.copy_(torch.log(torch.tensor(sc.opacities) / (1 - torch.tensor(sc.opacities))).cuda())
+    r = hz.SlamRenderer(g, W, H)
+    return g, r, sc
+
+
+def _observe(hz, r, Tcw):
+    with torch.no_grad():
+        T = torch.tensor(Tcw, dtype=torch.float32, device="cuda")
+        rgb, sur, _ = r.render_rgb(T, tracking=True)
+        return hz.Frame(rgb.clone(), sur[0].clone(), T)
+
+
+@pytest.mark.gpu
+def test_tracking_recovers_a_perturbed_pose(syn, hz):
+    g, r, _ = _world(syn, hz)
+    T_true = pose(0.02, (0.01, -0.01, 0.02)).astype(np.float32)
+    fr = _observe(hz, r, T_true)
+    T0 = torch.tensor(pose(0.03, (0.03, -0.02, 0.05)), dtype=torch.float32)
+    e0 = float(torch.linalg.norm(T0[:3, 3] - torch.tensor(T_true[:3, 3])))
+    T_est, hist = r.track(fr, T0, iters=120)
+    e1 = float(torch.linalg.norm(T_est.cpu()[:3, 3] - torch.tensor(T_true[:3, 3])))
+    assert hist[-1] < 0.5 * hist[0] and e1 < 0.5 * e0, (hist[0], hist[-1], e0, e1)
+    assert r.tracking_counts > 5 and len(g) == 6000              # Gaussians untouched by tracking
+
+
+@pytest.mark.gpu
+def test_mapping_reduces_the_loss_and_densify_prune_keep_state_consistent(syn, hz):
+    g, r, sc = _world(syn, hz)
+    frames = [_observe(hz, r, pose(0.0, (0, 0, 0))), _observe(hz, r, pose(0.03, (0.02, 0.0, 0.01)))]
+    with torch.no_grad():      # damage the map: colours and opacities
+        g.rgb.add_(0.15 * torch.randn_like(g.rgb))
+        g.logit_opacities.add_(0.5 * torch.randn_like(g.logit_opacities))
+    losses = r.map_frames(frames, iters=80)
+    assert np.mean(losses[-10:]) < 0.7 * np.mean(losses[:10]), (losses[:3], losses[-3:])
+    # remove a block of the map: the silhouette drops there and densification refills it
+    with torch.no_grad():
+        hole = (g.xyz[:, 0].abs() < 0.4) & (g.xyz[:, 1].abs() < 0.3)
+    g.prune(hole)
+    n0 = len(g)
+    added = r.densify(frames[0])
+    assert added > 100 and len(g) == n0 + added and g.opt.state[g.xyz]["exp_avg"].shape[0] == len(g)
+    more = r.map_frames(frames, iters=5)
+    assert all(math.isfinite(v) for v in more)
+    with torch.no_grad():
+        g.logit_opacities[:50] = -9.0
+    assert r.remove_low_opacity() >= 50 and g.opt.state[g.rgb]["exp_avg"].shape[0] == len(g)
