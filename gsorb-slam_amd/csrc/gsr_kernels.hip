@@ -53,7 +53,7 @@ __device__ __forceinline__ void load_cov3d(const SplatInputs& in, const FramePar
 
 __global__ void __launch_bounds__(256)
 K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomView g,
-             TileRec* __restrict__ tiles)
+             PairRec* __restrict__ tpairs)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= f.P) return;
@@ -83,17 +83,29 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
     g.g1[idx] = make_float4(pr.conic_c, in.opacities[idx], pr.p_view.z, __int_as_float(pr.radius));
     g.col[idx] = c;
     if (radii_out) radii_out[idx] = pr.radius;
-    // count the splat into its tiles; a splat with few tiles keeps the slot each atomic returns
-    const int w = pr.x1 - pr.x0, ntl = w * (pr.y1 - pr.y0);
+    // count the splat into its tiles (two horizontally adjacent tiles per 64-bit atomic); a splat with
+    // few tiles keeps the slot each atomic returns
+    const int w = pr.x1 - pr.x0, ntl = w * (pr.y1 - pr.y0), pw = (f.grid_x + 1) >> 1;
     if (ntl <= GSR_SLOTS) {
-        uint32_t sl[GSR_SLOTS] = {0u, 0u, 0u, 0u};
+        uint32_t sl[GSR_SLOTS + 1] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int k = 0; k < GSR_SLOTS; k++)
-            if (k < ntl) sl[k] = atomicAdd(&tiles[(pr.y0 + k / w) * f.grid_x + pr.x0 + k % w].cnt_small, 1u);
+        for (int k = 0; k < GSR_SLOTS; k++) {
+            if (k >= ntl) continue;
+            const int x = pr.x0 + k % w, y = pr.y0 + k / w;
+            if ((x & 1) && x > pr.x0) continue; // counted together with its even neighbour
+            const bool odd_alone = (x & 1) != 0, with_next = !odd_alone && x + 1 < pr.x1;
+            const unsigned long long inc = odd_alone ? (1ull << 32) : (with_next ? ((1ull << 32) | 1ull) : 1ull);
+            const unsigned long long old = atomicAdd(&tpairs[y * pw + (x >> 1)].cnt_small, inc);
+            sl[k] = odd_alone ? (uint32_t)(old >> 32) : (uint32_t)old;
+            if (with_next) sl[k + 1] = (uint32_t)(old >> 32);
+        }
         g.slots[idx] = make_uint4(sl[0], sl[1], sl[2], sl[3]);
     } else {
         for (int y = pr.y0; y < pr.y1; y++)
-            for (int x = pr.x0; x < pr.x1; x++) atomicAdd(&tiles[y * f.grid_x + x].cnt_big, 1u);
+            for (int p = pr.x0 >> 1; p <= (pr.x1 - 1) >> 1; p++) {
+                const unsigned long long inc = (2 * p >= pr.x0 ? 1ull : 0ull) | (2 * p + 1 < pr.x1 ? (1ull << 32) : 0ull);
+                atomicAdd(&tpairs[y * pw + p].cnt_big, inc);
+            }
     }
 }
 
@@ -121,16 +133,26 @@ K_mark_visible(int P, const float* __restrict__ means3D, const float* __restrict
 // ===================================================================================
 // tile binning
 // ===================================================================================
+// PAIRED: the counts come from the rasterizer's PairRec array (tile (ty,tx) = word tx&1 of pair
+// ty*pw + tx/2); otherwise from the TileRec's own counters (the k-NN buckets).
+template <bool PAIRED>
 __global__ void __launch_bounds__(1024)
 K_scan_tiles(int T, TileRec* __restrict__ tiles, uint2* __restrict__ ranges,
-             GeomHeader* __restrict__ hdr, uint32_t capacity)
+             GeomHeader* __restrict__ hdr, uint32_t capacity, const PairRec* __restrict__ tpairs, int grid_x)
 {
+    auto counts = [&](int i, uint32_t& cs, uint32_t& cb) {
+        if (PAIRED) {
+            const int ty = i / grid_x, tx = i - ty * grid_x, sh = (tx & 1) * 32;
+            const PairRec& r = tpairs[ty * ((grid_x + 1) >> 1) + (tx >> 1)];
+            cs = (uint32_t)(r.cnt_small >> sh); cb = (uint32_t)(r.cnt_big >> sh);
+        } else { cs = tiles[i].cnt_small; cb = tiles[i].cnt_big; }
+    };
     __shared__ uint32_t part[1024];
     const int tid = threadIdx.x;
     const int per = (T + 1023) / 1024;
     const int b = tid * per, e = min(T, b + per);
     uint32_t s = 0;
-    for (int i = b; i < e; i++) s += tiles[i].cnt_small + tiles[i].cnt_big;
+    for (int i = b; i < e; i++) { uint32_t cs, cb; counts(i, cs, cb); s += cs + cb; }
     part[tid] = s;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
@@ -141,7 +163,9 @@ K_scan_tiles(int T, TileRec* __restrict__ tiles, uint2* __restrict__ ranges,
     }
     uint32_t run = part[tid] - s;
     for (int i = b; i < e; i++) {
-        const uint32_t cs = tiles[i].cnt_small, c = cs + tiles[i].cnt_big;
+        uint32_t cs, cb;
+        counts(i, cs, cb);
+        const uint32_t c = cs + cb;
         ranges[i] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u); // empty tiles read (0,0) like the reference's memset
         tiles[i].start = run;
         tiles[i].cur_big = run + cs;
