@@ -17,7 +17,7 @@ _LIB = None
 
 EXPORTS = ["gsr_forward", "gsr_forward_ws", "gsr_ws_status", "gsr_backward", "gsr_mark_visible",
            "gsr_visible_filter", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
-           "gsr_debug_export", "gsr_knn_bytes", "gsr_dist2", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
+           "gsr_debug_export", "gsr_acc_view", "gsr_knn_bytes", "gsr_dist2", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
 
 
 def library_path() -> str:
@@ -39,7 +39,7 @@ class ForwardArgs(C.Structure):
                 ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("cam_pos", C.c_void_p),
                 ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int),
                 ("out_color", C.c_void_p), ("out_depth", C.c_void_p), ("radii", C.c_void_p),
-                ("profile_events", C.POINTER(C.c_void_p))]
+                ("profile_events", C.POINTER(C.c_void_p)), ("band_y0", C.c_int), ("band_y1", C.c_int)]
 
 
 class BackwardArgs(C.Structure):
@@ -54,7 +54,8 @@ class BackwardArgs(C.Structure):
                 ("dL_dmean2D", C.c_void_p), ("dL_dconic", C.c_void_p), ("dL_dopacity", C.c_void_p),
                 ("dL_dcolor", C.c_void_p), ("dL_dmean3D", C.c_void_p), ("dL_dcov3D", C.c_void_p),
                 ("dL_dsh", C.c_void_p), ("dL_dscale", C.c_void_p), ("dL_drot", C.c_void_p),
-                ("profile_events", C.POINTER(C.c_void_p))]
+                ("profile_events", C.POINTER(C.c_void_p)), ("band_y0", C.c_int), ("band_y1", C.c_int),
+                ("stages", C.c_int)]
 
 
 class DebugArrays(C.Structure):
@@ -95,6 +96,8 @@ def lib():
     L.gsr_debug_export.restype = C.c_int
     L.gsr_debug_export.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(DebugArrays), C.c_void_p]
+    L.gsr_acc_view.restype = C.c_int
+    L.gsr_acc_view.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.gsr_knn_bytes.restype = C.c_size_t
     L.gsr_knn_bytes.argtypes = [C.c_int]
     L.gsr_dist2.restype = C.c_int
@@ -173,17 +176,18 @@ class ForwardState:
     binning: torch.Tensor
     image: torch.Tensor
     ws_binning_bytes: int = 0
+    band: tuple = (0, 0)
     keep: list = field(default_factory=list)
 
 
 def _fwd_args(s: Settings, means3D, opacities, colors, shs, scales, rotations, cov3D, color, depth, radii,
-              events=None):
+              events=None, band=(0, 0)):
     P = int(means3D.shape[0])
     M = 0 if shs is None or shs.numel() == 0 else int(shs.shape[1])
     a = ForwardArgs(P, s.sh_degree, M, _p(s.bg), s.image_width, s.image_height, _p(means3D), _p(shs), _p(colors),
                     _p(opacities), _p(scales), s.scale_modifier, _p(rotations), _p(cov3D), _p(s.viewmatrix),
                     _p(s.projmatrix), _p(s.campos), s.tanfovx, s.tanfovy, int(s.prefiltered), _p(color),
-                    _p(depth), _p(radii), events)
+                    _p(depth), _p(radii), events, int(band[0]), int(band[1]))
     return a, P, M
 
 
@@ -198,14 +202,14 @@ def _prep(s: Settings, means3D, opacities, colors, shs, scales, rotations, cov3D
 
 
 def forward(s: Settings, means3D, opacities, colors=None, shs=None, scales=None, rotations=None,
-            cov3D_precomp=None) -> ForwardState:
+            cov3D_precomp=None, band=(0, 0), out=None) -> ForwardState:
     """gsr_forward with torch-owned blobs (the reference's resizeFunctional, src/Rasterizer.cu:127-134)."""
     L = lib()
     dev, ins = _prep(s, means3D, opacities, colors, shs, scales, rotations, cov3D_precomp)
     H, W = s.image_height, s.image_width
     P = int(ins["means3D"].shape[0])
-    color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-    depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    color = out[0] if out is not None else torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    depth = out[1] if out is not None else torch.empty((1, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((max(P, 1),), dtype=torch.int32, device=dev)
     blobs = {}
 
@@ -218,11 +222,11 @@ def forward(s: Settings, means3D, opacities, colors=None, shs=None, scales=None,
 
     cbs = [mk("geom"), mk("binning"), mk("image")]
     a, P, M = _fwd_args(s, ins["means3D"], ins["opacities"], ins["colors"], ins["shs"], ins["scales"],
-                        ins["rotations"], ins["cov3D"], color, depth, radii)
+                        ins["rotations"], ins["cov3D"], color, depth, radii, None, band)
     with torch.cuda.device(dev):
         R = _check(L.gsr_forward(C.byref(a), cbs[0], None, cbs[1], None, cbs[2], None, _stream()))
     return ForwardState(s, P, M, R, ins, color, depth, radii[:P], blobs["geom"], blobs["binning"],
-                        blobs["image"])
+                        blobs["image"], band=tuple(band))
 
 
 class Workspace:
@@ -279,7 +283,7 @@ def alloc_grads(P: int, M: int, dev) -> Grads:
     return Grads(e(P, 3), e(P, 2, 2), e(P, 1), e(P, 3), e(P, 3), e(P, 6), e(P, M, 3), e(P, 3), e(P, 4))
 
 
-def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None) -> Grads:
+def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None, stages: int = 0) -> Grads:
     """gsr_backward; output shapes follow src/Rasterizer.cu:253-261."""
     L = lib()
     s = st.settings
@@ -297,7 +301,8 @@ def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None)
                      _p(st.radii), _p(st.geom), _p(st.binning), _p(st.image), st.ws_binning_bytes, _p(g),
                      _p(out.dL_dmeans2D), _p(out.dL_dconic), _p(out.dL_dopacity), _p(out.dL_dcolors),
                      _p(out.dL_dmeans3D), _p(out.dL_dcov3D), _p(out.dL_dsh) if M > 0 else None,
-                     _p(out.dL_dscales) if has_sr else None, _p(out.dL_drotations) if has_sr else None, events)
+                     _p(out.dL_dscales) if has_sr else None, _p(out.dL_drotations) if has_sr else None, events,
+                     int(st.band[0]), int(st.band[1]), int(stages))
     with torch.cuda.device(dev):
         _check(L.gsr_backward(C.byref(a), _stream()))
     if not has_sr:
@@ -369,3 +374,12 @@ def dist2(points, workspace=None):
         with torch.cuda.device(dev):
             _check(L.gsr_dist2(P, _p(p), _p(out), _p(ws), ws.numel(), _stream()))
     return out
+
+
+def acc_view(st: ForwardState) -> torch.Tensor:
+    """The packed per-splat backward accumulators of a forward state, as a float32 view [P*12] into its
+    geometry blob (what tile-band sharding all-reduces between the blend and per-splat stages)."""
+    ptr, n = C.c_void_p(), C.c_size_t()
+    _check(lib().gsr_acc_view(_p(st.geom), st.P, C.byref(ptr), C.byref(n)))
+    off = ptr.value - st.geom.data_ptr()
+    return st.geom[off:off + n.value * 4].view(torch.float32)

@@ -29,7 +29,7 @@ struct StageTimer {
     void end(int i) const { if (ev && ev[2 * i + 1]) (void)hipEventRecord((hipEvent_t)ev[2 * i + 1], st); }
 };
 
-FrameParams frame_params(int P, int D, int M, int W, int H, float tfx, float tfy, float mod)
+FrameParams frame_params(int P, int D, int M, int W, int H, float tfx, float tfy, float mod, int by0 = 0, int by1 = 0)
 {
     FrameParams f;
     f.P = P; f.D = D; f.M = M; f.W = W; f.H = H;
@@ -39,6 +39,9 @@ FrameParams frame_params(int P, int D, int M, int W, int H, float tfx, float tfy
     f.focal_y = H / (2.0f * tfy); // rasterizer_impl.cu:227-228
     f.focal_x = W / (2.0f * tfx);
     f.scale_modifier = mod;
+    if (by0 == 0 && by1 == 0) by1 = f.grid_y;
+    f.band_y0 = std::max(0, std::min(by0, f.grid_y));
+    f.band_y1 = std::max(f.band_y0, std::min(by1, f.grid_y));
     return f;
 }
 
@@ -73,7 +76,7 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     const int P = a->P, T = f.grid_x * f.grid_y;
     const StageTimer tm{a->profile_events, st};
     tm.begin(GSR_FWD_FILL);
-    hipLaunchKernelGGL(gsr::K_fill, dim3(blocks256(P)), dim3(256), 0, st, P, f.grid_x, f.grid_y, gv, iv.tiles, bv.pairs);
+    hipLaunchKernelGGL(gsr::K_fill, dim3(blocks256(P)), dim3(256), 0, st, P, f.grid_x, f.grid_y, f.band_y0, f.band_y1, gv, iv.tiles, bv.pairs);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_FILL);
     tm.begin(GSR_FWD_SORT);
@@ -83,8 +86,10 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SORT);
     tm.begin(GSR_FWD_BLEND);
-    hipLaunchKernelGGL(gsr::K_blend_fwd, dim3(4 * T), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
-                       f.grid_x, T, a->out_color, a->out_depth);
+    const int Tb = (f.band_y1 - f.band_y0) * f.grid_x; // tiles of the band
+    if (Tb > 0)
+        hipLaunchKernelGGL(gsr::K_blend_fwd, dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
+                           f.grid_x, Tb, f.band_y0 * f.grid_x, a->out_color, a->out_depth);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_BLEND);
     return GSR_OK;
@@ -94,7 +99,7 @@ int forward_head(const gsr_forward_args* a, char* geom, char* image, hipStream_t
                  GeomView* gv, ImageView* iv, FrameParams* fo)
 {
     const int P = a->P, W = a->width, H = a->height;
-    const FrameParams f = frame_params(P, a->D, a->M, W, H, a->tan_fovx, a->tan_fovy, a->scale_modifier);
+    const FrameParams f = frame_params(P, a->D, a->M, W, H, a->tan_fovx, a->tan_fovy, a->scale_modifier, a->band_y0, a->band_y1);
     const int T = f.grid_x * f.grid_y;
     geom_layout(geom, P, gv);
     image_layout(image, W, H, iv);
@@ -222,7 +227,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
     if (a->shs && (!a->dL_dsh || a->M <= 0 || !a->cam_pos)) return GSR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int P = a->P, W = a->width, H = a->height;
-    const FrameParams f = frame_params(P, a->D, a->M, W, H, a->tan_fovx, a->tan_fovy, a->scale_modifier);
+    const FrameParams f = frame_params(P, a->D, a->M, W, H, a->tan_fovx, a->tan_fovy, a->scale_modifier, a->band_y0, a->band_y1);
     const int T = f.grid_x * f.grid_y;
     GeomView gv; ImageView iv; BinView bv;
     geom_layout(a->geom_buffer, P, &gv);
@@ -234,23 +239,32 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
         binning_layout(a->binning_buffer, cap, &bv);
     }
     const StageTimer tm{a->profile_events, st};
-    tm.begin(GSR_BWD_CLEAR);
-    GSR_HIP(hipMemsetAsync(gv.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
-    tm.end(GSR_BWD_CLEAR);
-    tm.begin(GSR_BWD_BLEND);
-    hipLaunchKernelGGL(gsr::K_blend_bwd, dim3(4 * T), dim3(64), 0, st, iv, bv, gv, a->background, W, H, f.grid_x, T, a->dL_dpix);
-    GSR_LAUNCHED();
-    tm.end(GSR_BWD_BLEND);
-    const gsr::SplatInputs in = splat_inputs(a->means3D, a->scales, a->rotations, nullptr, a->shs, a->cov3D_precomp,
-                                             a->colors_precomp, a->viewmatrix, a->projmatrix, a->cam_pos);
-    gsr::SplatGrads o;
-    o.dL_dmean2D = a->dL_dmean2D; o.dL_dconic = a->dL_dconic; o.dL_dopacity = a->dL_dopacity;
-    o.dL_dcolor = a->dL_dcolor; o.dL_dmean3D = a->dL_dmean3D; o.dL_dcov3D = a->dL_dcov3D;
-    o.dL_dsh = a->dL_dsh; o.dL_dscale = a->dL_dscale; o.dL_drot = a->dL_drot;
-    tm.begin(GSR_BWD_SPLAT);
-    hipLaunchKernelGGL(gsr::K_splat_bwd, dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o);
-    GSR_LAUNCHED();
-    tm.end(GSR_BWD_SPLAT);
+    const int stages = a->stages ? a->stages : (GSR_STAGE_CLEAR | GSR_STAGE_BLEND | GSR_STAGE_SPLAT);
+    const int Tb = (f.band_y1 - f.band_y0) * f.grid_x;
+    if (stages & GSR_STAGE_CLEAR) {
+        tm.begin(GSR_BWD_CLEAR);
+        GSR_HIP(hipMemsetAsync(gv.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
+        tm.end(GSR_BWD_CLEAR);
+    }
+    if ((stages & GSR_STAGE_BLEND) && Tb > 0) {
+        tm.begin(GSR_BWD_BLEND);
+        hipLaunchKernelGGL(gsr::K_blend_bwd, dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, W, H, f.grid_x, Tb,
+                           f.band_y0 * f.grid_x, a->dL_dpix);
+        GSR_LAUNCHED();
+        tm.end(GSR_BWD_BLEND);
+    }
+    if (stages & GSR_STAGE_SPLAT) {
+        const gsr::SplatInputs in = splat_inputs(a->means3D, a->scales, a->rotations, nullptr, a->shs, a->cov3D_precomp,
+                                                 a->colors_precomp, a->viewmatrix, a->projmatrix, a->cam_pos);
+        gsr::SplatGrads o;
+        o.dL_dmean2D = a->dL_dmean2D; o.dL_dconic = a->dL_dconic; o.dL_dopacity = a->dL_dopacity;
+        o.dL_dcolor = a->dL_dcolor; o.dL_dmean3D = a->dL_dmean3D; o.dL_dcov3D = a->dL_dcov3D;
+        o.dL_dsh = a->dL_dsh; o.dL_dscale = a->dL_dscale; o.dL_drot = a->dL_drot;
+        tm.begin(GSR_BWD_SPLAT);
+        hipLaunchKernelGGL(gsr::K_splat_bwd, dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o);
+        GSR_LAUNCHED();
+        tm.end(GSR_BWD_SPLAT);
+    }
     return GSR_OK;
 }
 
@@ -279,6 +293,16 @@ int gsr_visible_filter(int P, int width, int height, const float* means3D, const
                                              viewmatrix, projmatrix, nullptr);
     hipLaunchKernelGGL(gsr::K_filter_radii, dim3(blocks256(P)), dim3(256), 0, (hipStream_t)stream, f, in, radii);
     GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_acc_view(char* geom, int P, float** acc, size_t* count)
+{
+    if (!geom || P < 0 || !acc || !count) return GSR_EINVAL;
+    GeomView gv;
+    geom_layout(geom, P, &gv);
+    *acc = gv.acc;
+    *count = (size_t)P * GSR_ACC_STRIDE;
     return GSR_OK;
 }
 

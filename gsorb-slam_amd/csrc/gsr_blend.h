@@ -70,11 +70,11 @@ __device__ __forceinline__ void stage_entry(float4* sA, float4* sB, int lane, fl
 
 __global__ void __launch_bounds__(64)
 K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
-            int grid_x, int ntiles, float* __restrict__ out_color, float* __restrict__ out_depth)
+            int grid_x, int ntiles, int tile0, float* __restrict__ out_color, float* __restrict__ out_depth)
 {
     __shared__ float4 sA[64], sB[64], sC[64];
     const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
-    const uint32_t tile = w >> 2, quad = w & 3u;
+    const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u; // tile0: first tile of the band
     const int tx = tile % grid_x, ty = tile / grid_x;
     const int lane = threadIdx.x;
     const int X0 = tx * 16 + (int)(quad & 1u) * 8, Y0 = ty * 16 + (int)(quad >> 1) * 8;
@@ -139,11 +139,11 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
 
 __global__ void __launch_bounds__(64)
 K_blend_bwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
-            int grid_x, int ntiles, const float* __restrict__ dL_dpix)
+            int grid_x, int ntiles, int tile0, const float* __restrict__ dL_dpix)
 {
     __shared__ float4 sA[64], sB[64], sC[64];
     const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
-    const uint32_t tile = w >> 2, quad = w & 3u;
+    const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u;
     const int tx = tile % grid_x, ty = tile / grid_x;
     const int lane = threadIdx.x;
     const int X0 = tx * 16 + (int)(quad & 1u) * 8, Y0 = ty * 16 + (int)(quad >> 1) * 8;

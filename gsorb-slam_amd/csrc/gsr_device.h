@@ -139,6 +139,7 @@ struct FrameParams {
     float tan_fovx, tan_fovy;
     float focal_x, focal_y;
     float scale_modifier;
+    int band_y0, band_y1; // tile rows this call bins and blends (whole image: 0, grid_y)
 };
 
 // ---------------------------------------------------------------------------------
@@ -178,7 +179,7 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float swap32_add(float a, float b)
 {

@@ -85,6 +85,7 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
     if (radii_out) radii_out[idx] = pr.radius;
     // count the splat into its tiles (two horizontally adjacent tiles per 64-bit atomic); a splat with
     // few tiles keeps the slot each atomic returns
+    pr.y0 = max(pr.y0, f.band_y0); pr.y1 = max(pr.y0, min(pr.y1, f.band_y1)); // only the band's tile rows are binned
     const int w = pr.x1 - pr.x0, ntl = w * (pr.y1 - pr.y0), pw = (f.grid_x + 1) >> 1;
     if (ntl <= GSR_SLOTS) {
         uint32_t sl[GSR_SLOTS + 1] = {0u, 0u, 0u, 0u, 0u};
@@ -180,7 +181,8 @@ K_scan_tiles(int T, TileRec* __restrict__ tiles, uint2* __restrict__ ranges,
 }
 
 __global__ void __launch_bounds__(256)
-K_fill(int P, int grid_x, int grid_y, GeomView g, TileRec* __restrict__ tiles, uint64_t* __restrict__ pairs)
+K_fill(int P, int grid_x, int grid_y, int band_y0, int band_y1, GeomView g, TileRec* __restrict__ tiles,
+       uint64_t* __restrict__ pairs)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P || g.hdr->overflow) return;
@@ -190,6 +192,7 @@ K_fill(int P, int grid_x, int grid_y, GeomView g, TileRec* __restrict__ tiles, u
     const float4 a = g.g0[idx];
     int x0, y0, x1, y1;
     tile_rect(a.x, a.y, radius, grid_x, grid_y, x0, y0, x1, y1);
+    y0 = max(y0, band_y0); y1 = max(y0, min(y1, band_y1)); // same clipping as the count pass
     const uint64_t key = ((uint64_t)__float_as_uint(b.z) << 32) | (uint32_t)idx;
     const int w = x1 - x0, ntl = w * (y1 - y0);
     if (ntl <= GSR_SLOTS) { // slots were assigned when the splat was counted: no atomics

@@ -65,3 +65,91 @@ def shard_by_depth_slabs(depths: torch.Tensor, world: int):
     depth. Returns a list of index tensors (front to back)."""
     order = torch.argsort(depths)
     return list(torch.tensor_split(order, world))
+
+
+# ======================================================================================
+# Scheme A — tile-band sharding (replicated map, sharded image). SURVEY.md §8e, DESIGN.md §7.
+#
+# Every rank holds the whole map and renders only tile rows [y0, y1) of the frame (C ABI:
+# gsr_forward_args.band_y0/band_y1). A band render is bit-identical to the same rows of the
+# one-GPU render, so the gathered image IS the one-GPU image. Exchanges per iteration:
+#   forward : one all-gather of the band pixels (4 floats/pixel in total over all ranks: 13 MB at 1200x680)
+#   backward: one all-reduce of the packed per-splat accumulators (12 floats/splat: 48 MB at 1 M)
+#             between the blend stage and the per-splat stage (gsr_backward_args.stages)
+# after which every rank holds the full, identical gradients and steps its replica of the
+# optimiser — no parameter broadcast. Use it when the map fits one GPU (always, with 288 GB)
+# and the per-frame latency is what matters (tracking / mapping inner loops).
+# ======================================================================================
+def band_rows(grid_y: int, world: int, row_cost=None):
+    """Split tile rows 0..grid_y into `world` contiguous bands [(y0,y1)...]. With `row_cost`
+    (e.g. the rendered-pair count per tile row of the previous frame) the bands are balanced by
+    cumulative cost, otherwise by row count. Bands may be empty when world > grid_y."""
+    if row_cost is None:
+        cuts = [(grid_y * r) // world for r in range(world + 1)]
+    else:
+        cost = torch.as_tensor(row_cost, dtype=torch.float64).flatten()
+        assert cost.numel() == grid_y
+        cum = torch.cumsum(cost + 1e-9, 0)
+        cuts = [0]
+        for r in range(1, world):
+            target = float(cum[-1]) * r / world
+            y = int(torch.searchsorted(cum, torch.tensor(target, dtype=torch.float64)).item()) + 1
+            cuts.append(min(max(y, cuts[-1]), grid_y))
+        cuts.append(grid_y)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+class HipBandBackend:
+    """The product backend: C ABI through gsorb-slam_amd/capi.py (no fallback)."""
+
+    def __init__(self, capi):
+        self.capi = capi
+
+    def forward(self, settings, band, out, **splats):
+        return self.capi.forward(settings, band=band, out=out, **splats)
+
+    def backward_partial(self, st, dL_dpix):
+        """clear + blend backward of this rank's band; returns the flat buffer to sum over ranks"""
+        self._grads = self.capi.alloc_grads(st.P, st.M, st.geom.device)
+        self.capi.backward(st, dL_dpix, grads=self._grads, stages=1 | 2)
+        return self.capi.acc_view(st)
+
+    def backward_finish(self, st, dL_dpix, summed):
+        # `summed` is the accumulator view itself (all-reduced in place)
+        return self.capi.backward(st, dL_dpix, grads=self._grads, stages=4)
+
+
+class TileBandRenderer:
+    def __init__(self, backend, group=None, tile: int = 16):
+        self.backend, self.group, self.tile = backend, group, tile
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def bands(self, height: int, row_cost=None):
+        return band_rows((height + self.tile - 1) // self.tile, self.world, row_cost)
+
+    def forward(self, settings, height: int, width: int, device, row_cost=None, **splats):
+        """Returns (color [3,H,W], depth [1,H,W], state). The images are complete on every rank."""
+        bands = self.bands(height, row_cost)
+        img = torch.zeros((4, height, width), dtype=torch.float32, device=device)
+        st = self.backend.forward(settings, bands[self.rank], (img[0:3], img[3:4]), **splats)
+        if self.world > 1:
+            rows = [(min(height, y0 * self.tile), min(height, y1 * self.tile)) for y0, y1 in bands]
+            hmax = max(b - a for a, b in rows)
+            mine = torch.zeros((4, hmax, width), dtype=torch.float32, device=device)
+            a, b = rows[self.rank]
+            mine[:, :b - a] = img[:, a:b]
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine, group=self.group)
+            for r, (a, b) in enumerate(rows):
+                if r != self.rank:
+                    img[:, a:b] = parts[r][:, :b - a]
+        return img[0:3], img[3:4], st
+
+    def backward(self, st, dL_dpix):
+        """dL_dpix [3,H,W] must be the same on every rank (the loss is evaluated on the gathered
+        image). Returns the full gradients, identical on every rank."""
+        part = self.backend.backward_partial(st, dL_dpix)
+        if self.world > 1:
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group)
+        return self.backend.backward_finish(st, dL_dpix, part)

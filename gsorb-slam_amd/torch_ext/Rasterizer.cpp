@@ -90,6 +90,7 @@ RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& mea
     a.out_color = out_color.data_ptr<float>(); a.out_depth = out_depth.data_ptr<float>();
     a.radii = P ? radii.data_ptr<int>() : nullptr;
     a.profile_events = nullptr;
+    a.band_y0 = a.band_y1 = 0;
     const int rendered = gsr_forward(&a, resize_blob, &geomBuffer, resize_blob, &binningBuffer, resize_blob,
                                      &imgBuffer, current_stream(device));
     check(rendered, "RasterizeGaussiansCUDA");
@@ -151,6 +152,8 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
         a.dL_dscale = has_sr ? dL_dscales.data_ptr<float>() : nullptr;
         a.dL_drot = has_sr ? dL_drotations.data_ptr<float>() : nullptr;
         a.profile_events = nullptr;
+        a.band_y0 = a.band_y1 = 0;
+        a.stages = 0;
         check(gsr_backward(&a, current_stream(device)), "RasterizeGaussiansBackwardCUDA");
     }
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,

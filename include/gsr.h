@@ -65,6 +65,11 @@ typedef struct gsr_forward_args {
     /* Optional profiling hook (host array of 2*GSR_FWD_STAGES hipEvent_t, or NULL): events
      * [2i] and [2i+1] are recorded on `stream` around stage i; NULL entries are skipped. */
     void** profile_events;
+    /* Tile-band sharding (multi-GPU scheme A): only tile rows [band_y0, band_y1) are binned,
+     * sorted and blended, and only their pixels of out_color / out_depth are written; radii still cover
+     * every splat. 0,0 (the zero-initialised default) means the whole image. A band render is bit-identical
+     * to the same rows of the full render. */
+    int band_y0, band_y1;
 } gsr_forward_args;
 
 /* forward stages, in launch order */
@@ -128,7 +133,20 @@ typedef struct gsr_backward_args {
     float* dL_dscale;            /* [P,3] or NULL when cov3D_precomp is used */
     float* dL_drot;              /* [P,4] or NULL when cov3D_precomp is used */
     void** profile_events;       /* like gsr_forward_args.profile_events, 2*GSR_BWD_STAGES entries */
+    int band_y0, band_y1;        /* must equal the matching forward's band */
+    /* Which stages to run: bit 0 clear the per-splat accumulators, bit 1 blend backward (accumulates
+     * into them), bit 2 per-splat stage (reads them, writes the dL_d* outputs). 0 = all three. Band
+     * sharding runs (1|2) on every rank, sums the accumulators across ranks (gsr_acc_view + one
+     * all-reduce), then runs 4. */
+    int stages;
 } gsr_backward_args;
+
+#define GSR_STAGE_CLEAR 1
+#define GSR_STAGE_BLEND 2
+#define GSR_STAGE_SPLAT 4
+
+/* The packed per-splat accumulators inside a geometry blob: count floats (12 per splat). */
+int gsr_acc_view(char* geom, int P, float** acc, size_t* count);
 
 /* Rasterizer::backward (rasterizer_impl.cu:405-498). Never allocates, never syncs. */
 int gsr_backward(const gsr_backward_args* args, void* stream);

@@ -208,3 +208,47 @@ def test_properties_at_baseline_size(gsr, syn):
     assert rel_err(g2.dL_dmeans3D.cpu().numpy(), 2.0 * a.cpu().numpy()) < 1e-5
     inv = st.radii == 0
     assert float(g2.dL_dmeans3D[inv].abs().sum()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------
+# tile-band sharding (multi-GPU scheme A) simulated on one GPU: the bands of a frame rendered one
+# after the other must reproduce the one-call render bit for bit, and the band accumulators summed
+# (what the all-reduce does) must give the one-call gradients.
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_tile_bands_equal_full_frame(gsr, syn, world):
+    import torch
+    capi = gsr.capi
+    sharded = __import__("gsorb_slam_amd.sharded", fromlist=["x"])
+    cam = syn.make_camera(320, 200, 250.0, 250.0)   # 13 tile rows, the last one partial (200 = 12*16 + 8)
+    sc = syn.make_scene(30000, cam, seed=21, scale_mult=2.0)
+    dev = torch.device("cuda:0")
+    s = capi.Settings.from_camera(cam, dev)
+    t = lambda a: torch.tensor(a, device=dev)
+    kw = dict(means3D=t(sc.means3D), opacities=t(sc.opacities), colors=t(sc.colors), scales=t(sc.scales),
+              rotations=t(sc.rotations))
+    full = capi.forward(s, **kw)
+    dpix = t(sc.dL_dpix)
+    gfull = capi.backward(full, dpix)
+    img = torch.full((4, cam.height, cam.width), float("nan"), device=dev)
+    bands = sharded.band_rows((cam.height + 15) // 16, world)
+    assert bands[0][0] == 0 and bands[-1][1] == 13 and all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
+    acc_sum, states, R = None, [], 0
+    for b in bands:
+        st = capi.forward(s, band=b, out=(img[0:3], img[3:4]), **kw)
+        assert torch.equal(st.radii, full.radii)            # radii cover every splat on every rank
+        R += st.num_rendered
+        grads = capi.alloc_grads(st.P, st.M, dev)
+        capi.backward(st, dpix, grads=grads, stages=1 | 2)
+        a = capi.acc_view(st)
+        acc_sum = a.clone() if acc_sum is None else acc_sum + a
+        states.append((st, grads))
+    assert R == full.num_rendered                             # the bands partition the (splat, tile) pairs
+    assert torch.equal(img[0:3], full.color) and torch.equal(img[3:4], full.depth)   # bit-exact
+    st, grads = states[-1]
+    capi.acc_view(st).copy_(acc_sum)
+    g = capi.backward(st, dpix, grads=grads, stages=4)
+    for name in ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dscales", "dL_drotations"):
+        a, b = getattr(g, name), getattr(gfull, name)
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+        assert err < 1e-5, (name, err)   # same terms, different float summation order (atomics) only

@@ -89,3 +89,103 @@ def test_two_rank_layer_compositing_matches_single_process_render():
     assert res["front"]
     np.testing.assert_allclose(res["grad_rgb"], np.broadcast_to(np.linspace(0.5, 1.5, 128, dtype=np.float32), (3, 96, 128)), rtol=1e-6)
     assert np.isfinite(res["grad_ds"]).all() and np.abs(res["grad_ds"][1]).max() > 0   # silhouette shades what is behind
+
+
+# ---------------------------------------------------------------------------------------
+# scheme A: tile-band sharding. The host logic (band split, band all-gather, accumulator all-reduce)
+# runs over gloo with a CPU stand-in backend built on the oracle: the stand-in renders the whole
+# frame and keeps ONLY its band rows (everything else is poisoned with NaN so a wrong gather shows),
+# and its partial backward is the oracle backward of dL_dpix restricted to the band rows — linear in
+# the pixels, so summing over bands is the full gradient, exactly like the packed accumulators.
+class _OracleBandBackend:
+    def __init__(self, oracle_mod, cam, sc):
+        self.o, self.cam, self.sc = oracle_mod.Oracle(), cam, sc
+
+    def forward(self, settings, band, out, **_):
+        sc = self.sc
+        f = self.o.forward(copy_stages=False, means3D=sc.means3D, opacities=sc.opacities, cam=self.cam,
+                           colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+        a, b = min(self.cam.height, band[0] * 16), min(self.cam.height, band[1] * 16)
+        out[0].fill_(float("nan")); out[1].fill_(float("nan"))
+        out[0][:, a:b] = torch.tensor(f.color[:, a:b]); out[1][:, a:b] = torch.tensor(f.depth[:, a:b])
+        return (a, b)
+
+    def backward_partial(self, st, dL_dpix):
+        a, b = st
+        g = np.zeros((3, self.cam.height, self.cam.width), np.float32)
+        g[:, a:b] = dL_dpix.numpy()[:, a:b]
+        bw = self.o.backward(g)
+        self.shapes = [(n, getattr(bw, n).shape) for n in ("dL_dmeans3D", "dL_dopacity", "dL_dcolors", "dL_dscales", "dL_drotations")]
+        return torch.tensor(np.concatenate([getattr(bw, n).ravel() for n, _ in self.shapes]))
+
+    def backward_finish(self, st, dL_dpix, summed):
+        out, off = {}, 0
+        for n, shp in self.shapes:
+            k = int(np.prod(shp)); out[n] = summed[off:off + k].numpy().reshape(shp); off += k
+        return out
+
+
+def _band_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from conftest import load_package
+        from oracle import oracle
+        gsr = load_package()
+        syn = gsr.synthetic
+        sharded = __import__("gsorb_slam_amd.sharded", fromlist=["x"])
+        cam = syn.make_camera(128, 88, 100.0, 100.0)    # 6 tile rows, the last one partial
+        sc = syn.make_scene(1200, cam, seed=5, scale_mult=2.5)
+        r = sharded.TileBandRenderer(_OracleBandBackend(oracle, cam, sc))
+        assert (r.rank, r.world) == (rank, world)
+        color, depth, st = r.forward(None, cam.height, cam.width, "cpu")
+        dpix = torch.tensor(sc.dL_dpix)
+        grads = r.backward(st, dpix)
+        if rank == 1:       # any rank holds the complete frame and the complete gradients
+            o = oracle.Oracle()
+            f = o.forward(copy_stages=False, means3D=sc.means3D, opacities=sc.opacities, cam=cam, colors=sc.colors,
+                          scales=sc.scales, rotations=sc.rotations)
+            bw = o.backward(sc.dL_dpix)
+            q.put(dict(color=color.numpy(), depth=depth.numpy(), full_color=f.color, full_depth=f.depth,
+                       grads=grads, full={n: getattr(bw, n) for n in grads}, bands=r.bands(cam.height)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_tile_bands_reproduce_the_single_process_frame_and_gradients():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_band_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res["bands"] == [(0, 3), (3, 6)]
+    np.testing.assert_array_equal(res["color"], res["full_color"])     # bit-exact: no NaN left, no row misplaced
+    np.testing.assert_array_equal(res["depth"], res["full_depth"])
+    for n, g in res["grads"].items():
+        ref = res["full"][n]
+        assert np.abs(g - ref).max() <= 1e-5 * (np.abs(ref).max() + 1e-30), n   # fp32 sum of two partials
+
+
+def test_band_rows_partition_and_balance():
+    sharded = __import__("gsorb_slam_amd.sharded", fromlist=["x"]) if "gsorb_slam_amd" in sys.modules else None
+    if sharded is None:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from conftest import load_package
+        load_package()
+        sharded = __import__("gsorb_slam_amd.sharded", fromlist=["x"])
+    for gy, w in [(43, 1), (43, 2), (43, 8), (5, 8), (1, 3)]:
+        b = sharded.band_rows(gy, w)
+        assert len(b) == w and b[0][0] == 0 and b[-1][1] == gy
+        assert all(b[i][1] == b[i + 1][0] and b[i][0] <= b[i][1] for i in range(w - 1))
+    cost = np.ones(40); cost[:10] = 9.0          # a heavy top quarter
+    b = sharded.band_rows(40, 4, cost)
+    assert b[0][0] == 0 and b[-1][1] == 40 and all(b[i][1] == b[i + 1][0] for i in range(3))
+    loads = [cost[a:c].sum() for a, c in b]
+    assert max(loads) <= 1.35 * (cost.sum() / 4)   # uniform rows would put 90 of 120 on rank 0
