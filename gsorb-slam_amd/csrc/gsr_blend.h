@@ -164,7 +164,7 @@ K_blend_bwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
     float S0 = 0.f, S1 = 0.f, S2 = 0.f;
     const int slot = reduce9_slot_of(lane); // which of the nine sums this lane commits (-1: none)
 
-    const int ntodo = min(n, (int)wave_max_u32(last)); // nothing at list position >= this touches the quad
+    const int ntodo = __builtin_amdgcn_readfirstlane(min(n, (int)wave_max_u32(last))); // nothing at list position >= this touches the quad
 
     // back to front: list position of batch entry k is ntodo-1-k
     uint32_t id_next = lane < ntodo ? plist[ntodo - 1 - lane] : 0u;
@@ -223,6 +223,282 @@ K_blend_bwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
             const float mine = reduce9(v, lane);
             const uint32_t sid = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(Cc.w));
             if (slot >= 0) unsafeAtomicAdd(&g.acc[(size_t)sid * GSR_ACC_STRIDE + slot], mine);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// =====================================================================================
+// Backward, "patch rows" variant: the wave still owns an 8x8 quad, but its four 16-lane DPP rows are
+// four INDEPENDENT 4x4 pixel patches, each walking its own hit list. Small splats touch few pixels of
+// an 8x8 quad (~16 of 64 lanes useful on the 1 M-splat workload); a 4x4 patch is hit by half as many
+// splats as the quad and uses ~8 of its 16 lanes, so the same wave retires ~1.7x fewer iterations.
+//   gather : 64 list entries per step, exact quad-level cull, survivors COMPACTED into LDS (mbcnt)
+//            until more than Q-64 are parked or the list ends;
+//   lists  : one lane per parked entry runs the exact cull against the four patches and appends the
+//            entry's index to the byte list of every patch it can reach (list order is kept);
+//   blend  : row r walks list r; per iteration the nine partial sums are reduced inside the 16-lane
+//            row (transposing, all full-rate DPP) and nine lanes per row add them into the entry's
+//            LDS accumulator (ds_add_f32) — the four rows usually work on four different splats;
+//   flush  : LDS accumulators -> one 9-lane global atomic per parked entry that was hit (7 per
+//            instruction), i.e. the same number of L2 atomic records as the quad kernel. Issuing the
+//            atomics per PATCH instead would double them and hit the L2 atomic ceiling (~20 G records/s,
+//            scripts/atomic_bench2.hip).
+// Per (pixel, splat) arithmetic is identical to K_blend_bwd.
+// =====================================================================================
+#define GSR_ROWQ 128
+
+__device__ __forceinline__ int mbcnt64(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Exact cull of one parked entry (conic already scaled by log2 e) against the 2x2 patches of 4x4 pixel
+// centres of the quad at (X0, Y0); same construction and margin as quad_reach. h[j*2+i]: x-half i, y-half j.
+__device__ __forceinline__ void patch_reach4(const float4 A, const float4 B, float X0, float Y0, bool (&h)[4])
+{
+    const float ca = A.z, cb = A.w, cc = B.x;
+    const bool degenerate = !(ca > 0.f) || !(cc > 0.f);
+    const float tau = __log2f(255.0f * B.y) + 0.0145f;
+    float dl[2], dh[2], dc[2], el[2], eh[2], ec[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        dl[i] = A.x - (X0 + 4.f * i + 3.f); dh[i] = A.x - (X0 + 4.f * i);
+        dc[i] = fminf(fmaxf(0.f, dl[i]), dh[i]);
+        el[i] = A.y - (Y0 + 4.f * i + 3.f); eh[i] = A.y - (Y0 + 4.f * i);
+        ec[i] = fminf(fmaxf(0.f, el[i]), eh[i]);
+    }
+    // minimiser of the 1-D parabola on a side; its rounding error enters q only to second order
+    const float kx = -cb * __builtin_amdgcn_rcpf(cc), ky = -cb * __builtin_amdgcn_rcpf(ca);
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float dxc = dc[i], dyc = ec[j];
+            const float dy = fminf(fmaxf(kx * dxc, el[j]), eh[j]);
+            const float qx = 0.5f * (ca * dxc * dxc + cc * dy * dy) + cb * dxc * dy;
+            const float dx = fminf(fmaxf(ky * dyc, dl[i]), dh[i]);
+            const float qy = 0.5f * (ca * dx * dx + cc * dyc * dyc) + cb * dx * dyc;
+            const float q = fminf(dxc != 0.f ? qx : 3.0e38f, dyc != 0.f ? qy : 3.0e38f);
+            h[j * 2 + i] = degenerate || (dxc == 0.f && dyc == 0.f) || !(q > tau);
+        }
+}
+
+// Transposing reduction of nine values inside each 16-lane row. Stage s pairs lanes through a DPP
+// permutation that flips bit (3-s) of the lane number; the lane keeps one value of a pair and hands the
+// other to its partner, so the live registers go 9 -> 5 -> 3 -> 2 -> 1. 27 VALU. On return lane l of the
+// row holds the row total of value rows_slot_of(l).
+__device__ __forceinline__ int rows_slot_of(int l)
+{
+    if (l & 1) return l == 1 ? 8 : -1;
+    return ((l >> 3) & 1) | (((l >> 2) & 1) << 1) | (((l >> 1) & 1) << 2);
+}
+template <int CTRL>
+__device__ __forceinline__ float tr_pair(bool hi, float even, float odd)
+{
+    const float keep = hi ? odd : even, give = hi ? even : odd;
+    return keep + dpp_f<CTRL>(give);
+}
+__device__ __forceinline__ float row_reduce9(const float (&v)[9], int l)
+{
+    // Stages 1 and 2 select by DPP bank (a bank = 4 lanes): the lanes of banks {0,1} / {2,3} (stage 1) and
+    // {0,2} / {1,3} (stage 2) are exactly the lanes that keep the even / odd value of a pair, so two
+    // bank-masked v_add_f32_dpp writing one register replace two v_cndmask + one add. Hand-written
+    // because the compiler cannot express a partial-bank destination; s_nop covers the VALU-write ->
+    // DPP-read hazard at the block entry, inside the block every DPP source is >= 4 instructions old.
+    float a0, a1, a2, a3, a4, c0, c1, c2;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %14, %14 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %5, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %5, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %6, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %6, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %7, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(c0), "=&v"(c1), "=&v"(c2)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]));
+    const bool b1 = (l & 2) != 0, b0 = (l & 1) != 0;
+    const float d0 = tr_pair<0x1B>(b1, c0, c1);                                             // quad_perm [3,2,1,0]  l <-> l^3
+    const float d1 = c2 + dpp_f<0x1B>(c2);
+    return tr_pair<0xB1>(b0, d0, d1);                                                       // quad_perm [1,0,3,2]  l <-> l^1
+}
+
+template <int Q, int FL>
+__global__ void __launch_bounds__(64)
+K_blend_bwd_rows(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
+                 int grid_x, int ntiles, int tile0, const float* __restrict__ dL_dpix)
+{
+    __shared__ float4 E0[Q], E1[Q];    // (px, py, a', b')   (c', opacity, red, green)      ' = times log2 e
+    __shared__ float2 E2[Q];           // (blue, list position)
+    __shared__ uint32_t ID[Q];
+    __shared__ float ACC[Q * 9 + 64];  // + one private sink word per lane
+    __shared__ uint8_t LIST[4 * Q];
+    const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
+    const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u;
+    const int tx = tile % grid_x, ty = tile / grid_x;
+    const int lane = threadIdx.x, r = lane >> 4, l = lane & 15;
+    const int X0 = tx * 16 + (int)(quad & 1u) * 8, Y0 = ty * 16 + (int)(quad >> 1) * 8;
+    const int px = X0 + (r & 1) * 4 + (l & 3), py = Y0 + (r >> 1) * 4 + (l >> 2);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py, X0f = (float)X0, Y0f = (float)Y0;
+    const uint2 range = im.ranges[tile];
+    const int n = g.hdr->overflow ? 0 : (int)(range.y - range.x);
+    const uint32_t* __restrict__ plist = bn.point_list + range.x;
+    const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+
+    const float T_final = inside ? im.final_T[pix] : 0.f;
+    float T = T_final;
+    const uint32_t last = inside ? im.n_contrib[pix] : 0u;
+    const float g0 = inside ? dL_dpix[pix] : 0.f, g1 = inside ? dL_dpix[HW + pix] : 0.f,
+                g2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
+    const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+    float S0 = 0.f, S1 = 0.f, S2 = 0.f;
+    const int slot = rows_slot_of(l);
+    const int fe = (lane * 57) >> 9, fc = lane - 9 * fe; // lane / 9, lane % 9: flush lane -> (entry, component)
+    const float kLog2e = 1.4426950408889634f;
+
+    for (int i = lane; i < Q * 9 + 64; i += 64) ACC[i] = 0.f;
+    const int ntodo = __builtin_amdgcn_readfirstlane(min(n, (int)wave_max_u32(last)));
+
+    // gather pipeline: the ids of the next two steps and the geometry of the next step are in flight
+    int k0 = 0;
+    // (all prefetches are unconditional loads from clamped, always valid addresses so that the compiler
+    // can count them: the colour gather must not wait for the loads issued after it)
+    if (ntodo <= 0) return;
+    uint32_t id_c = plist[max(ntodo - 1 - lane, 0)];
+    uint32_t id_n = plist[max(ntodo - 1 - (lane + 64), 0)];
+    float4 a_c = g.g0[id_c], b_c = g.g1[id_c];
+    while (k0 < ntodo) {
+        // ---- gather + quad cull + compaction (back to front: entry k sits at list position ntodo-1-k)
+        int count = 0;
+        do {
+            const uint32_t id = id_c;
+            const float4 a = a_c, b = b_c;
+            const int k = k0 + lane;
+            const bool hit = k < ntodo && quad_reach(a, b, X0f, Y0f);
+            float4 c;
+            if (hit) c = g.col[id];
+            id_c = id_n;
+            a_c = g.g0[id_c]; b_c = g.g1[id_c];
+            id_n = plist[max(ntodo - 1 - (k + 128), 0)];
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int e = count + mbcnt64(m);
+                E0[e] = make_float4(a.x, a.y, a.z * kLog2e, a.w * kLog2e);
+                E1[e] = make_float4(b.x * kLog2e, b.y, c.x, c.y);
+                E2[e] = make_float2(c.z, __uint_as_float((uint32_t)(ntodo - 1 - k)));
+                ID[e] = id;
+            }
+            count += (int)__popcll(m);
+            k0 += 64;
+        } while (k0 < ntodo && count <= Q - 64);
+        if (count == 0) continue;
+        __builtin_amdgcn_wave_barrier();
+        // ---- per-patch hit lists
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (int eb = 0; eb < count; eb += 64) {
+            const int e = eb + lane;
+            bool h[4] = {false, false, false, false};
+            if (e < count) patch_reach4(E0[e], E1[e], X0f, Y0f, h);
+            const unsigned long long m0 = __ballot(h[0]), m1 = __ballot(h[1]), m2 = __ballot(h[2]), m3 = __ballot(h[3]);
+            if (h[0]) LIST[0 * Q + c0 + mbcnt64(m0)] = (uint8_t)e;
+            if (h[1]) LIST[1 * Q + c1 + mbcnt64(m1)] = (uint8_t)e;
+            if (h[2]) LIST[2 * Q + c2 + mbcnt64(m2)] = (uint8_t)e;
+            if (h[3]) LIST[3 * Q + c3 + mbcnt64(m3)] = (uint8_t)e;
+            c0 += (int)__popcll(m0); c1 += (int)__popcll(m1); c2 += (int)__popcll(m2); c3 += (int)__popcll(m3);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- blend: row r walks its own list
+        const int mycnt = r == 0 ? c0 : r == 1 ? c1 : r == 2 ? c2 : c3;
+        const int maxc = max(max(c0, c1), max(c2, c3));
+        const uint8_t* __restrict__ mylist = LIST + r * Q;
+        // iterations in which two rows work on the same parked entry: those must accumulate atomically
+        unsigned long long cm[(Q + 63) / 64];
+#pragma unroll
+        for (int b = 0; b < (Q + 63) / 64; b++) {
+            const int t = b * 64 + lane;
+            bool coll = false;
+            if (t < maxc) {
+                const int v0 = t < c0 ? (int)LIST[0 * Q + t] : 0x100, v1 = t < c1 ? (int)LIST[1 * Q + t] : 0x101;
+                const int v2 = t < c2 ? (int)LIST[2 * Q + t] : 0x102, v3 = t < c3 ? (int)LIST[3 * Q + t] : 0x103;
+                coll = v0 == v1 || v0 == v2 || v0 == v3 || v1 == v2 || v1 == v3 || v2 == v3;
+            }
+            cm[b] = __ballot(coll);
+        }
+        // One iteration on an entry already in registers. Accumulation is a plain LDS read-modify-write
+        // (LDS float atomics retire ~1 lane per 3 cycles: 36 lanes per iteration would make the kernel
+        // LDS-bound); only the iterations flagged in cm (two rows on one entry) use the atomic.
+        auto step = [&](const int it, const int idx, const float4 A, const float4 B, const float2 Cz) {
+            const bool act = it < mycnt;
+            const bool commit = slot >= 0 && act;
+            float* const accp = &ACC[commit ? idx * 9 + slot : Q * 9 + lane]; // idle lanes: private sink word
+            const float acc_old = *accp;
+            const float dx = A.x - pxf, dy = A.y - pyf;
+            const float power2 = pair_power(dx, dy, A.z, A.w, B.x); // = power * log2(e)
+            const float Graw = __builtin_amdgcn_exp2f(power2);
+            const float araw = fminf(0.99f, B.y * Graw);
+            const bool valid = act && __float_as_uint(Cz.y) < last && power2 <= 0.0f && araw >= GSR_ALPHA_MIN;
+            const float alpha = valid ? araw : 0.f, G = valid ? Graw : 0.f;
+            const float ia = __builtin_amdgcn_rcpf(1.f - alpha);
+            T = T * ia;
+            const float dcol = alpha * T;
+            const float e0 = B.z - S0, e1 = B.w - S1, e2 = Cz.x - S2;
+            float dL_dalpha = (e0 * g0 + e1 * g1 + e2 * g2) * T;
+            dL_dalpha = fmaf(-T_final * ia, bg_dot, dL_dalpha);
+            S0 = fmaf(alpha, e0, S0); S1 = fmaf(alpha, e1, S1); S2 = fmaf(alpha, e2, S2);
+            const float u = G * dL_dalpha, udx = u * dx, udy = u * dy;
+            float v[9];
+            v[0] = u;
+            v[1] = udx;
+            v[2] = udy;
+            v[3] = udx * dx;
+            v[4] = udx * dy;
+            v[5] = udy * dy;
+            v[6] = dcol * g0;
+            v[7] = dcol * g1;
+            v[8] = dcol * g2;
+            const float mine = row_reduce9(v, l);
+            const bool collide = Q <= 64 ? ((cm[0] >> it) & 1ull) != 0ull : ((cm[it >> 6] >> (it & 63)) & 1ull) != 0ull;
+            if (!collide) *accp = acc_old + (commit ? mine : 0.f);
+            else if (commit) unsafeAtomicAdd(accp, mine);
+        };
+        // software pipeline, unrolled by two so that the two register sets alternate without copies:
+        // the entry of the next iteration and the list byte of the one after are always in flight
+        int idx0 = 0 < mycnt ? (int)mylist[0] : 0; // entry 0 is always parked: finite data for idle rows
+        float4 A0 = E0[idx0], B0 = E1[idx0];
+        float2 C0 = E2[idx0];
+        int raw1 = (int)mylist[1], raw0, idx1;
+        float4 A1, B1;
+        float2 C1;
+        for (int it = 0; it < maxc; it += 2) {
+            idx1 = it + 1 < mycnt ? raw1 : 0;
+            A1 = E0[idx1]; B1 = E1[idx1]; C1 = E2[idx1];
+            raw0 = (int)mylist[min(it + 2, Q - 1)];
+            step(it, idx0, A0, B0, C0);
+            if (it + 1 >= maxc) break;
+            idx0 = it + 2 < mycnt ? raw0 : 0;
+            A0 = E0[idx0]; B0 = E1[idx0]; C0 = E2[idx0];
+            raw1 = (int)mylist[min(it + 3, Q - 1)];
+            step(it + 1, idx1, A1, B1, C1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- flush: seven parked entries per instruction, nine consecutive lanes per 48-byte record
+        for (int fb = 0; fb < count; fb += 7) {
+            const int e = fb + fe;
+            if (lane < 63 && e < count) {
+                const float val = ACC[e * 9 + fc];
+                if (val != 0.f) {
+                    ACC[e * 9 + fc] = 0.f;
+                    unsafeAtomicAdd(&g.acc[(size_t)ID[e] * GSR_ACC_STRIDE + fc], val);
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }

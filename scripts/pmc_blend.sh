@@ -1,0 +1,23 @@
+#!/bin/bash
+# SQ counters of the blend kernels (separate passes, kernel-trace only). Usage: scripts/pmc_blend.sh <tag> [env...]
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp
+out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
+mkdir -p $out
+for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT" "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM"; do
+  n=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  env "$@" rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$n -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --steps 3 --warmup 1 > $out/$n.log 2>&1
+done
+python - <<PY
+import csv,glob,collections
+agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
+for f in glob.glob("$out/*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k=row["Kernel_Name"].split("(")[0]
+        if "blend" not in k: continue
+        agg[k][row["Counter_Name"]]+=float(row["Counter_Value"])
+    
+for k,v in agg.items():
+    print(k)
+    for c,x in sorted(v.items()): print("   %-24s %.4g"%(c,x/4))   # 1 warmup + 3 steps
+PY
