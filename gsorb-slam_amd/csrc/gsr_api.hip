@@ -5,7 +5,6 @@
 #include "gsr_kernels.hip"
 #include "gsr_knn.h"
 
-#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 
@@ -249,19 +248,8 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
     }
     if ((stages & GSR_STAGE_BLEND) && Tb > 0) {
         tm.begin(GSR_BWD_BLEND);
-        static const int variant = getenv("GSR_BWD_VARIANT") ? atoi(getenv("GSR_BWD_VARIANT")) : 1;
-        if (variant == 0)
-            hipLaunchKernelGGL(gsr::K_blend_bwd, dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, W, H, f.grid_x, Tb,
-                               f.band_y0 * f.grid_x, a->dL_dpix);
-        else if (variant == 1)
-            hipLaunchKernelGGL((gsr::K_blend_bwd_rows<GSR_ROWQ, 0>), dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, W, H,
-                               f.grid_x, Tb, f.band_y0 * f.grid_x, a->dL_dpix);
-        else if (variant == 2)
-            hipLaunchKernelGGL((gsr::K_blend_bwd_rows<GSR_ROWQ, 1>), dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, W, H,
-                               f.grid_x, Tb, f.band_y0 * f.grid_x, a->dL_dpix);
-        else
-            hipLaunchKernelGGL((gsr::K_blend_bwd_rows<GSR_ROWQ, 2>), dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, W, H,
-                               f.grid_x, Tb, f.band_y0 * f.grid_x, a->dL_dpix);
+        hipLaunchKernelGGL(gsr::K_blend_bwd<GSR_ROWQ>, dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, W, H, f.grid_x, Tb,
+                           f.band_y0 * f.grid_x, a->dL_dpix);
         GSR_LAUNCHED();
         tm.end(GSR_BWD_BLEND);
     }

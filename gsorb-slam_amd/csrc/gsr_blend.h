@@ -15,10 +15,8 @@
 // parked in LDS and visited, in list order, through wave-uniform LDS broadcast reads.
 // Colours are gathered only for surviving entries.
 //
-// Backward: every lane forms its nine partial sums for the splat, a transposing wave
-// reduction (gsr_device.h: reduce9, 29 VALU ops using v_permlane{32,16}_swap) leaves each of
-// the nine totals in its own lane, and those nine lanes issue ONE global atomic instruction
-// that lands in the splat's 48-byte accumulator record (a single cache line).
+// Backward: same wave-per-quad launch, but the four 16-lane DPP rows of the wave are four independent
+// 4x4 patches, each with its own hit list (see K_blend_bwd below).
 //
 // What is computed per (pixel, splat) pair is the reference's arithmetic
 // (DGR/cuda_rasterizer/forward.cu:339-391, backward.cu:470-555).
@@ -58,13 +56,12 @@ __device__ __forceinline__ bool quad_reach(const float4 a, const float4 b, float
     return !(q > tau);
 }
 
-// Parks a surviving entry in LDS with its conic pre-multiplied by log2(e): the hit loop then forms
-// power*log2(e) directly and uses the hardware exp2 (one multiply less per pixel-splat pair). Forward
-// and backward stage identically, so both evaluate bit-identical alphas.
+// Parks a surviving entry in LDS with its conic pre-scaled for pair_power2 (gsr_device.h): the hit loop
+// forms power*log2(e) in five ops and uses the hardware exp2. Forward and backward stage identically,
+// so both evaluate bit-identical alphas.
 __device__ __forceinline__ void stage_entry(float4* sA, float4* sB, int lane, float4 a, float4 b)
 {
-    const float kLog2e = 1.4426950408889634f;
-    a.z *= kLog2e; a.w *= kLog2e; b.x *= kLog2e;
+    a.z *= -0.5f * GSR_LOG2E; a.w *= -GSR_LOG2E; b.x *= -0.5f * GSR_LOG2E;
     sA[lane] = a; sB[lane] = b;
 }
 
@@ -109,7 +106,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
             hits &= hits - 1;
             const float4 A = sA[jj], B = sB[jj], Cc = sC[jj];
             const float dx = A.x - pxf, dy = A.y - pyf;
-            const float power2 = pair_power(dx, dy, A.z, A.w, B.x); // = power * log2(e): same sign as power
+            const float power2 = pair_power2(dx, dy, A.z, A.w, B.x); // = power * log2(e): same sign as power
             const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(power2));
             const bool valid = !done && power2 <= 0.0f && alpha >= GSR_ALPHA_MIN;
             const float test_T = T * (1.f - alpha);
@@ -137,127 +134,40 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
     }
 }
 
-__global__ void __launch_bounds__(64)
-K_blend_bwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
-            int grid_x, int ntiles, int tile0, const float* __restrict__ dL_dpix)
-{
-    __shared__ float4 sA[64], sB[64], sC[64];
-    const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
-    const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u;
-    const int tx = tile % grid_x, ty = tile / grid_x;
-    const int lane = threadIdx.x;
-    const int X0 = tx * 16 + (int)(quad & 1u) * 8, Y0 = ty * 16 + (int)(quad >> 1) * 8;
-    const int px = X0 + (lane & 7), py = Y0 + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py, X0f = (float)X0, Y0f = (float)Y0;
-    const uint2 range = im.ranges[tile];
-    const int n = g.hdr->overflow ? 0 : (int)(range.y - range.x);
-    const uint32_t* __restrict__ plist = bn.point_list + range.x;
-    const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-
-    const float T_final = inside ? im.final_T[pix] : 0.f;
-    float T = T_final;
-    const uint32_t last = inside ? im.n_contrib[pix] : 0u;
-    const float g0 = inside ? dL_dpix[pix] : 0.f, g1 = inside ? dL_dpix[HW + pix] : 0.f,
-                g2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
-    const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
-    float S0 = 0.f, S1 = 0.f, S2 = 0.f;
-    const int slot = reduce9_slot_of(lane); // which of the nine sums this lane commits (-1: none)
-
-    const int ntodo = __builtin_amdgcn_readfirstlane(min(n, (int)wave_max_u32(last))); // nothing at list position >= this touches the quad
-
-    // back to front: list position of batch entry k is ntodo-1-k
-    uint32_t id_next = lane < ntodo ? plist[ntodo - 1 - lane] : 0u;
-    for (int base = 0; base < ntodo; base += 64) {
-        const uint32_t id = id_next;
-        const int k = base + lane;
-        const bool have = k < ntodo;
-        if (k + 64 < ntodo) id_next = plist[ntodo - 1 - (k + 64)];
-        bool hit = false;
-        if (have) {
-            const float4 a = g.g0[id];
-            const float4 b = g.g1[id];
-            hit = quad_reach(a, b, X0f, Y0f);
-            if (hit) {
-                float4 c = g.col[id];
-                c.w = __uint_as_float(id);
-                stage_entry(sA, sB, lane, a, b);
-                sC[lane] = c;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        unsigned long long hits = __ballot(hit);
-        while (hits) {
-            const int jj = (int)__builtin_ctzll(hits);
-            hits &= hits - 1;
-            const uint32_t pos = (uint32_t)(ntodo - 1 - (base + jj));
-            const float4 A = sA[jj], B = sB[jj], Cc = sC[jj];
-            const float dx = A.x - pxf, dy = A.y - pyf;
-            const float power2 = pair_power(dx, dy, A.z, A.w, B.x); // = power * log2(e)
-            const float Graw = __builtin_amdgcn_exp2f(power2);
-            const float araw = fminf(0.99f, B.y * Graw);
-            const bool valid = pos < last && power2 <= 0.0f && araw >= GSR_ALPHA_MIN;
-            if (!__any(valid)) continue;
-            const float alpha = valid ? araw : 0.f, G = valid ? Graw : 0.f;
-            const float ia = __builtin_amdgcn_rcpf(1.f - alpha);
-            T = T * ia; // T <- T / (1 - alpha); unchanged where the pair did not blend (alpha = 0)
-            const float dcol = alpha * T;
-            // S = colour accumulated behind this splat (the reference's accum_rec, updated eagerly:
-            // last_alpha*last_color + (1-last_alpha)*accum_rec == fma(alpha, c - S, S) one step later)
-            const float e0 = Cc.x - S0, e1 = Cc.y - S1, e2 = Cc.z - S2;
-            float dL_dalpha = (e0 * g0 + e1 * g1 + e2 * g2) * T;
-            dL_dalpha = fmaf(-T_final * ia, bg_dot, dL_dalpha);
-            S0 = fmaf(alpha, e0, S0); S1 = fmaf(alpha, e1, S1); S2 = fmaf(alpha, e2, S2);
-            // raw moments of u = G*dL/dalpha; conic, opacity and the NDC scale are applied per splat
-            const float u = G * dL_dalpha, udx = u * dx, udy = u * dy;
-            float v[9];
-            v[0] = u;
-            v[1] = udx;
-            v[2] = udy;
-            v[3] = udx * dx;
-            v[4] = udx * dy;
-            v[5] = udy * dy;
-            v[6] = dcol * g0;
-            v[7] = dcol * g1;
-            v[8] = dcol * g2;
-            const float mine = reduce9(v, lane);
-            const uint32_t sid = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(Cc.w));
-            if (slot >= 0) unsafeAtomicAdd(&g.acc[(size_t)sid * GSR_ACC_STRIDE + slot], mine);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 // =====================================================================================
-// Backward, "patch rows" variant: the wave still owns an 8x8 quad, but its four 16-lane DPP rows are
-// four INDEPENDENT 4x4 pixel patches, each walking its own hit list. Small splats touch few pixels of
+// Backward ("patch rows"): the wave still owns an 8x8 quad, but its four 16-lane DPP rows are four
+// INDEPENDENT 4x4 pixel patches, each walking its own hit list. Small splats touch few pixels of
 // an 8x8 quad (~16 of 64 lanes useful on the 1 M-splat workload); a 4x4 patch is hit by half as many
 // splats as the quad and uses ~8 of its 16 lanes, so the same wave retires ~1.7x fewer iterations.
 //   gather : 64 list entries per step, exact quad-level cull, survivors COMPACTED into LDS (mbcnt)
 //            until more than Q-64 are parked or the list ends;
 //   lists  : one lane per parked entry runs the exact cull against the four patches and appends the
 //            entry's index to the byte list of every patch it can reach (list order is kept);
-//   blend  : row r walks list r; per iteration the nine partial sums are reduced inside the 16-lane
-//            row (transposing, all full-rate DPP) and nine lanes per row add them into the entry's
-//            LDS accumulator (ds_add_f32) — the four rows usually work on four different splats;
+//   blend  : row r walks list r (entries software-pipelined through two register sets); per iteration
+//            the nine partial sums are reduced inside the 16-lane row (transposing, bank-masked DPP
+//            adds) and nine lanes per row add them into the entry's LDS accumulator with a plain
+//            read-modify-write — the four rows usually work on four different splats; the iterations
+//            in which two rows meet on one entry are found beforehand and use ds_add_f32 instead
+//            (LDS float atomics retire ~1 lane per 3 cycles: using them always costs +100 us);
 //   flush  : LDS accumulators -> one 9-lane global atomic per parked entry that was hit (7 per
 //            instruction), i.e. the same number of L2 atomic records as the quad kernel. Issuing the
 //            atomics per PATCH instead would double them and hit the L2 atomic ceiling (~20 G records/s,
 //            scripts/atomic_bench2.hip).
-// Per (pixel, splat) arithmetic is identical to K_blend_bwd.
 // =====================================================================================
-#define GSR_ROWQ 128
+#define GSR_ROWQ 96 // parked entries per round; 96 beats 64/80/128 on the 1 M workload (LDS 8.7 KB per wave)
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int mbcnt64(unsigned long long m)
 {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// Exact cull of one parked entry (conic already scaled by log2 e) against the 2x2 patches of 4x4 pixel
-// centres of the quad at (X0, Y0); same construction and margin as quad_reach. h[j*2+i]: x-half i, y-half j.
+// Exact cull of one parked entry (conic staged for pair_power2, i.e. in log2 units) against the 2x2
+// patches of 4x4 pixel centres of the quad at (X0, Y0); same construction and margin as quad_reach.
+// h[j*2+i]: x-half i, y-half j.
 __device__ __forceinline__ void patch_reach4(const float4 A, const float4 B, float X0, float Y0, bool (&h)[4])
 {
-    const float ca = A.z, cb = A.w, cc = B.x;
+    const float ca = -2.f * A.z, cb = -A.w, cc = -2.f * B.x; // log2(e) * (a, b, c)
     const bool degenerate = !(ca > 0.f) || !(cc > 0.f);
     const float tau = __log2f(255.0f * B.y) + 0.0145f;
     float dl[2], dh[2], dc[2], el[2], eh[2], ec[2];
@@ -299,7 +209,9 @@ __device__ __forceinline__ float tr_pair(bool hi, float even, float odd)
     const float keep = hi ? odd : even, give = hi ? even : odd;
     return keep + dpp_f<CTRL>(give);
 }
-__device__ __forceinline__ float row_reduce9(const float (&v)[9], int l)
+// `early` is any value that must already be in a register when the reduction starts (the caller's LDS
+// accumulator read: naming it here keeps the compiler from sinking that load behind the reduction).
+__device__ __forceinline__ float row_reduce9(const float (&v)[9], int l, float early)
 {
     // Stages 1 and 2 select by DPP bank (a bank = 4 lanes): the lanes of banks {0,1} / {2,3} (stage 1) and
     // {0,2} / {1,3} (stage 2) are exactly the lanes that keep the even / odd value of a pair, so two
@@ -323,21 +235,19 @@ __device__ __forceinline__ float row_reduce9(const float (&v)[9], int l)
         "v_add_f32_dpp %6, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
         "v_add_f32_dpp %7, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf"
         : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(c0), "=&v"(c1), "=&v"(c2)
-        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]));
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(early));
     const bool b1 = (l & 2) != 0, b0 = (l & 1) != 0;
     const float d0 = tr_pair<0x1B>(b1, c0, c1);                                             // quad_perm [3,2,1,0]  l <-> l^3
     const float d1 = c2 + dpp_f<0x1B>(c2);
     return tr_pair<0xB1>(b0, d0, d1);                                                       // quad_perm [1,0,3,2]  l <-> l^1
 }
 
-template <int Q, int FL>
+template <int Q>
 __global__ void __launch_bounds__(64)
-K_blend_bwd_rows(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
+K_blend_bwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
                  int grid_x, int ntiles, int tile0, const float* __restrict__ dL_dpix)
 {
-    __shared__ float4 E0[Q], E1[Q];    // (px, py, a', b')   (c', opacity, red, green)      ' = times log2 e
-    __shared__ float2 E2[Q];           // (blue, list position)
-    __shared__ uint32_t ID[Q];
+    __shared__ float4 E0[Q], E1[Q], E2[Q]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, list position, splat id, -)
     __shared__ float ACC[Q * 9 + 64];  // + one private sink word per lane
     __shared__ uint8_t LIST[4 * Q];
     const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
@@ -359,11 +269,10 @@ K_blend_bwd_rows(ImageView im, BinView bn, GeomView g, const float* __restrict__
     const float g0 = inside ? dL_dpix[pix] : 0.f, g1 = inside ? dL_dpix[HW + pix] : 0.f,
                 g2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
     const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
+    const v2f g01 = {g0, g1};
     float S0 = 0.f, S1 = 0.f, S2 = 0.f;
     const int slot = rows_slot_of(l);
     const int fe = (lane * 57) >> 9, fc = lane - 9 * fe; // lane / 9, lane % 9: flush lane -> (entry, component)
-    const float kLog2e = 1.4426950408889634f;
-
     for (int i = lane; i < Q * 9 + 64; i += 64) ACC[i] = 0.f;
     const int ntodo = __builtin_amdgcn_readfirstlane(min(n, (int)wave_max_u32(last)));
 
@@ -391,10 +300,9 @@ K_blend_bwd_rows(ImageView im, BinView bn, GeomView g, const float* __restrict__
             const unsigned long long m = __ballot(hit);
             if (hit) {
                 const int e = count + mbcnt64(m);
-                E0[e] = make_float4(a.x, a.y, a.z * kLog2e, a.w * kLog2e);
-                E1[e] = make_float4(b.x * kLog2e, b.y, c.x, c.y);
-                E2[e] = make_float2(c.z, __uint_as_float((uint32_t)(ntodo - 1 - k)));
-                ID[e] = id;
+                E0[e] = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
+                E1[e] = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, c.x, c.y);
+                E2[e] = make_float4(c.z, __uint_as_float((uint32_t)(ntodo - 1 - k)), __uint_as_float(id), 0.f);
             }
             count += (int)__popcll(m);
             k0 += 64;
@@ -435,13 +343,14 @@ K_blend_bwd_rows(ImageView im, BinView bn, GeomView g, const float* __restrict__
         // One iteration on an entry already in registers. Accumulation is a plain LDS read-modify-write
         // (LDS float atomics retire ~1 lane per 3 cycles: 36 lanes per iteration would make the kernel
         // LDS-bound); only the iterations flagged in cm (two rows on one entry) use the atomic.
-        auto step = [&](const int it, const int idx, const float4 A, const float4 B, const float2 Cz) {
+        auto step = [&](const int it, const int idx, const float4 A, const float4 B, const float4 Cz) {
             const bool act = it < mycnt;
             const bool commit = slot >= 0 && act;
             float* const accp = &ACC[commit ? idx * 9 + slot : Q * 9 + lane]; // idle lanes: private sink word
             const float acc_old = *accp;
+            __builtin_amdgcn_sched_barrier(0); // issue the accumulator read here, a whole iteration ahead of its use
             const float dx = A.x - pxf, dy = A.y - pyf;
-            const float power2 = pair_power(dx, dy, A.z, A.w, B.x); // = power * log2(e)
+            const float power2 = pair_power2(dx, dy, A.z, A.w, B.x); // = power * log2(e)
             const float Graw = __builtin_amdgcn_exp2f(power2);
             const float araw = fminf(0.99f, B.y * Graw);
             const bool valid = act && __float_as_uint(Cz.y) < last && power2 <= 0.0f && araw >= GSR_ALPHA_MIN;
@@ -450,21 +359,25 @@ K_blend_bwd_rows(ImageView im, BinView bn, GeomView g, const float* __restrict__
             T = T * ia;
             const float dcol = alpha * T;
             const float e0 = B.z - S0, e1 = B.w - S1, e2 = Cz.x - S2;
-            float dL_dalpha = (e0 * g0 + e1 * g1 + e2 * g2) * T;
+            float dL_dalpha = fmaf(e2, g2, fmaf(e1, g1, e0 * g0)) * T;
             dL_dalpha = fmaf(-T_final * ia, bg_dot, dL_dalpha);
             S0 = fmaf(alpha, e0, S0); S1 = fmaf(alpha, e1, S1); S2 = fmaf(alpha, e2, S2);
-            const float u = G * dL_dalpha, udx = u * dx, udy = u * dy;
+            const float u = G * dL_dalpha;
+            const v2f d = {dx, dy};
+            const v2f ud = u * d;      // two-wide products: v_pk_mul_f32
+            const v2f m = ud.x * d;
+            const v2f gc = dcol * g01;
             float v[9];
             v[0] = u;
-            v[1] = udx;
-            v[2] = udy;
-            v[3] = udx * dx;
-            v[4] = udx * dy;
-            v[5] = udy * dy;
-            v[6] = dcol * g0;
-            v[7] = dcol * g1;
+            v[1] = ud.x;
+            v[2] = ud.y;
+            v[3] = m.x;
+            v[4] = m.y;
+            v[5] = ud.y * dy;
+            v[6] = gc.x;
+            v[7] = gc.y;
             v[8] = dcol * g2;
-            const float mine = row_reduce9(v, l);
+            const float mine = row_reduce9(v, l, acc_old);
             const bool collide = Q <= 64 ? ((cm[0] >> it) & 1ull) != 0ull : ((cm[it >> 6] >> (it & 63)) & 1ull) != 0ull;
             if (!collide) *accp = acc_old + (commit ? mine : 0.f);
             else if (commit) unsafeAtomicAdd(accp, mine);
@@ -472,11 +385,9 @@ K_blend_bwd_rows(ImageView im, BinView bn, GeomView g, const float* __restrict__
         // software pipeline, unrolled by two so that the two register sets alternate without copies:
         // the entry of the next iteration and the list byte of the one after are always in flight
         int idx0 = 0 < mycnt ? (int)mylist[0] : 0; // entry 0 is always parked: finite data for idle rows
-        float4 A0 = E0[idx0], B0 = E1[idx0];
-        float2 C0 = E2[idx0];
+        float4 A0 = E0[idx0], B0 = E1[idx0], C0 = E2[idx0];
         int raw1 = (int)mylist[1], raw0, idx1;
-        float4 A1, B1;
-        float2 C1;
+        float4 A1, B1, C1;
         for (int it = 0; it < maxc; it += 2) {
             idx1 = it + 1 < mycnt ? raw1 : 0;
             A1 = E0[idx1]; B1 = E1[idx1]; C1 = E2[idx1];
@@ -496,7 +407,7 @@ K_blend_bwd_rows(ImageView im, BinView bn, GeomView g, const float* __restrict__
                 const float val = ACC[e * 9 + fc];
                 if (val != 0.f) {
                     ACC[e * 9 + fc] = 0.f;
-                    unsafeAtomicAdd(&g.acc[(size_t)ID[e] * GSR_ACC_STRIDE + fc], val);
+                    unsafeAtomicAdd(&g.acc[(size_t)__float_as_uint(E2[e].z) * GSR_ACC_STRIDE + fc], val);
                 }
             }
         }

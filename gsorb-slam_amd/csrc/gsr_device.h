@@ -148,81 +148,21 @@ struct FrameParams {
 // same bits: the library is built with -ffp-contract=off and the contractions
 // below are explicit.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ float pair_power(float dx, float dy, float ca, float cb, float cc)
+// log2(e) * power, power = -0.5*(a dx^2 + c dy^2) - b dx dy (reference forward.cu:348, backward.cu:492),
+// from a conic the staging code has already scaled: ca2 = -0.5*log2(e)*a, cb2 = -log2(e)*b,
+// cc2 = -0.5*log2(e)*c. Five VALU ops; forward and backward call this one function on identically
+// staged values, so both see bit-identical alphas (v_exp_f32 is a base-2 exponential).
+#define GSR_LOG2E 1.4426950408889634f
+__device__ __forceinline__ float pair_power2(float dx, float dy, float ca2, float cb2, float cc2)
 {
-    // -0.5*(a dx^2 + c dy^2) - b dx dy      (reference forward.cu:348, backward.cu:492)
-    const float q = fmaf(ca * dx, dx, (cc * dy) * dy);
-    return fmaf(-0.5f, q, -((cb * dx) * dy));
+    const float t = fmaf(ca2, dx, cb2 * dy);
+    return fmaf(t, dx, (cc2 * dy) * dy);
 }
 
-// wave64 all-lane sum; result valid in lane 63 (DPP row rotations + row broadcasts).
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
-{
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false)); // row_ror:8
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false)); // row_ror:4
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false)); // row_ror:2
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false)); // row_ror:1
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false)); // row_bcast:15 -> rows 1,3
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false)); // row_bcast:31 -> rows 2,3
-    return v;
-}
-
-// ---------------------------------------------------------------------------------
-// Transposing wave64 reduction of nine values (the backward blend's per-splat sums).
-// Instead of nine independent 6-step butterflies (54 DPP adds + 9 readlanes + selects), each
-// exchange step halves the number of live registers: gfx950's v_permlane32_swap /
-// v_permlane16_swap move half a register between two values, so one add reduces two
-// values at once. ~25 VALU instructions; on return lane reduce9_lane_of(k) holds sum_k.
-//   v_permlane32_swap a,b : a[32:63] <-> b[0:31]
-//   v_permlane16_swap a,b : a.row1 <-> b.row0, a.row3 <-> b.row2   (row = 16 lanes)
-// ---------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float swap32_add(float a, float b)
-{
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]); // [a.lo+a.hi | b.lo+b.hi]
-}
-__device__ __forceinline__ float swap16_add(float a, float b)
-{
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]); // rows [a01, b01, a23, b23]
-}
-// lane that ends up holding the total of value k (k = 0..8)
-__host__ __device__ constexpr int reduce9_lane_of(int k)
-{
-    return k == 0 ? 0 : k == 4 ? 8 : k == 2 ? 16 : k == 6 ? 24 : k == 1 ? 32 : k == 5 ? 40 : k == 3 ? 48 : k == 7 ? 56 : 63;
-}
-// inverse: which value (0..8) this lane owns after reduce9, or -1
-__device__ __forceinline__ int reduce9_slot_of(int lane)
-{
-    if (lane == 63) return 8;
-    if (lane & 7) return -1;
-    const int g = lane >> 3, r = g >> 1;          // 8-lane group, row
-    const int base = (r == 0) ? 0 : (r == 1) ? 2 : (r == 2) ? 1 : 3; // rows hold values [0,2,1,3] (+4 in the upper half-row)
-    return base + ((g & 1) ? 4 : 0);
-}
-__device__ __forceinline__ float reduce9(const float (&v)[9], int lane)
-{
-    // 64 -> 32 lanes per value
-    const float w0 = swap32_add(v[0], v[1]), w1 = swap32_add(v[2], v[3]);
-    const float w2 = swap32_add(v[4], v[5]), w3 = swap32_add(v[6], v[7]);
-    // 32 -> 16: rows of x0 = [v0, v2, v1, v3], rows of x1 = [v4, v6, v5, v7]
-    const float x0 = swap16_add(w0, w1), x1 = swap16_add(w2, w3);
-    // 16 -> 8: lower half-rows keep x0, upper half-rows keep x1
-    const bool up = (lane & 8) != 0;
-    const float keep = up ? x1 : x0, send = up ? x0 : x1;
-    float y = keep + dpp_f<0x128>(send);            // row_ror:8 swaps the half-rows
-    // 8 -> 1 inside each 8-lane group
-    y += dpp_f<0x141>(y);                           // row_half_mirror: i <-> 7-i
-    y += dpp_f<0xB1>(y);                            // quad_perm [1,0,3,2]
-    y += dpp_f<0x4E>(y);                            // quad_perm [2,3,0,1]
-    // the ninth value: plain DPP butterfly, total lands in lane 63
-    const float z = wave_sum_to_lane63(v[8]);
-    return lane == 63 ? z : y;
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
