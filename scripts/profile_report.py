@@ -1,0 +1,92 @@
+"""Turns gpurun_out/prof_<tag>/ (scripts/profile_round.sh) into the committed summaries under profiles/:
+   <tag>_kernel_stats.md, <tag>_pmc.md, <tag>_bench.json and r01_traffic.json (read by bench.py)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01x"
+note = sys.argv[2] if len(sys.argv) > 2 else ""
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+
+
+def short(name):
+    name = name.split("(")[0].replace("void ", "")
+    if "gsr::" not in name:
+        return name.split("<")[0]
+    name = name.replace("gsr::", "")
+    return name if name.startswith("K_tile_sort") or name.startswith("K_scan") else name.split("<")[0]
+
+
+bench = None
+for line in open(os.path.join(src, "bench.json")):
+    if line.startswith("{"):
+        bench = json.loads(line)
+json.dump(bench, open(os.path.join(dst, tag + "_bench.json"), "w"), indent=1)
+
+# ---- kernel stats
+rows = []
+for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    rows = list(csv.DictReader(open(f)))
+with open(os.path.join(dst, tag + "_kernel_stats.md"), "w") as o:
+    o.write("# Round 1, profile %s — %s\n\n" % (tag, note))
+    o.write("Command (MI355X box, scripts/profile_round.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu`\n\n")
+    c = bench["config"]
+    o.write("Workload: %d Gaussians, %dx%d, V = %d visible, R = %d tile instances; one step = gsr_forward_ws + gsr_backward.\n\n"
+            % (c["splats"], c["width"], c["height"], c["visible"], c["tile_instances"]))
+    r = bench["roofline"]
+    o.write("Un-profiled bench.py of the same build (profiles/%s_bench.json): %.3f ms/step; live HIP-event averages: K_blend_bwd %.1f us, K_blend_fwd %.1f us.\n\n"
+            % (tag, bench["ms_per_step"], r["avg_launch_ms"] * 1e3, r["fwd_blend_avg_launch_ms"] * 1e3))
+    o.write("| kernel | calls | avg us | min us | max us | % of GPU time |\n|---|---|---|---|---|---|\n")
+    for x in rows:
+        if float(x["Percentage"]) < 0.1:
+            continue
+        o.write("| %s | %s | %.1f | %.1f | %.1f | %s |\n" % (short(x["Name"]), x["Calls"], float(x["AverageNs"]) / 1e3,
+                                                         float(x["MinNs"]) / 1e3, float(x["MaxNs"]) / 1e3, x["Percentage"]))
+
+# ---- PMC
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = short(row["Kernel_Name"])
+        if not k.startswith("K_"):
+            continue
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        cnt[k][row["Counter_Name"]] += 1
+avg = {k: {c: v / cnt[k][c] for c, v in d.items()} for k, d in agg.items()}
+order = ["K_preprocess", "K_scan_tiles<true>", "K_fill", "K_tile_sort<true>", "K_tile_sort<false>", "K_blend_fwd", "K_blend_bwd", "K_splat_bwd"]
+sq = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
+      "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_LDS_BANK_CONFLICT"]
+stats_avg = {short(x["Name"]): float(x["AverageNs"]) / 1e3 for x in rows}
+with open(os.path.join(dst, tag + "_pmc.md"), "w") as o:
+    o.write("# Round 1, profile %s — PMC counters (rocprofv3 --pmc, separate passes, --kernel-trace only)\n\n" % tag)
+    o.write("Per launch, averaged over the launches of `bench.py --no-cpu --steps 3 --warmup 1`. SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in quad-cycles (x4 = shader cycles).\n\n")
+    o.write("| kernel | " + " | ".join(sq) + " |\n|---|" + "---|" * len(sq) + "\n")
+    for k in order:
+        if k in avg:
+            o.write("| %s | " % k + " | ".join("%.3g" % avg[k].get(c, float("nan")) for c in sq) + " |\n")
+    o.write("\nVALU pipe occupancy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * 2.4 GHz * kernel time):\n\n")
+    for k in ("K_blend_fwd", "K_blend_bwd"):
+        if k in avg and k in stats_avg:
+            busy_us = avg[k]["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / 2.4e3
+            o.write("* %s: %.3g wave-level VALU instructions, VALU busy %.0f us of %.0f us (%.0f %%), %.2f cycles per instruction\n"
+                    % (k, avg[k]["SQ_INSTS_VALU"], busy_us, stats_avg[k], 100 * busy_us / stats_avg[k],
+                       avg[k]["SQ_ACTIVE_INST_VALU"] * 4 / avg[k]["SQ_INSTS_VALU"]))
+    o.write("\n## L2 <-> fabric traffic\n\nFETCH_SIZE / WRITE_SIZE are reported in KB. Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports 1/2 of the bytes of a streaming read; traffic = 2*FETCH_SIZE + WRITE_SIZE.\n\n")
+    o.write("| kernel | FETCH_SIZE KB | WRITE_SIZE KB | traffic MB (2F+W) | TCC hit rate |\n|---|---|---|---|---|\n")
+    tj = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1 --no-cpu; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch",
+          "profile": tag, "workload": "1M splats 1200x680", "kernels": {}}
+    for k in order:
+        if k in avg and "FETCH_SIZE" in avg[k]:
+            F, Wr = avg[k]["FETCH_SIZE"], avg[k].get("WRITE_SIZE", 0.0)
+            hit, miss = avg[k].get("TCC_HIT_sum", float("nan")), avg[k].get("TCC_MISS_sum", float("nan"))
+            tr = (2 * F + Wr) * 1024
+            o.write("| %s | %.0f | %.0f | %.1f | %.2f |\n" % (k, F, Wr, tr / 1e6, hit / (hit + miss) if hit == hit else float("nan")))
+            tj["kernels"][k] = {"fetch_size_kb": F, "write_size_kb": Wr, "traffic_bytes": tr}
+    json.dump(tj, open(os.path.join(dst, "r01_traffic.json"), "w"), indent=1)
+print("written", tag)
