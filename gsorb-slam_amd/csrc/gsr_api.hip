@@ -239,7 +239,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
         binning_layout(a->binning_buffer, cap, &bv);
     }
     const StageTimer tm{a->profile_events, st};
-    const int stages = a->stages ? a->stages : (GSR_STAGE_CLEAR | GSR_STAGE_BLEND | GSR_STAGE_SPLAT);
+    const int stages = a->stages ? a->stages : (GSR_STAGE_BLEND | GSR_STAGE_SPLAT); // accumulators are clean by invariant
     const int Tb = (f.band_y1 - f.band_y0) * f.grid_x;
     if (stages & GSR_STAGE_CLEAR) {
         tm.begin(GSR_BWD_CLEAR);

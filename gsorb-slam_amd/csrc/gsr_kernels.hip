@@ -8,11 +8,12 @@
 //   K_fill         per splat : (depth bits<<32 | id) into its tiles' segments (unordered)
 //   K_tile_sort    per tile  : bitonic sort of the tile's segment in LDS -> point_list
 //                              ((depth, id) ascending == the reference's stable radix order)
-//   K_blend_fwd    per tile  : front-to-back alpha blend, one wave per tile, 4 pixels per lane
-//                              (one per 8x8 quad), ballot culling + wave-uniform quad masks
+//   K_blend_fwd    per quad  : front-to-back alpha blend, one wave per 8x8 quad, one pixel per lane,
+//                              exact ellipse-vs-quad culling (gsr_blend.h)
 // Backward (replaces rasterizer_impl.cu:405-498):
-//   K_blend_bwd    per tile  : back-to-front re-walk, DPP wave reduction, one 9-lane atomic
-//                              per (tile, splat) into a packed per-splat accumulator
+//   K_blend_bwd    per quad  : back-to-front re-walk, four independent 4x4 patch rows per wave, in-row DPP
+//                              reduction, LDS merge, one 9-lane atomic per (quad, splat) into a packed
+//                              per-splat accumulator (gsr_blend.h)
 //   K_splat_bwd    per splat : conic/mean2D/colour gradients -> mean3D, cov3D, scale, rot, SH
 //
 // No global sort and no per-instance keys: per-tile counting replaces the
@@ -57,6 +58,10 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= f.P) return;
+    { // the backward accumulators start every frame at zero (K_splat_bwd re-zeroes what it consumed)
+        float4* const ap = reinterpret_cast<float4*>(g.acc + (size_t)idx * GSR_ACC_STRIDE);
+        ap[0] = ap[1] = ap[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const float3 p = make_float3(in.means3D[3 * (size_t)idx], in.means3D[3 * (size_t)idx + 1], in.means3D[3 * (size_t)idx + 2]);
     float cov[6];
     load_cov3d(in, f, idx, cov);
@@ -148,32 +153,56 @@ K_scan_tiles(int T, TileRec* __restrict__ tiles, uint2* __restrict__ ranges,
             cs = (uint32_t)(r.cnt_small >> sh); cb = (uint32_t)(r.cnt_big >> sh);
         } else { cs = tiles[i].cnt_small; cb = tiles[i].cnt_big; }
     };
-    __shared__ uint32_t part[1024];
-    const int tid = threadIdx.x;
+    // each thread owns `per` consecutive tiles (its counts stay in registers when per <= 8), the block
+    // scan is one shuffle scan per wave plus one over the 16 wave totals: two barriers in all
+    __shared__ uint32_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int per = (T + 1023) / 1024;
     const int b = tid * per, e = min(T, b + per);
+    uint32_t ks[8], kb[8];
     uint32_t s = 0;
-    for (int i = b; i < e; i++) { uint32_t cs, cb; counts(i, cs, cb); s += cs + cb; }
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan
-        uint32_t v = tid >= off ? part[tid - off] : 0u;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    if (per <= 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            ks[j] = kb[j] = 0u;
+            if (j < per && b + j < e) counts(b + j, ks[j], kb[j]);
+            s += ks[j] + kb[j];
+        }
+    } else {
+        for (int i = b; i < e; i++) { uint32_t cs, cb; counts(i, cs, cb); s += cs + cb; }
     }
-    uint32_t run = part[tid] - s;
-    for (int i = b; i < e; i++) {
-        uint32_t cs, cb;
-        counts(i, cs, cb);
+    uint32_t inc = s; // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t x = wsum[j];
+        if (j < wv) wbase += x;
+        total += x;
+    }
+    uint32_t run = wbase + inc - s;
+    auto emit = [&](int i, uint32_t cs, uint32_t cb) {
         const uint32_t c = cs + cb;
         ranges[i] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u); // empty tiles read (0,0) like the reference's memset
         tiles[i].start = run;
         tiles[i].cur_big = run + cs;
         run += c;
+    };
+    if (per <= 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (j < per && b + j < e) emit(b + j, ks[j], kb[j]);
+    } else {
+        for (int i = b; i < e; i++) { uint32_t cs, cb; counts(i, cs, cb); emit(i, cs, cb); }
     }
-    if (tid == 1023) {
-        const uint32_t total = part[1023];
+    if (tid == 0) {
+
         hdr->num_rendered = total;
         hdr->overflow = total > capacity ? 1u : 0u;
         hdr->capacity = capacity;
@@ -352,9 +381,13 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o)
         if (o.dL_drot) reinterpret_cast<float4*>(o.dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
-    const float* acc = g.acc + i * GSR_ACC_STRIDE;
+    float* const acc = g.acc + i * GSR_ACC_STRIDE;
     const float4 q0 = reinterpret_cast<const float4*>(acc)[0], q1 = reinterpret_cast<const float4*>(acc)[1];
     const float q8 = acc[8];
+    { // consumed: leave the record clean for the next backward on this geometry blob
+        float4* const ap = reinterpret_cast<float4*>(acc);
+        ap[0] = ap[1] = ap[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     // K_blend_bwd accumulated the raw moments of u = G*dL/dalpha: {u, u dx, u dy, u dx^2, u dx dy, u dy^2};
     // the reference's per-pixel terms (backward.cu:536-554) are these moments times conic / opacity:
     const float4 ga = g.g0[idx], gb = g.g1[idx];

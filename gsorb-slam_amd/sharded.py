@@ -109,9 +109,10 @@ class HipBandBackend:
         return self.capi.forward(settings, band=band, out=out, **splats)
 
     def backward_partial(self, st, dL_dpix):
-        """clear + blend backward of this rank's band; returns the flat buffer to sum over ranks"""
+        """blend backward of this rank's band (the accumulators are zero after a forward); returns the flat
+        buffer to sum over ranks"""
         self._grads = self.capi.alloc_grads(st.P, st.M, st.geom.device)
-        self.capi.backward(st, dL_dpix, grads=self._grads, stages=1 | 2)
+        self.capi.backward(st, dL_dpix, grads=self._grads, stages=2)
         return self.capi.acc_view(st)
 
     def backward_finish(self, st, dL_dpix, summed):

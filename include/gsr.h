@@ -135,9 +135,11 @@ typedef struct gsr_backward_args {
     void** profile_events;       /* like gsr_forward_args.profile_events, 2*GSR_BWD_STAGES entries */
     int band_y0, band_y1;        /* must equal the matching forward's band */
     /* Which stages to run: bit 0 clear the per-splat accumulators, bit 1 blend backward (accumulates
-     * into them), bit 2 per-splat stage (reads them, writes the dL_d* outputs). 0 = all three. Band
-     * sharding runs (1|2) on every rank, sums the accumulators across ranks (gsr_acc_view + one
-     * all-reduce), then runs 4. */
+     * into them), bit 2 per-splat stage (reads them, writes the dL_d* outputs, leaves them zero).
+     * 0 = blend + per-splat: the accumulators are zero after every forward and after every per-splat
+     * stage, so an explicit clear is only needed to discard a blend stage that was not followed by the
+     * per-splat stage. Band sharding runs 2 on every rank, sums the accumulators across ranks
+     * (gsr_acc_view + one all-reduce), then runs 4. */
     int stages;
 } gsr_backward_args;
 

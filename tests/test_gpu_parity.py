@@ -252,3 +252,33 @@ def test_tile_bands_equal_full_frame(gsr, syn, world):
         a, b = getattr(g, name), getattr(gfull, name)
         err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
         assert err < 1e-5, (name, err)   # same terms, different float summation order (atomics) only
+
+
+@pytest.mark.gpu
+def test_backward_twice_on_one_forward_state(gsr, syn):
+    """The per-splat accumulators are zeroed by the forward and re-zeroed by the per-splat stage, not by a
+    memset in gsr_backward: a second backward on the same state must reproduce the first one, and an
+    explicit GSR_STAGE_CLEAR must discard a blend stage that was not consumed."""
+    import torch
+    capi = gsr.capi
+    cam = syn.make_camera(256, 160, 200.0, 200.0)
+    sc = syn.make_scene(20000, cam, seed=8, scale_mult=2.0, frac_behind=0.1)
+    dev = torch.device("cuda:0")
+    s = capi.Settings.from_camera(cam, dev)
+    t = lambda a: torch.tensor(a, device=dev)
+    st = capi.forward(s, means3D=t(sc.means3D), opacities=t(sc.opacities), colors=t(sc.colors), scales=t(sc.scales),
+                      rotations=t(sc.rotations))
+    dpix = t(sc.dL_dpix)
+    g1 = capi.backward(st, dpix)
+    ref = {n: getattr(g1, n).clone() for n in ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dscales")}
+    assert float(capi.acc_view(st).abs().max()) == 0.0
+    g2 = capi.backward(st, dpix)
+    for n, r in ref.items():
+        err = float((getattr(g2, n) - r).abs().max() / (r.abs().max() + 1e-30))
+        assert err < 1e-5, (n, err)
+    capi.backward(st, dpix, stages=2)                      # blend only: accumulators now hold one frame's sums
+    assert float(capi.acc_view(st).abs().max()) > 0.0
+    g3 = capi.backward(st, dpix, stages=1 | 2 | 4)         # explicit clear discards them
+    for n, r in ref.items():
+        err = float((getattr(g3, n) - r).abs().max() / (r.abs().max() + 1e-30))
+        assert err < 1e-5, (n, err)
