@@ -46,11 +46,11 @@ __device__ __forceinline__ bool quad_reach(const float4 a, const float4 b, float
     if (dxc == 0.f && dyc == 0.f) return true;
     float q = 3.0e38f;
     if (dxc != 0.f) { // a vertical side faces the centre: minimise over dy
-        const float dy = fminf(fmaxf(-cb * dxc / cc, dyl), dyh);
+        const float dy = fminf(fmaxf(-cb * dxc * __builtin_amdgcn_rcpf(cc), dyl), dyh); // minimiser: its rounding enters q to 2nd order
         q = fminf(q, 0.5f * (ca * dxc * dxc + cc * dy * dy) + cb * dxc * dy);
     }
     if (dyc != 0.f) {
-        const float dx = fminf(fmaxf(-cb * dyc / ca, dxl), dxh);
+        const float dx = fminf(fmaxf(-cb * dyc * __builtin_amdgcn_rcpf(ca), dxl), dxh);
         q = fminf(q, 0.5f * (ca * dx * dx + cc * dyc * dyc) + cb * dx * dyc);
     }
     return !(q > tau);

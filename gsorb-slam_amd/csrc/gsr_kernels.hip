@@ -244,31 +244,55 @@ __device__ __forceinline__ void cex(uint64_t& a, uint64_t& b)
     if (a > b) { const uint64_t t = a; a = b; b = t; }
 }
 
-// runs the stages of block size k_from..k_to that fit inside one LDS chunk of `cap` keys.
-// All strides are powers of two: indices are formed with shifts and masks (lk = log2 k).
-__device__ __forceinline__ void lds_sort_stages(uint64_t* s, int cap, int k_from, int k_to, int j_first_override)
+// The network is run in "trips": every thread loads a group of four keys e0<e1<e2<e3 chosen so that TWO
+// consecutive passes of the network pair keys inside the group, applies both in registers and stores the
+// group back — half the LDS traffic and half the barriers of one pass per round trip. A key belongs to
+// exactly one group per trip, so one barrier per trip is enough. cap >= 4, a power of two.
+//   flip trip  (stage k): flip(k) then disperse(k/4):  e = base + {x, x+k/4, k-1-x-k/4, k-1-x}
+//   pair trip  (g)      : disperse(2g) then disperse(g): e = base + {0, g, 2g, 3g}
+//   single trip         : disperse(1) on consecutive keys
+__device__ __forceinline__ void trip4(uint64_t* s, int e0, int e1, int e2, int e3, const bool flip, const bool first)
 {
-    for (int k = k_from, lk = 31 - __builtin_clz(k_from); k <= k_to; k <<= 1, lk++) {
-        int lj;
-        if (j_first_override > 0) lj = 31 - __builtin_clz(j_first_override); // continue a global-stage merge: disperse only
-        else {
-            const int hm = (k >> 1) - 1; // flip: pair (blk*k + off, blk*k + k-1-off), off < k/2
-            for (int i = threadIdx.x; i < cap / 2; i += blockDim.x) {
-                const int off = i & hm, blk = i >> (lk - 1);
-                const int lo = (blk << lk) + off, hi = (blk << lk) + (k - 1 - off);
-                cex(s[lo], s[hi]);
-            }
-            __syncthreads();
-            lj = lk - 2;
+    uint64_t a = s[e0], b = s[e1], c = s[e2], d = s[e3];
+    if (first) { if (flip) { cex(a, d); cex(b, c); } else { cex(a, c); cex(b, d); } }
+    cex(a, b); cex(c, d);
+    s[e0] = a; s[e1] = b; s[e2] = c; s[e3] = d;
+}
+// disperse passes j = 2^lj ... 1 (all strides < cap)
+__device__ __forceinline__ void lds_disperse_from(uint64_t* s, int cap, int lj)
+{
+    for (; lj >= 1; lj -= 2) { // passes 2g and g, g = 2^(lj-1)
+        const int lg = lj - 1, g = 1 << lg;
+        for (int grp = threadIdx.x; grp < cap / 4; grp += blockDim.x) {
+            const int base = ((grp >> lg) << (lg + 2)) + (grp & (g - 1));
+            trip4(s, base, base + g, base + 2 * g, base + 3 * g, false, true);
         }
-        for (; lj >= 0; lj--) { // disperse: pair (lo, lo + j), j = 1 << lj
-            const int j = 1 << lj, jm = j - 1;
-            for (int i = threadIdx.x; i < cap / 2; i += blockDim.x) {
-                const int lo = ((i >> lj) << (lj + 1)) + (i & jm);
-                cex(s[lo], s[lo + j]);
-            }
-            __syncthreads();
+        __syncthreads();
+    }
+    if (lj == 0) {
+        for (int grp = threadIdx.x; grp < cap / 4; grp += blockDim.x) trip4(s, 4 * grp, 4 * grp + 1, 4 * grp + 2, 4 * grp + 3, false, false);
+        __syncthreads();
+    }
+}
+// full sort of `cap` keys in LDS
+__device__ __forceinline__ void lds_sort(uint64_t* s, int cap)
+{
+    for (int grp = threadIdx.x; grp < cap / 4; grp += blockDim.x) { // stages k = 2 and k = 4 on four consecutive keys
+        uint64_t a = s[4 * grp], b = s[4 * grp + 1], c = s[4 * grp + 2], d = s[4 * grp + 3];
+        cex(a, b); cex(c, d);
+        cex(a, d); cex(b, c);
+        cex(a, b); cex(c, d);
+        s[4 * grp] = a; s[4 * grp + 1] = b; s[4 * grp + 2] = c; s[4 * grp + 3] = d;
+    }
+    __syncthreads();
+    for (int k = 8, lk = 3; k <= cap; k <<= 1, lk++) {
+        const int lq = lk - 2, q = 1 << lq;
+        for (int grp = threadIdx.x; grp < cap / 4; grp += blockDim.x) {
+            const int base = (grp >> lq) << lk, x = grp & (q - 1);
+            trip4(s, base + x, base + x + q, base + k - 1 - x - q, base + k - 1 - x, true, true);
         }
+        __syncthreads();
+        lds_disperse_from(s, cap, lk - 3);
     }
 }
 
@@ -288,11 +312,11 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
     if (n == 0 || (n <= GSR_SORT_SMALL) != SMALL) return;
     uint64_t* seg = pairs + r.x;
     if (n <= GSR_SORT_CAP) {
-        int n2 = 2;
+        int n2 = 4;
         while (n2 < n) n2 <<= 1;
         for (int i = threadIdx.x; i < n2; i += 256) s[i] = i < n ? seg[i] : ~0ull;
         __syncthreads();
-        lds_sort_stages(s, n2, 2, n2, 0);
+        lds_sort(s, n2);
         for (int i = threadIdx.x; i < n; i += 256) point_list[r.x + i] = (uint32_t)s[i];
         return;
     }
@@ -305,7 +329,7 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
         if (base >= n) break;
         for (int i = threadIdx.x; i < GSR_SORT_CAP; i += 256) s[i] = base + i < n ? seg[base + i] : ~0ull;
         __syncthreads();
-        lds_sort_stages(s, GSR_SORT_CAP, 2, GSR_SORT_CAP, 0);
+        lds_sort(s, GSR_SORT_CAP);
         for (int i = threadIdx.x; i < GSR_SORT_CAP; i += 256) if (base + i < n) seg[base + i] = s[i];
         __syncthreads();
     }
@@ -329,7 +353,7 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
             if (base >= n) break;
             for (int i = threadIdx.x; i < GSR_SORT_CAP; i += 256) s[i] = base + i < n ? seg[base + i] : ~0ull;
             __syncthreads();
-            lds_sort_stages(s, GSR_SORT_CAP, GSR_SORT_CAP, GSR_SORT_CAP, GSR_SORT_CAP / 2);
+            lds_disperse_from(s, GSR_SORT_CAP, 11); // strides 2048 ... 1 (GSR_SORT_CAP / 2 = 2^11)
             for (int i = threadIdx.x; i < GSR_SORT_CAP; i += 256) if (base + i < n) seg[base + i] = s[i];
             __syncthreads();
         }
