@@ -28,6 +28,12 @@ namespace gsr {
 
 #define GSR_ALPHA_MIN (1.0f / 255.0f)
 
+// number of set bits of m below this lane
+__device__ __forceinline__ int mbcnt64(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // Can the splat reach alpha >= 1/255 on some pixel centre of the quad whose pixel centres
 // span [X0, X0+7] x [Y0, Y0+7]? alpha >= 1/255  <=>  Q(d) := 0.5*(a dx^2 + c dy^2) + b dx dy
 // <= ln(255*opacity), with d = splat centre - pixel. The minimum of the convex Q over the
@@ -85,22 +91,32 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t last = 0u;
     bool done = !inside;
+    // every entry that passes the quad cull is also logged (list position, id) for the backward, which
+    // then re-walks only those instead of culling the whole tile list again
+    uint2* __restrict__ qh = bn.qhits + 4 * (size_t)range.x + (size_t)quad * (size_t)n;
+    int qc = 0;
 
-    uint32_t id_next = lane < n ? plist[lane] : 0u;
+    // gather pipeline: the ids of the next two batches and the geometry of the next batch are in flight
+    // (unconditional loads from clamped, always valid addresses: the compiler can count them, so the
+    // colour gather does not wait for the loads issued after it)
+    if (n > 0) {
+    uint32_t id_c = plist[min(lane, n - 1)], id_n = plist[min(lane + 64, n - 1)];
+    float4 a_c = g.g0[id_c], b_c = g.g1[id_c];
     for (int base = 0; base < n; base += 64) {
         if (__all(done)) break;
-        const uint32_t id = id_next;
-        const bool have = base + lane < n;
-        if (base + 64 + lane < n) id_next = plist[base + 64 + lane];
-        bool hit = false;
-        if (have) {
-            const float4 a = g.g0[id];
-            const float4 b = g.g1[id];
-            hit = quad_reach(a, b, X0f, Y0f);
-            if (hit) { stage_entry(sA, sB, lane, a, b); sC[lane] = g.col[id]; }
-        }
+        const uint32_t id = id_c;
+        const float4 a = a_c, b = b_c;
+        const bool hit = base + lane < n && quad_reach(a, b, X0f, Y0f);
+        float4 c;
+        if (hit) c = g.col[id];
+        id_c = id_n;
+        a_c = g.g0[id_c]; b_c = g.g1[id_c];
+        id_n = plist[min(base + 128 + lane, n - 1)];
+        if (hit) { stage_entry(sA, sB, lane, a, b); sC[lane] = c; }
         __builtin_amdgcn_wave_barrier();
         unsigned long long hits = __ballot(hit);
+        if (hit) qh[qc + mbcnt64(hits)] = make_uint2((uint32_t)(base + lane), id);
+        qc += (int)__popcll(hits);
         while (hits) {
             const int jj = (int)__builtin_ctzll(hits);
             hits &= hits - 1;
@@ -123,6 +139,8 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
         }
         __builtin_amdgcn_wave_barrier();
     }
+    }
+    if (lane == 0) im.qcount[4 * tile + quad] = (uint32_t)qc;
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
         im.final_T[pix] = T;
@@ -139,8 +157,9 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
 // INDEPENDENT 4x4 pixel patches, each walking its own hit list. Small splats touch few pixels of
 // an 8x8 quad (~16 of 64 lanes useful on the 1 M-splat workload); a 4x4 patch is hit by half as many
 // splats as the quad and uses ~8 of its 16 lanes, so the same wave retires ~1.7x fewer iterations.
-//   gather : 64 list entries per step, exact quad-level cull, survivors COMPACTED into LDS (mbcnt)
-//            until more than Q-64 are parked or the list ends;
+//   gather : the forward logged which list entries reach the quad (qhits: list position + id), so the
+//            backward never touches the rest of the tile list: 64 records per step, back to front,
+//            records behind every pixel's last contributor dropped, the rest parked in LDS;
 //   lists  : one lane per parked entry runs the exact cull against the four patches and appends the
 //            entry's index to the byte list of every patch it can reach (list order is kept);
 //   blend  : row r walks list r (entries software-pipelined through two register sets); per iteration
@@ -154,13 +173,8 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
 //            atomics per PATCH instead would double them and hit the L2 atomic ceiling (~20 G records/s,
 //            scripts/atomic_bench2.hip).
 // =====================================================================================
-#define GSR_ROWQ 96 // parked entries per round; 96 beats 64/80/128 on the 1 M workload (LDS 8.7 KB per wave)
+#define GSR_ROWQ 64 // parked entries per round = one gather step; 64 beats 96 and 128 (LDS 5.9 KB per wave)
 typedef float v2f __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ int mbcnt64(unsigned long long m)
-{
-    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
 
 // Exact cull of one parked entry (conic staged for pair_power2, i.e. in log2 units) against the 2x2
 // patches of 4x4 pixel centres of the quad at (X0, Y0); same construction and margin as quad_reach.
@@ -276,37 +290,40 @@ K_blend_bwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
     for (int i = lane; i < Q * 9 + 64; i += 64) ACC[i] = 0.f;
     const int ntodo = __builtin_amdgcn_readfirstlane(min(n, (int)wave_max_u32(last)));
 
-    // gather pipeline: the ids of the next two steps and the geometry of the next step are in flight
+    // The forward logged the entries that reach this quad (list position, id), in list order; walk them
+    // back to front. Gather pipeline: the records of the next two steps and the geometry of the next step
+    // are in flight (unconditional loads from clamped, always valid addresses so that the compiler can
+    // count them: the colour gather must not wait for the loads issued after it).
+    const int cq = (int)im.qcount[4 * tile + quad];
+    const uint2* __restrict__ qh = bn.qhits + 4 * (size_t)range.x + (size_t)quad * (size_t)n;
+    if (ntodo <= 0 || cq <= 0) return;
     int k0 = 0;
-    // (all prefetches are unconditional loads from clamped, always valid addresses so that the compiler
-    // can count them: the colour gather must not wait for the loads issued after it)
-    if (ntodo <= 0) return;
-    uint32_t id_c = plist[max(ntodo - 1 - lane, 0)];
-    uint32_t id_n = plist[max(ntodo - 1 - (lane + 64), 0)];
-    float4 a_c = g.g0[id_c], b_c = g.g1[id_c];
-    while (k0 < ntodo) {
-        // ---- gather + quad cull + compaction (back to front: entry k sits at list position ntodo-1-k)
+    uint2 rec_c = qh[max(cq - 1 - lane, 0)];
+    uint2 rec_n = qh[max(cq - 1 - (lane + 64), 0)];
+    float4 a_c = g.g0[rec_c.y], b_c = g.g1[rec_c.y];
+    while (k0 < cq) {
+        // ---- gather + compaction (records past the last contributor of every pixel are dropped)
         int count = 0;
         do {
-            const uint32_t id = id_c;
+            const uint32_t id = rec_c.y, pos = rec_c.x;
             const float4 a = a_c, b = b_c;
             const int k = k0 + lane;
-            const bool hit = k < ntodo && quad_reach(a, b, X0f, Y0f);
+            const bool hit = k < cq && pos < (uint32_t)ntodo;
             float4 c;
             if (hit) c = g.col[id];
-            id_c = id_n;
-            a_c = g.g0[id_c]; b_c = g.g1[id_c];
-            id_n = plist[max(ntodo - 1 - (k + 128), 0)];
+            rec_c = rec_n;
+            a_c = g.g0[rec_c.y]; b_c = g.g1[rec_c.y];
+            rec_n = qh[max(cq - 1 - (k + 128), 0)];
             const unsigned long long m = __ballot(hit);
             if (hit) {
                 const int e = count + mbcnt64(m);
                 E0[e] = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
                 E1[e] = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, c.x, c.y);
-                E2[e] = make_float4(c.z, __uint_as_float((uint32_t)(ntodo - 1 - k)), __uint_as_float(id), 0.f);
+                E2[e] = make_float4(c.z, __uint_as_float(pos), __uint_as_float(id), 0.f);
             }
             count += (int)__popcll(m);
             k0 += 64;
-        } while (k0 < ntodo && count <= Q - 64);
+        } while (k0 < cq && count <= Q - 64);
         if (count == 0) continue;
         __builtin_amdgcn_wave_barrier();
         // ---- per-patch hit lists

@@ -71,10 +71,13 @@ struct ImageView {
     uint2* ranges;
     TileRec* tiles;
     PairRec* tpairs;
+    uint32_t* qcount; // [4*T] quad-hit records the forward blend wrote per 8x8 quad
 };
 struct BinView {
     uint64_t* pairs;
     uint32_t* point_list;
+    uint2* qhits;     // [4*R] (list position, splat id) of every list entry that can reach a quad, in list order;
+                      // the quad q of a tile with range [x, x+n) owns qhits[4x + q*n .. 4x + (q+1)*n)
 };
 
 __host__ __device__ inline size_t gsr_align_up(size_t x) { return (x + GSR_ALIGN - 1) & ~(size_t)(GSR_ALIGN - 1); }
@@ -109,6 +112,7 @@ __host__ __device__ inline size_t image_layout(char* base, int W, int H, ImageVi
         if (np == 0) np = 1;
         g.tpairs = (PairRec*)(base + off); off = gsr_align_up(off + np * sizeof(PairRec));
     }
+    g.qcount = (uint32_t*)(base + off); off = gsr_align_up(off + T * 16);
     if (v) *v = g;
     return off;
 }
@@ -119,14 +123,15 @@ __host__ __device__ inline size_t binning_layout(char* base, size_t R, BinView* 
     BinView g;
     g.pairs = (uint64_t*)(base + off); off = gsr_align_up(off + R * 8);
     g.point_list = (uint32_t*)(base + off); off = gsr_align_up(off + R * 4);
+    g.qhits = (uint2*)(base + off); off = gsr_align_up(off + R * 32);
     if (v) *v = g;
     return off;
 }
 // largest R such that binning_layout(R) <= bytes
 __host__ inline size_t binning_capacity(size_t bytes)
 {
-    if (bytes < 2 * GSR_ALIGN) return 0;
-    size_t r = (bytes - 2 * GSR_ALIGN) / 12;
+    if (bytes < 3 * GSR_ALIGN) return 0;
+    size_t r = (bytes - 3 * GSR_ALIGN) / 44;
     while (r > 0 && binning_layout(nullptr, r, nullptr) > bytes) r--;
     return r;
 }
