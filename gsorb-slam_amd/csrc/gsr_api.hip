@@ -48,6 +48,7 @@ FrameParams frame_params(int P, int D, int M, int W, int H, float tfx, float tfy
 int check_forward(const gsr_forward_args* a)
 {
     if (!a || a->P < 0 || a->width <= 0 || a->height <= 0) return GSR_EINVAL;
+    if (a->P > (int)GSR_ID_MASK) return GSR_EINVAL; // the quad-hit log keeps ids in 28 bits (268 M splats = 30 GB of geometry blob)
     if (!a->out_color || !a->out_depth) return GSR_EINVAL;
     if (a->P == 0) return GSR_OK;
     if (!a->means3D || !a->opacities || !a->viewmatrix || !a->projmatrix || !a->background) return GSR_EINVAL;
@@ -88,7 +89,7 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     tm.begin(GSR_FWD_BLEND);
     const int Tb = (f.band_y1 - f.band_y0) * f.grid_x; // tiles of the band
     if (Tb > 0)
-        hipLaunchKernelGGL(gsr::K_blend_fwd, dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
+        hipLaunchKernelGGL(gsr::K_blend_fwd<GSR_FWDQ>, dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
                            f.grid_x, Tb, f.band_y0 * f.grid_x, a->out_color, a->out_depth);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_BLEND);

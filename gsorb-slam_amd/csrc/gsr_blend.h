@@ -1,22 +1,18 @@
 // gsr_blend.h — the two blend kernels (forward alpha compositing and its backward).
 //
-// Mapping (wave64-first): ONE wave per 8x8 pixel quad, one pixel per lane; the four quads of
-// a 16x16 tile are four INDEPENDENT single-wave workgroups that walk the same per-tile list.
-//   * a workgroup is a single wave: no s_barrier anywhere; LDS is only a broadcast buffer
-//     the wave writes and reads in program order;
-//   * 4x more, 4x shorter waves than one-wave-per-tile: ~12 waves per SIMD keep the VALU
-//     issuing (a wave issues at most one instruction per 4 cycles) and even out the per-tile
-//     load imbalance;
-//   * block ids are remapped so the four quads of a tile (and neighbouring tiles) run on
-//     the same XCD and share its L2 for the per-splat gathers.
-// Each batch of 64 list entries is gathered straight into registers (one entry per lane),
-// culled by its owning lane with an EXACT test (does the iso-alpha ellipse alpha = 1/255
-// intersect the quad's rectangle of pixel centres?), and only the surviving entries are
-// parked in LDS and visited, in list order, through wave-uniform LDS broadcast reads.
-// Colours are gathered only for surviving entries.
-//
-// Backward: same wave-per-quad launch, but the four 16-lane DPP rows of the wave are four independent
-// 4x4 patches, each with its own hit list (see K_blend_bwd below).
+// Mapping (wave64-first): ONE wave per 8x8 pixel quad; the four quads of a 16x16 tile are four
+// INDEPENDENT single-wave workgroups that walk the same per-tile list, and inside the wave the four
+// 16-lane DPP rows are four independent 4x4 pixel "patches", each with its own hit list ("patch rows").
+//   * a workgroup is a single wave: no s_barrier anywhere; LDS holds the parked entries, the per-patch
+//     byte lists and (backward) the accumulators, all written and read by the wave in program order;
+//   * small splats light ~16 of the 64 lanes of a quad but ~8 of the 16 lanes of a patch, and a patch
+//     is hit by half as many splats as the quad: the wave retires ~0.6x the iterations of a
+//     one-splat-per-wave-iteration loop;
+//   * block ids are remapped so the four quads of a tile (and neighbouring tiles) run on the same XCD
+//     and share its L2 for the per-splat gathers.
+// Culling is EXACT at both levels (does the iso-alpha ellipse alpha = 1/255 intersect the rectangle of
+// pixel centres of the quad / of the patch?). The forward culls and logs its verdicts (qhits: list
+// position, id, 4-bit patch mask); the backward walks the log and never culls.
 //
 // What is computed per (pixel, splat) pair is the reference's arithmetic
 // (DGR/cuda_rasterizer/forward.cu:339-391, backward.cu:470-555).
@@ -27,6 +23,9 @@
 namespace gsr {
 
 #define GSR_ALPHA_MIN (1.0f / 255.0f)
+// a quad-hit record keeps the splat id in the low 28 bits of .y and the 4-bit patch mask above it
+#define GSR_ID_BITS 28
+#define GSR_ID_MASK 0x0FFFFFFFu
 
 // number of set bits of m below this lane
 __device__ __forceinline__ int mbcnt64(unsigned long long m)
@@ -62,106 +61,16 @@ __device__ __forceinline__ bool quad_reach(const float4 a, const float4 b, float
     return !(q > tau);
 }
 
-// Parks a surviving entry in LDS with its conic pre-scaled for pair_power2 (gsr_device.h): the hit loop
-// forms power*log2(e) in five ops and uses the hardware exp2. Forward and backward stage identically,
-// so both evaluate bit-identical alphas.
-__device__ __forceinline__ void stage_entry(float4* sA, float4* sB, int lane, float4 a, float4 b)
-{
-    a.z *= -0.5f * GSR_LOG2E; a.w *= -GSR_LOG2E; b.x *= -0.5f * GSR_LOG2E;
-    sA[lane] = a; sB[lane] = b;
-}
-
-__global__ void __launch_bounds__(64)
-K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
-            int grid_x, int ntiles, int tile0, float* __restrict__ out_color, float* __restrict__ out_depth)
-{
-    __shared__ float4 sA[64], sB[64], sC[64];
-    const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
-    const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u; // tile0: first tile of the band
-    const int tx = tile % grid_x, ty = tile / grid_x;
-    const int lane = threadIdx.x;
-    const int X0 = tx * 16 + (int)(quad & 1u) * 8, Y0 = ty * 16 + (int)(quad >> 1) * 8;
-    const int px = X0 + (lane & 7), py = Y0 + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py, X0f = (float)X0, Y0f = (float)Y0;
-    const uint2 range = im.ranges[tile];
-    const int n = g.hdr->overflow ? 0 : (int)(range.y - range.x);
-    const uint32_t* __restrict__ plist = bn.point_list + range.x;
-
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
-    uint32_t last = 0u;
-    bool done = !inside;
-    // every entry that passes the quad cull is also logged (list position, id) for the backward, which
-    // then re-walks only those instead of culling the whole tile list again
-    uint2* __restrict__ qh = bn.qhits + 4 * (size_t)range.x + (size_t)quad * (size_t)n;
-    int qc = 0;
-
-    // gather pipeline: the ids of the next two batches and the geometry of the next batch are in flight
-    // (unconditional loads from clamped, always valid addresses: the compiler can count them, so the
-    // colour gather does not wait for the loads issued after it)
-    if (n > 0) {
-    uint32_t id_c = plist[min(lane, n - 1)], id_n = plist[min(lane + 64, n - 1)];
-    float4 a_c = g.g0[id_c], b_c = g.g1[id_c];
-    for (int base = 0; base < n; base += 64) {
-        if (__all(done)) break;
-        const uint32_t id = id_c;
-        const float4 a = a_c, b = b_c;
-        const bool hit = base + lane < n && quad_reach(a, b, X0f, Y0f);
-        float4 c;
-        if (hit) c = g.col[id];
-        id_c = id_n;
-        a_c = g.g0[id_c]; b_c = g.g1[id_c];
-        id_n = plist[min(base + 128 + lane, n - 1)];
-        if (hit) { stage_entry(sA, sB, lane, a, b); sC[lane] = c; }
-        __builtin_amdgcn_wave_barrier();
-        unsigned long long hits = __ballot(hit);
-        if (hit) qh[qc + mbcnt64(hits)] = make_uint2((uint32_t)(base + lane), id);
-        qc += (int)__popcll(hits);
-        while (hits) {
-            const int jj = (int)__builtin_ctzll(hits);
-            hits &= hits - 1;
-            const float4 A = sA[jj], B = sB[jj], Cc = sC[jj];
-            const float dx = A.x - pxf, dy = A.y - pyf;
-            const float power2 = pair_power2(dx, dy, A.z, A.w, B.x); // = power * log2(e): same sign as power
-            const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(power2));
-            const bool valid = !done && power2 <= 0.0f && alpha >= GSR_ALPHA_MIN;
-            const float test_T = T * (1.f - alpha);
-            const bool stop = valid && test_T < 0.0001f;
-            const bool upd = valid && !stop;
-            done = done || stop;
-            const float wgt = upd ? alpha * T : 0.f;
-            C0 = fmaf(Cc.x, wgt, C0);
-            C1 = fmaf(Cc.y, wgt, C1);
-            C2 = fmaf(Cc.z, wgt, C2);
-            Dp = (upd && T > 0.5f) ? B.z : Dp; // median depth (forward.cu:374-379)
-            T = upd ? test_T : T;
-            last = upd ? (uint32_t)(base + jj + 1) : last;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    }
-    if (lane == 0) im.qcount[4 * tile + quad] = (uint32_t)qc;
-    if (inside) {
-        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
-        im.final_T[pix] = T;
-        im.n_contrib[pix] = last;
-        out_color[pix] = C0 + T * bg[0];
-        out_color[HW + pix] = C1 + T * bg[1];
-        out_color[2 * HW + pix] = C2 + T * bg[2];
-        out_depth[pix] = Dp;
-    }
-}
-
 // =====================================================================================
 // Backward ("patch rows"): the wave still owns an 8x8 quad, but its four 16-lane DPP rows are four
 // INDEPENDENT 4x4 pixel patches, each walking its own hit list. Small splats touch few pixels of
 // an 8x8 quad (~16 of 64 lanes useful on the 1 M-splat workload); a 4x4 patch is hit by half as many
 // splats as the quad and uses ~8 of its 16 lanes, so the same wave retires ~1.7x fewer iterations.
-//   gather : the forward logged which list entries reach the quad (qhits: list position + id), so the
-//            backward never touches the rest of the tile list: 64 records per step, back to front,
+//   gather : the forward logged which list entries reach the quad and which of its patches (qhits), so
+//            the backward never touches the rest of the tile list: 64 records per step, back to front,
 //            records behind every pixel's last contributor dropped, the rest parked in LDS;
-//   lists  : one lane per parked entry runs the exact cull against the four patches and appends the
-//            entry's index to the byte list of every patch it can reach (list order is kept);
+//   lists  : one lane per parked entry appends the entry's index to the byte list of every patch in
+//            its mask (list order is kept);
 //   blend  : row r walks list r (entries software-pipelined through two register sets); per iteration
 //            the nine partial sums are reduced inside the 16-lane row (transposing, bank-masked DPP
 //            adds) and nine lanes per row add them into the entry's LDS accumulator with a plain
@@ -173,6 +82,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
 //            atomics per PATCH instead would double them and hit the L2 atomic ceiling (~20 G records/s,
 //            scripts/atomic_bench2.hip).
 // =====================================================================================
+#define GSR_FWDQ 96 // forward: gathers until more than 32 entries are parked (2-3 steps of ~22 quad hits)
 #define GSR_ROWQ 64 // parked entries per round = one gather step; 64 beats 96 and 128 (LDS 5.9 KB per wave)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -300,26 +210,26 @@ K_blend_bwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
     int k0 = 0;
     uint2 rec_c = qh[max(cq - 1 - lane, 0)];
     uint2 rec_n = qh[max(cq - 1 - (lane + 64), 0)];
-    float4 a_c = g.g0[rec_c.y], b_c = g.g1[rec_c.y];
+    float4 a_c = g.g0[rec_c.y & GSR_ID_MASK], b_c = g.g1[rec_c.y & GSR_ID_MASK];
     while (k0 < cq) {
         // ---- gather + compaction (records past the last contributor of every pixel are dropped)
         int count = 0;
         do {
-            const uint32_t id = rec_c.y, pos = rec_c.x;
+            const uint32_t id = rec_c.y & GSR_ID_MASK, pos = rec_c.x, pmask = rec_c.y >> GSR_ID_BITS;
             const float4 a = a_c, b = b_c;
             const int k = k0 + lane;
             const bool hit = k < cq && pos < (uint32_t)ntodo;
             float4 c;
             if (hit) c = g.col[id];
             rec_c = rec_n;
-            a_c = g.g0[rec_c.y]; b_c = g.g1[rec_c.y];
+            a_c = g.g0[rec_c.y & GSR_ID_MASK]; b_c = g.g1[rec_c.y & GSR_ID_MASK];
             rec_n = qh[max(cq - 1 - (k + 128), 0)];
             const unsigned long long m = __ballot(hit);
             if (hit) {
                 const int e = count + mbcnt64(m);
                 E0[e] = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
                 E1[e] = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, c.x, c.y);
-                E2[e] = make_float4(c.z, __uint_as_float(pos), __uint_as_float(id), 0.f);
+                E2[e] = make_float4(c.z, __uint_as_float(pos), __uint_as_float(id), __uint_as_float(pmask));
             }
             count += (int)__popcll(m);
             k0 += 64;
@@ -331,7 +241,10 @@ K_blend_bwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
         for (int eb = 0; eb < count; eb += 64) {
             const int e = eb + lane;
             bool h[4] = {false, false, false, false};
-            if (e < count) patch_reach4(E0[e], E1[e], X0f, Y0f, h);
+            if (e < count) { // the forward already ran the patch cull: its verdict travels in the record
+                const uint32_t pm = __float_as_uint(E2[e].w);
+                h[0] = (pm & 1u) != 0u; h[1] = (pm & 2u) != 0u; h[2] = (pm & 4u) != 0u; h[3] = (pm & 8u) != 0u;
+            }
             const unsigned long long m0 = __ballot(h[0]), m1 = __ballot(h[1]), m2 = __ballot(h[2]), m3 = __ballot(h[3]);
             if (h[0]) LIST[0 * Q + c0 + mbcnt64(m0)] = (uint8_t)e;
             if (h[1]) LIST[1 * Q + c1 + mbcnt64(m1)] = (uint8_t)e;
@@ -429,6 +342,142 @@ K_blend_bwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// =====================================================================================
+// Forward ("patch rows"), same wave/row mapping as K_blend_bwd: the wave owns an 8x8 quad, its four
+// 16-lane rows are four independent 4x4 patches with their own hit lists. Per round: gather (64 list
+// entries per step, exact quad cull, survivors compacted into LDS until more than Q-64 are parked),
+// patch lists (exact patch cull; the entry is logged for the backward as (list position, id | mask<<28)),
+// blend (row r walks list r, entries software-pipelined). A row whose 16 pixels are all done idles; the
+// wave leaves when every pixel is done.
+// =====================================================================================
+template <int Q>
+__global__ void __launch_bounds__(64)
+K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
+                 int grid_x, int ntiles, int tile0, float* __restrict__ out_color, float* __restrict__ out_depth)
+{
+    __shared__ float4 E0[Q], E1[Q], E2[Q]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, depth, list position, id)
+    __shared__ uint8_t LIST[4 * Q];
+    const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
+    const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u;
+    const int tx = tile % grid_x, ty = tile / grid_x;
+    const int lane = threadIdx.x, r = lane >> 4, l = lane & 15;
+    const int X0 = tx * 16 + (int)(quad & 1u) * 8, Y0 = ty * 16 + (int)(quad >> 1) * 8;
+    const int px = X0 + (r & 1) * 4 + (l & 3), py = Y0 + (r >> 1) * 4 + (l >> 2);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py, X0f = (float)X0, Y0f = (float)Y0;
+    const uint2 range = im.ranges[tile];
+    const int n = g.hdr->overflow ? 0 : (int)(range.y - range.x);
+    const uint32_t* __restrict__ plist = bn.point_list + range.x;
+
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    uint32_t last = 0u;
+    bool done = !inside;
+    uint2* __restrict__ qh = bn.qhits + 4 * (size_t)range.x + (size_t)quad * (size_t)n;
+    int qc = 0;
+
+    if (n > 0) {
+        int base = 0;
+        uint32_t id_c = plist[min(lane, n - 1)], id_n = plist[min(lane + 64, n - 1)];
+        float4 a_c = g.g0[id_c], b_c = g.g1[id_c];
+        while (base < n) {
+            const unsigned long long dmask = __ballot(done);
+            if (dmask == ~0ull) break;
+            // ---- gather + quad cull + compaction
+            int count = 0;
+            do {
+                const uint32_t id = id_c;
+                const float4 a = a_c, b = b_c;
+                const int k = base + lane;
+                const bool hit = k < n && quad_reach(a, b, X0f, Y0f);
+                float4 c;
+                if (hit) c = g.col[id];
+                id_c = id_n;
+                a_c = g.g0[id_c]; b_c = g.g1[id_c];
+                id_n = plist[min(k + 128, n - 1)];
+                const unsigned long long m = __ballot(hit);
+                if (hit) {
+                    const int e = count + mbcnt64(m);
+                    E0[e] = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
+                    E1[e] = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, c.x, c.y);
+                    E2[e] = make_float4(c.z, b.z, __uint_as_float((uint32_t)k), __uint_as_float(id));
+                }
+                count += (int)__popcll(m);
+                base += 64;
+            } while (base < n && count <= Q - 64);
+            if (count == 0) continue;
+            __builtin_amdgcn_wave_barrier();
+            // ---- per-patch hit lists + the log for the backward
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            for (int eb = 0; eb < count; eb += 64) {
+                const int e = eb + lane;
+                bool h[4] = {false, false, false, false};
+                float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < count) { patch_reach4(E0[e], E1[e], X0f, Y0f, h); z = E2[e]; }
+                const unsigned long long m0 = __ballot(h[0]), m1 = __ballot(h[1]), m2 = __ballot(h[2]), m3 = __ballot(h[3]);
+                if (h[0]) LIST[0 * Q + c0 + mbcnt64(m0)] = (uint8_t)e;
+                if (h[1]) LIST[1 * Q + c1 + mbcnt64(m1)] = (uint8_t)e;
+                if (h[2]) LIST[2 * Q + c2 + mbcnt64(m2)] = (uint8_t)e;
+                if (h[3]) LIST[3 * Q + c3 + mbcnt64(m3)] = (uint8_t)e;
+                c0 += (int)__popcll(m0); c1 += (int)__popcll(m1); c2 += (int)__popcll(m2); c3 += (int)__popcll(m3);
+                const uint32_t pm = (h[0] ? 1u : 0u) | (h[1] ? 2u : 0u) | (h[2] ? 4u : 0u) | (h[3] ? 8u : 0u);
+                const unsigned long long ma = m0 | m1 | m2 | m3;
+                if (pm) qh[qc + mbcnt64(ma)] = make_uint2(__float_as_uint(z.z), __float_as_uint(z.w) | (pm << GSR_ID_BITS));
+                qc += (int)__popcll(ma);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- blend: row r walks its own list; a finished row idles
+            const bool rowdone = ((dmask >> (16 * r)) & 0xFFFFull) == 0xFFFFull;
+            const int mycnt = rowdone ? 0 : (r == 0 ? c0 : r == 1 ? c1 : r == 2 ? c2 : c3);
+            const int maxc = max(max(c0, c1), max(c2, c3));
+            const uint8_t* __restrict__ mylist = LIST + r * Q;
+            auto step = [&](const int it, const float4 A, const float4 B, const float4 Cz) {
+                const bool act = it < mycnt;
+                const float dx = A.x - pxf, dy = A.y - pyf;
+                const float power2 = pair_power2(dx, dy, A.z, A.w, B.x); // = power * log2(e): same sign as power
+                const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(power2));
+                const bool valid = act && !done && power2 <= 0.0f && alpha >= GSR_ALPHA_MIN;
+                const float test_T = T * (1.f - alpha);
+                const bool stop = valid && test_T < 0.0001f;
+                const bool upd = valid && !stop;
+                done = done || stop;
+                const float wgt = upd ? alpha * T : 0.f;
+                C0 = fmaf(B.z, wgt, C0);
+                C1 = fmaf(B.w, wgt, C1);
+                C2 = fmaf(Cz.x, wgt, C2);
+                Dp = (upd && T > 0.5f) ? Cz.y : Dp; // median depth (forward.cu:374-379)
+                T = upd ? test_T : T;
+                last = upd ? __float_as_uint(Cz.z) + 1u : last;
+            };
+            int idx0 = 0 < mycnt ? (int)mylist[0] : 0; // entry 0 is always parked: finite data for idle rows
+            float4 A0 = E0[idx0], B0 = E1[idx0], Z0 = E2[idx0];
+            int raw1 = (int)mylist[1], raw0, idx1;
+            float4 A1, B1, Z1;
+            for (int it = 0; it < maxc; it += 2) {
+                idx1 = it + 1 < mycnt ? raw1 : 0;
+                A1 = E0[idx1]; B1 = E1[idx1]; Z1 = E2[idx1];
+                raw0 = (int)mylist[min(it + 2, Q - 1)];
+                step(it, A0, B0, Z0);
+                if (it + 1 >= maxc) break;
+                idx0 = it + 2 < mycnt ? raw0 : 0;
+                A0 = E0[idx0]; B0 = E1[idx0]; Z0 = E2[idx0];
+                raw1 = (int)mylist[min(it + 3, Q - 1)];
+                step(it + 1, A1, B1, Z1);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (lane == 0) im.qcount[4 * tile + quad] = (uint32_t)qc;
+    if (inside) {
+        const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
+        im.final_T[pix] = T;
+        im.n_contrib[pix] = last;
+        out_color[pix] = C0 + T * bg[0];
+        out_color[HW + pix] = C1 + T * bg[1];
+        out_color[2 * HW + pix] = C2 + T * bg[2];
+        out_depth[pix] = Dp;
     }
 }
 

@@ -41,7 +41,7 @@ typedef char* (*gsr_alloc_fn)(void* user, size_t bytes);
 
 /* Arguments of Rasterizer::forward (rasterizer.h:34-58), same meaning and order. */
 typedef struct gsr_forward_args {
-    int P;                       /* number of Gaussians */
+    int P;                       /* number of Gaussians (< 2^28: ids share a word with a 4-bit mask) */
     int D;                       /* active SH degree (0..3) */
     int M;                       /* SH coefficients per Gaussian (0 when colours are precomputed) */
     const float* background;     /* [3] */
