@@ -109,13 +109,12 @@ int forward_head(const gsr_forward_args* a, char* geom, char* image, hipStream_t
                                              a->projmatrix, a->cam_pos);
     const StageTimer tm{a->profile_events, st};
     tm.begin(GSR_FWD_PREPROCESS);
-    GSR_HIP(hipMemsetAsync(iv->tpairs, 0, (size_t)((f.grid_x + 1) / 2) * f.grid_y * sizeof(PairRec), st));
-    hipLaunchKernelGGL(gsr::K_preprocess, dim3(blocks256(P)), dim3(256), 0, st, f, in, a->radii, *gv, iv->tpairs);
+    GSR_HIP(hipMemsetAsync(iv->tiles, 0, (size_t)T * sizeof(TileRec), st));
+    hipLaunchKernelGGL(gsr::K_preprocess, dim3(blocks256(P)), dim3(256), 0, st, f, in, a->radii, *gv, iv->tiles);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_PREPROCESS);
     tm.begin(GSR_FWD_SCAN);
-    hipLaunchKernelGGL(gsr::K_scan_tiles<true>, dim3(1), dim3(1024), 0, st, T, iv->tiles, iv->ranges, gv->hdr, capacity,
-                       (const PairRec*)iv->tpairs, f.grid_x);
+    hipLaunchKernelGGL(gsr::K_scan_tiles<true>, dim3(1), dim3(1024), 0, st, T, iv->tiles, iv->ranges, gv->hdr, capacity, f.grid_x);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SCAN);
     *fo = f;
@@ -326,8 +325,7 @@ int gsr_dist2(int P, const float* points, float* mean_dists, char* workspace, si
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_knn_code, dim3(blocks256(P)), dim3(256), 0, st, P, shift, points, k.bbox, k.buckets, k.code, k.slot);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_scan_tiles<false>, dim3(1), dim3(1024), 0, st, nb, k.buckets, k.ranges, k.hdr, 0xFFFFFFFFu,
-                       (const PairRec*)nullptr, 1);
+    hipLaunchKernelGGL(gsr::K_scan_tiles<false>, dim3(1), dim3(1024), 0, st, nb, k.buckets, k.ranges, k.hdr, 0xFFFFFFFFu, 1);
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_knn_fill, dim3(blocks256(P)), dim3(256), 0, st, P, shift, k.code, k.slot, k.buckets, k.pairs);
     GSR_LAUNCHED();

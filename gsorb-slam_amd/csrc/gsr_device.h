@@ -8,7 +8,7 @@
 //     g1   float4[P]  {conic_c, opacity, depth, radius}  radius stored as int bits
 //     col  float4[P]  {r, g, b, clamp-flags}             colour the blend uses (SH result or
 //                                                        copy of colors_precomp)
-//     slots uint4[P]     list slot the splat took in each of its (<= 4) tiles at count time
+//     slots u32[P]       rank of the splat in its class counter (rectangles up to 2x2 tiles, see TileRec)
 //     acc  float[P][12]  backward accumulators: moments of u = G*dL/dalpha over the splat's pixels
 //                        {sum u, u*dx, u*dy, u*dx^2, u*dx*dy, u*dy^2}, dcolor.rgb, pad
 //   image blob     (gsr_image_bytes(W,H)):
@@ -17,7 +17,7 @@
 //     pairs u64[R] (depth bits << 32 | splat id, grouped per tile), point_list u32[R]
 //
 // The reference keeps 79 B/splat + 24 B/instance (rasterizer_impl.h:21-65); this
-// layout is 64 B/splat (+48 scratch) and 12 B/instance, and every per-splat
+// layout is 52 B/splat (+48 scratch) and 12 B/instance (+32 B of quad-hit log), and every per-splat
 // gather of the blend kernels is a 16-byte aligned vector load.
 #pragma once
 
@@ -38,31 +38,31 @@ struct GeomHeader {
 static_assert(sizeof(GeomHeader) == 256, "header is one aligned slot");
 
 // Per-tile binning record, padded to its own 64-byte line: device-scope atomics on
-// counters that share a line serialise (measured 12 vs 23 G atomics/s on MI355X).
-//   cnt_small : splats touching <= GSR_SLOTS tiles; the returning atomic at count time IS the
-//               splat's slot in the tile's segment, so the fill pass needs no atomic for them
-//   cnt_big   : splats touching more tiles; they take slots start+cnt_small+k in the fill pass
+// counters that share a line serialise (measured 12 vs 23 G atomics/s on MI355X), and the chip
+// retires only ~20 G device-scope atomics/s in total, so the count pass is built to issue as few
+// as possible: a splat whose tile rectangle is at most 2x2 (almost all of them) is counted with ONE
+// returning atomic on the class counter cls[(w-1) + 2*(h-1)] of its top-left ("anchor") tile, and
+// the value returned is its rank in that class. The scan kernel lays every tile's list segment out
+// as nine runs — one per (class, anchor) that covers the tile:
+//     run 0: 1x1 at t | 1: 2x1 at t | 2: 2x1 at t-(1,0) | 3: 1x2 at t | 4: 1x2 at t-(0,1)
+//     5: 2x2 at t | 6: 2x2 at t-(1,0) | 7: 2x2 at t-(0,1) | 8: 2x2 at t-(1,1)
+// run 0 starts at `start`, runs 1..8 at off[0..7]; the fill pass writes the splat at run start + rank
+// in each of its tiles with no further atomic. Larger rectangles are counted per tile in cnt_big and
+// take slots from cur_big in the fill pass.
+// (cnt_small is the plain per-bucket counter of the k-NN path, which shares the scan and sort kernels.)
 struct TileRec {
     uint32_t cnt_small, cnt_big, start, cur_big;
-    uint32_t pad[12];
+    uint32_t cls[4];
+    uint32_t off[8];
 };
 static_assert(sizeof(TileRec) == 64, "one cache line per tile");
-// The rasterizer counts two horizontally adjacent tiles (2k, 2k+1 of a tile row) with ONE 64-bit
-// atomic: low word = even tile, high word = odd tile. A splat is a few pixels wide, so most of
-// the tiles it touches come in such pairs: ~28 % fewer device-scope atomics in the count pass.
-struct PairRec {
-    unsigned long long cnt_small, cnt_big;
-    uint32_t pad[12];
-};
-static_assert(sizeof(PairRec) == 64, "one cache line per tile pair");
-#define GSR_SLOTS 4
 
 struct GeomView {
     GeomHeader* hdr;
     float4* g0;
     float4* g1;
     float4* col;
-    uint4* slots;
+    uint32_t* slots;
     float* acc;
 };
 struct ImageView {
@@ -70,7 +70,6 @@ struct ImageView {
     uint32_t* n_contrib;
     uint2* ranges;
     TileRec* tiles;
-    PairRec* tpairs;
     uint32_t* qcount; // [4*T] quad-hit records the forward blend wrote per 8x8 quad
 };
 struct BinView {
@@ -90,7 +89,7 @@ __host__ __device__ inline size_t geom_layout(char* base, int P, GeomView* v)
     g.g0 = (float4*)(base + off); off = gsr_align_up(off + Pz * 16);
     g.g1 = (float4*)(base + off); off = gsr_align_up(off + Pz * 16);
     g.col = (float4*)(base + off); off = gsr_align_up(off + Pz * 16);
-    g.slots = (uint4*)(base + off); off = gsr_align_up(off + Pz * 16);
+    g.slots = (uint32_t*)(base + off); off = gsr_align_up(off + Pz * 4);
     g.acc = (float*)(base + off); off = gsr_align_up(off + Pz * GSR_ACC_STRIDE * 4);
     if (v) *v = g;
     return off;
@@ -106,12 +105,6 @@ __host__ __device__ inline size_t image_layout(char* base, int W, int H, ImageVi
     g.n_contrib = (uint32_t*)(base + off); off = gsr_align_up(off + N * 4);
     g.ranges = (uint2*)(base + off); off = gsr_align_up(off + T * 8);
     g.tiles = (TileRec*)(base + off); off = gsr_align_up(off + T * sizeof(TileRec));
-    {
-        const size_t gx = (size_t)((W + GSR_TILE - 1) / GSR_TILE), gy = (size_t)((H + GSR_TILE - 1) / GSR_TILE);
-        size_t np = ((gx + 1) / 2) * gy;
-        if (np == 0) np = 1;
-        g.tpairs = (PairRec*)(base + off); off = gsr_align_up(off + np * sizeof(PairRec));
-    }
     g.qcount = (uint32_t*)(base + off); off = gsr_align_up(off + T * 16);
     if (v) *v = g;
     return off;

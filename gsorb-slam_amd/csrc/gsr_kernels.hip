@@ -54,7 +54,7 @@ __device__ __forceinline__ void load_cov3d(const SplatInputs& in, const FramePar
 
 __global__ void __launch_bounds__(256)
 K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomView g,
-             PairRec* __restrict__ tpairs)
+             TileRec* __restrict__ tiles)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= f.P) return;
@@ -88,30 +88,15 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
     g.g1[idx] = make_float4(pr.conic_c, in.opacities[idx], pr.p_view.z, __int_as_float(pr.radius));
     g.col[idx] = c;
     if (radii_out) radii_out[idx] = pr.radius;
-    // count the splat into its tiles (two horizontally adjacent tiles per 64-bit atomic); a splat with
-    // few tiles keeps the slot each atomic returns
+    // count the splat into its tiles: ONE returning atomic for a rectangle of at most 2x2 tiles (see TileRec)
     pr.y0 = max(pr.y0, f.band_y0); pr.y1 = max(pr.y0, min(pr.y1, f.band_y1)); // only the band's tile rows are binned
-    const int w = pr.x1 - pr.x0, ntl = w * (pr.y1 - pr.y0), pw = (f.grid_x + 1) >> 1;
-    if (ntl <= GSR_SLOTS) {
-        uint32_t sl[GSR_SLOTS + 1] = {0u, 0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int k = 0; k < GSR_SLOTS; k++) {
-            if (k >= ntl) continue;
-            const int x = pr.x0 + k % w, y = pr.y0 + k / w;
-            if ((x & 1) && x > pr.x0) continue; // counted together with its even neighbour
-            const bool odd_alone = (x & 1) != 0, with_next = !odd_alone && x + 1 < pr.x1;
-            const unsigned long long inc = odd_alone ? (1ull << 32) : (with_next ? ((1ull << 32) | 1ull) : 1ull);
-            const unsigned long long old = atomicAdd(&tpairs[y * pw + (x >> 1)].cnt_small, inc);
-            sl[k] = odd_alone ? (uint32_t)(old >> 32) : (uint32_t)old;
-            if (with_next) sl[k + 1] = (uint32_t)(old >> 32);
-        }
-        g.slots[idx] = make_uint4(sl[0], sl[1], sl[2], sl[3]);
+    const int w = pr.x1 - pr.x0, h = pr.y1 - pr.y0;
+    if (w * h == 0) return;
+    if (w <= 2 && h <= 2) {
+        g.slots[idx] = atomicAdd(&tiles[pr.y0 * f.grid_x + pr.x0].cls[(w - 1) + 2 * (h - 1)], 1u);
     } else {
         for (int y = pr.y0; y < pr.y1; y++)
-            for (int p = pr.x0 >> 1; p <= (pr.x1 - 1) >> 1; p++) {
-                const unsigned long long inc = (2 * p >= pr.x0 ? 1ull : 0ull) | (2 * p + 1 < pr.x1 ? (1ull << 32) : 0ull);
-                atomicAdd(&tpairs[y * pw + p].cnt_big, inc);
-            }
+            for (int x = pr.x0; x < pr.x1; x++) atomicAdd(&tiles[y * f.grid_x + x].cnt_big, 1u);
     }
 }
 
@@ -139,19 +124,32 @@ K_mark_visible(int P, const float* __restrict__ means3D, const float* __restrict
 // ===================================================================================
 // tile binning
 // ===================================================================================
-// PAIRED: the counts come from the rasterizer's PairRec array (tile (ty,tx) = word tx&1 of pair
-// ty*pw + tx/2); otherwise from the TileRec's own counters (the k-NN buckets).
-template <bool PAIRED>
+// One block: per-tile counts -> list segments (start, the nine run offsets, cursor of the big splats),
+// ranges, num_rendered and the overflow flag.
+template <bool RASTER>
 __global__ void __launch_bounds__(1024)
 K_scan_tiles(int T, TileRec* __restrict__ tiles, uint2* __restrict__ ranges,
-             GeomHeader* __restrict__ hdr, uint32_t capacity, const PairRec* __restrict__ tpairs, int grid_x)
+             GeomHeader* __restrict__ hdr, uint32_t capacity, int grid_x)
 {
+    // RASTER: the nine (class, anchor) runs that cover tile i (TileRec); otherwise the record's own counters
+    auto runs = [&](int i, uint32_t (&c)[9]) {
+        const int ty = i / grid_x, tx = i - ty * grid_x;
+        const bool L = tx > 0, U = ty > 0;
+        const TileRec& t = tiles[i];
+        c[0] = t.cls[0]; c[1] = t.cls[1]; c[3] = t.cls[2]; c[5] = t.cls[3];
+        c[2] = L ? tiles[i - 1].cls[1] : 0u;
+        c[6] = L ? tiles[i - 1].cls[3] : 0u;
+        c[4] = U ? tiles[i - grid_x].cls[2] : 0u;
+        c[7] = U ? tiles[i - grid_x].cls[3] : 0u;
+        c[8] = (L && U) ? tiles[i - grid_x - 1].cls[3] : 0u;
+    };
     auto counts = [&](int i, uint32_t& cs, uint32_t& cb) {
-        if (PAIRED) {
-            const int ty = i / grid_x, tx = i - ty * grid_x, sh = (tx & 1) * 32;
-            const PairRec& r = tpairs[ty * ((grid_x + 1) >> 1) + (tx >> 1)];
-            cs = (uint32_t)(r.cnt_small >> sh); cb = (uint32_t)(r.cnt_big >> sh);
-        } else { cs = tiles[i].cnt_small; cb = tiles[i].cnt_big; }
+        if (RASTER) {
+            uint32_t c[9];
+            runs(i, c);
+            cs = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] + c[8];
+        } else cs = tiles[i].cnt_small;
+        cb = tiles[i].cnt_big;
     };
     // each thread owns `per` consecutive tiles (its counts stay in registers when per <= 8), the block
     // scan is one shuffle scan per wave plus one over the 16 wave totals: two barriers in all
@@ -192,6 +190,13 @@ K_scan_tiles(int T, TileRec* __restrict__ tiles, uint2* __restrict__ ranges,
         ranges[i] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u); // empty tiles read (0,0) like the reference's memset
         tiles[i].start = run;
         tiles[i].cur_big = run + cs;
+        if (RASTER) {
+            uint32_t k[9];
+            runs(i, k);
+            uint32_t o = run + k[0];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { tiles[i].off[j] = o; o += k[j + 1]; }
+        }
         run += c;
     };
     if (per <= 8) {
@@ -223,13 +228,22 @@ K_fill(int P, int grid_x, int grid_y, int band_y0, int band_y1, GeomView g, Tile
     tile_rect(a.x, a.y, radius, grid_x, grid_y, x0, y0, x1, y1);
     y0 = max(y0, band_y0); y1 = max(y0, min(y1, band_y1)); // same clipping as the count pass
     const uint64_t key = ((uint64_t)__float_as_uint(b.z) << 32) | (uint32_t)idx;
-    const int w = x1 - x0, ntl = w * (y1 - y0);
-    if (ntl <= GSR_SLOTS) { // slots were assigned when the splat was counted: no atomics
-        const uint4 s4 = g.slots[idx];
-        const uint32_t sl[GSR_SLOTS] = {s4.x, s4.y, s4.z, s4.w};
+    const int w = x1 - x0, h = y1 - y0;
+    if (w * h == 0) return;
+    if (w <= 2 && h <= 2) { // the rank was taken when the splat was counted: no atomics
+        const uint32_t rank = g.slots[idx];
+        const int cls = (w - 1) + 2 * (h - 1);
+        // run of (class, this anchor) inside the tile at anchor + (dx, dy)   (see TileRec)
+        const int first = cls == 0 ? 0 : cls == 1 ? 1 : cls == 2 ? 3 : 5;
 #pragma unroll
-        for (int k = 0; k < GSR_SLOTS; k++)
-            if (k < ntl) pairs[tiles[(y0 + k / w) * grid_x + x0 + k % w].start + sl[k]] = key;
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 2; dx++) {
+                if (dx >= w || dy >= h) continue;
+                const int run = first + (cls == 3 ? dx + 2 * dy : dx + dy);
+                const TileRec& t = tiles[(y0 + dy) * grid_x + x0 + dx];
+                pairs[(run == 0 ? t.start : t.off[run - 1]) + rank] = key;
+            }
     } else {
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++) pairs[atomicAdd(&tiles[y * grid_x + x].cur_big, 1u)] = key;
