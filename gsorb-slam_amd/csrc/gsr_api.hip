@@ -114,7 +114,8 @@ int forward_head(const gsr_forward_args* a, char* geom, char* image, hipStream_t
     GSR_LAUNCHED();
     tm.end(GSR_FWD_PREPROCESS);
     tm.begin(GSR_FWD_SCAN);
-    hipLaunchKernelGGL(gsr::K_scan_tiles<true>, dim3(1), dim3(1024), 0, st, T, iv->tiles, iv->ranges, gv->hdr, capacity, f.grid_x);
+    hipLaunchKernelGGL(gsr::K_tile_runs, dim3(blocks256(T)), dim3(256), 0, st, T, f.grid_x, iv->tiles);
+    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, T, iv->tiles, iv->ranges, gv->hdr, capacity);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SCAN);
     *fo = f;
@@ -325,7 +326,7 @@ int gsr_dist2(int P, const float* points, float* mean_dists, char* workspace, si
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_knn_code, dim3(blocks256(P)), dim3(256), 0, st, P, shift, points, k.bbox, k.buckets, k.code, k.slot);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_scan_tiles<false>, dim3(1), dim3(1024), 0, st, nb, k.buckets, k.ranges, k.hdr, 0xFFFFFFFFu, 1);
+    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, nb, k.buckets, k.ranges, k.hdr, 0xFFFFFFFFu);
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_knn_fill, dim3(blocks256(P)), dim3(256), 0, st, P, shift, k.code, k.slot, k.buckets, k.pairs);
     GSR_LAUNCHED();

@@ -46,7 +46,7 @@ static_assert(sizeof(GeomHeader) == 256, "header is one aligned slot");
 // as nine runs — one per (class, anchor) that covers the tile:
 //     run 0: 1x1 at t | 1: 2x1 at t | 2: 2x1 at t-(1,0) | 3: 1x2 at t | 4: 1x2 at t-(0,1)
 //     5: 2x2 at t | 6: 2x2 at t-(1,0) | 7: 2x2 at t-(0,1) | 8: 2x2 at t-(1,1)
-// run 0 starts at `start`, runs 1..8 at off[0..7]; the fill pass writes the splat at run start + rank
+// run 0 starts at `start`, runs 1..8 at start + off[0..7]; the fill pass writes the splat at run start + rank
 // in each of its tiles with no further atomic. Larger rectangles are counted per tile in cnt_big and
 // take slots from cur_big in the fill pass.
 // (cnt_small is the plain per-bucket counter of the k-NN path, which shares the scan and sort kernels.)

@@ -124,33 +124,38 @@ K_mark_visible(int P, const float* __restrict__ means3D, const float* __restrict
 // ===================================================================================
 // tile binning
 // ===================================================================================
-// One block: per-tile counts -> list segments (start, the nine run offsets, cursor of the big splats),
-// ranges, num_rendered and the overflow flag.
-template <bool RASTER>
+// Per tile: the nine (class, anchor) runs that cover it (TileRec) -> cnt_small = their sum, off[j] = where
+// run j+1 starts relative to the segment start. One thread per tile; the one-block scan below then only
+// reads two counters per tile.
+__global__ void __launch_bounds__(256)
+K_tile_runs(int T, int grid_x, TileRec* __restrict__ tiles)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T) return;
+    const int ty = i / grid_x, tx = i - ty * grid_x;
+    const bool L = tx > 0, U = ty > 0;
+    const uint4 me = *reinterpret_cast<const uint4*>(tiles[i].cls);
+    const uint4 le = L ? *reinterpret_cast<const uint4*>(tiles[i - 1].cls) : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 up = U ? *reinterpret_cast<const uint4*>(tiles[i - grid_x].cls) : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t ul = (L && U) ? tiles[i - grid_x - 1].cls[3] : 0u;
+    const uint32_t c[9] = {me.x, me.y, le.y, me.z, up.z, me.w, le.w, up.w, ul};
+    uint32_t o = c[0];
+    uint32_t off[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { off[j] = o; o += c[j + 1]; }
+    tiles[i].cnt_small = o;
+    uint4* const dst = reinterpret_cast<uint4*>(tiles[i].off);
+    dst[0] = make_uint4(off[0], off[1], off[2], off[3]);
+    dst[1] = make_uint4(off[4], off[5], off[6], off[7]);
+}
+
+// One block: per-tile counts (cnt_small, cnt_big) -> list segments (start, cursor of the big splats),
+// ranges, num_rendered and the overflow flag. Shared with the k-NN path (buckets instead of tiles).
 __global__ void __launch_bounds__(1024)
 K_scan_tiles(int T, TileRec* __restrict__ tiles, uint2* __restrict__ ranges,
-             GeomHeader* __restrict__ hdr, uint32_t capacity, int grid_x)
+             GeomHeader* __restrict__ hdr, uint32_t capacity)
 {
-    // RASTER: the nine (class, anchor) runs that cover tile i (TileRec); otherwise the record's own counters
-    auto runs = [&](int i, uint32_t (&c)[9]) {
-        const int ty = i / grid_x, tx = i - ty * grid_x;
-        const bool L = tx > 0, U = ty > 0;
-        const TileRec& t = tiles[i];
-        c[0] = t.cls[0]; c[1] = t.cls[1]; c[3] = t.cls[2]; c[5] = t.cls[3];
-        c[2] = L ? tiles[i - 1].cls[1] : 0u;
-        c[6] = L ? tiles[i - 1].cls[3] : 0u;
-        c[4] = U ? tiles[i - grid_x].cls[2] : 0u;
-        c[7] = U ? tiles[i - grid_x].cls[3] : 0u;
-        c[8] = (L && U) ? tiles[i - grid_x - 1].cls[3] : 0u;
-    };
-    auto counts = [&](int i, uint32_t& cs, uint32_t& cb) {
-        if (RASTER) {
-            uint32_t c[9];
-            runs(i, c);
-            cs = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7] + c[8];
-        } else cs = tiles[i].cnt_small;
-        cb = tiles[i].cnt_big;
-    };
+    auto counts = [&](int i, uint32_t& cs, uint32_t& cb) { cs = tiles[i].cnt_small; cb = tiles[i].cnt_big; };
     // each thread owns `per` consecutive tiles (its counts stay in registers when per <= 8), the block
     // scan is one shuffle scan per wave plus one over the 16 wave totals: two barriers in all
     __shared__ uint32_t wsum[16];
@@ -190,13 +195,6 @@ K_scan_tiles(int T, TileRec* __restrict__ tiles, uint2* __restrict__ ranges,
         ranges[i] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u); // empty tiles read (0,0) like the reference's memset
         tiles[i].start = run;
         tiles[i].cur_big = run + cs;
-        if (RASTER) {
-            uint32_t k[9];
-            runs(i, k);
-            uint32_t o = run + k[0];
-#pragma unroll
-            for (int j = 0; j < 8; j++) { tiles[i].off[j] = o; o += k[j + 1]; }
-        }
         run += c;
     };
     if (per <= 8) {
@@ -242,7 +240,7 @@ K_fill(int P, int grid_x, int grid_y, int band_y0, int band_y1, GeomView g, Tile
                 if (dx >= w || dy >= h) continue;
                 const int run = first + (cls == 3 ? dx + 2 * dy : dx + dy);
                 const TileRec& t = tiles[(y0 + dy) * grid_x + x0 + dx];
-                pairs[(run == 0 ? t.start : t.off[run - 1]) + rank] = key;
+                pairs[t.start + (run == 0 ? 0u : t.off[run - 1]) + rank] = key;
             }
     } else {
         for (int y = y0; y < y1; y++)
