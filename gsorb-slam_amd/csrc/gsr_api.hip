@@ -77,7 +77,7 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     const int P = a->P, T = f.grid_x * f.grid_y;
     const StageTimer tm{a->profile_events, st};
     tm.begin(GSR_FWD_FILL);
-    hipLaunchKernelGGL(gsr::K_fill, dim3(blocks256(P)), dim3(256), 0, st, P, f.grid_x, f.grid_y, f.band_y0, f.band_y1, gv, iv.tiles, bv.pairs);
+    hipLaunchKernelGGL(gsr::K_fill, dim3(blocks256(P)), dim3(256), 0, st, P, f.grid_x, gv, iv.tiles, bv.pairs);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_FILL);
     tm.begin(GSR_FWD_SORT);

@@ -9,7 +9,8 @@
 //     g1   float4[P]  {conic_c, opacity, depth, radius}  radius stored as int bits
 //     col  float4[P]  {r, g, b, clamp-flags}             colour the blend uses (SH result or
 //                                                        copy of colors_precomp)
-//     slots u32[P]       rank of the splat in its class counter (rectangles up to 2x2 tiles, see TileRec)
+//     slots uint4[P]     what the fill pass needs: rank in the class counter (rectangles up to 2x2 tiles,
+//                        see TileRec), depth bits, band-clipped tile rectangle
 //     acc  float[P][12]  backward accumulators: moments of u = G*dL/dalpha over the splat's pixels
 //                        {sum u, u*dx, u*dy, u*dx^2, u*dx*dy, u*dy^2}, dcolor.rgb, pad
 //   image blob     (gsr_image_bytes(W,H)):
@@ -79,7 +80,7 @@ struct GeomView {
 #else
     float4* col;
 #endif
-    uint32_t* slots;
+    uint4* slots; // {rank in the class counter, depth bits, x0 | y0 << 16, x1 | y1 << 16} (band-clipped tile rectangle; x1 == x0: not binned)
     float* acc;
 };
 struct ImageView {
@@ -112,7 +113,7 @@ __host__ __device__ inline size_t geom_layout(char* base, int P, GeomView* v)
     off = gsr_align_up(off + Pz * 32);
     g.col = (float4*)(base + off); off = gsr_align_up(off + Pz * 16);
 #endif
-    g.slots = (uint32_t*)(base + off); off = gsr_align_up(off + Pz * 4);
+    g.slots = (uint4*)(base + off); off = gsr_align_up(off + Pz * 16);
     g.acc = (float*)(base + off); off = gsr_align_up(off + Pz * GSR_ACC_STRIDE * 4);
     if (v) *v = g;
     return off;

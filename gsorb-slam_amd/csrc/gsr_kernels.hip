@@ -69,6 +69,7 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
     const bool vis = project_splat(p, cov, f, in.view, in.proj, pr);
     if (!vis) {
         g.g1[idx] = make_float4(0.f, 0.f, 0.f, 0.f); // radius 0 marks the splat invisible
+        g.slots[idx] = make_uint4(0u, 0u, 0u, 0u);
         if (radii_out) radii_out[idx] = 0;
         return;
     }
@@ -91,10 +92,14 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
     // count the splat into its tiles: ONE returning atomic for a rectangle of at most 2x2 tiles (see TileRec)
     pr.y0 = max(pr.y0, f.band_y0); pr.y1 = max(pr.y0, min(pr.y1, f.band_y1)); // only the band's tile rows are binned
     const int w = pr.x1 - pr.x0, h = pr.y1 - pr.y0;
-    if (w * h == 0) return;
+    const uint32_t zbits = __float_as_uint(pr.p_view.z);
+    const uint32_t r0 = (uint32_t)pr.x0 | ((uint32_t)pr.y0 << 16), r1 = (uint32_t)pr.x1 | ((uint32_t)pr.y1 << 16);
+    if (w * h == 0) { g.slots[idx] = make_uint4(0u, 0u, 0u, 0u); return; }
     if (w <= 2 && h <= 2) {
-        g.slots[idx] = atomicAdd(&tiles[pr.y0 * f.grid_x + pr.x0].cls[(w - 1) + 2 * (h - 1)], 1u);
+        const uint32_t rank = atomicAdd(&tiles[pr.y0 * f.grid_x + pr.x0].cls[(w - 1) + 2 * (h - 1)], 1u);
+        g.slots[idx] = make_uint4(rank, zbits, r0, r1);
     } else {
+        g.slots[idx] = make_uint4(0u, zbits, r0, r1);
         for (int y = pr.y0; y < pr.y1; y++)
             for (int x = pr.x0; x < pr.x1; x++) atomicAdd(&tiles[y * f.grid_x + x].cnt_big, 1u);
     }
@@ -213,23 +218,17 @@ K_scan_tiles(int T, TileRec* __restrict__ tiles, uint2* __restrict__ ranges,
 }
 
 __global__ void __launch_bounds__(256)
-K_fill(int P, int grid_x, int grid_y, int band_y0, int band_y1, GeomView g, TileRec* __restrict__ tiles,
-       uint64_t* __restrict__ pairs)
+K_fill(int P, int grid_x, GeomView g, TileRec* __restrict__ tiles, uint64_t* __restrict__ pairs)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P || g.hdr->overflow) return;
-    const float4 b = g.g1[idx];
-    const int radius = __float_as_int(b.w);
-    if (radius <= 0) return;
-    const float4 a = g.g0[idx];
-    int x0, y0, x1, y1;
-    tile_rect(a.x, a.y, radius, grid_x, grid_y, x0, y0, x1, y1);
-    y0 = max(y0, band_y0); y1 = max(y0, min(y1, band_y1)); // same clipping as the count pass
-    const uint64_t key = ((uint64_t)__float_as_uint(b.z) << 32) | (uint32_t)idx;
+    const uint4 br = g.slots[idx]; // everything this pass needs, written by K_preprocess
+    const int x0 = (int)(br.z & 0xFFFFu), y0 = (int)(br.z >> 16), x1 = (int)(br.w & 0xFFFFu), y1 = (int)(br.w >> 16);
+    const uint64_t key = ((uint64_t)br.y << 32) | (uint32_t)idx;
     const int w = x1 - x0, h = y1 - y0;
     if (w * h == 0) return;
     if (w <= 2 && h <= 2) { // the rank was taken when the splat was counted: no atomics
-        const uint32_t rank = g.slots[idx];
+        const uint32_t rank = br.x;
         const int cls = (w - 1) + 2 * (h - 1);
         // run of (class, this anchor) inside the tile at anchor + (dx, dy)   (see TileRec)
         const int first = cls == 0 ? 0 : cls == 1 ? 1 : cls == 2 ? 3 : 5;
