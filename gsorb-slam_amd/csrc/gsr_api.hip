@@ -155,6 +155,22 @@ const char* gsr_error_string(int code)
 }
 const char* gsr_last_hip_error(void) { return hipGetErrorString(t_last_hip); }
 
+// one pinned word + one event per host thread (never freed: a thread renders for the life of the process)
+struct Staging {
+    uint32_t* host = nullptr;
+    hipEvent_t ev = nullptr;
+    bool tried = false;
+    bool ready()
+    {
+        if (!tried) {
+            tried = true;
+            if (hipHostMalloc((void**)&host, 64, hipHostMallocDefault) != hipSuccess) host = nullptr;
+            if (host && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(host); host = nullptr; }
+        }
+        return host != nullptr;
+    }
+};
+
 int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geom_alloc, void* geom_user,
                 gsr_alloc_fn binning_alloc, void* binning_user, gsr_alloc_fn image_alloc,
                 void* image_user, void* stream)
@@ -172,20 +188,49 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geom_alloc, void* geom_u
         const int rc = forward_empty(a, geom, st);
         return rc != GSR_OK ? rc : 0;
     }
-    GeomView gv; ImageView iv; FrameParams f;
-    int rc = forward_head(a, geom, image, st, 0xFFFFFFFFu, &gv, &iv, &f);
-    if (rc != GSR_OK) return rc;
-    // the one device->host read of the forward (reference rasterizer_impl.cu:285)
-    uint32_t R = 0;
-    GSR_HIP(hipMemcpyAsync(&R, &gv.hdr->num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    GSR_HIP(hipStreamSynchronize(st));
-    if (R > 0x7FFFFFFFu) return GSR_EOVERFLOW;
-    char* binning = binning_alloc(binning_user, gsr_binning_bytes(R));
+    // The binning blob must be sized before num_rendered is known on the host (the one device->host read of
+    // the forward, reference rasterizer_impl.cu:285). Instead of stalling the GPU while the host waits for
+    // that number, the blob is requested with a capacity guessed from this thread's previous frames and the
+    // tail kernels are enqueued right behind the head; the host then waits only for the head. A guess that
+    // turns out too small costs one more request and a second tail (its first run exits on the overflow flag).
+    static thread_local uint32_t t_last_R = 0;
+    static thread_local Staging t_stage;
+    const uint32_t floor_c = (uint32_t)std::min<size_t>((size_t)a->P * 4 + 4096, 0x7FFFFFFFu);
+    const uint32_t guess = std::max(floor_c, (uint32_t)std::min<size_t>((size_t)t_last_R + t_last_R / 4 + 4096, 0x7FFFFFFFu));
+    char* binning = binning_alloc(binning_user, gsr_binning_bytes(guess));
     if (!binning) return GSR_EALLOC;
+    GeomView gv; ImageView iv; FrameParams f;
+    int rc = forward_head(a, geom, image, st, guess, &gv, &iv, &f);
+    if (rc != GSR_OK) return rc;
+    uint32_t R = 0;
+    const bool staged = t_stage.ready();
+    if (staged) {
+        GSR_HIP(hipMemcpyAsync(t_stage.host, &gv.hdr->num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipEventRecord(t_stage.ev, st));
+    } else { // no pinned staging word: plain blocking read
+        GSR_HIP(hipMemcpyAsync(&R, &gv.hdr->num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipStreamSynchronize(st));
+    }
     BinView bv;
-    binning_layout(binning, R, &bv);
+    binning_layout(binning, guess, &bv);
     rc = forward_tail(a, gv, iv, bv, f, st);
-    return rc != GSR_OK ? rc : (int)R;
+    if (rc != GSR_OK) return rc;
+    if (staged) {
+        GSR_HIP(hipEventSynchronize(t_stage.ev));
+        R = *t_stage.host;
+    }
+    if (R > 0x7FFFFFFFu) return GSR_EOVERFLOW;
+    t_last_R = R;
+    if (R > guess) {
+        binning = binning_alloc(binning_user, gsr_binning_bytes(R));
+        if (!binning) return GSR_EALLOC;
+        hipLaunchKernelGGL(gsr::K_set_capacity, dim3(1), dim3(1), 0, st, gv.hdr, R);
+        GSR_LAUNCHED();
+        binning_layout(binning, R, &bv);
+        rc = forward_tail(a, gv, iv, bv, f, st);
+        if (rc != GSR_OK) return rc;
+    }
+    return (int)R;
 }
 
 int gsr_forward_ws(const gsr_forward_args* a, char* geom, char* binning, size_t binning_bytes,
@@ -230,15 +275,10 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
     const int P = a->P, W = a->width, H = a->height;
     const FrameParams f = frame_params(P, a->D, a->M, W, H, a->tan_fovx, a->tan_fovy, a->scale_modifier, a->band_y0, a->band_y1);
     const int T = f.grid_x * f.grid_y;
-    GeomView gv; ImageView iv; BinView bv;
+    GeomView gv; ImageView iv;
     geom_layout(a->geom_buffer, P, &gv);
     image_layout(a->image_buffer, W, H, &iv);
-    if (a->R >= 0) binning_layout(a->binning_buffer, (size_t)a->R, &bv);
-    else { // workspace mode: the layout was fixed by the capacity, which follows from the size
-        const size_t cap = binning_capacity(a->binning_bytes);
-        if (cap == 0) return GSR_EINVAL;
-        binning_layout(a->binning_buffer, cap, &bv);
-    }
+    // (the binning blob's layout follows the capacity the forward ran with; the kernel reads it from the header)
     const StageTimer tm{a->profile_events, st};
     const int stages = a->stages ? a->stages : (GSR_STAGE_BLEND | GSR_STAGE_SPLAT); // accumulators are clean by invariant
     const int Tb = (f.band_y1 - f.band_y0) * f.grid_x;
@@ -249,7 +289,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
     }
     if ((stages & GSR_STAGE_BLEND) && Tb > 0) {
         tm.begin(GSR_BWD_BLEND);
-        hipLaunchKernelGGL(gsr::K_blend_bwd<GSR_ROWQ>, dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, W, H, f.grid_x, Tb,
+        hipLaunchKernelGGL(gsr::K_blend_bwd<GSR_ROWQ>, dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, W, H, f.grid_x, Tb,
                            f.band_y0 * f.grid_x, a->dL_dpix);
         GSR_LAUNCHED();
         tm.end(GSR_BWD_BLEND);
@@ -360,7 +400,10 @@ int gsr_debug_export(int P, int width, int height, int R, const char* geom, cons
     if (out->final_T) GSR_HIP(hipMemcpyAsync(out->final_T, iv.final_T, N * 4, hipMemcpyDeviceToDevice, st));
     if (out->n_contrib) GSR_HIP(hipMemcpyAsync(out->n_contrib, iv.n_contrib, N * 4, hipMemcpyDeviceToDevice, st));
     if (binning && R > 0) {
-        binning_layout(const_cast<char*>(binning), (size_t)R, &bv);
+        GeomHeader h;
+        GSR_HIP(hipMemcpyAsync(&h, geom, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipStreamSynchronize(st));
+        binning_layout(const_cast<char*>(binning), (size_t)h.capacity, &bv);
         if (out->point_list) GSR_HIP(hipMemcpyAsync(out->point_list, bv.point_list, (size_t)R * 4, hipMemcpyDeviceToDevice, st));
         if (out->point_list_keys) {
             hipLaunchKernelGGL(gsr::K_export_keys, dim3(T), dim3(256), 0, st, T, iv.ranges, bv.point_list, gv, out->point_list_keys);

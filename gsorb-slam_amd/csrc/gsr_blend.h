@@ -168,7 +168,7 @@ __device__ __forceinline__ float row_reduce9(const float (&v)[9], int l, float e
 
 template <int Q>
 __global__ void __launch_bounds__(64)
-K_blend_bwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
+K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* __restrict__ bg, int W, int H,
                  int grid_x, int ntiles, int tile0, const float* __restrict__ dL_dpix)
 {
     __shared__ float4 E0[Q], E1[Q], E2[Q]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, list position, splat id, -)
@@ -181,10 +181,11 @@ K_blend_bwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
     const int X0 = tx * 16 + (int)(quad & 1u) * 8, Y0 = ty * 16 + (int)(quad >> 1) * 8;
     const int px = X0 + (r & 1) * 4 + (l & 3), py = Y0 + (r >> 1) * 4 + (l >> 2);
     const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py, X0f = (float)X0, Y0f = (float)Y0;
+    const float pxf = (float)px, pyf = (float)py;
     const uint2 range = im.ranges[tile];
     const int n = g.hdr->overflow ? 0 : (int)(range.y - range.x);
-    const uint32_t* __restrict__ plist = bn.point_list + range.x;
+    BinView bn; // the layout of the binning blob follows the capacity the forward ran with (kept in the header)
+    binning_layout(binning, (size_t)g.hdr->capacity, &bn);
     const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
 
     const float T_final = inside ? im.final_T[pix] : 0.f;

@@ -217,6 +217,13 @@ K_scan_tiles(int T, TileRec* __restrict__ tiles, uint2* __restrict__ ranges,
     }
 }
 
+// the forward's capacity guess was too small: switch the header to the exact capacity before the tail re-runs
+__global__ void K_set_capacity(GeomHeader* hdr, uint32_t capacity)
+{
+    hdr->capacity = capacity;
+    hdr->overflow = hdr->num_rendered > capacity ? 1u : 0u;
+}
+
 __global__ void __launch_bounds__(256)
 K_fill(int P, int grid_x, GeomView g, TileRec* __restrict__ tiles, uint64_t* __restrict__ pairs)
 {

@@ -98,7 +98,9 @@ int gsr_forward_ws(const gsr_forward_args* args, char* geom, char* binning, size
 int gsr_ws_status(const char* geom, void* stream, int* num_rendered, int* overflow);
 
 /* Arguments of Rasterizer::backward (rasterizer.h:60-88). R is what gsr_forward
- * returned; pass R < 0 and binning_bytes after gsr_forward_ws (num_rendered stays on the device). */
+ * returned; pass R < 0 after gsr_forward_ws (num_rendered stays on the device). The layout of the binning
+ * blob follows the capacity the forward ran with, which the kernels read from the geometry header: R and
+ * binning_bytes are not needed to find anything. */
 typedef struct gsr_backward_args {
     int P, D, M, R;
     const float* background;
@@ -118,7 +120,7 @@ typedef struct gsr_backward_args {
     char* geom_buffer;           /* the three blobs of the matching forward; geom is also scratch */
     char* binning_buffer;
     char* image_buffer;
-    size_t binning_bytes;        /* only read when R < 0: the size given to gsr_forward_ws */
+    size_t binning_bytes;        /* unused (kept for layout compatibility of the struct) */
     const float* dL_dpix;        /* [3,H,W] */
     /* Outputs. Unlike the reference (src/Rasterizer.cu:253-261 zero-fills nine
      * tensors first) every non-NULL output is FULLY written, zeros included,

@@ -5,7 +5,7 @@ R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0
 from conftest import load_package
 gsr=load_package(); syn=gsr.synthetic
 import diff_gaussian_rasterization as dgr
-for P in (300000, 1000000):
+for P in (30000, 300000, 1000000):
     cam=syn.make_camera(**syn.REPLICA); sc=syn.make_scene(P,cam,seed=0)
     t=lambda a: torch.tensor(a,dtype=torch.float32,device='cuda')
     st=dgr.GaussianRasterizationSettings(cam.height,cam.width,cam.tanfovx,cam.tanfovy,t(cam.bg),1.0,t(cam.viewmatrix),t(cam.projmatrix),0,t(cam.campos),False)

@@ -282,3 +282,44 @@ def test_backward_twice_on_one_forward_state(gsr, syn):
     for n, r in ref.items():
         err = float((getattr(g3, n) - r).abs().max() / (r.abs().max() + 1e-30))
         assert err < 1e-5, (n, err)
+
+
+@pytest.mark.gpu
+def test_forward_capacity_guess_too_small_reruns_the_tail(gsr, syn):
+    """gsr_forward sizes the binning blob from a per-thread guess and enqueues the tail before it knows
+    num_rendered; a fresh thread starts with the floor 4P+4096, which a fat scene (R/P ~ 8) exceeds: the
+    second request + second tail must give exactly what a call with a sufficient guess gives."""
+    import threading
+    import torch
+    capi = gsr.capi
+    cam = syn.make_camera(**syn.TUM1)
+    sc = syn.make_scene(10000, cam, seed=3, scale_mult=4.0, color_mode="depth")
+    dev = torch.device("cuda:0")
+    s = capi.Settings.from_camera(cam, dev)
+    t = lambda a: torch.tensor(a, device=dev)
+    kw = dict(means3D=t(sc.means3D), opacities=t(sc.opacities), colors=t(sc.colors), scales=t(sc.scales), rotations=t(sc.rotations))
+    out = {}
+
+    def run():
+        with torch.cuda.device(dev):
+            a = capi.forward(s, **kw)          # fresh thread: floor guess, too small
+            ga = capi.backward(a, t(sc.dL_dpix))
+            b = capi.forward(s, **kw)          # guess from the previous frame: large enough
+            out.update(a=a, b=b, ga=ga, da=capi.debug_export(a), db=capi.debug_export(b))
+            torch.cuda.synchronize()
+
+    th = threading.Thread(target=run)
+    th.start()
+    th.join()
+    a, b = out["a"], out["b"]
+    assert a.num_rendered == b.num_rendered and a.num_rendered > 4 * 10000 + 4096
+    assert a.binning.numel() < b.binning.numel()          # exact size after the re-run, guess (R*1.25) afterwards
+    assert torch.equal(a.color, b.color) and torch.equal(a.depth, b.depth)
+    np.testing.assert_array_equal(out["da"]["point_list"], out["db"]["point_list"])
+    o, f = oracle.forward_scene(sc)
+    assert a.num_rendered == f.num_rendered
+    np.testing.assert_array_equal(out["da"]["point_list"], f.stages["point_list"])
+    gb = capi.backward(b, t(sc.dL_dpix))
+    for n in ("dL_dmeans3D", "dL_dopacity", "dL_dscales"):
+        x, y = getattr(out["ga"], n), getattr(gb, n)
+        assert float((x - y).abs().max() / (y.abs().max() + 1e-30)) < 1e-5
