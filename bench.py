@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--splats", type=int, default=1_000_000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--scale-mult", type=float, default=1.0, help="splat size multiplier (1 = the headline workload; >1: fatter splats, for experiments)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,7 +95,7 @@ def main():
     P = a.splats
     cam = syn.make_camera(**syn.REPLICA)
     W, H = cam.width, cam.height
-    sc = syn.make_scene(P, cam, seed=rank)  # each rank: its own scene shard
+    sc = syn.make_scene(P, cam, seed=rank, scale_mult=a.scale_mult)  # each rank: its own scene shard
     s = gsr.capi.Settings.from_camera(cam, device=dev)
     t = lambda x: torch.as_tensor(x, dtype=torch.float32, device=dev).contiguous()
     ins = dict(means3D=t(sc.means3D), opacities=t(sc.opacities), colors=t(sc.colors), shs=None,

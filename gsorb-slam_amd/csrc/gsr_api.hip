@@ -77,7 +77,9 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     const int P = a->P, T = f.grid_x * f.grid_y;
     const StageTimer tm{a->profile_events, st};
     tm.begin(GSR_FWD_FILL);
-    hipLaunchKernelGGL(gsr::K_fill, dim3(blocks256(P)), dim3(256), 0, st, P, f.grid_x, gv, iv.tiles, bv.pairs);
+    hipLaunchKernelGGL(gsr::K_anchor_table, dim3(T), dim3(GSR_ANCHOR_ROW), 0, st, T, f.grid_x, iv.tiles, iv.tier2, iv.run4, iv.anchor);
+    GSR_LAUNCHED();
+    hipLaunchKernelGGL(gsr::K_fill, dim3(blocks256(P)), dim3(256), 0, st, P, f.grid_x, gv, iv.tiles, iv.anchor, bv.pairs);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_FILL);
     tm.begin(GSR_FWD_SORT);
@@ -109,12 +111,12 @@ int forward_head(const gsr_forward_args* a, char* geom, char* image, hipStream_t
                                              a->projmatrix, a->cam_pos);
     const StageTimer tm{a->profile_events, st};
     tm.begin(GSR_FWD_PREPROCESS);
-    GSR_HIP(hipMemsetAsync(iv->tiles, 0, (size_t)T * sizeof(TileRec), st));
-    hipLaunchKernelGGL(gsr::K_preprocess, dim3(blocks256(P)), dim3(256), 0, st, f, in, a->radii, *gv, iv->tiles);
+    GSR_HIP(hipMemsetAsync(iv->tiles, 0, (size_t)T * (sizeof(TileRec) + sizeof(Cls4Rec)) + 256, st)); // tiles, cls4, tier2
+    hipLaunchKernelGGL(gsr::K_preprocess, dim3(blocks256(P)), dim3(256), 0, st, f, in, a->radii, *gv, iv->tiles, iv->cls4, iv->tier2);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_PREPROCESS);
     tm.begin(GSR_FWD_SCAN);
-    hipLaunchKernelGGL(gsr::K_tile_runs, dim3(blocks256(T)), dim3(256), 0, st, T, f.grid_x, iv->tiles);
+    hipLaunchKernelGGL(gsr::K_tile_runs, dim3((T + 15) / 16), dim3(256), 0, st, T, f.grid_x, iv->tiles, iv->cls4, iv->tier2, iv->run4);
     hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, T, iv->tiles, iv->ranges, gv->hdr, capacity);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SCAN);

@@ -58,6 +58,22 @@ struct TileRec {
     uint32_t off[8];
 };
 static_assert(sizeof(TileRec) == 64, "one cache line per tile");
+// Second tier of the same scheme for rectangles up to 4x4 tiles that are not <= 2x2 (fat splats): class
+// counter c[(w-1) + 4*(h-1)] of the anchor tile, again one returning atomic per splat. A tile is covered
+// by up to 16 anchors (dx, dy in 0..3 to its upper left) x the classes wide/high enough to reach it: its
+// runs are laid out behind the nine first-tier runs, run4[(dy*4+dx)*16 + class] = offset from `start`.
+// `tier2` (one word per frame, next to the records) tells the run kernel whether any such splat exists.
+struct Cls4Rec {
+    uint32_t c[16];
+};
+static_assert(sizeof(Cls4Rec) == 64, "one cache line per tile");
+#define GSR_RUN4 256
+// Anchor table: what the fill pass reads. Row A holds, for every class (w, h <= 4) anchored at tile A and every
+// tile (dx, dy) of its rectangle, the absolute list position where that (class, anchor) run starts in tile
+// A + (dx, dy): entry anchor_base(w, h) + dy*w + dx (100 entries, rows padded to 128). One or two cache
+// lines per splat instead of two scattered gathers per (splat, tile).
+#define GSR_ANCHOR_ROW 128
+__host__ __device__ constexpr int anchor_base(int w, int h) { return 5 * h * (h - 1) + h * w * (w - 1) / 2; }
 
 // The per-splat records the blend kernels gather are interleaved (GSR_GSTRIDE float4 per splat): a random
 // gather pulls a whole 128-byte L2 line per touched address, so g0, g1 and col of one splat share a line
@@ -88,6 +104,10 @@ struct ImageView {
     uint32_t* n_contrib;
     uint2* ranges;
     TileRec* tiles;
+    Cls4Rec* cls4;    // [T] second-tier class counters, directly behind `tiles` (one memset clears both + tier2)
+    uint32_t* tier2;  // [64] word 0: some splat used the second tier this frame
+    uint32_t* run4;   // [T][GSR_RUN4] second-tier run offsets
+    uint32_t* anchor; // [T][GSR_ANCHOR_ROW] absolute run starts per (anchor, class, covered tile)
     uint32_t* qcount; // [4*T] quad-hit records the forward blend wrote per 8x8 quad
 };
 struct BinView {
@@ -128,7 +148,11 @@ __host__ __device__ inline size_t image_layout(char* base, int W, int H, ImageVi
     g.final_T = (float*)(base + off); off = gsr_align_up(off + N * 4);
     g.n_contrib = (uint32_t*)(base + off); off = gsr_align_up(off + N * 4);
     g.ranges = (uint2*)(base + off); off = gsr_align_up(off + T * 8);
-    g.tiles = (TileRec*)(base + off); off = gsr_align_up(off + T * sizeof(TileRec));
+    g.tiles = (TileRec*)(base + off); off = off + T * sizeof(TileRec);
+    g.cls4 = (Cls4Rec*)(base + off); off = off + T * sizeof(Cls4Rec);
+    g.tier2 = (uint32_t*)(base + off); off = gsr_align_up(off + 256);
+    g.run4 = (uint32_t*)(base + off); off = gsr_align_up(off + T * GSR_RUN4 * 4);
+    g.anchor = (uint32_t*)(base + off); off = gsr_align_up(off + T * GSR_ANCHOR_ROW * 4);
     g.qcount = (uint32_t*)(base + off); off = gsr_align_up(off + T * 16);
     if (v) *v = g;
     return off;

@@ -54,7 +54,7 @@ __device__ __forceinline__ void load_cov3d(const SplatInputs& in, const FramePar
 
 __global__ void __launch_bounds__(256)
 K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomView g,
-             TileRec* __restrict__ tiles)
+             TileRec* __restrict__ tiles, Cls4Rec* __restrict__ cls4, uint32_t* __restrict__ tier2)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= f.P) return;
@@ -98,6 +98,10 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
     if (w <= 2 && h <= 2) {
         const uint32_t rank = atomicAdd(&tiles[pr.y0 * f.grid_x + pr.x0].cls[(w - 1) + 2 * (h - 1)], 1u);
         g.slots[idx] = make_uint4(rank, zbits, r0, r1);
+    } else if (w <= 4 && h <= 4) { // second tier: still one atomic
+        const uint32_t rank = atomicAdd(&cls4[pr.y0 * f.grid_x + pr.x0].c[(w - 1) + 4 * (h - 1)], 1u);
+        g.slots[idx] = make_uint4(rank, zbits, r0, r1);
+        tier2[0] = 1u;
     } else {
         g.slots[idx] = make_uint4(0u, zbits, r0, r1);
         for (int y = pr.y0; y < pr.y1; y++)
@@ -129,29 +133,65 @@ K_mark_visible(int P, const float* __restrict__ means3D, const float* __restrict
 // ===================================================================================
 // tile binning
 // ===================================================================================
-// Per tile: the nine (class, anchor) runs that cover it (TileRec) -> cnt_small = their sum, off[j] = where
-// run j+1 starts relative to the segment start. One thread per tile; the one-block scan below then only
-// reads two counters per tile.
+// Per tile, 16 lanes per tile: cnt_small and the run offsets of its list segment.
+//   first tier (TileRec): the nine (class, anchor) runs that cover the tile, off[j] = where run j+1 starts
+//   relative to the segment start (lane 0 of the group);
+//   second tier (Cls4Rec), only when some splat used it this frame: one lane per anchor (dx, dy) up-left of
+//   the tile sums the classes of its anchor that reach the tile, a 16-lane shuffle scan orders the anchors,
+//   and each lane writes the run offsets of its anchor behind the first-tier runs.
+// The one-block scan below then only reads two counters per tile.
 __global__ void __launch_bounds__(256)
-K_tile_runs(int T, int grid_x, TileRec* __restrict__ tiles)
+K_tile_runs(int T, int grid_x, TileRec* __restrict__ tiles, const Cls4Rec* __restrict__ cls4,
+            const uint32_t* __restrict__ tier2, uint32_t* __restrict__ run4)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= T) return;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), nb = threadIdx.x & 15, dx = nb & 3, dy = nb >> 2;
+    if (i >= T) return; // whole 16-lane groups leave together
     const int ty = i / grid_x, tx = i - ty * grid_x;
-    const bool L = tx > 0, U = ty > 0;
-    const uint4 me = *reinterpret_cast<const uint4*>(tiles[i].cls);
-    const uint4 le = L ? *reinterpret_cast<const uint4*>(tiles[i - 1].cls) : make_uint4(0u, 0u, 0u, 0u);
-    const uint4 up = U ? *reinterpret_cast<const uint4*>(tiles[i - grid_x].cls) : make_uint4(0u, 0u, 0u, 0u);
-    const uint32_t ul = (L && U) ? tiles[i - grid_x - 1].cls[3] : 0u;
-    const uint32_t c[9] = {me.x, me.y, le.y, me.z, up.z, me.w, le.w, up.w, ul};
-    uint32_t o = c[0];
-    uint32_t off[8];
+    uint32_t o1 = 0;
+    if (nb == 0) {
+        const bool L = tx > 0, U = ty > 0;
+        const uint4 me = *reinterpret_cast<const uint4*>(tiles[i].cls);
+        const uint4 le = L ? *reinterpret_cast<const uint4*>(tiles[i - 1].cls) : make_uint4(0u, 0u, 0u, 0u);
+        const uint4 up = U ? *reinterpret_cast<const uint4*>(tiles[i - grid_x].cls) : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t ul = (L && U) ? tiles[i - grid_x - 1].cls[3] : 0u;
+        const uint32_t c[9] = {me.x, me.y, le.y, me.z, up.z, me.w, le.w, up.w, ul};
+        uint32_t o = c[0];
+        uint32_t off[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) { off[j] = o; o += c[j + 1]; }
-    tiles[i].cnt_small = o;
-    uint4* const dst = reinterpret_cast<uint4*>(tiles[i].off);
-    dst[0] = make_uint4(off[0], off[1], off[2], off[3]);
-    dst[1] = make_uint4(off[4], off[5], off[6], off[7]);
+        for (int j = 0; j < 8; j++) { off[j] = o; o += c[j + 1]; }
+        uint4* const dst = reinterpret_cast<uint4*>(tiles[i].off);
+        dst[0] = make_uint4(off[0], off[1], off[2], off[3]);
+        dst[1] = make_uint4(off[4], off[5], off[6], off[7]);
+        o1 = o;
+    }
+    o1 = (uint32_t)__shfl((int)o1, 0, 16);
+    uint32_t total = 0;
+    if (tier2[0]) {
+        const bool have = tx >= dx && ty >= dy;
+        uint32_t cnt[16];
+        uint32_t sum = 0;
+        const uint4* const src = reinterpret_cast<const uint4*>(cls4[have ? i - dy * grid_x - dx : i].c);
+        const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+        const uint32_t raw[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int w = (c & 3) + 1, h = (c >> 2) + 1;
+            cnt[c] = (have && w > dx && h > dy && !(w <= 2 && h <= 2)) ? raw[c] : 0u;
+            sum += cnt[c];
+        }
+        uint32_t inc = sum; // inclusive scan over the 16 anchors of the tile
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 16);
+            if (nb >= off) inc += o;
+        }
+        total = (uint32_t)__shfl((int)inc, 15, 16);
+        uint32_t o = o1 + inc - sum; // behind the first-tier runs
+        uint32_t* const row = run4 + (size_t)i * GSR_RUN4 + nb * 16;
+#pragma unroll
+        for (int c = 0; c < 16; c++) { row[c] = o; o += cnt[c]; }
+    }
+    if (nb == 0) tiles[i].cnt_small = o1 + total;
 }
 
 // One block: per-tile counts (cnt_small, cnt_big) -> list segments (start, cursor of the big splats),
@@ -217,6 +257,33 @@ K_scan_tiles(int T, TileRec* __restrict__ tiles, uint2* __restrict__ ranges,
     }
 }
 
+// After the scan: the anchor table (gsr_device.h). One block per anchor tile, one thread per entry.
+__global__ void __launch_bounds__(GSR_ANCHOR_ROW)
+K_anchor_table(int T, int grid_x, const TileRec* __restrict__ tiles, const uint32_t* __restrict__ tier2,
+               const uint32_t* __restrict__ run4, uint32_t* __restrict__ anchor)
+{
+    const int A = blockIdx.x, e = threadIdx.x;
+    if (e >= 100) return;
+    int w = 1, h = 1; // decode e -> class (w, h) and tile (dx, dy) of its rectangle
+#pragma unroll
+    for (int hh = 1; hh <= 4; hh++)
+#pragma unroll
+        for (int ww = 1; ww <= 4; ww++)
+            if (e >= anchor_base(ww, hh)) { w = ww; h = hh; }
+    const int k = e - anchor_base(w, h), dx = k % w, dy = k / w;
+    const bool first_tier = w <= 2 && h <= 2;
+    if (!first_tier && !tier2[0]) return;
+    const int ax = A % grid_x, t = A + dy * grid_x + dx;
+    if (ax + dx >= grid_x || t >= T) return; // no rectangle of this class is anchored here
+    uint32_t pos = tiles[t].start;
+    if (first_tier) {
+        const int c2 = (w - 1) + 2 * (h - 1);
+        const int run = (c2 == 0 ? 0 : c2 == 1 ? 1 : c2 == 2 ? 3 : 5) + (c2 == 3 ? dx + 2 * dy : dx + dy);
+        if (run) pos += tiles[t].off[run - 1];
+    } else pos += run4[(size_t)t * GSR_RUN4 + (dy * 4 + dx) * 16 + (w - 1) + 4 * (h - 1)];
+    anchor[(size_t)A * GSR_ANCHOR_ROW + e] = pos;
+}
+
 // the forward's capacity guess was too small: switch the header to the exact capacity before the tail re-runs
 __global__ void K_set_capacity(GeomHeader* hdr, uint32_t capacity)
 {
@@ -225,7 +292,8 @@ __global__ void K_set_capacity(GeomHeader* hdr, uint32_t capacity)
 }
 
 __global__ void __launch_bounds__(256)
-K_fill(int P, int grid_x, GeomView g, TileRec* __restrict__ tiles, uint64_t* __restrict__ pairs)
+K_fill(int P, int grid_x, GeomView g, TileRec* __restrict__ tiles, const uint32_t* __restrict__ anchor,
+       uint64_t* __restrict__ pairs)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P || g.hdr->overflow) return;
@@ -234,20 +302,12 @@ K_fill(int P, int grid_x, GeomView g, TileRec* __restrict__ tiles, uint64_t* __r
     const uint64_t key = ((uint64_t)br.y << 32) | (uint32_t)idx;
     const int w = x1 - x0, h = y1 - y0;
     if (w * h == 0) return;
-    if (w <= 2 && h <= 2) { // the rank was taken when the splat was counted: no atomics
-        const uint32_t rank = br.x;
-        const int cls = (w - 1) + 2 * (h - 1);
-        // run of (class, this anchor) inside the tile at anchor + (dx, dy)   (see TileRec)
-        const int first = cls == 0 ? 0 : cls == 1 ? 1 : cls == 2 ? 3 : 5;
+    if (w <= 4 && h <= 4) { // the rank was taken when the splat was counted: no atomics, one table row per splat
+        const uint32_t* __restrict__ row = anchor + (size_t)(y0 * grid_x + x0) * GSR_ANCHOR_ROW + anchor_base(w, h);
+        const int ntl = w * h;
 #pragma unroll
-        for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-            for (int dx = 0; dx < 2; dx++) {
-                if (dx >= w || dy >= h) continue;
-                const int run = first + (cls == 3 ? dx + 2 * dy : dx + dy);
-                const TileRec& t = tiles[(y0 + dy) * grid_x + x0 + dx];
-                pairs[t.start + (run == 0 ? 0u : t.off[run - 1]) + rank] = key;
-            }
+        for (int k = 0; k < 16; k++)
+            if (k < ntl) pairs[row[k] + br.x] = key;
     } else {
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++) pairs[atomicAdd(&tiles[y * grid_x + x].cur_big, 1u)] = key;
