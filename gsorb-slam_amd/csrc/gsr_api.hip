@@ -85,7 +85,7 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     tm.begin(GSR_FWD_SORT);
     hipLaunchKernelGGL(gsr::K_tile_sort<true>, dim3(T), dim3(256), 0, st, T, iv.ranges, gv.hdr, bv.pairs, bv.point_list);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_tile_sort<false>, dim3(T), dim3(256), 0, st, T, iv.ranges, gv.hdr, bv.pairs, bv.point_list);
+    hipLaunchKernelGGL(gsr::K_tile_sort<false>, dim3(T), dim3(GSR_SORT_BIG_THREADS), 0, st, T, iv.ranges, gv.hdr, bv.pairs, bv.point_list);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SORT);
     tm.begin(GSR_FWD_BLEND);
