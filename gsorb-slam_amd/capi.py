@@ -377,7 +377,7 @@ def dist2(points, workspace=None):
 
 
 def acc_view(st: ForwardState) -> torch.Tensor:
-    """The packed per-splat backward accumulators of a forward state, as a float32 view [P*12] into its
+    """The packed per-splat backward accumulators of a forward state, as a float32 view [P*16] into its
     geometry blob (what tile-band sharding all-reduces between the blend and per-splat stages)."""
     ptr, n = C.c_void_p(), C.c_size_t()
     _check(lib().gsr_acc_view(_p(st.geom), st.P, C.byref(ptr), C.byref(n)))

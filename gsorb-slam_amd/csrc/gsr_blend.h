@@ -331,7 +331,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             step(it + 1, idx1, A1, B1, C1);
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- flush: seven parked entries per instruction, nine consecutive lanes per 48-byte record
+        // ---- flush: seven parked entries per instruction, nine consecutive lanes per 64-byte record
         for (int fb = 0; fb < count; fb += 7) {
             const int e = fb + fe;
             if (lane < 63 && e < count) {

@@ -11,7 +11,8 @@
 //                                                        copy of colors_precomp)
 //     slots uint4[P]     what the fill pass needs: rank in the class counter (rectangles up to 2x2 tiles,
 //                        see TileRec), depth bits, band-clipped tile rectangle
-//     acc  float[P][12]  backward accumulators: moments of u = G*dL/dalpha over the splat's pixels
+//     acc  float[P][16]  backward accumulators (one 64-byte line per splat: 48-byte records straddle lines and
+//                        the L2 atomic rate drops from 20 to 13 G records/s): moments of u = G*dL/dalpha
 //                        {sum u, u*dx, u*dy, u*dx^2, u*dx*dy, u*dy^2}, dcolor.rgb, pad
 //   image blob     (gsr_image_bytes(W,H)):
 //     final_T f32[N], n_contrib u32[N], ranges uint2[T], tiles TileRec[T] (one 64-B line each)
@@ -29,7 +30,7 @@
 #define GSR_TILE 16
 #define GSR_TILE_PIX 256
 #define GSR_ALIGN 256
-#define GSR_ACC_STRIDE 12
+#define GSR_ACC_STRIDE 16 // floats; 9 used
 
 struct GeomHeader {
     uint32_t num_rendered;

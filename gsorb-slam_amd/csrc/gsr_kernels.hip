@@ -60,7 +60,7 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
     if (idx >= f.P) return;
     { // the backward accumulators start every frame at zero (K_splat_bwd re-zeroes what it consumed)
         float4* const ap = reinterpret_cast<float4*>(g.acc + (size_t)idx * GSR_ACC_STRIDE);
-        ap[0] = ap[1] = ap[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ap[0] = ap[1] = ap[2] = ap[3] = make_float4(0.f, 0.f, 0.f, 0.f); // the whole 64-byte line
     }
     const float3 p = make_float3(in.means3D[3 * (size_t)idx], in.means3D[3 * (size_t)idx + 1], in.means3D[3 * (size_t)idx + 2]);
     float cov[6];
@@ -489,7 +489,7 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o)
     const float q8 = acc[8];
     { // consumed: leave the record clean for the next backward on this geometry blob
         float4* const ap = reinterpret_cast<float4*>(acc);
-        ap[0] = ap[1] = ap[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ap[0] = ap[1] = ap[2] = ap[3] = make_float4(0.f, 0.f, 0.f, 0.f); // the whole 64-byte line
     }
     // K_blend_bwd accumulated the raw moments of u = G*dL/dalpha: {u, u dx, u dy, u dx^2, u dx dy, u dy^2};
     // the reference's per-pixel terms (backward.cu:536-554) are these moments times conic / opacity:

@@ -74,7 +74,7 @@ def shard_by_depth_slabs(depths: torch.Tensor, world: int):
 # gsr_forward_args.band_y0/band_y1). A band render is bit-identical to the same rows of the
 # one-GPU render, so the gathered image IS the one-GPU image. Exchanges per iteration:
 #   forward : one all-gather of the band pixels (4 floats/pixel in total over all ranks: 13 MB at 1200x680)
-#   backward: one all-reduce of the packed per-splat accumulators (12 floats/splat: 48 MB at 1 M)
+#   backward: one all-reduce of the packed per-splat accumulators (16 floats/splat: 64 MB at 1 M)
 #             between the blend stage and the per-splat stage (gsr_backward_args.stages)
 # after which every rank holds the full, identical gradients and steps its replica of the
 # optimiser — no parameter broadcast. Use it when the map fits one GPU (always, with 288 GB)
