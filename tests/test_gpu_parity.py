@@ -323,3 +323,30 @@ def test_forward_capacity_guess_too_small_reruns_the_tail(gsr, syn):
     for n in ("dL_dmeans3D", "dL_dopacity", "dL_dscales"):
         x, y = getattr(out["ga"], n), getattr(gb, n)
         assert float((x - y).abs().max() / (y.abs().max() + 1e-30)) < 1e-5
+
+
+@pytest.mark.gpu
+def test_large_frame_more_than_8192_tiles(gsr, syn):
+    """3840x2160 = 240x135 = 32400 tiles: the one-block scan works through more than eight tiles per thread
+    and tile coordinates no longer fit a byte. Integer stages bit-exact, image within tolerance."""
+    cam = syn.make_camera(3840, 2160, 2000.0, 2000.0)
+    sc = syn.make_scene(60000, cam, seed=4, scale_mult=6.0, frac_offscreen=0.1)
+    o, f = oracle.forward_scene(sc, omp=True)
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    d = gsr.debug_export(st)
+    assert st.num_rendered == f.num_rendered
+    np.testing.assert_array_equal(st.radii.cpu().numpy(), f.radii)
+    np.testing.assert_array_equal(d["ranges"], f.stages["ranges"])
+    np.testing.assert_array_equal(d["point_list"], f.stages["point_list"])
+    mc, md = o.margins(f)
+    ok = mc >= EPS_MARGIN
+    assert (~ok).mean() < 1e-2
+    col = st.color.cpu().numpy()
+    assert np.abs(col - f.color)[:, ok].max() <= TOL * max(1.0, float(np.abs(f.color).max()))
+    g_in = sc.dL_dpix * ok[None]
+    b = o.backward(g_in)
+    gr = gsr.backward(st, g_in)
+    for n in ("dL_dmeans3D", "dL_dopacity", "dL_dcolors", "dL_dscales", "dL_drotations"):
+        e = rel_err(getattr(gr, n).cpu().numpy(), getattr(b, n))
+        assert e <= TOL, (n, e)
