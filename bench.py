@@ -129,7 +129,7 @@ def main():
 
     def step(fe=None, be=None):
         st = gsr.forward_ws(s, ws, ins, None, events=fe)
-        gsr.backward(st, grad_in, grads=grads, events=be)
+        gsr.backward(st, grad_in, grads=grads, events=be, once=True)  # one backward per forward: no accumulator re-zero
 
     for _ in range(a.warmup):
         step()

@@ -177,6 +177,7 @@ class ForwardState:
     image: torch.Tensor
     ws_binning_bytes: int = 0
     band: tuple = (0, 0)
+    dirty: bool = False   # a backward ran its per-splat stage without GSR_STAGE_REZERO: clear before the next one
     keep: list = field(default_factory=list)
 
 
@@ -283,8 +284,14 @@ def alloc_grads(P: int, M: int, dev) -> Grads:
     return Grads(e(P, 3), e(P, 2, 2), e(P, 1), e(P, 3), e(P, 3), e(P, 6), e(P, M, 3), e(P, 3), e(P, 4))
 
 
-def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None, stages: int = 0) -> Grads:
-    """gsr_backward; output shapes follow src/Rasterizer.cu:253-261."""
+def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None, stages: int = 0, once: bool = False) -> Grads:
+    """gsr_backward; output shapes follow src/Rasterizer.cu:253-261. `once`: the caller runs one backward per
+    forward (blend + per-splat without the re-zero of the accumulators); a later call on the same state
+    is then started with a clear."""
+    if stages == 0:
+        stages = (2 | 4) if once else (2 | 4 | 8)
+        if st.dirty:
+            stages |= 1
     L = lib()
     s = st.settings
     dev = s.viewmatrix.device
@@ -303,6 +310,8 @@ def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None,
                      _p(out.dL_dmeans3D), _p(out.dL_dcov3D), _p(out.dL_dsh) if M > 0 else None,
                      _p(out.dL_dscales) if has_sr else None, _p(out.dL_drotations) if has_sr else None, events,
                      int(st.band[0]), int(st.band[1]), int(stages))
+    if stages & 4:
+        st.dirty = not (stages & 8)
     with torch.cuda.device(dev):
         _check(L.gsr_backward(C.byref(a), _stream()))
     if not has_sr:

@@ -282,7 +282,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
     image_layout(a->image_buffer, W, H, &iv);
     // (the binning blob's layout follows the capacity the forward ran with; the kernel reads it from the header)
     const StageTimer tm{a->profile_events, st};
-    const int stages = a->stages ? a->stages : (GSR_STAGE_BLEND | GSR_STAGE_SPLAT); // accumulators are clean by invariant
+    const int stages = a->stages ? a->stages : (GSR_STAGE_BLEND | GSR_STAGE_SPLAT | GSR_STAGE_REZERO); // accumulators are clean by invariant
     const int Tb = (f.band_y1 - f.band_y0) * f.grid_x;
     if (stages & GSR_STAGE_CLEAR) {
         tm.begin(GSR_BWD_CLEAR);
@@ -304,7 +304,8 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
         o.dL_dcolor = a->dL_dcolor; o.dL_dmean3D = a->dL_dmean3D; o.dL_dcov3D = a->dL_dcov3D;
         o.dL_dsh = a->dL_dsh; o.dL_dscale = a->dL_dscale; o.dL_drot = a->dL_drot;
         tm.begin(GSR_BWD_SPLAT);
-        hipLaunchKernelGGL(gsr::K_splat_bwd, dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o);
+        if (stages & GSR_STAGE_REZERO) hipLaunchKernelGGL(gsr::K_splat_bwd<true>, dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o);
+        else hipLaunchKernelGGL(gsr::K_splat_bwd<false>, dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o);
         GSR_LAUNCHED();
         tm.end(GSR_BWD_SPLAT);
     }

@@ -465,6 +465,7 @@ __device__ __forceinline__ void st3(float* p, size_t i, float a, float b, float 
     if (p) { p[3 * i] = a; p[3 * i + 1] = b; p[3 * i + 2] = c; }
 }
 
+template <bool REZERO>
 __global__ void __launch_bounds__(256)
 K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o)
 {
@@ -487,7 +488,7 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o)
     float* const acc = g.acc + i * GSR_ACC_STRIDE;
     const float4 q0 = reinterpret_cast<const float4*>(acc)[0], q1 = reinterpret_cast<const float4*>(acc)[1];
     const float q8 = acc[8];
-    { // consumed: leave the record clean for the next backward on this geometry blob
+    if (REZERO) { // consumed: leave the record clean for the next backward on this geometry blob
         float4* const ap = reinterpret_cast<float4*>(acc);
         ap[0] = ap[1] = ap[2] = ap[3] = make_float4(0.f, 0.f, 0.f, 0.f); // the whole 64-byte line
     }

@@ -59,8 +59,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos,
                 geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer)
+        # the graph node knows how often it ran: the first backward skips the re-zero of the per-splat
+        # accumulators (stages 2|4), a repeated one (retain_graph) starts with a clear (1|2|4)
+        stages = 7 if getattr(ctx, "backward_ran", False) else 6
+        ctx.backward_ran = True
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations) = _C.rasterize_gaussians_backward(*args)
+         grad_rotations) = _C.rasterize_gaussians_backward_staged(*args, stages)
 
         def like(g, x):
             return None if x.numel() == 0 else g.reshape(x.shape)

@@ -99,14 +99,14 @@ RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& mea
 
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
            torch::Tensor>
-RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Tensor& means3D,
-                               const torch::Tensor& radii, const torch::Tensor& colors, const torch::Tensor& scales,
-                               const torch::Tensor& rotations, const float scale_modifier,
-                               const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
-                               const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
-                               const torch::Tensor& dL_dout_color, const torch::Tensor& sh, const int degree,
-                               const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
-                               const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer)
+RasterizeGaussiansBackwardStaged(const torch::Tensor& background, const torch::Tensor& means3D,
+                                 const torch::Tensor& radii, const torch::Tensor& colors, const torch::Tensor& scales,
+                                 const torch::Tensor& rotations, const float scale_modifier,
+                                 const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+                                 const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                                 const torch::Tensor& dL_dout_color, const torch::Tensor& sh, const int degree,
+                                 const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
+                                 const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const int stages)
 {
     const int P = (int)means3D.size(0);
     const int H = (int)dL_dout_color.size(1), W = (int)dL_dout_color.size(2);
@@ -153,11 +153,29 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
         a.dL_drot = has_sr ? dL_drotations.data_ptr<float>() : nullptr;
         a.profile_events = nullptr;
         a.band_y0 = a.band_y1 = 0;
-        a.stages = 0;
+        a.stages = stages;
         check(gsr_backward(&a, current_stream(device)), "RasterizeGaussiansBackwardCUDA");
     }
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
                            dL_drotations);
+}
+
+// The reference's stateless entry point: any number of calls per forward (stages 0 = blend + per-splat +
+// re-zero of the accumulators).
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor>
+RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Tensor& means3D,
+                               const torch::Tensor& radii, const torch::Tensor& colors, const torch::Tensor& scales,
+                               const torch::Tensor& rotations, const float scale_modifier,
+                               const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+                               const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                               const torch::Tensor& dL_dout_color, const torch::Tensor& sh, const int degree,
+                               const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
+                               const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer)
+{
+    return RasterizeGaussiansBackwardStaged(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                            cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
+                                            degree, campos, geomBuffer, R, binningBuffer, imageBuffer, 0);
 }
 
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix)
@@ -264,14 +282,19 @@ torch::autograd::tensor_list _RasterizeGaussians::backward(torch::autograd::Auto
                &projmatrix = saved[12], &camera_center = saved[13];
     torch::Tensor grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
         grad_scales, grad_rotations;
+    // the graph node knows how often it ran: the first backward skips the re-zero of the accumulators, a
+    // repeated one (retain_graph) starts with a clear
+    const bool again = ctx->saved_data.count("backward_ran") != 0;
+    ctx->saved_data["backward_ran"] = true;
+    const int stages = again ? (GSR_STAGE_CLEAR | GSR_STAGE_BLEND | GSR_STAGE_SPLAT) : (GSR_STAGE_BLEND | GSR_STAGE_SPLAT);
     std::tie(grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
              grad_scales, grad_rotations) =
-        RasterizeGaussiansBackwardCUDA(bg, means3D, radii, colors_precomp, scales, rotations,
-                                       (float)ctx->saved_data["scale_modifier"].toDouble(), cov3Ds_precomp,
-                                       viewmatrix, projmatrix, (float)ctx->saved_data["tanfovx"].toDouble(),
-                                       (float)ctx->saved_data["tanfovy"].toDouble(), grad_out_color, sh,
-                                       (int)ctx->saved_data["sh_degree"].toInt(), camera_center, geomBuffer,
-                                       (int)ctx->saved_data["num_rendered"].toInt(), binningBuffer, imgBuffer);
+        RasterizeGaussiansBackwardStaged(bg, means3D, radii, colors_precomp, scales, rotations,
+                                         (float)ctx->saved_data["scale_modifier"].toDouble(), cov3Ds_precomp,
+                                         viewmatrix, projmatrix, (float)ctx->saved_data["tanfovx"].toDouble(),
+                                         (float)ctx->saved_data["tanfovy"].toDouble(), grad_out_color, sh,
+                                         (int)ctx->saved_data["sh_degree"].toInt(), camera_center, geomBuffer,
+                                         (int)ctx->saved_data["num_rendered"].toInt(), binningBuffer, imgBuffer, stages);
     auto shaped = [](const torch::Tensor& g, const torch::Tensor& like) {
         return like.numel() == 0 ? torch::Tensor() : g.reshape(like.sizes());
     };

@@ -42,6 +42,19 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
                                const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer);
 
+// RasterizeGaussiansBackwardCUDA with an explicit stage mask (gsr_backward_args.stages, include/gsr.h): lets a
+// caller that runs one backward per forward skip the re-zero of the per-splat accumulators.
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor>
+RasterizeGaussiansBackwardStaged(const torch::Tensor& background, const torch::Tensor& means3D,
+                                 const torch::Tensor& radii, const torch::Tensor& colors, const torch::Tensor& scales,
+                                 const torch::Tensor& rotations, const float scale_modifier,
+                                 const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+                                 const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                                 const torch::Tensor& dL_dout_color, const torch::Tensor& sh, const int degree,
+                                 const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
+                                 const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const int stages);
+
 // include/Rasterizer.cuh:73-76
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix);
 

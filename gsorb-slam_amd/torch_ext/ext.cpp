@@ -39,6 +39,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.def("rasterize_gaussians", &RasterizeGaussians);
     m.def("rasterize_gaussians_backward", &ORB_SLAM2::RasterizeGaussiansBackwardCUDA);
+    m.def("rasterize_gaussians_backward_staged", &ORB_SLAM2::RasterizeGaussiansBackwardStaged);
     m.def("mark_visible", &ORB_SLAM2::markVisible);
     m.def("filter_radii", &FilterRadii);
     m.def("distCUDA2", [](const torch::Tensor& points) { return distCUDA2(points, points.is_cuda() ? points.device() : torch::Device(torch::kCUDA, 0)); });

@@ -138,8 +138,11 @@ typedef struct gsr_backward_args {
     int band_y0, band_y1;        /* must equal the matching forward's band */
     /* Which stages to run: bit 0 clear the per-splat accumulators, bit 1 blend backward (accumulates
      * into them), bit 2 per-splat stage (reads them, writes the dL_d* outputs, leaves them zero).
-     * 0 = blend + per-splat: the accumulators are zero after every forward and after every per-splat
-     * stage, so an explicit clear is only needed to discard a blend stage that was not followed by the
+     * 0 = blend + per-splat + re-zero (GSR_STAGE_REZERO): the accumulators are zero after every forward,
+     * and with the re-zero also after every per-splat stage, so any number of backward calls may follow one
+     * forward. A caller that runs ONE backward per forward may pass GSR_STAGE_BLEND | GSR_STAGE_SPLAT and
+     * save 64 bytes of stores per splat; a further backward on that state must then start with
+     * GSR_STAGE_CLEAR. An explicit clear also discards a blend stage that was not followed by the
      * per-splat stage. Band sharding runs 2 on every rank, sums the accumulators across ranks
      * (gsr_acc_view + one all-reduce), then runs 4. */
     int stages;
@@ -148,6 +151,7 @@ typedef struct gsr_backward_args {
 #define GSR_STAGE_CLEAR 1
 #define GSR_STAGE_BLEND 2
 #define GSR_STAGE_SPLAT 4
+#define GSR_STAGE_REZERO 8 /* the per-splat stage zeroes the accumulators it consumed */
 
 /* The packed per-splat accumulators inside a geometry blob: count floats (12 per splat). */
 int gsr_acc_view(char* geom, int P, float** acc, size_t* count);

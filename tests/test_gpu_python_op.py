@@ -101,3 +101,25 @@ def test_cov3d_precomp_and_no_grad_paths(syn):
         im2, _, _ = r(means3D=t(sc.means3D), means2D=torch.zeros(sc.P, 3, device="cuda"), opacities=t(sc.opacities),
                       colors_precomp=t(sc.colors), scales=t(sc.scales), rotations=t(sc.rotations))
     assert torch.allclose(im2, im.detach(), atol=1e-5)
+
+
+def test_backward_twice_with_retain_graph(syn):
+    """The autograd node's first backward skips the re-zero of the per-splat accumulators; a second backward
+    on the retained graph must start with a clear and reproduce the first gradients. The stateless
+    _C.rasterize_gaussians_backward may be called any number of times."""
+    import diff_gaussian_rasterization as dgr
+    cam = syn.make_camera(192, 128, 150.0, 150.0)
+    sc = syn.make_scene(6000, cam, seed=12, scale_mult=2.0)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    r = dgr.GaussianRasterizer(_settings(dgr, cam))
+    means, op, col = t(sc.means3D).requires_grad_(True), t(sc.opacities).requires_grad_(True), t(sc.colors).requires_grad_(True)
+    scl, rot = t(sc.scales).requires_grad_(True), t(sc.rotations).requires_grad_(True)
+    im, _, _ = r(means3D=means, means2D=torch.zeros_like(means, requires_grad=True), opacities=op, colors_precomp=col,
+                 scales=scl, rotations=rot)
+    loss = (im * t(sc.dL_dpix)).sum()
+    g1 = torch.autograd.grad(loss, [means, op, col, scl, rot], retain_graph=True)
+    g2 = torch.autograd.grad(loss, [means, op, col, scl, rot], retain_graph=True)
+    g3 = torch.autograd.grad(loss, [means, op, col, scl, rot])
+    for a, b, c in zip(g1, g2, g3):
+        scale = float(a.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) / scale < 1e-5 and float((a - c).abs().max()) / scale < 1e-5
