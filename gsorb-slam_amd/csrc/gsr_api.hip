@@ -83,7 +83,7 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     GSR_LAUNCHED();
     tm.end(GSR_FWD_FILL);
     tm.begin(GSR_FWD_SORT);
-    hipLaunchKernelGGL(gsr::K_tile_sort<true>, dim3(T), dim3(256), 0, st, T, iv.ranges, gv.hdr, bv.pairs, bv.point_list);
+    hipLaunchKernelGGL(gsr::K_tile_sort<true>, dim3(T), dim3(GSR_SORT_SMALL_THREADS), 0, st, T, iv.ranges, gv.hdr, bv.pairs, bv.point_list);
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_tile_sort<false>, dim3(T), dim3(GSR_SORT_BIG_THREADS), 0, st, T, iv.ranges, gv.hdr, bv.pairs, bv.point_list);
     GSR_LAUNCHED();
@@ -373,7 +373,7 @@ int gsr_dist2(int P, const float* points, float* mean_dists, char* workspace, si
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_knn_fill, dim3(blocks256(P)), dim3(256), 0, st, P, shift, k.code, k.slot, k.buckets, k.pairs);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_tile_sort<true>, dim3(nb), dim3(256), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order);
+    hipLaunchKernelGGL(gsr::K_tile_sort<true>, dim3(nb), dim3(GSR_SORT_SMALL_THREADS), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order);
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_tile_sort<false>, dim3(nb), dim3(256), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order);
     GSR_LAUNCHED();

@@ -322,64 +322,113 @@ __device__ __forceinline__ void cex(uint64_t& a, uint64_t& b)
     if (a > b) { const uint64_t t = a; a = b; b = t; }
 }
 
-// The network is run in "trips": every thread loads a group of four keys e0<e1<e2<e3 chosen so that TWO
-// consecutive passes of the network pair keys inside the group, applies both in registers and stores the
-// group back — half the LDS traffic and half the barriers of one pass per round trip. A key belongs to
-// exactly one group per trip, so one barrier per trip is enough. cap >= 4, a power of two.
-//   flip trip  (stage k): flip(k) then disperse(k/4):  e = base + {x, x+k/4, k-1-x-k/4, k-1-x}
-//   pair trip  (g)      : disperse(2g) then disperse(g): e = base + {0, g, 2g, 3g}
-//   single trip         : disperse(1) on consecutive keys
-__device__ __forceinline__ void trip4(uint64_t* s, int e0, int e1, int e2, int e3, const bool flip, const bool first)
+// The network is run in "trips": every thread loads a group of K = 2^G keys chosen so that G consecutive
+// passes of the network pair keys inside the group, applies them in registers and stores the group back —
+// 1/G of the LDS traffic and of the synchronisations of one pass per round trip. A key belongs to exactly
+// one group per trip, so one synchronisation per trip is enough; with one wave per block (ONEWAVE) that
+// is no s_barrier at all. cap >= K, a power of two.
+//   first trip          : stages k = 2 .. K on K consecutive keys (a complete sort of the group)
+//   flip trip (stage k) : flip(k) then disperse(k/4) .. disperse(k/2^G): the group is {x + m*k/2^G} and its
+//                         mirror images {k-1 - (x + m*k/2^G)}, m < K/2
+//   disperse trip       : up to G disperse passes of adjacent strides: the group is {x + q*2^low}, q < K
+// Keys live in LDS at a bank-swizzled position: key i sits at i ^ fold(i), fold = (bits 5-9) ^ (bits 10-14)
+// brought down to bits 0-4. A trip makes the lanes of a wave differ in whatever index bits are NOT in the
+// group's field; the fold spreads any five of them over the 32 bank pairs. The map is linear over XOR, so
+// the K addresses of a group are one swizzled base XOR per-trip constants.
+__device__ __forceinline__ int swz(int i) { return i ^ ((i >> 5) & 31) ^ ((i >> 10) & 31); }
+
+template <bool ONEWAVE>
+__device__ __forceinline__ void sort_sync()
 {
-    uint64_t a = s[e0], b = s[e1], c = s[e2], d = s[e3];
-    if (first) { if (flip) { cex(a, d); cex(b, c); } else { cex(a, c); cex(b, d); } }
-    cex(a, b); cex(c, d);
-    s[e0] = a; s[e1] = b; s[e2] = c; s[e3] = d;
+    if (ONEWAVE) __builtin_amdgcn_wave_barrier();
+    else __syncthreads();
 }
-// disperse passes j = 2^lj ... 1 (all strides < cap)
+// disperse passes on local bits nb-1 .. 0 of the register group (local order ascending with the index)
+template <int G>
+__device__ __forceinline__ void reg_disperse(uint64_t (&r)[1 << G], int nb)
+{
+#pragma unroll
+    for (int b = G - 1; b >= 0; b--) {
+        if (b >= nb) continue;
+#pragma unroll
+        for (int q = 0; q < (1 << G); q++)
+            if (!(q & (1 << b))) cex(r[q], r[q | (1 << b)]);
+    }
+}
+// disperse passes with strides 2^lj ... 1 (all strides < cap)
+template <int G, bool ONEWAVE>
 __device__ __forceinline__ void lds_disperse_from(uint64_t* s, int cap, int lj)
 {
-    for (; lj >= 1; lj -= 2) { // passes 2g and g, g = 2^(lj-1)
-        const int lg = lj - 1, g = 1 << lg;
-        for (int grp = threadIdx.x; grp < cap / 4; grp += blockDim.x) {
-            const int base = ((grp >> lg) << (lg + 2)) + (grp & (g - 1));
-            trip4(s, base, base + g, base + 2 * g, base + 3 * g, false, true);
+    constexpr int K = 1 << G;
+    while (lj >= 0) {
+        const int low = lj - G + 1 > 0 ? lj - G + 1 : 0, nb = lj - low + 1;
+        for (int grp = threadIdx.x; grp < cap / K; grp += blockDim.x) {
+            const int x = swz(((grp >> low) << (low + G)) | (grp & ((1 << low) - 1)));
+            uint64_t r[K];
+#pragma unroll
+            for (int q = 0; q < K; q++) r[q] = s[x ^ swz(q << low)];
+            reg_disperse<G>(r, nb);
+#pragma unroll
+            for (int q = 0; q < K; q++) s[x ^ swz(q << low)] = r[q];
         }
-        __syncthreads();
-    }
-    if (lj == 0) {
-        for (int grp = threadIdx.x; grp < cap / 4; grp += blockDim.x) trip4(s, 4 * grp, 4 * grp + 1, 4 * grp + 2, 4 * grp + 3, false, false);
-        __syncthreads();
+        sort_sync<ONEWAVE>();
+        lj = low - 1;
     }
 }
 // full sort of `cap` keys in LDS
+template <int G, bool ONEWAVE>
 __device__ __forceinline__ void lds_sort(uint64_t* s, int cap)
 {
-    for (int grp = threadIdx.x; grp < cap / 4; grp += blockDim.x) { // stages k = 2 and k = 4 on four consecutive keys
-        uint64_t a = s[4 * grp], b = s[4 * grp + 1], c = s[4 * grp + 2], d = s[4 * grp + 3];
-        cex(a, b); cex(c, d);
-        cex(a, d); cex(b, c);
-        cex(a, b); cex(c, d);
-        s[4 * grp] = a; s[4 * grp + 1] = b; s[4 * grp + 2] = c; s[4 * grp + 3] = d;
-    }
-    __syncthreads();
-    for (int k = 8, lk = 3; k <= cap; k <<= 1, lk++) {
-        const int lq = lk - 2, q = 1 << lq;
-        for (int grp = threadIdx.x; grp < cap / 4; grp += blockDim.x) {
-            const int base = (grp >> lq) << lk, x = grp & (q - 1);
-            trip4(s, base + x, base + x + q, base + k - 1 - x - q, base + k - 1 - x, true, true);
+    constexpr int K = 1 << G, H = K / 2;
+    for (int grp = threadIdx.x; grp < cap / K; grp += blockDim.x) { // stages k = 2 .. K inside the group
+        uint64_t r[K];
+#pragma unroll
+        for (int q = 0; q < K; q++) r[q] = s[swz(grp * K) ^ q]; // q < 32: swz(q) = q
+#pragma unroll
+        for (int st = 1; st <= G; st++) {
+#pragma unroll
+            for (int q = 0; q < K; q++)
+                if (!(q & (1 << (st - 1)))) cex(r[q], r[q ^ ((1 << st) - 1)]); // flip inside blocks of 2^st
+            reg_disperse<G>(r, st - 1);
         }
-        __syncthreads();
-        lds_disperse_from(s, cap, lk - 3);
+#pragma unroll
+        for (int q = 0; q < K; q++) s[swz(grp * K) ^ q] = r[q];
+    }
+    sort_sync<ONEWAVE>();
+    for (int k = 2 * K, lk = G + 1; k <= cap; k <<= 1, lk++) {
+        const int low = lk - G; // the group spans bits low .. lk-1
+        for (int grp = threadIdx.x; grp < cap / K; grp += blockDim.x) {
+            const int xl = ((grp >> low) << lk) | (grp & ((1 << low) - 1));
+            // mirror image of x in its block of k: base + k-1 - offset; its field bits are all ones, so
+            // "minus m << low" is an XOR as well
+            const int x = swz(xl), mirror = swz((xl | (k - 1)) - (xl & (k - 1)));
+            uint64_t r[K];
+#pragma unroll
+            for (int m = 0; m < H; m++) { r[m] = s[x ^ swz(m << low)]; r[H + m] = s[mirror ^ swz(m << low)]; }
+#pragma unroll
+            for (int m = 0; m < H; m++) cex(r[m], r[H + m]); // flip(k)
+#pragma unroll
+            for (int b = G - 2; b >= 0; b--) // disperse(k/4) ... : in the mirrored half a set bit means a LOWER index
+#pragma unroll
+                for (int m = 0; m < H; m++)
+                    if (!(m & (1 << b))) { cex(r[m], r[m | (1 << b)]); cex(r[H + (m | (1 << b))], r[H + m]); }
+#pragma unroll
+            for (int m = 0; m < H; m++) { s[x ^ swz(m << low)] = r[m]; s[mirror ^ swz(m << low)] = r[H + m]; }
+        }
+        sort_sync<ONEWAVE>();
+        lds_disperse_from<G, ONEWAVE>(s, cap, low - 1);
     }
 }
 
-// Two instantiations share the tiles: SMALL sorts tiles of <= 1024 entries with 8 KB of LDS (many
-// blocks per CU), the other takes the longer lists with 32 KB; each skips the other's tiles.
+// Two instantiations share the tiles: SMALL sorts tiles of <= 1024 entries with ONE wave (16 keys per lane
+// and trip, 8 KB of LDS, no s_barrier), the other takes the longer lists with 256 threads and 32 KB; each
+// skips the other's tiles.
 #define GSR_SORT_SMALL 1024
-#define GSR_SORT_BIG_THREADS 256 // 1024 threads per 4096-key tile measured no faster (252 vs 242 us on the fat scene)
+#define GSR_SORT_G 4              // 16 keys per thread and trip
+#define GSR_SORT_SMALL_THREADS 64
+#define GSR_SORT_BIG_THREADS 256  // 1024 threads per 4096-key tile measured no faster
 template <bool SMALL>
-__global__ void __launch_bounds__(SMALL ? 256 : GSR_SORT_BIG_THREADS)
+__global__ void __launch_bounds__(SMALL ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS)
 K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __restrict__ hdr,
             uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list)
 {
@@ -391,12 +440,12 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
     if (n == 0 || (n <= GSR_SORT_SMALL) != SMALL) return;
     uint64_t* seg = pairs + r.x;
     if (n <= GSR_SORT_CAP) {
-        int n2 = 4;
+        int n2 = 1 << GSR_SORT_G;
         while (n2 < n) n2 <<= 1;
-        for (int i = threadIdx.x; i < n2; i += blockDim.x) s[i] = i < n ? seg[i] : ~0ull;
-        __syncthreads();
-        lds_sort(s, n2);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) point_list[r.x + i] = (uint32_t)s[i];
+        for (int i = threadIdx.x; i < n2; i += blockDim.x) s[swz(i)] = i < n ? seg[i] : ~0ull;
+        sort_sync<SMALL>();
+        lds_sort<GSR_SORT_G, SMALL>(s, n2);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) point_list[r.x + i] = (uint32_t)s[swz(i)];
         return;
     }
     // oversize tile: chunk-local stages in LDS, long-stride stages in global memory
@@ -406,10 +455,10 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
     for (int c = 0; c < nchunks; c++) {
         const long base = (long)c * GSR_SORT_CAP;
         if (base >= n) break;
-        for (int i = threadIdx.x; i < GSR_SORT_CAP; i += blockDim.x) s[i] = base + i < n ? seg[base + i] : ~0ull;
+        for (int i = threadIdx.x; i < GSR_SORT_CAP; i += blockDim.x) s[swz(i)] = base + i < n ? seg[base + i] : ~0ull;
         __syncthreads();
-        lds_sort(s, GSR_SORT_CAP);
-        for (int i = threadIdx.x; i < GSR_SORT_CAP; i += blockDim.x) if (base + i < n) seg[base + i] = s[i];
+        lds_sort<GSR_SORT_G, false>(s, GSR_SORT_CAP);
+        for (int i = threadIdx.x; i < GSR_SORT_CAP; i += blockDim.x) if (base + i < n) seg[base + i] = s[swz(i)];
         __syncthreads();
     }
     for (long k = 2L * GSR_SORT_CAP; k <= n2; k <<= 1) {
@@ -430,10 +479,10 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
         for (int c = 0; c < nchunks; c++) { // remaining strides are chunk-local
             const long base = (long)c * GSR_SORT_CAP;
             if (base >= n) break;
-            for (int i = threadIdx.x; i < GSR_SORT_CAP; i += blockDim.x) s[i] = base + i < n ? seg[base + i] : ~0ull;
+            for (int i = threadIdx.x; i < GSR_SORT_CAP; i += blockDim.x) s[swz(i)] = base + i < n ? seg[base + i] : ~0ull;
             __syncthreads();
-            lds_disperse_from(s, GSR_SORT_CAP, 11); // strides 2048 ... 1 (GSR_SORT_CAP / 2 = 2^11)
-            for (int i = threadIdx.x; i < GSR_SORT_CAP; i += blockDim.x) if (base + i < n) seg[base + i] = s[i];
+            lds_disperse_from<GSR_SORT_G, false>(s, GSR_SORT_CAP, 11); // strides 2048 ... 1 (GSR_SORT_CAP / 2 = 2^11)
+            for (int i = threadIdx.x; i < GSR_SORT_CAP; i += blockDim.x) if (base + i < n) seg[base + i] = s[swz(i)];
             __syncthreads();
         }
     }
