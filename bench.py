@@ -173,11 +173,13 @@ def main():
         alg_bytes = 40 * R + 20 * N + 36 * V
         achieved = alg_bytes / (bwd_blend_ms * 1e-3) / 1e9
         total_alg = 152 * P + 340 * V + 128 * R + 44 * N   # whole fwd+bwd
+        valu_busy = None
         traffic = None   # HBM/fabric bytes per launch of the dominant kernel: PMC counters cannot be read live,
         try:             # so the committed rocprofv3 --pmc summary of this same command is quoted
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             if P == 1_000_000:
                 traffic = tj["kernels"]["K_blend_bwd"]["traffic_bytes"]
+                valu_busy = tj["kernels"]["K_blend_bwd"].get("valu_busy_frac")
         except Exception:
             traffic = None
         out = {
@@ -194,6 +196,9 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes": alg_bytes, "avg_launch_ms": bwd_blend_ms,
                          "fwd_blend_avg_launch_ms": fwd_blend_ms,
+                         # the kernel is VALU-issue-bound, not HBM-bound: share of the launch during
+                         # which the VALU pipes were issuing, from the committed PMC summary (profiles/)
+                         "valu_busy_frac": valu_busy,
                          "whole_step": {"algorithmic_bytes": total_alg,
                                         "achieved": total_alg / (ms_step * 1e-3) / 1e9,
                                         "frac": total_alg / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}},

@@ -88,5 +88,9 @@ with open(os.path.join(dst, tag + "_pmc.md"), "w") as o:
             tr = (2 * F + Wr) * 1024
             o.write("| %s | %.0f | %.0f | %.1f | %.2f |\n" % (k, F, Wr, tr / 1e6, hit / (hit + miss) if hit == hit else float("nan")))
             tj["kernels"][k] = {"fetch_size_kb": F, "write_size_kb": Wr, "traffic_bytes": tr}
+    for k in ("K_blend_fwd", "K_blend_bwd"):   # what actually bounds the blend kernels: VALU issue
+        if k in avg and k in stats_avg and k in tj["kernels"]:
+            tj["kernels"][k]["valu_instructions"] = avg[k]["SQ_INSTS_VALU"]
+            tj["kernels"][k]["valu_busy_frac"] = avg[k]["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / 2.4e3 / stats_avg[k]
     json.dump(tj, open(os.path.join(dst, "r01_traffic.json"), "w"), indent=1)
 print("written", tag)
