@@ -2,26 +2,25 @@
 //
 // Data layout in HBM (all sub-arrays 256-byte aligned inside caller-owned blobs):
 //
-//   geometry blob  (gsr_geom_bytes(P)):
-//     GeomHeader                         256 B   {num_rendered, overflow, capacity}
-//     (g0, g1, col interleaved: one 48-byte record per splat)
-//     g0   float4     {x, y, conic_a, conic_b}           pixel centre + half of the conic
-//     g1   float4[P]  {conic_c, opacity, depth, radius}  radius stored as int bits
-//     col  float4[P]  {r, g, b, clamp-flags}             colour the blend uses (SH result or
-//                                                        copy of colors_precomp)
-//     slots uint4[P]     what the fill pass needs: rank in the class counter (rectangles up to 2x2 tiles,
-//                        see TileRec), depth bits, band-clipped tile rectangle
-//     acc  float[P][16]  backward accumulators (one 64-byte line per splat: 48-byte records straddle lines and
+//   geometry blob  (gsr_geom_bytes(P)), 128 B per splat:
+//     GeomHeader                         256 B   {num_rendered, overflow, capacity of the binning blob}
+//     rec  48 B[P]  the per-splat record the blend kernels gather, interleaved so that it costs one L2 line:
+//          g0  {x, y, conic_a, conic_b}            pixel centre + half of the conic
+//          g1  {conic_c, opacity, depth, radius}   radius stored as int bits (0: culled)
+//          col {r, g, b, clamp-flags}              colour the blend uses (SH result or copy of colors_precomp)
+//     slots uint4[P]     bin record for the fill pass: rank in the splat's class counter (TileRec / Cls4Rec),
+//                        depth bits, band-clipped tile rectangle
+//     acc  float[P][16]  backward accumulators, one 64-byte line per splat (48-byte records straddle lines and
 //                        the L2 atomic rate drops from 20 to 13 G records/s): moments of u = G*dL/dalpha
-//                        {sum u, u*dx, u*dy, u*dx^2, u*dx*dy, u*dy^2}, dcolor.rgb, pad
+//                        {sum u, u*dx, u*dy, u*dx^2, u*dx*dy, u*dy^2}, dcolor.rgb, 7 unused
 //   image blob     (gsr_image_bytes(W,H)):
-//     final_T f32[N], n_contrib u32[N], ranges uint2[T], tiles TileRec[T] (one 64-B line each)
-//   binning blob   (gsr_binning_bytes(R)):
-//     pairs u64[R] (depth bits << 32 | splat id, grouped per tile), point_list u32[R]
+//     final_T f32[N], n_contrib u32[N], ranges uint2[T], tiles TileRec[T] + cls4 Cls4Rec[T] + tier2 flag (cleared
+//     by one memset per frame), run4 u32[T][256], anchor u32[T][128], qcount u32[4T]
+//   binning blob   (gsr_binning_bytes(capacity)), 44 B per tile instance:
+//     pairs u64[R] (depth bits << 32 | splat id, grouped per tile), point_list u32[R],
+//     qhits uint2[4R] (the forward's log of quad hits for the backward)
 //
-// The reference keeps 79 B/splat + 24 B/instance (rasterizer_impl.h:21-65); this
-// layout is 52 B/splat (+48 scratch) and 12 B/instance (+32 B of quad-hit log), and every per-splat
-// gather of the blend kernels is a 16-byte aligned vector load.
+// The reference keeps 79 B/splat + 24 B/instance + radix-sort temporaries (rasterizer_impl.h:21-65).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -43,7 +42,7 @@ static_assert(sizeof(GeomHeader) == 256, "header is one aligned slot");
 // Per-tile binning record, padded to its own 64-byte line: device-scope atomics on
 // counters that share a line serialise (measured 12 vs 23 G atomics/s on MI355X), and the chip
 // retires only ~20 G device-scope atomics/s in total, so the count pass is built to issue as few
-// as possible: a splat whose tile rectangle is at most 2x2 (almost all of them) is counted with ONE
+// as possible: a splat whose tile rectangle is at most 2x2 (almost all of a freshly initialised map) is counted with ONE
 // returning atomic on the class counter cls[(w-1) + 2*(h-1)] of its top-left ("anchor") tile, and
 // the value returned is its rank in that class. The scan kernel lays every tile's list segment out
 // as nine runs — one per (class, anchor) that covers the tile:

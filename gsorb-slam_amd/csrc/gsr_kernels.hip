@@ -2,23 +2,23 @@
 // Gaussian-splat rasterizer. Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off.
 //
 // Forward  (replaces rasterizer_impl.cu:199-345 of the reference's DGR tree):
-//   K_preprocess   per splat : project, cull, radius, tile rectangle, colour; counts the
-//                              splat into every tile it touches (tile_count atomics)
-//   K_scan_tiles   1 block   : tile_count -> ranges (start,end), cursors, num_rendered
-//   K_fill         per splat : (depth bits<<32 | id) into its tiles' segments (unordered)
+//   K_preprocess   per splat : project, cull, radius, tile rectangle, colour; ONE count atomic per splat on the
+//                              (class, anchor) counter of its tile rectangle (gsr_device.h: TileRec, Cls4Rec)
+//   K_tile_runs    per tile  : the (class, anchor) runs that cover a tile -> its count and run offsets
+//   K_scan_tiles   1 block   : counts -> segment starts, ranges, num_rendered, overflow flag
+//   K_anchor_table per anchor: absolute run starts per (anchor, class, covered tile)
+//   K_fill         per splat : (depth bits<<32 | id) at run start + rank in each of its tiles (no atomics)
 //   K_tile_sort    per tile  : bitonic sort of the tile's segment in LDS -> point_list
 //                              ((depth, id) ascending == the reference's stable radix order)
-//   K_blend_fwd    per quad  : front-to-back alpha blend, one wave per 8x8 quad, one pixel per lane,
-//                              exact ellipse-vs-quad culling (gsr_blend.h)
+//   K_blend_fwd    per quad  : front-to-back alpha blend, one wave per 8x8 quad, four independent 4x4 patch
+//                              rows per wave, exact culling, logs its hits for the backward (gsr_blend.h)
 // Backward (replaces rasterizer_impl.cu:405-498):
-//   K_blend_bwd    per quad  : back-to-front re-walk, four independent 4x4 patch rows per wave, in-row DPP
-//                              reduction, LDS merge, one 9-lane atomic per (quad, splat) into a packed
-//                              per-splat accumulator (gsr_blend.h)
+//   K_blend_bwd    per quad  : back-to-front walk of the forward's log, in-row DPP reduction, LDS merge, one
+//                              9-lane atomic per (quad, splat) into the per-splat accumulator (gsr_blend.h)
 //   K_splat_bwd    per splat : conic/mean2D/colour gradients -> mean3D, cov3D, scale, rot, SH
 //
-// No global sort and no per-instance keys: per-tile counting replaces the
-// reference's 64-bit radix sort of R instances (6 passes over 24 B/instance) by
-// one 8 B/instance write and one LDS-resident sort per tile.
+// No global sort and no (tile | depth) keys: per-tile counting replaces the reference's 64-bit radix sort of
+// R instances (6 passes over 24 B/instance) by one 8 B/instance write and one LDS-resident sort per tile.
 #include "gsr_device.h"
 #include "gsr_splat_math.h"
 
