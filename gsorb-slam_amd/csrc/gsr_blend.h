@@ -195,7 +195,9 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
                 g2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
     const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
     const v2f g01 = {g0, g1};
-    float S0 = 0.f, S1 = 0.f, S2 = 0.f;
+    // colour accumulated behind the current splat, already contracted with the pixel's upstream gradient:
+    // the reference's accum_rec enters dL/dalpha only through accum_rec . dL_dpix, a scalar recursion
+    float Sg = 0.f;
     const int slot = rows_slot_of(l);
     const int fe = (lane * 57) >> 9, fc = lane - 9 * fe; // lane / 9, lane % 9: flush lane -> (entry, component)
     for (int i = lane; i < Q * 9 + 64; i += 64) ACC[i] = 0.f;
@@ -289,10 +291,9 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             const float ia = __builtin_amdgcn_rcpf(1.f - alpha);
             T = T * ia;
             const float dcol = alpha * T;
-            const float e0 = B.z - S0, e1 = B.w - S1, e2 = Cz.x - S2;
-            float dL_dalpha = fmaf(e2, g2, fmaf(e1, g1, e0 * g0)) * T;
-            dL_dalpha = fmaf(-T_final * ia, bg_dot, dL_dalpha);
-            S0 = fmaf(alpha, e0, S0); S1 = fmaf(alpha, e1, S1); S2 = fmaf(alpha, e2, S2);
+            const float eg = fmaf(Cz.x, g2, fmaf(B.w, g1, B.z * g0)) - Sg; // (colour - accum_rec) . dL_dpix
+            const float dL_dalpha = fmaf(-T_final * ia, bg_dot, eg * T);
+            Sg = fmaf(alpha, eg, Sg); // accum_rec <- alpha*colour + (1-alpha)*accum_rec, contracted
             const float u = G * dL_dalpha;
             const v2f d = {dx, dy};
             const v2f ud = u * d;      // two-wide products: v_pk_mul_f32
