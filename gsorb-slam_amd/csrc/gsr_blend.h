@@ -195,6 +195,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
                 g2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
     const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
     const v2f g01 = {g0, g1};
+    const float nTf_bg = -T_final * bg_dot;
     // colour accumulated behind the current splat, already contracted with the pixel's upstream gradient:
     // the reference's accum_rec enters dL/dalpha only through accum_rec . dL_dpix, a scalar recursion
     float Sg = 0.f;
@@ -292,7 +293,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             T = T * ia;
             const float dcol = alpha * T;
             const float eg = fmaf(Cz.x, g2, fmaf(B.w, g1, B.z * g0)) - Sg; // (colour - accum_rec) . dL_dpix
-            const float dL_dalpha = fmaf(-T_final * ia, bg_dot, eg * T);
+            const float dL_dalpha = fmaf(nTf_bg, ia, eg * T); // - T_final/(1-alpha) * (bg . dL_dpix)
             Sg = fmaf(alpha, eg, Sg); // accum_rec <- alpha*colour + (1-alpha)*accum_rec, contracted
             const float u = G * dL_dalpha;
             const v2f d = {dx, dy};
