@@ -200,6 +200,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     // the reference's accum_rec enters dL/dalpha only through accum_rec . dL_dpix, a scalar recursion
     float Sg = 0.f;
     const int slot = rows_slot_of(l);
+    const uint32_t slot_b = slot < 0 ? 0u : 4u * (uint32_t)slot, sink_b = 4u * (uint32_t)(Q * 9 + lane);
     const int fe = (lane * 57) >> 9, fc = lane - 9 * fe; // lane / 9, lane % 9: flush lane -> (entry, component)
     for (int i = lane; i < Q * 9 + 64; i += 64) ACC[i] = 0.f;
     const int ntodo = __builtin_amdgcn_readfirstlane(min(n, (int)wave_max_u32(last)));
@@ -280,7 +281,8 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
         auto step = [&](const int it, const int idx, const float4 A, const float4 B, const float4 Cz) {
             const bool act = it < mycnt;
             const bool commit = slot >= 0 && act;
-            float* const accp = &ACC[commit ? idx * 9 + slot : Q * 9 + lane]; // idle lanes: private sink word
+            // byte offsets: one mad and one select; idle lanes use a private sink word
+            float* const accp = reinterpret_cast<float*>(reinterpret_cast<char*>(ACC) + (commit ? (uint32_t)idx * 36u + slot_b : sink_b));
             const float acc_old = *accp;
             __builtin_amdgcn_sched_barrier(0); // issue the accumulator read here, a whole iteration ahead of its use
             const float dx = A.x - pxf, dy = A.y - pyf;
