@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(64)
 K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
                  int grid_x, int ntiles, int tile0, float* __restrict__ out_color, float* __restrict__ out_depth)
 {
-    __shared__ float4 E0[Q], E1[Q], E2[Q]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, depth, list position, id)
+    __shared__ float4 E0[Q], E1[Q], E2[Q]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, depth, list position + 1, id)
     __shared__ uint8_t LIST[4 * Q];
     const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
     const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u;
@@ -407,7 +407,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                     const int e = count + mbcnt64(m);
                     E0[e] = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
                     E1[e] = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, c.x, c.y);
-                    E2[e] = make_float4(c.z, b.z, __uint_as_float((uint32_t)k), __uint_as_float(id));
+                    E2[e] = make_float4(c.z, b.z, __uint_as_float((uint32_t)k + 1u), __uint_as_float(id));
                 }
                 count += (int)__popcll(m);
                 base += 64;
@@ -429,7 +429,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                 c0 += (int)__popcll(m0); c1 += (int)__popcll(m1); c2 += (int)__popcll(m2); c3 += (int)__popcll(m3);
                 const uint32_t pm = (h[0] ? 1u : 0u) | (h[1] ? 2u : 0u) | (h[2] ? 4u : 0u) | (h[3] ? 8u : 0u);
                 const unsigned long long ma = m0 | m1 | m2 | m3;
-                if (pm) qh[qc + mbcnt64(ma)] = make_uint2(__float_as_uint(z.z), __float_as_uint(z.w) | (pm << GSR_ID_BITS));
+                if (pm) qh[qc + mbcnt64(ma)] = make_uint2(__float_as_uint(z.z) - 1u, __float_as_uint(z.w) | (pm << GSR_ID_BITS));
                 qc += (int)__popcll(ma);
             }
             __builtin_amdgcn_wave_barrier();
@@ -454,7 +454,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                 C2 = fmaf(Cz.x, wgt, C2);
                 Dp = (upd && T > 0.5f) ? Cz.y : Dp; // median depth (forward.cu:374-379)
                 T = upd ? test_T : T;
-                last = upd ? __float_as_uint(Cz.z) + 1u : last;
+                last = upd ? __float_as_uint(Cz.z) : last;
             };
             int idx0 = 0 < mycnt ? (int)mylist[0] : 0; // entry 0 is always parked: finite data for idle rows
             float4 A0 = E0[idx0], B0 = E1[idx0], Z0 = E2[idx0];
@@ -464,11 +464,13 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                 idx1 = it + 1 < mycnt ? raw1 : 0;
                 A1 = E0[idx1]; B1 = E1[idx1]; Z1 = E2[idx1];
                 raw0 = (int)mylist[min(it + 2, Q - 1)];
+                __builtin_amdgcn_sched_barrier(0); // keep the prefetch above the iteration it overlaps with
                 step(it, A0, B0, Z0);
                 if (it + 1 >= maxc) break;
                 idx0 = it + 2 < mycnt ? raw0 : 0;
                 A0 = E0[idx0]; B0 = E1[idx0]; Z0 = E2[idx0];
                 raw1 = (int)mylist[min(it + 3, Q - 1)];
+                __builtin_amdgcn_sched_barrier(0);
                 step(it + 1, A1, B1, Z1);
             }
             __builtin_amdgcn_wave_barrier();
