@@ -55,7 +55,7 @@ def cpu_baseline(sc, P, W, H, budget_s=20.0):
     o.forward(copy_stages=False, **kw)
     o.backward(sc.dL_dpix, accum_double=False)
     first = time.perf_counter() - t0
-    reps = int(max(1, min(5, (budget_s - first) // max(first, 1e-3))))
+    reps = int(max(1, min(10, (budget_s - first) // max(first, 1e-3))))   # median of 10 after a warm-up
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter()
@@ -64,7 +64,7 @@ def cpu_baseline(sc, P, W, H, budget_s=20.0):
         ts.append(time.perf_counter() - t0)
     t = float(np.median(ts)) if ts else first
     return {"value": P * W * H / t, "unit": "splats*pixels/s", "cores": cores, "kind": "port",
-            "sample": f"{len(ts) or 1} fwd+bwd of the same {P}-splat {W}x{H} scene (median), oracle/libgsr_oracle_omp.so, "
+            "sample": f"{len(ts) or 1} fwd+bwd of the same {P}-splat {W}x{H} scene after one warm-up (median), oracle/libgsr_oracle_omp.so, "
                       f"{t * 1e3:.0f} ms each"}
 
 
