@@ -40,6 +40,9 @@ def _cases(syn):
         "fat-clamped": dict(P=1500, cam=SMALL, mult=14.0, Tcw=pose(0.2), frac_offscreen=0.4),   # fov clamp, long lists
         "dense-long-lists": dict(P=200000, cam=SMALL, mult=1.2),                           # > 256 and > 4096 entries per tile
         "replica-300k": dict(P=300000, cam=syn.REPLICA),                                 # BASELINE configs[1]
+        # ~30 overlapping layers of near-identical colours per pixel, lists of ~10k entries: the case in which a
+        # reformulated accum_rec recursion once lost accuracy (scripts/fuzz_parity.py found it)
+        "deep-stack-depth": dict(P=40000, cam=dict(width=48, height=448, fx=40.0, fy=42.0), mode="depth", mult=8.0),
     }
 
 
@@ -49,7 +52,7 @@ def _build(syn, P, cam, mode="rgb", mult=1.0, Tcw=None, bg=(0, 0, 0), seed=0, **
 
 
 CASE_NAMES = ["small-rgb", "tum-10k-rgb", "tum-10k-depth-fat", "odd-sh3-pose-bg", "odd-sh1", "fat-clamped",
-              "dense-long-lists", "replica-300k"]
+              "dense-long-lists", "replica-300k", "deep-stack-depth"]
 
 
 @pytest.mark.parametrize("name", CASE_NAMES)
