@@ -120,7 +120,8 @@ __device__ __forceinline__ void patch_reach4(const float4 A, const float4 B, flo
 
 // Transposing reduction of nine values inside each 16-lane row. Stage s pairs lanes through a DPP
 // permutation that flips bit (3-s) of the lane number; the lane keeps one value of a pair and hands the
-// other to its partner, so the live registers go 9 -> 5 -> 3 -> 2 -> 1. 27 VALU. On return lane l of the
+// other to its partner, so the live registers go 9 -> 5 -> 3 -> 2 -> 1 (21 VALU with the bank-masked first two
+// stages of row_reduce9, 27 with selects throughout). On return lane l of the
 // row holds the row total of value rows_slot_of(l).
 __device__ __forceinline__ int rows_slot_of(int l)
 {
