@@ -92,7 +92,9 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     const int Tb = (f.band_y1 - f.band_y0) * f.grid_x; // tiles of the band
     if (Tb > 0)
         hipLaunchKernelGGL(gsr::K_blend_fwd<GSR_FWDQ>, dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
-                           f.grid_x, Tb, f.band_y0 * f.grid_x, a->out_color, a->out_depth);
+                           f.grid_x, Tb, f.band_y0 * f.grid_x, a->out_color, a->out_depth, P);
+    else // an empty band launches no blend kernel: clear the backward accumulators here
+        GSR_HIP(hipMemsetAsync(gv.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
     GSR_LAUNCHED();
     tm.end(GSR_FWD_BLEND);
     return GSR_OK;

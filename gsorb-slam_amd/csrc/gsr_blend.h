@@ -366,7 +366,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
 template <int Q>
 __global__ void __launch_bounds__(64)
 K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
-                 int grid_x, int ntiles, int tile0, float* __restrict__ out_color, float* __restrict__ out_depth)
+                 int grid_x, int ntiles, int tile0, float* __restrict__ out_color, float* __restrict__ out_depth, int P)
 {
     __shared__ float4 E0[Q], E1[Q], E2[Q]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, depth, list position + 1, id)
     __shared__ uint8_t LIST[4 * Q];
@@ -490,6 +490,14 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
         out_color[HW + pix] = C1 + T * bg[1];
         out_color[2 * HW + pix] = C2 + T * bg[2];
         out_depth[pix] = Dp;
+    }
+    { // The backward accumulators (64 bytes per splat) must be zero when the forward is done. Clearing them is
+      // pure memory traffic and this kernel is pure VALU work, so every block clears its share here for free
+      // (inside K_preprocess the same stores cost ~10 us at 1 M splats). Last thing the wave does: nothing waits for them.
+        const size_t total = (size_t)P * (GSR_ACC_STRIDE / 4), per = (total + gridDim.x - 1) / gridDim.x;
+        const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < total ? b0 + per : total;
+        float4* const acc4 = reinterpret_cast<float4*>(g.acc);
+        for (size_t i = b0 + threadIdx.x; i < b1; i += 64) acc4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 

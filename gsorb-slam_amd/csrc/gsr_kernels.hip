@@ -58,10 +58,6 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= f.P) return;
-    { // the backward accumulators start every frame at zero (K_splat_bwd re-zeroes what it consumed)
-        float4* const ap = reinterpret_cast<float4*>(g.acc + (size_t)idx * GSR_ACC_STRIDE);
-        ap[0] = ap[1] = ap[2] = ap[3] = make_float4(0.f, 0.f, 0.f, 0.f); // the whole 64-byte line
-    }
     const float3 p = make_float3(in.means3D[3 * (size_t)idx], in.means3D[3 * (size_t)idx + 1], in.means3D[3 * (size_t)idx + 2]);
     float cov[6];
     load_cov3d(in, f, idx, cov);
