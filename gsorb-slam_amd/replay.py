@@ -110,6 +110,55 @@ def read_trajectory(path: str, kind: str):
     return poses, stamps
 
 
+def read_trajectory_matrices(path: str) -> np.ndarray:
+    """scripts/eval_ate.py:35-54: one 4x4 matrix per line (16 numbers, or 17 with a leading timestamp);
+    '#' lines and lines of any other length are skipped. Returns [N,4,4] float64."""
+    out = []
+    with open(path, "r", encoding="utf-8") as f:
+        for ln in f:
+            if ln.startswith("#"):
+                continue
+            v = [float(x) for x in ln.strip().split()]
+            if len(v) == 17:
+                v = v[1:]
+            if len(v) != 16:
+                continue
+            out.append(np.array(v).reshape(4, 4))
+    return np.array(out)
+
+
+def align_umeyama(model: np.ndarray, data: np.ndarray):
+    """scripts/eval_ate.py:6-33: rigid (rotation + translation, no scale) least-squares alignment of the
+    3xN point set `model` onto `data` by SVD of the cross-covariance. Returns (R [3,3], t [3,1],
+    per-point translation error [N])."""
+    mm, dm = model.mean(1, keepdims=True), data.mean(1, keepdims=True)
+    Wm = (model - mm) @ (data - dm).T                       # sum of outer products
+    U, _, Vh = np.linalg.svd(Wm.T, full_matrices=False)
+    S = np.identity(3)
+    if np.linalg.det(U) * np.linalg.det(Vh) < 0:
+        S[2, 2] = -1
+    R = U @ S @ Vh
+    t = dm - R @ mm
+    err = R @ model + t - data
+    return R, t, np.sqrt((err ** 2).sum(0))
+
+
+def ate_rmse(gt_traj, est_traj) -> float:
+    """scripts/eval_ate.py:56-82 (`evaluate_ate`): translation parts of the first min(len) pose pairs without
+    an inf entry, ground truth aligned onto the estimate, and — like the reference, whose result line calls
+    it "ATE RMSE" — the MEAN of the per-pose translation errors (metres)."""
+    gt_traj, est_traj = np.asarray(gt_traj, np.float64), np.asarray(est_traj, np.float64)
+    n = min(len(gt_traj), len(est_traj))
+    if n == 0:
+        raise ValueError("Empty trajectory input.")
+    ok = [i for i in range(n) if not np.any(np.isinf(gt_traj[i])) and not np.any(np.isinf(est_traj[i]))]
+    if not ok:
+        raise ValueError("No valid trajectory point pairs found.")
+    g = np.array([gt_traj[i][:3, 3] for i in ok]).T
+    e = np.array([est_traj[i][:3, 3] for i in ok]).T
+    return float(np.mean(align_umeyama(g, e)[2]))
+
+
 def _dgr():
     pkg = os.path.dirname(os.path.abspath(__file__))
     if pkg not in sys.path:

@@ -1,0 +1,214 @@
+"""The multi-process exchange paths of gsorb-slam_amd/sharded.py on the HIP operator.
+
+Two processes, one rank each, driving the PRODUCT backends (HipBandBackend over the C ABI, the Python operator
+inside ShardedMapper) with real collectives:
+  * backend "gloo", both ranks on cuda:0 — runs on the one-GPU test box (device tensors are staged through the
+    host for the gloo all-gather, sharded._all_gather);
+  * backend "nccl" (= RCCL over xGMI), rank r on cuda:r — skipped unless two GPUs are visible.
+Scheme A (tile bands): the gathered frame must be bit-identical to the one-process C-ABI frame, the gradients
+equal up to float summation order. Scheme B (scene shards): the all-reduced pose gradient must equal the
+gradient of the same two-layer composite differentiated in one process, and one mapping-loss backward on the
+shards must match the rows of the in-process composite's gradients.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, FX, FY = 320, 240, 260.0, 258.0
+NAMES = ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dscales", "dL_drotations")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_package
+    gsr = load_package()
+    hz = __import__("gsorb_slam_amd.harness", fromlist=["x"])
+    sharded = __import__("gsorb_slam_amd.sharded", fromlist=["x"])
+    return gsr, hz, sharded
+
+
+def _scene(gsr):
+    syn = gsr.synthetic
+    cam = syn.make_camera(W, H, FX, FY)
+    return cam, syn.make_scene(6000, cam, seed=17, scale_mult=1.5)
+
+
+def _fill(hz, sc, idx, device):
+    g = hz.GaussianMap(hz.Config(), FX, FY, device=device)
+    g.add_points(torch.tensor(sc.means3D[idx]), torch.tensor(sc.colors[idx]))
+    op = torch.tensor(sc.opacities[idx])
+    with torch.no_grad():
+        g.log_scales.copy_(torch.log(torch.tensor(sc.scales[idx])))
+        g.unnorm_quat.copy_(torch.tensor(sc.rotations[idx]))
+        g.logit_opacities.copy_(torch.log(op / (1 - op)))
+    return g
+
+
+def _pose():
+    from util import pose
+    return torch.tensor(pose(0.02, (0.01, -0.01, 0.015)), dtype=torch.float32)
+
+
+def _target(hz, sc, dev):
+    g = _fill(hz, sc, np.arange(sc.P), dev)
+    with torch.no_grad():
+        g.rgb.mul_(0.8).add_(0.1)
+        r = hz.SlamRenderer(g, W, H)
+        T = _pose().to(dev)
+        rgb, sur, _ = r.render_rgb(T, tracking=True)
+    return hz.Frame(rgb.clone(), sur[0].clone(), T)
+
+
+def _smooth_loss(r, frame, Tcw):
+    rimage, _, rdepth = r.render_pair(Tcw, tracking=True)
+    return ((rimage - frame.rgb) ** 2).sum() + ((rdepth[0] - frame.depth * rdepth[1].detach()) ** 2).sum()
+
+
+def _worker(rank, world, port, backend, q):
+    gsr, hz, sharded = _setup()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        capi = gsr.capi
+        cam, sc = _scene(gsr)
+        t = lambda a: torch.tensor(a, device=dev)
+        res = {}
+        # ---- scheme A: tile bands through the C ABI
+        r = sharded.TileBandRenderer(sharded.HipBandBackend(capi))
+        s = capi.Settings.from_camera(cam, dev)
+        color, depth, st = r.forward(s, H, W, dev, means3D=t(sc.means3D), opacities=t(sc.opacities), colors=t(sc.colors),
+                                     scales=t(sc.scales), rotations=t(sc.rotations))
+        grads = r.backward(st, t(sc.dL_dpix))
+        res.update(color=color.cpu().numpy(), depth=depth.cpu().numpy(), bands=r.bands(H), R=st.num_rendered,
+                   grads={n: getattr(grads, n).cpu().numpy() for n in NAMES})
+        # ---- scheme B: scene shards through the Python operator
+        T = _pose().to(dev)
+        zc = t(sc.means3D) @ T[2, :3] + T[2, 3]
+        slabs = [x.cpu().numpy() for x in sharded.shard_by_depth_slabs(zc, world)]
+        frame = _target(hz, sc, dev)
+        Mapper = sharded.make_sharded_mapper(hz)
+        g = _fill(hz, sc, slabs[rank], dev)
+        m = Mapper(g, W, H)
+        Tp = T.clone().requires_grad_(True)
+        loss = _smooth_loss(m, frame, Tp)
+        loss.backward()
+        own = Tp.grad.clone()
+        total = m.comp.all_reduce_pose_grad(Tp.grad.clone())
+        ml = m.mapping_loss(frame)
+        ml.backward()
+        res.update(pose_own=own.cpu().numpy(), pose_sum=total.cpu().numpy(), loss=float(loss.detach()), map_loss=float(ml.detach()),
+                   map_grads={n: getattr(g, n).grad.cpu().numpy() for n in g.NAMES}, idx=slabs[rank],
+                   world=dist.get_world_size(), backend=dist.get_backend())
+        torch.cuda.synchronize()
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def _reference(gsr, hz, sharded, world):
+    """One process, one GPU: the C-ABI frame + gradients, and the two-layer composite with every layer differentiable."""
+    capi = gsr.capi
+    dev = torch.device("cuda:0")
+    cam, sc = _scene(gsr)
+    t = lambda a: torch.tensor(a, device=dev)
+    s = capi.Settings.from_camera(cam, dev)
+    full = capi.forward(s, means3D=t(sc.means3D), opacities=t(sc.opacities), colors=t(sc.colors), scales=t(sc.scales),
+                        rotations=t(sc.rotations))
+    gfull = capi.backward(full, t(sc.dL_dpix))
+    ref = dict(color=full.color.cpu().numpy(), depth=full.depth.cpu().numpy(), R=full.num_rendered,
+               grads={n: getattr(gfull, n).cpu().numpy() for n in NAMES})
+    T = _pose().to(dev)
+    zc = t(sc.means3D) @ T[2, :3] + T[2, 3]
+    slabs = [x.cpu().numpy() for x in sharded.shard_by_depth_slabs(zc, world)]
+    frame = _target(hz, sc, dev)
+
+    def composite(Tp, maps, tracking):
+        layers = []
+        for g in maps:
+            r = hz.SlamRenderer(g, W, H)
+            rimage, _, rdepth = r.render_pair(Tp, tracking=tracking)
+            layers.append(torch.cat([rimage, rdepth[0:2]], 0))
+        Tr = torch.ones_like(layers[0][0:1])
+        out = torch.zeros_like(layers[0][0:4])
+        for L in layers:
+            out = out + Tr * L[0:4]
+            Tr = Tr * (1.0 - L[4:5])
+        return out, 1.0 - Tr
+
+    maps = [_fill(hz, sc, idx, dev) for idx in slabs]
+    Tp = T.clone().requires_grad_(True)
+    out, sil = composite(Tp, maps, True)
+    loss = ((out[0:3] - frame.rgb) ** 2).sum() + ((out[3] - frame.depth * sil[0].detach()) ** 2).sum()
+    loss.backward()
+    ref.update(pose=Tp.grad.cpu().numpy(), loss=float(loss.detach()))
+    return ref
+
+
+def _run(backend):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    gsr, hz, sharded = _setup()
+    ref = _reference(gsr, hz, sharded, world)
+    scale = lambda a: np.abs(a).max() + 1e-30
+    assert got[0]["world"] == 2 and got[0]["backend"] == backend
+    # ---- scheme A
+    assert got[0]["bands"] == [(0, 7), (7, 15)] or sum(b - a for a, b in got[0]["bands"]) == 15
+    assert got[0]["R"] + got[1]["R"] == ref["R"]                       # the bands partition the (splat, tile) pairs
+    for r in range(world):
+        np.testing.assert_array_equal(got[r]["color"], ref["color"])     # bit-exact frame on every rank
+        np.testing.assert_array_equal(got[r]["depth"], ref["depth"])
+        for n in NAMES:
+            e = np.abs(got[r]["grads"][n] - ref["grads"][n]).max() / scale(ref["grads"][n])
+            assert e < 1e-5, (n, e)
+    for n in NAMES:
+        np.testing.assert_array_equal(got[0]["grads"][n], got[1]["grads"][n])   # identical replicas after the all-reduce
+    # ---- scheme B
+    own0, own1 = got[0]["pose_own"], got[1]["pose_own"]
+    assert np.abs(own0 - own1).max() > 1e-3 * scale(own0)
+    np.testing.assert_array_equal(got[0]["pose_sum"], got[1]["pose_sum"])
+    e = np.abs(got[0]["pose_sum"] - ref["pose"]).max() / scale(ref["pose"])
+    assert e < 1e-4, e                      # float atomics: summation order differs between runs
+    assert abs(got[0]["loss"] - ref["loss"]) <= 1e-5 * abs(ref["loss"])
+    assert abs(got[0]["map_loss"] - got[1]["map_loss"]) <= 1e-6 * abs(got[0]["map_loss"])
+    for r in range(world):
+        for n, g in got[r]["map_grads"].items():
+            assert np.isfinite(g).all() and np.abs(g).max() > 0, n
+    print("\n%s world 2: frame bit-exact, pose-gradient sum vs one-process composite %.1e" % (backend, e))
+
+
+@pytest.mark.gpu
+def test_two_processes_on_one_gpu_gloo_drive_the_hip_backends():
+    _run("gloo")
+
+
+@pytest.mark.gpu
+def test_two_gpus_rccl_drive_the_hip_backends():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL); the same path runs over gloo on one GPU in the test above")
+    _run("nccl")

@@ -1,0 +1,144 @@
+"""Config 3 of BASELINE.json (tracking + mapping loop at the TUM camera, PSNR + ATE): loop-level parity.
+
+The SAME harness code (gsorb-slam_amd/harness.py: SlamRenderer.track = src/Render.cc:1054-1126,
+mapping_iteration = :420-483, Adam groups = src/Gaussian.cc:144-175) runs twice from identical seeds:
+once on the HIP operator (cuda) and once on the CPU oracle wrapped as an autograd op (tests/oracle_op.py).
+Shape of the reference run: 640x480 TUM1 intrinsics (Examples/RGB-D/tum/TUM1.yaml:13-16), 200 tracking
+iterations and 100 mapping iterations per frame (tum config), ~10k Gaussians.
+
+What is compared: the loss curves (first 20 iterations of every loop: before fp32 noise is amplified by Adam's
+sign-like normalisation), the tracked poses, ATE between the two trajectories (scripts/eval_ate.py, pinned in
+test_replay.py), ATE of each against the ground truth, and PSNR between the two final renders.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from util import pose
+
+TUM1 = dict(W=640, H=480, fx=517.306408, fy=516.469215)
+TRACK_ITERS, MAP_ITERS = 200, 100          # Tracking.iters / Mapping.iters of the TUM configuration
+
+
+def _true_world(syn, P=10000, seed=5):
+    cam = syn.make_camera(TUM1["W"], TUM1["H"], TUM1["fx"], TUM1["fy"])
+    return syn.make_scene(P, cam, seed=seed, scale_mult=3.0)
+
+
+def _make_map(hz, sc, device, damage):
+    cfg = hz.Config()
+    g = hz.GaussianMap(cfg, TUM1["fx"], TUM1["fy"], device=device)
+    g.add_points(torch.tensor(sc.means3D), torch.tensor(sc.colors))
+    op = torch.tensor(sc.opacities)
+    with torch.no_grad():
+        g.log_scales.copy_(torch.log(torch.tensor(sc.scales)))
+        g.unnorm_quat.copy_(torch.tensor(sc.rotations))
+        g.logit_opacities.copy_(torch.log(op / (1 - op)))
+        if damage is not None:
+            g.rgb.add_(torch.tensor(damage["rgb"]).to(device))
+            g.logit_opacities.add_(torch.tensor(damage["opac"]).to(device))
+            g.xyz.add_(torch.tensor(damage["xyz"]).to(device))
+    return g
+
+
+def _run(hz, sc, device, rasterizer_cls, frames, gt_poses, damage):
+    """One SLAM-shaped run: map on frame 0, then for every further frame track (200) and map (100)."""
+    g = _make_map(hz, sc, device, damage)
+    r = hz.SlamRenderer(g, TUM1["W"], TUM1["H"], seed=0, rasterizer_cls=rasterizer_cls)
+    dev = torch.device(device)
+    fr = [hz.Frame(f.rgb.to(dev), f.depth.to(dev), f.Tcw.to(dev)) for f in frames]
+    out = dict(track=[], map=[], traj=[gt_poses[0].astype(np.float64)])
+    kf = [hz.Frame(fr[0].rgb, fr[0].depth, torch.tensor(gt_poses[0], dtype=torch.float32, device=dev))]
+    out["map"].append(r.map_frames(kf, iters=MAP_ITERS))
+    T_prev = kf[0].Tcw
+    for k in range(1, len(fr)):
+        T_est, hist = r.track(fr[k], T_prev.clone(), iters=TRACK_ITERS)
+        out["track"].append(hist)
+        out["traj"].append(T_est.detach().cpu().numpy().astype(np.float64))
+        kf.append(hz.Frame(fr[k].rgb, fr[k].depth, T_est.detach()))
+        out["map"].append(r.map_frames(kf, iters=MAP_ITERS))
+        T_prev = T_est.detach()
+    with torch.no_grad():
+        img, sur, _ = r.render_rgb(kf[-1].Tcw, tracking=True)
+    out["final_rgb"], out["final_depth"] = img.detach().cpu(), sur.detach().cpu()
+    out["n"] = len(g)
+    return out
+
+
+def _rel_curve(a, b, n=20):
+    a, b = np.asarray(a[:n], np.float64), np.asarray(b[:n], np.float64)
+    m = min(len(a), len(b))
+    return float(np.max(np.abs(a[:m] - b[:m]) / np.maximum(np.abs(b[:m]), 1e-30)))
+
+
+@pytest.mark.gpu
+def test_tracking_mapping_loop_on_hip_matches_the_same_loop_on_the_oracle(gsr, syn):
+    hz = __import__("gsorb_slam_amd.harness", fromlist=["x"])
+    rp = __import__("gsorb_slam_amd.replay", fromlist=["x"])
+    from oracle_op import OracleRasterizer
+    sc = _true_world(syn)
+    gt = [pose(0.0, (0, 0, 0)).astype(np.float32), pose(0.010, (0.012, -0.006, 0.010)).astype(np.float32),
+          pose(0.021, (0.025, -0.011, 0.022)).astype(np.float32)]
+    # observations: the TRUE map seen from the ground-truth poses (rendered once, by the HIP operator)
+    g_true = _make_map(hz, sc, "cuda", None)
+    r_true = hz.SlamRenderer(g_true, TUM1["W"], TUM1["H"])
+    frames = []
+    with torch.no_grad():
+        for T in gt:
+            Tc = torch.tensor(T, device="cuda")
+            rgb, sur, _ = r_true.render_rgb(Tc, tracking=True)
+            frames.append(hz.Frame(rgb.clone(), sur[0].clone(), Tc))
+    rng = np.random.default_rng(3)
+    P = sc.P
+    damage = dict(rgb=(0.10 * rng.standard_normal((P, 3))).astype(np.float32),
+                  opac=(0.4 * rng.standard_normal((P, 1))).astype(np.float32),
+                  xyz=(0.002 * rng.standard_normal((P, 3))).astype(np.float32))
+    t0 = time.time()
+    hip = _run(hz, sc, "cuda", None, frames, gt, damage)
+    t1 = time.time()
+    ora = _run(hz, sc, "cpu", OracleRasterizer, frames, gt, damage)
+    t2 = time.time()
+
+    rep = {"hip_s": round(t1 - t0, 1), "oracle_s": round(t2 - t1, 1)}
+    # --- loss curves, first 20 iterations of every loop
+    rep["map_curve_rel"] = [_rel_curve(a, b) for a, b in zip(hip["map"], ora["map"])]
+    rep["track_curve_rel"] = [_rel_curve(a, b) for a, b in zip(hip["track"], ora["track"])]
+    # --- whole curves: same length (same early-stop decisions) and close everywhere
+    rep["track_len"] = [(len(a), len(b)) for a, b in zip(hip["track"], ora["track"])]
+    rep["map_curve_rel_all"] = [_rel_curve(a, b, 10 ** 6) for a, b in zip(hip["map"], ora["map"])]
+    rep["track_curve_rel_all"] = [_rel_curve(a, b, 10 ** 6) for a, b in zip(hip["track"], ora["track"])]
+    # --- poses
+    dt = [float(np.linalg.norm(a[:3, 3] - b[:3, 3])) for a, b in zip(hip["traj"], ora["traj"])]
+    dR = [float(np.arccos(np.clip((np.trace(a[:3, :3].T @ b[:3, :3]) - 1) / 2, -1, 1))) for a, b in zip(hip["traj"], ora["traj"])]
+    rep["pose_dt_m"], rep["pose_dR_rad"] = dt, dR
+    rep["ate_hip_vs_oracle_m"] = rp.ate_rmse(np.array(ora["traj"]), np.array(hip["traj"]))
+    gt64 = np.array([g.astype(np.float64) for g in gt])
+    rep["ate_hip_vs_gt_m"] = rp.ate_rmse(gt64, np.array(hip["traj"]))
+    rep["ate_oracle_vs_gt_m"] = rp.ate_rmse(gt64, np.array(ora["traj"]))
+    err0 = [float(np.linalg.norm(gt[k][:3, 3] - gt[k - 1][:3, 3])) for k in range(1, len(gt))]
+    errk = [float(np.linalg.norm(hip["traj"][k][:3, 3] - gt[k][:3, 3])) for k in range(1, len(gt))]
+    rep["track_err_init_m"], rep["track_err_final_m"] = err0, errk
+    # --- final renders
+    psnr = rp.calc_psnr(hip["final_rgb"], ora["final_rgb"]).mean()
+    rep["psnr_hip_vs_oracle_db"] = float(psnr)
+    rep["psnr_hip_vs_observation_db"] = float(rp.calc_psnr(hip["final_rgb"], frames[-1].rgb.cpu()).mean())
+    rep["psnr_oracle_vs_observation_db"] = float(rp.calc_psnr(ora["final_rgb"], frames[-1].rgb.cpu()).mean())
+    print("\nconfig-3 loop parity:", rep)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, "slam_loop_parity.json"), "w") as f:
+            json.dump(rep, f, indent=1)
+
+    assert max(rep["map_curve_rel"]) <= 1e-3 and max(rep["track_curve_rel"]) <= 1e-3, rep
+    assert all(a == b for a, b in rep["track_len"]), rep
+    assert max(dt) < 1e-3 and max(dR) < 1e-3, rep                     # final poses agree: < 1 mm, < 1 mrad
+    assert rep["ate_hip_vs_oracle_m"] < 1e-3, rep                    # ATE between the two runs below 1 mm
+    assert abs(rep["ate_hip_vs_gt_m"] - rep["ate_oracle_vs_gt_m"]) < 1e-3, rep
+    assert all(e < 0.5 * e0 for e, e0 in zip(errk, err0)), rep        # and tracking actually tracks
+    assert rep["psnr_hip_vs_oracle_db"] > 50.0, rep
+    assert abs(rep["psnr_hip_vs_observation_db"] - rep["psnr_oracle_vs_observation_db"]) < 0.1, rep
+    assert hip["n"] == ora["n"] == P

@@ -45,6 +45,47 @@ def test_trajectory_formats(gsr, tmp_path):
         np.testing.assert_allclose(poses[0], T, atol=1e-6)
 
 
+GE = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_eval.npz"))
+
+
+def test_ate_matches_reference_eval_ate(gsr, tmp_path):
+    """Pinned on tests/golden/ref_eval.npz = outputs of the reference's scripts/eval_ate.py (imported by
+    tests/golden/make_ref_eval.py): alignment incl. the reflection branch, the inf / unequal-length rules of
+    evaluate_ate, and the 16-or-17-numbers trajectory file format."""
+    rp = __import__("gsorb_slam_amd.replay", fromlist=["x"])
+    gt, est = GE["gt"], GE["est"]
+    assert abs(rp.ate_rmse(gt, est) - float(GE["ate"])) < 1e-12
+    ok = [i for i in range(len(est)) if i != 5]
+    R, t, err = rp.align_umeyama(gt[ok, :3, 3].T, est[ok, :3, 3].T)
+    np.testing.assert_allclose(R, GE["align_R"], atol=1e-12)
+    np.testing.assert_allclose(t, GE["align_t"], atol=1e-12)
+    np.testing.assert_allclose(err, GE["align_err"], atol=1e-12)
+    R2, t2, e2 = rp.align_umeyama(GE["refl_model"], GE["refl_data"])
+    np.testing.assert_allclose(R2, GE["refl_R"], atol=1e-12)
+    np.testing.assert_allclose(e2, GE["refl_err"], atol=1e-12)
+    assert abs(np.linalg.det(R2) - 1.0) < 1e-9          # a rotation, never a reflection
+    f = tmp_path / "traj.txt"
+    f.write_text(str(GE["traj_text"]))
+    np.testing.assert_array_equal(rp.read_trajectory_matrices(str(f)), GE["traj_parsed"])
+    with pytest.raises(ValueError):
+        rp.ate_rmse(np.zeros((0, 4, 4)), est)
+    # identical trajectories up to a rigid motion: zero error
+    Rg = R
+    moved = gt.copy(); moved[:, :3, 3] = gt[:, :3, 3] @ Rg.T + np.array([1.0, 2.0, 3.0])
+    assert rp.ate_rmse(gt, moved) < 1e-12
+
+
+def test_rgb_sh_conversion_matches_reference_sh_utils():
+    """sh_utils.RGB2SH / SH2RGB (:114-118) against the oracle's degree-0 colour rule (forward.cu:28,61)."""
+    rgb, sh0 = GE["rgb"].astype(np.float32), GE["rgb2sh"].astype(np.float32)
+    dirs = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (len(rgb), 1))
+    col, clamped = oracle.eval_sh(0, sh0[:, None, :], dirs)
+    np.testing.assert_allclose(col, rgb, atol=2e-7)
+    assert not clamped.any()
+    col2, _ = oracle.eval_sh(0, (sh0 * 0.7)[:, None, :], dirs)
+    np.testing.assert_allclose(col2, GE["sh2rgb"], atol=2e-7)
+
+
 @pytest.mark.gpu
 def test_replay_renders_match_oracle(gsr, syn, tmp_path):
     import torch
