@@ -9,9 +9,16 @@ synthetic scene whose inputs are already resident in HBM, through the C ABI
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: weak scaling. The path partitions by scene shard: every rank owns its own
-1 M-Gaussian shard (different seed) and renders it to its own layer; there is no data-path
-collective inside the timed region, only the barriers around it.
+N > 1, headline line: weak scaling. The rasterize path itself partitions by scene shard: every rank owns
+its own 1 M-Gaussian shard (different seed) and renders it to its own layer; there is no data-path
+collective inside that timed region, only the barriers around it.
+
+`shard_step` (same JSON line, --mode all | shard-step): the step that DOES exchange data — one sharded mapping
+iteration and one sharded tracking iteration of gsorb-slam_amd/sharded.py:ShardedMapper (src/Render.cc:420-483,
+:1054-1126 with the map split into depth slabs over the ranks; BASELINE.json config 4: --splats Gaussians in
+TOTAL, strong scaling). Its timed region contains the two rasterizer forwards + backwards of the rank's shard,
+the all-gather of the layers (6 floats/pixel), the compositing, the losses, the scalar / pose-gradient
+all-reduce and the Adam step, over RCCL ("nccl") when N > 1.
 
 The JSON line also carries
   roofline     : the dominant kernel (backward blend) against the HBM roofline, timed live
@@ -68,12 +75,92 @@ def cpu_baseline(sc, P, W, H, budget_s=20.0):
                       f"{t * 1e3:.0f} ms each"}
 
 
+def shard_step(a, gsr, td, rank, world, dev):
+    """One sharded MAPPING iteration and one sharded TRACKING iteration (sharded.ShardedMapper) with every
+    collective inside the timed region. --splats Gaussians in TOTAL, split into depth slabs (strong scaling)."""
+    syn = gsr.synthetic
+    hz = __import__("gsorb_slam_amd.harness", fromlist=["x"])
+    sharded = __import__("gsorb_slam_amd.sharded", fromlist=["x"])
+    camd = syn.CAMERAS[a.camera]
+    cam = syn.make_camera(**camd)
+    W, H = cam.width, cam.height
+    sc = syn.make_scene(a.splats, cam, seed=1234, scale_mult=a.scale_mult)      # the SAME scene on every rank
+    z = torch.tensor(sc.means3D[:, 2])
+    idx = sharded.shard_by_depth_slabs(z, world)[rank].numpy()
+    g = hz.GaussianMap(hz.Config(), camd["fx"], camd["fy"], device=dev)
+    g.add_points(torch.tensor(sc.means3D[idx]), torch.tensor(sc.colors[idx]))
+    op = torch.tensor(sc.opacities[idx])
+    with torch.no_grad():
+        g.log_scales.copy_(torch.log(torch.tensor(sc.scales[idx])))
+        g.unnorm_quat.copy_(torch.tensor(sc.rotations[idx]))
+        g.logit_opacities.copy_(torch.log(op / (1 - op)))
+    m = sharded.make_sharded_mapper(hz)(g, W, H)
+    T = torch.eye(4, device=dev)
+    with torch.no_grad():
+        rgb, sur, _ = m.render_pair(T, tracking=True)
+        frame = hz.Frame((rgb * 0.9 + 0.05).clone(), sur[0].clone(), T.clone())
+
+    def barrier():
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, n, warm=3):
+        for _ in range(warm):
+            fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            td.all_reduce(tt, op=td.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt / max(n, 1) * 1e3
+
+    n = max(a.shard_steps, 1)
+    map_ms = timed(lambda: m.mapping_iteration([frame]), n)
+    # tracking: one track() call of n pose iterations (it stops early only if the loss stalls: count what ran)
+    ran = {}
+    def track_once():
+        ran["n"] = len(m.track(frame, T, iters=n)[1])
+    track_once()
+    barrier()
+    t0 = time.perf_counter()
+    track_once()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = float(tt.item())
+    track_ms = dt / max(ran["n"], 1) * 1e3
+    layer_bytes = 7 * W * H * 4    # rgb(3) + depth + silhouette + surface depth + the row that carries the order key
+    return {"what": "one sharded mapping iteration / one sharded tracking iteration (two rasterizer fwd+bwd of the rank's depth slab, "
+                    "layer all-gather, compositing, losses, scalar or pose-gradient all-reduce, Adam step) — collectives INSIDE the timed region",
+            "scaling": "strong", "total_splats": a.splats, "splats_per_rank": int(len(idx)), "width": W, "height": H,
+            "backend": (td.get_backend() if world > 1 else "none (single process)"),
+            "rccl_ranks": (td.get_world_size() if world > 1 else 1),
+            "mapping_ms_per_iter": map_ms, "tracking_ms_per_iter": track_ms,
+            "mapping_splats_pixels_per_s": 2 * a.splats * W * H / (map_ms * 1e-3),
+            "collectives_per_mapping_iter": {"all_gather_bytes_per_rank": layer_bytes, "all_reduce_floats": 3},
+            "collectives_per_tracking_iter": {"all_gather_bytes_per_rank": layer_bytes, "all_reduce_floats": 7},
+            "timed_iters": n}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--splats", type=int, default=1_000_000)
+    ap.add_argument("--camera", choices=["replica", "tum", "scannet"], default="replica",
+                    help="replica = the headline 1200x680 frame; scannet + --splats 2000000 = the config-5 shape")
+    ap.add_argument("--mode", choices=["all", "rasterize", "shard-step"], default="all",
+                    help="rasterize: the headline fwd+bwd line only; shard-step: only the sharded mapping/tracking step; all: both")
+    ap.add_argument("--shard-steps", type=int, default=20, help="timed iterations of each shard_step loop")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--scale-mult", type=float, default=1.0, help="splat size multiplier (1 = the headline workload; >1: fatter splats, for experiments)")
     a = ap.parse_args()
@@ -82,6 +169,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = world > 1
+    td = None
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -91,9 +179,28 @@ def main():
 
     gsr = entry.load_package()
     gsr.lib()  # fails loudly if the HIP extension is missing
+    out = {}
+    if a.mode in ("all", "rasterize"):
+        out = rasterize(a, gsr, td, rank, world, dev)
+    if a.mode in ("all", "shard-step"):
+        ss = shard_step(a, gsr, td, rank, world, dev)
+        if a.mode == "shard-step":
+            out = {"metric": "ms per sharded mapping iteration (collectives in the timed region)", "value": ss["mapping_ms_per_iter"],
+                   "unit": "ms", "n_gpus": world, "steps": ss["timed_iters"], "warmup": 3, "ms_per_step": ss["mapping_ms_per_iter"],
+                   "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "config": {"workload": f"{a.splats} Gaussians in total, depth slabs over {world} rank(s), {ss['width']}x{ss['height']}"}}
+        out["shard_step"] = ss
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist:
+        td.destroy_process_group()
+
+
+def rasterize(a, gsr, td, rank, world, dev):
+    dist = world > 1
     syn = gsr.synthetic
     P = a.splats
-    cam = syn.make_camera(**syn.REPLICA)
+    cam = syn.make_camera(**syn.CAMERAS[a.camera])
     W, H = cam.width, cam.height
     sc = syn.make_scene(P, cam, seed=rank, scale_mult=a.scale_mult)  # each rank: its own scene shard
     s = gsr.capi.Settings.from_camera(cam, device=dev)
@@ -177,18 +284,19 @@ def main():
         traffic = None   # HBM/fabric bytes per launch of the dominant kernel: PMC counters cannot be read live,
         try:             # so the committed rocprofv3 --pmc summary of this same command is quoted
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if P == 1_000_000:
+            if P == 1_000_000 and a.camera == "replica" and a.scale_mult == 1.0:
                 traffic = tj["kernels"]["K_blend_bwd"]["traffic_bytes"]
                 valu_busy = tj["kernels"]["K_blend_bwd"].get("valu_busy_frac")
         except Exception:
             traffic = None
         out = {
-            "metric": "splats*pixels/s (fwd+bwd) @1M Gaussians 1200x680",
+            "metric": "splats*pixels/s (fwd+bwd) @1M Gaussians 1200x680" if (P == 1_000_000 and a.camera == "replica")
+                      else f"splats*pixels/s (fwd+bwd) @{P} Gaussians {W}x{H}",
             "value": value, "unit": "splats*pixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{P} random-init Gaussians per GPU (SinglePixel scale init, camera frame), "
-                                   f"{W}x{H} Replica camera, RGB colours, fwd+bwd rasterize through the C ABI "
+                                   f"{W}x{H} {a.camera} camera, RGB colours, fwd+bwd rasterize through the C ABI "
                                    f"(gsr_forward_ws + gsr_backward), inputs resident in HBM",
                        "splats": P, "width": W, "height": H, "visible": V, "tile_instances": R,
                        "parallelism": f"scene-shard x{world}" if world > 1 else "single GPU"},
@@ -205,9 +313,8 @@ def main():
         }
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(sc, P, W, H)
-        print(json.dumps(out), flush=True)
-    if dist:
-        td.destroy_process_group()
+        return out
+    return {}
 
 
 if __name__ == "__main__":

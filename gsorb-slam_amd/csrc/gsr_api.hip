@@ -159,11 +159,15 @@ const char* gsr_error_string(int code)
 }
 const char* gsr_last_hip_error(void) { return hipGetErrorString(t_last_hip); }
 
-// one pinned word + one event per host thread (never freed: a thread renders for the life of the process)
+// One pinned word + one event per host thread AND device (never freed: a thread renders for the life of the
+// process). An event belongs to the device that was current when it was created: a thread that renders on
+// cuda:0 and then on cuda:1 (RasterizeGaussiansCUDA takes device_num; the reference defines GPU0..GPU2) must not
+// record device 0's event on a stream of device 1, so the slot is looked up by hipGetDevice.
 struct Staging {
     uint32_t* host = nullptr;
     hipEvent_t ev = nullptr;
     bool tried = false;
+    uint32_t last_R = 0; // tile instances of this thread's previous frame on this device (capacity guess)
     bool ready()
     {
         if (!tried) {
@@ -174,6 +178,14 @@ struct Staging {
         return host != nullptr;
     }
 };
+#define GSR_MAX_DEVICES 16
+static Staging* staging_slot()
+{
+    static thread_local Staging t_stage[GSR_MAX_DEVICES + 1];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= GSR_MAX_DEVICES) dev = GSR_MAX_DEVICES; // shared overflow slot: blocking read only
+    return &t_stage[dev];
+}
 
 int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geom_alloc, void* geom_user,
                 gsr_alloc_fn binning_alloc, void* binning_user, gsr_alloc_fn image_alloc,
@@ -197,20 +209,27 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geom_alloc, void* geom_u
     // that number, the blob is requested with a capacity guessed from this thread's previous frames and the
     // tail kernels are enqueued right behind the head; the host then waits only for the head. A guess that
     // turns out too small costs one more request and a second tail (its first run exits on the overflow flag).
-    static thread_local uint32_t t_last_R = 0;
-    static thread_local Staging t_stage;
-    const uint32_t floor_c = (uint32_t)std::min<size_t>((size_t)a->P * 4 + 4096, 0x7FFFFFFFu);
-    const uint32_t guess = std::max(floor_c, (uint32_t)std::min<size_t>((size_t)t_last_R + t_last_R / 4 + 4096, 0x7FFFFFFFu));
+    // Guess: 1.25x this thread's previous frame on this device, at least P (a first frame of fat splats pays the
+    // second request once; 44 B per instance: a floor of 4P would pin 176 MB at 1 M splats whatever R is).
+    Staging& t_stage = *staging_slot();
+    const uint32_t floor_c = (uint32_t)std::min<size_t>((size_t)a->P + 4096, 0x7FFFFFFFu);
+    const uint32_t guess = std::max(floor_c, (uint32_t)std::min<size_t>((size_t)t_stage.last_R + t_stage.last_R / 4 + 4096, 0x7FFFFFFFu));
     char* binning = binning_alloc(binning_user, gsr_binning_bytes(guess));
     if (!binning) return GSR_EALLOC;
     GeomView gv; ImageView iv; FrameParams f;
     int rc = forward_head(a, geom, image, st, guess, &gv, &iv, &f);
     if (rc != GSR_OK) return rc;
     uint32_t R = 0;
-    const bool staged = t_stage.ready();
+    int cur_dev = 0;
+    bool staged = hipGetDevice(&cur_dev) == hipSuccess && cur_dev >= 0 && cur_dev < GSR_MAX_DEVICES && t_stage.ready();
     if (staged) {
         GSR_HIP(hipMemcpyAsync(t_stage.host, &gv.hdr->num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        GSR_HIP(hipEventRecord(t_stage.ev, st));
+        if (hipEventRecord(t_stage.ev, st) != hipSuccess) { // e.g. the stream belongs to another device than the current one
+            (void)hipGetLastError();
+            GSR_HIP(hipStreamSynchronize(st));
+            R = *t_stage.host;
+            staged = false;
+        }
     } else { // no pinned staging word: plain blocking read
         GSR_HIP(hipMemcpyAsync(&R, &gv.hdr->num_rendered, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         GSR_HIP(hipStreamSynchronize(st));
@@ -224,7 +243,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geom_alloc, void* geom_u
         R = *t_stage.host;
     }
     if (R > 0x7FFFFFFFu) return GSR_EOVERFLOW;
-    t_last_R = R;
+    t_stage.last_R = R;
     if (R > guess) {
         binning = binning_alloc(binning_user, gsr_binning_bytes(R));
         if (!binning) return GSR_EALLOC;
@@ -274,7 +293,8 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
         !a->viewmatrix || !a->projmatrix || !a->background)
         return GSR_EINVAL;
     if ((a->scales != nullptr && a->rotations != nullptr) == (a->cov3D_precomp != nullptr)) return GSR_EINVAL;
-    if (a->shs && (!a->dL_dsh || a->M <= 0 || !a->cam_pos)) return GSR_EINVAL;
+    // K_splat_bwd writes dL_dsh[0 .. (D+1)^2) per splat and zero-fills up to M: an inconsistent D / M would write out of bounds
+    if (a->shs && (!a->dL_dsh || a->M <= 0 || !a->cam_pos || a->D < 0 || a->D > 3 || (a->D + 1) * (a->D + 1) > a->M)) return GSR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int P = a->P, W = a->width, H = a->height;
     const FrameParams f = frame_params(P, a->D, a->M, W, H, a->tan_fovx, a->tan_fovy, a->scale_modifier, a->band_y0, a->band_y1);

@@ -44,7 +44,9 @@ __device__ __forceinline__ bool quad_reach(const float4 a, const float4 b, float
     const float op = b.y;
     if (op < GSR_ALPHA_MIN) return false; // alpha = op*exp(power<=0) can never reach 1/255
     const float ca = a.z, cb = a.w, cc = b.x;
-    if (!(ca > 0.f) || !(cc > 0.f)) return true;
+    // the construction below needs a positive-definite conic; an indefinite one (possible with cov3D_precomp:
+    // ca, cc > 0 but ca*cc <= cb^2) is not culled: the reference would still blend it (forward.cu:346-358)
+    if (!(ca > 0.f) || !(cc > 0.f) || !(ca * cc > cb * cb)) return true;
     const float tau = __logf(255.0f * op) + 0.01f;
     const float dxl = a.x - (X0 + 7.f), dxh = a.x - X0, dyl = a.y - (Y0 + 7.f), dyh = a.y - Y0;
     const float dxc = fminf(fmaxf(0.f, dxl), dxh), dyc = fminf(fmaxf(0.f, dyl), dyh); // point of the range closest to 0
@@ -92,7 +94,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void patch_reach4(const float4 A, const float4 B, float X0, float Y0, bool (&h)[4])
 {
     const float ca = -2.f * A.z, cb = -A.w, cc = -2.f * B.x; // log2(e) * (a, b, c)
-    const bool degenerate = !(ca > 0.f) || !(cc > 0.f);
+    const bool degenerate = !(ca > 0.f) || !(cc > 0.f) || !(ca * cc > cb * cb); // not positive definite: never culled
     const float tau = __log2f(255.0f * B.y) + 0.0145f;
     float dl[2], dh[2], dc[2], el[2], eh[2], ec[2];
 #pragma unroll

@@ -88,6 +88,8 @@ def make_camera(width: int, height: int, fx: float, fy: float, Tcw: np.ndarray |
 
 REPLICA = dict(width=1200, height=680, fx=600.0, fy=600.0)          # Examples/RGB-D/replica.yaml:12-17
 TUM1 = dict(width=640, height=480, fx=517.306408, fy=516.469215)    # Examples/RGB-D/tum/TUM1.yaml:13-16
+SCANNET = dict(width=640, height=480, fx=577.590698, fy=578.729797)  # Examples/RGB-D/scannet.yaml:11-14
+CAMERAS = dict(replica=REPLICA, tum=TUM1, scannet=SCANNET)
 
 
 @dataclass

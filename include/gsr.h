@@ -58,7 +58,9 @@ typedef struct gsr_forward_args {
     const float* projmatrix;     /* [16] */
     const float* cam_pos;        /* [3] */
     float tan_fovx, tan_fovy;
-    int prefiltered;             /* accepted for signature parity; a culled splat is skipped, not trapped */
+    int prefiltered;             /* accepted for signature parity. Reference (auxiliary.h:156-160): true = the caller promises it culled
+                                  * already and a splat that still fails the frustum test makes the kernel printf + __trap(). Here such a
+                                  * splat is skipped (radius 0), as with false: no device trap, identical results. */
     float* out_color;            /* [3,H,W] fully written */
     float* out_depth;            /* [H,W]   fully written (median depth, forward.cu:374-379) */
     int* radii;                  /* [P] fully written, or NULL */
@@ -77,10 +79,18 @@ enum { GSR_FWD_PREPROCESS = 0, GSR_FWD_SCAN, GSR_FWD_FILL, GSR_FWD_SORT, GSR_FWD
 /* backward stages */
 enum { GSR_BWD_CLEAR = 0, GSR_BWD_BLEND, GSR_BWD_SPLAT, GSR_BWD_STAGES };
 
-/* Rasterizer::forward (rasterizer_impl.cu:199-345). Calls each allocator exactly
- * once (geometry and image before any kernel, binning once num_rendered is
- * known — one 4-byte device→host read on `stream`, like :285). Returns
- * num_rendered. `stream` is a hipStream_t (NULL = default stream). */
+/* Rasterizer::forward (rasterizer_impl.cu:199-345). Returns num_rendered (one 4-byte device→host read on
+ * `stream`, like :285). `stream` is a hipStream_t (NULL = default stream).
+ * Allocator contract (differs from the reference's "each callback exactly once"):
+ *   geom_alloc, image_alloc: called exactly once, before any kernel.
+ *   binning_alloc: called BEFORE num_rendered is known, with gsr_binning_bytes(capacity), capacity =
+ *     max(P + 4096, 1.25 * num_rendered of the calling thread's previous frame on this device + 4096), and the
+ *     tail kernels are enqueued behind the head at once; it is called a SECOND time, with
+ *     gsr_binning_bytes(num_rendered), only if that capacity was too small (the tail is then re-run).
+ *     Work on the first block may still be in flight on `stream` when the second request arrives: an adapter
+ *     must keep it alive until the stream reaches that point (torch's caching allocator does: a resize_ of the
+ *     same tensor frees stream-ordered) and must use the LAST block returned. 44 B per tile instance.
+ * P == 0: the binning allocator is called once with gsr_binning_bytes(0). */
 int gsr_forward(const gsr_forward_args* args,
                 gsr_alloc_fn geom_alloc, void* geom_user,
                 gsr_alloc_fn binning_alloc, void* binning_user,
@@ -153,7 +163,8 @@ typedef struct gsr_backward_args {
 #define GSR_STAGE_SPLAT 4
 #define GSR_STAGE_REZERO 8 /* the per-splat stage zeroes the accumulators it consumed */
 
-/* The packed per-splat accumulators inside a geometry blob: count floats (12 per splat). */
+/* The packed per-splat accumulators inside a geometry blob: count floats = 16 per splat (one 64-byte line:
+ * moments u, u*dx, u*dy, u*dx^2, u*dx*dy, u*dy^2 of u = G * dL/dalpha, the colour sums r, g, b, 7 unused). */
 int gsr_acc_view(char* geom, int P, float** acc, size_t* count);
 
 /* Rasterizer::backward (rasterizer_impl.cu:405-498). Never allocates, never syncs. */

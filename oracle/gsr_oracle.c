@@ -16,6 +16,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef GSRO_OMP
+#include <omp.h>
+#endif
 
 /* ---- DGR/cuda_rasterizer/auxiliary.h:22-39 ------------------------------------ */
 static const float SH_C0 = 0.28209479177387814f;
@@ -75,6 +78,17 @@ static uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 static int imax(int a, int b) { return a > b ? a : b; }
 
 /* DGR/cuda_rasterizer/rasterizer_impl.cu:36-51 */
+/* Test instrumentation: caps the OpenMP team (small scenes run slower on 256 threads than on 16). No-op in the
+ * single-thread build. */
+void gsro_set_threads(int n)
+{
+#ifdef GSRO_OMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 uint32_t gsro_higher_msb(uint32_t n)
 {
     uint32_t msb = sizeof(n) * 4, step = msb;

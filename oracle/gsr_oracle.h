@@ -36,6 +36,7 @@ extern "C" {
 
 /* DGR/cuda_rasterizer/rasterizer_impl.cu:36-51 (getHigherMsb) */
 uint32_t gsro_higher_msb(uint32_t n);
+void gsro_set_threads(int n); /* OpenMP build only: size of the thread team; no-op otherwise */
 
 /* DGR/cuda_rasterizer/rasterizer_impl.cu:55-67 + auxiliary.h:139-164 */
 void gsro_mark_visible(int P, const float* means3D, const float* viewmatrix,

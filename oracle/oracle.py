@@ -68,6 +68,8 @@ def _load(omp: bool):
     lib.gsro_eval_sh.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
     lib.gsro_dist2.restype = None
     lib.gsro_dist2.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    lib.gsro_set_threads.restype = None
+    lib.gsro_set_threads.argtypes = [C.c_int]
     lib.gsro_higher_msb.restype = C.c_uint32
     lib.gsro_higher_msb.argtypes = [C.c_uint32]
     return lib
@@ -80,6 +82,11 @@ def lib(omp: bool = False):
     if omp not in _LIBS:
         _LIBS[omp] = _load(omp)
     return _LIBS[omp]
+
+
+def set_threads(n: int) -> None:
+    """Caps the OpenMP team of the omp build (a 10k-splat scene is slower on 256 threads than on 16)."""
+    lib(True).gsro_set_threads(int(n))
 
 
 def _f32(a):

@@ -36,6 +36,7 @@ int main(int argc, char** argv)
     int32_t hdr[4];
     in.read(reinterpret_cast<char*>(hdr), sizeof(hdr));
     const int64_t P = hdr[0], W = hdr[1], H = hdr[2];
+    const bool direct = hdr[3] == 1; // 1: the file holds camera-frame means and ACTIVATED parameters, fed to the operator as they are
     float fl[4];
     in.read(reinterpret_cast<char*>(fl), sizeof(fl)); // tanfovx, tanfovy, unused, unused
     const auto dev = torch::Device(torch::kCUDA, 0);
@@ -52,15 +53,21 @@ int main(int argc, char** argv)
                                     torch::eye(4, dev), proj, 0, torch::zeros({3}, dev), false};
     GaussianRasterizer rasterizer(s);
 
-    // src/Render.cc:750-752
-    auto Tb = Tcw.unsqueeze(0).repeat({P, 1, 1});
-    auto m4 = torch::cat({xyz, torch::ones({P, 1}, dev)}, 1).unsqueeze(-1);
-    auto mean3D = Tb.bmm(m4).squeeze(-1).index({torch::indexing::Slice(), torch::indexing::Slice(0, 3)});
-    // :756-760
+    torch::Tensor mean3D, opacities, norm_qua, scales;
+    if (direct) { // the boundary alone: no torch arithmetic between the file and the operator
+        mean3D = xyz; opacities = logit_opac; norm_qua = unnorm_quat; scales = log_scales;
+        Tcw.mutable_grad() = torch::zeros_like(Tcw);
+    } else {
+        // src/Render.cc:750-752
+        auto Tb = Tcw.unsqueeze(0).repeat({P, 1, 1});
+        auto m4 = torch::cat({xyz, torch::ones({P, 1}, dev)}, 1).unsqueeze(-1);
+        mean3D = Tb.bmm(m4).squeeze(-1).index({torch::indexing::Slice(), torch::indexing::Slice(0, 3)});
+        // :756-760
+        opacities = torch::sigmoid(logit_opac);
+        norm_qua = torch::nn::functional::normalize(unnorm_quat);
+        scales = torch::exp(log_scales);
+    }
     auto mean2D = torch::zeros_like(mean3D).set_requires_grad(true);
-    auto opacities = torch::sigmoid(logit_opac);
-    auto norm_qua = torch::nn::functional::normalize(unnorm_quat);
-    auto scales = torch::exp(log_scales);
     mean2D.retain_grad();
 
     bool threw = false;

@@ -63,8 +63,11 @@ def eval_sh(deg, sh, d):
     return res + 0.5
 
 
-def render(scene, radii: np.ndarray, means2D_f32: np.ndarray, dL_dpix: np.ndarray | None = None):
-    """Returns dict(color [3,H,W], depth [H,W], grads{...}) in fp64."""
+def render(scene, radii: np.ndarray, means2D_f32: np.ndarray, dL_dpix: np.ndarray | None = None,
+           cov3D_precomp: np.ndarray | None = None, chunk: int = 4096):
+    """Returns dict(color [3,H,W], depth [H,W], grads{...}) in fp64. With `cov3D_precomp` [P,6] (upper triangle
+    xx xy xz yy yz zz, forward.cu:94-97) the 3D covariance is an input and scales / rotations are ignored.
+    The dense (pixel, splat) part runs in chunks of `chunk` pixels; gradients accumulate over the chunks."""
     cam = scene.cam
     W, H = cam.width, cam.height
     dd = torch.float64
@@ -101,6 +104,11 @@ def render(scene, radii: np.ndarray, means2D_f32: np.ndarray, dL_dpix: np.ndarra
     S = torch.diag_embed(scales * cam.scale_modifier)
     Mm = R @ S
     Sigma = Mm @ Mm.transpose(1, 2)
+    cov_in = None
+    if cov3D_precomp is not None:
+        cov_in = t64(cov3D_precomp).requires_grad_(True)
+        c6 = cov_in
+        Sigma = torch.stack([c6[:, 0], c6[:, 1], c6[:, 2], c6[:, 1], c6[:, 3], c6[:, 4], c6[:, 2], c6[:, 4], c6[:, 5]], 1).reshape(P, 3, 3)
 
     limx, limy = 1.3 * cam.tanfovx, 1.3 * cam.tanfovy
     tz = t[:, 2]
@@ -137,39 +145,51 @@ def render(scene, radii: np.ndarray, means2D_f32: np.ndarray, dL_dpix: np.ndarra
     order = order[vis[order]]
 
     ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
-    pxs, pys = xs.reshape(-1), ys.reshape(-1)
-    tix, tiy = pxs // 16, pys // 16
+    pxs_all, pys_all = xs.reshape(-1), ys.reshape(-1)
     o = order
-    member = (tix[:, None] >= x0[o][None]) & (tix[:, None] < x1[o][None]) & \
-             (tiy[:, None] >= y0[o][None]) & (tiy[:, None] < y1[o][None])
-    dx = px[o][None, :] - pxs[:, None].to(dd)
-    dy = py[o][None, :] - pys[:, None].to(dd)
-    power = -0.5 * (ca[o][None] * dx * dx + cc[o][None] * dy * dy) - cb[o][None] * dx * dy
-    araw = opac[o][None] * torch.exp(power)
-    alpha = araw - (araw - 0.99).clamp(min=0).detach()
-    valid = member & (power <= 0) & (alpha >= 1.0 / 255.0)
-    am = torch.where(valid, alpha, torch.zeros_like(alpha))
-    Tafter = torch.cumprod(1 - am, 1)
-    Tbefore = torch.cat([torch.ones(am.shape[0], 1, dtype=dd), Tafter[:, :-1]], 1)
-    stop = valid & (Tafter < 1e-4)
-    excluded = torch.cumsum(stop.to(torch.int64), 1) >= 1
-    inc = valid & ~excluded
-    w = torch.where(inc, am * Tbefore, torch.zeros_like(am))
-    Tfinal = torch.prod(torch.where(inc, 1 - am, torch.ones_like(am)), 1)
-    color = w @ col[o] + Tfinal[:, None] * bg[None]
-    med = inc & (Tbefore > 0.5)
-    # last index where med is true
-    idx = torch.arange(am.shape[1])[None].expand_as(med)
-    last = torch.where(med, idx, torch.full_like(idx, -1)).max(1).values if am.shape[1] else torch.full((am.shape[0],), -1)
-    dsel = torch.where(last >= 0, depth[o][last.clamp(min=0)] if am.shape[1] else torch.zeros(am.shape[0], dtype=dd),
-                       torch.zeros(am.shape[0], dtype=dd))
-    out = dict(color=color.T.reshape(3, H, W).detach().numpy(), depth=dsel.reshape(H, W).numpy(),
-               final_T=Tfinal.reshape(H, W).detach().numpy())
-    if dL_dpix is not None:
-        g = t64(dL_dpix).reshape(3, -1).T
-        loss = (color * g).sum()
-        leaves = [means, scales, rots, opac] + ([colors_in] if colors_in is not None else [shs_in])
-        grads = torch.autograd.grad(loss, leaves, allow_unused=True)
-        names = ["means3D", "scales", "rotations", "opacities", "colors" if colors_in is not None else "shs"]
-        out["grads"] = {n: (gg.numpy() if gg is not None else None) for n, gg in zip(names, grads)}
+    N = W * H
+    leaves = [means, opac] + ([colors_in] if colors_in is not None else [shs_in]) + \
+             ([cov_in] if cov_in is not None else [scales, rots])
+    names = ["means3D", "opacities", "colors" if colors_in is not None else "shs"] + \
+            (["cov3D"] if cov_in is not None else ["scales", "rotations"])
+    acc = [torch.zeros_like(l) for l in leaves]
+    g_all = None if dL_dpix is None else t64(dL_dpix).reshape(3, -1).T
+    color_out = np.zeros((N, 3)); depth_out = np.zeros(N); T_out = np.zeros(N)
+    for c0 in range(0, N, chunk):
+        pxs, pys = pxs_all[c0:c0 + chunk], pys_all[c0:c0 + chunk]
+        tix, tiy = pxs // 16, pys // 16
+        member = (tix[:, None] >= x0[o][None]) & (tix[:, None] < x1[o][None]) & \
+                 (tiy[:, None] >= y0[o][None]) & (tiy[:, None] < y1[o][None])
+        dx = px[o][None, :] - pxs[:, None].to(dd)
+        dy = py[o][None, :] - pys[:, None].to(dd)
+        power = -0.5 * (ca[o][None] * dx * dx + cc[o][None] * dy * dy) - cb[o][None] * dx * dy
+        araw = opac[o][None] * torch.exp(power)
+        alpha = araw - (araw - 0.99).clamp(min=0).detach()
+        valid = member & (power <= 0) & (alpha >= 1.0 / 255.0)
+        am = torch.where(valid, alpha, torch.zeros_like(alpha))
+        Tafter = torch.cumprod(1 - am, 1)
+        Tbefore = torch.cat([torch.ones(am.shape[0], 1, dtype=dd), Tafter[:, :-1]], 1)
+        stop = valid & (Tafter < 1e-4)
+        excluded = torch.cumsum(stop.to(torch.int64), 1) >= 1
+        inc = valid & ~excluded
+        w = torch.where(inc, am * Tbefore, torch.zeros_like(am))
+        Tfinal = torch.prod(torch.where(inc, 1 - am, torch.ones_like(am)), 1)
+        color = w @ col[o] + Tfinal[:, None] * bg[None]
+        med = inc & (Tbefore > 0.5)
+        idx = torch.arange(am.shape[1])[None].expand_as(med)
+        last = torch.where(med, idx, torch.full_like(idx, -1)).max(1).values if am.shape[1] else torch.full((am.shape[0],), -1)
+        dsel = torch.where(last >= 0, depth[o][last.clamp(min=0)] if am.shape[1] else torch.zeros(am.shape[0], dtype=dd),
+                           torch.zeros(am.shape[0], dtype=dd))
+        color_out[c0:c0 + chunk] = color.detach().numpy()
+        depth_out[c0:c0 + chunk] = dsel.numpy()
+        T_out[c0:c0 + chunk] = Tfinal.detach().numpy()
+        if g_all is not None:
+            loss = (color * g_all[c0:c0 + chunk]).sum()
+            grads = torch.autograd.grad(loss, leaves, allow_unused=True, retain_graph=True)
+            for a, gg in zip(acc, grads):
+                if gg is not None:
+                    a += gg
+    out = dict(color=color_out.T.reshape(3, H, W), depth=depth_out.reshape(H, W), final_T=T_out.reshape(H, W))
+    if g_all is not None:
+        out["grads"] = {n: a.numpy() for n, a in zip(names, acc)}
     return out

@@ -70,3 +70,35 @@ def test_no_cpu_fallback_when_library_is_missing(gsr, monkeypatch):
     monkeypatch.delenv("GSR_LIB_OVERRIDE")
     monkeypatch.setattr(gsr.capi, "_LIB", None)
     gsr.capi.lib()
+
+
+def test_argument_validation_rejects_inconsistent_sh_degree_before_any_gpu_work(gsr):
+    """gsr_forward checks 0 <= D <= 3 and (D+1)^2 <= M (csrc/gsr_api.hip:check_forward); gsr_backward must repeat it —
+    K_splat_bwd writes dL_dsh[0..(D+1)^2) per splat. Validation precedes every HIP call, so this runs without a GPU
+    (the non-NULL pointers below are never dereferenced)."""
+    import ctypes as C
+    capi = gsr.capi
+    L = capi.lib()
+    dummy = C.c_void_p(0x1000)
+    def bwd(D, M):
+        a = capi.BackwardArgs()
+        a.P, a.D, a.M, a.R, a.width, a.height = 10, D, M, 0, 64, 48
+        for n in ("background", "means3D", "shs", "scales", "rotations", "viewmatrix", "projmatrix", "cam_pos", "geom_buffer",
+                  "binning_buffer", "image_buffer", "dL_dpix", "dL_dsh"):
+            setattr(a, n, dummy)
+        L.gsr_backward.restype = C.c_int
+        return L.gsr_backward(C.byref(a), None)
+    EINVAL = -1
+    assert L.gsr_error_string(EINVAL).decode() == "invalid argument"
+    assert bwd(3, 9) == EINVAL        # degree 3 needs 16 coefficients
+    assert bwd(4, 25) == EINVAL and bwd(-1, 16) == EINVAL
+    assert bwd(2, 0) == EINVAL
+    def fwd(D, M):
+        a = capi.ForwardArgs()
+        a.P, a.D, a.M, a.width, a.height = 10, D, M, 64, 48
+        for n in ("background", "means3D", "shs", "opacities", "scales", "rotations", "viewmatrix", "projmatrix", "cam_pos",
+                  "out_color", "out_depth"):
+            setattr(a, n, dummy)
+        L.gsr_forward_ws.restype = C.c_int
+        return L.gsr_forward_ws(C.byref(a), dummy, dummy, C.c_size_t(1 << 20), dummy, None)
+    assert fwd(3, 9) == EINVAL and fwd(1, 3) == EINVAL

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
-from util import pose, rel_err
+from util import mixed_err, pose, rel_err
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -92,3 +92,49 @@ def test_render_start_splatting_pattern(syn):
     gq = b.dL_drotations.astype(np.float64)
     assert rel_err(g_q, (gq - q * (q * gq).sum(1, keepdims=True)) / nq) <= tol
     assert rel_err(g_m2d, b.dL_dmeans2D) <= tol
+
+
+def test_operator_boundary_alone_holds_1e4_and_exact_radii(syn):
+    """Second leg: the C++ operator fed pre-computed camera-frame means and ACTIVATED parameters (no torch bmm /
+    sigmoid / exp / normalize between the file and GaussianRasterizer::forward), so the libtorch boundary itself is
+    held to the bars of the C-ABI tests: radii bit-exact, image and every gradient within 1e-4, element-wise too."""
+    exe = _binary()
+    W, H, fx, fy = 320, 240, 260.0, 258.0
+    cam = syn.make_camera(W, H, fx, fy)
+    sc = syn.make_scene(5000, cam, seed=9, scale_mult=2.0, frac_behind=0.05, frac_offscreen=0.2)
+    P = sc.P
+    o, f = oracle.forward_scene(sc)
+    mc, md = o.margins(f)
+    ok = mc >= 1e-5
+    G = (sc.dL_dpix * ok[None]).astype(np.float32)
+    b = o.backward(G)
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "scene.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as fh:
+            np.array([P, W, H, 1], np.int32).tofile(fh)
+            np.array([cam.tanfovx, cam.tanfovy, 0, 0], np.float32).tofile(fh)
+            for a in (sc.means3D, sc.colors, sc.rotations, sc.opacities, sc.scales, np.eye(4), cam.projmatrix, G):
+                np.ascontiguousarray(a, np.float32).tofile(fh)
+        r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        raw = open(fout, "rb").read()
+    off = 0
+    def take(n, dt=np.float32):
+        nonlocal off
+        a = np.frombuffer(raw, dt, n, off)
+        off += n * 4
+        return a
+    flags = take(4, np.int32)
+    assert list(flags) == [1, 1, 0, 1]
+    image = take(3 * H * W).reshape(3, H, W); depth = take(H * W).reshape(H, W); radii = take(P, np.int32)
+    g_xyz = take(P * 3).reshape(P, 3); g_rgb = take(P * 3).reshape(P, 3); g_q = take(P * 4).reshape(P, 4)
+    g_o = take(P).reshape(P, 1); g_s = take(P * 3).reshape(P, 3); take(16)
+    g_m2d = take(P * 3).reshape(P, 3); vis = take(P, np.int32)
+    np.testing.assert_array_equal(radii, f.radii)                                   # exact
+    assert np.abs(image - f.color)[:, ok].max() <= 1e-4
+    assert np.array_equal(depth[md >= 1e-5], f.depth[0][md >= 1e-5])
+    np.testing.assert_array_equal(vis.astype(bool), oracle.mark_visible(sc.means3D, cam))
+    for name, got, ref in (("means3D", g_xyz, b.dL_dmeans3D), ("colors", g_rgb, b.dL_dcolors), ("rotations", g_q, b.dL_drotations),
+                           ("opacity", g_o, b.dL_dopacity), ("scales", g_s, b.dL_dscales), ("means2D", g_m2d, b.dL_dmeans2D)):
+        assert rel_err(got, ref) <= 1e-4, (name, rel_err(got, ref))
+        assert mixed_err(got, ref) <= 1.0, (name, mixed_err(got, ref))

@@ -3,7 +3,10 @@ seeded inputs.
 
 Bars (BASELINE.json north_star): tile/sort indices BIT-EXACT (radii, tiles_touched,
 num_rendered, sorted point_list, keys, ranges); rendered RGB/depth and all gradients within
-1e-4 relative (fp32), relative to each output tensor's own scale (tests/util.py:rel_err).
+1e-4 relative (fp32). Two metrics are asserted for every gradient tensor (tests/util.py):
+  rel_err   max|a-b| / max|b|                      <= 1e-4   (tensor scale)
+  mixed_err |a-b| <= 1e-4*|b| + 1e-6*max|b|  for EVERY element (element-wise, with the absolute floor
+            a sum of thousands of fp32 terms can resolve); images use |a-b| <= 1e-4 * max(1, max|ref|).
 
 exp() is not bit-reproducible between glibc and the GPU, so a pixel that sits within ~1e-7
 of one of the blend's branch thresholds (alpha<1/255, power>0, T(1-alpha)<1e-4, T>0.5) may
@@ -18,7 +21,7 @@ import pytest
 import torch
 
 from oracle import oracle
-from util import pose, rel_err
+from util import mixed_err, pose, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -61,7 +64,12 @@ def test_forward_backward_parity(gsr, syn, name):
     o, f = oracle.forward_scene(sc)
     mc, md = o.margins(f)
     ok_c, ok_d = mc >= EPS_MARGIN, md >= EPS_MARGIN
-    assert (~ok_c).mean() < 1e-2 and (~ok_d).mean() < 3e-2   # knife-edge pixels stay rare (more on very long lists)
+    # knife-edge pixels (margin < 1e-5: candidates, not flips) stay rare; the budget is what the oracle itself
+    # reports for these scenes x ~1.3 (observed: colour <= 1.6e-3, depth <= 2.4e-3; 2.3e-3 / 3.8e-3 on the
+    # 200k-splat 160x120 scene whose pixels see ~600 list entries each)
+    budget_c, budget_d = (3e-3, 5e-3) if name == "dense-long-lists" else (2e-3, 5e-3)
+    print("\n%s: knife-edge pixels colour %.2e depth %.2e" % (name, (~ok_c).mean(), (~ok_d).mean()))
+    assert (~ok_c).mean() <= budget_c and (~ok_d).mean() <= budget_d
     g_in = sc.dL_dpix * ok_c[None]
     b = o.backward(g_in)
 
@@ -99,10 +107,15 @@ def test_forward_backward_parity(gsr, syn, name):
     # ---- gradients ----
     gr = gsr.backward(st, g_in)
     torch.cuda.synchronize()
+    worst = {}
     for n in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh",
               "dL_dscales", "dL_drotations"):
-        e = rel_err(getattr(gr, n).cpu().numpy(), getattr(b, n))
+        got, ref = getattr(gr, n).cpu().numpy(), getattr(b, n)
+        e, m = rel_err(got, ref), mixed_err(got, ref)
+        worst[n] = (e, m)
         assert e <= TOL, (n, e)
+        assert m <= 1.0, (n, "element-wise bar |a-b| <= 1e-4|b| + 1e-6 max|b| exceeded by x%.2f" % m)
+    print("%s: gradients (tensor-scale rel_err, element-wise ratio):" % name, {k: "%.1e / %.2f" % v for k, v in worst.items()})
 
 
 def test_cov3d_precomp_path(gsr, syn):
@@ -152,6 +165,31 @@ def test_edge_cases(gsr, syn):
         gsr.forward(s, z(P, 4), torch.full((P, 1), .5, device="cuda"), colors=z(P, 3), scales=z(P, 3), rotations=q)
 
 
+def test_prefiltered_flag_skips_culled_splats_instead_of_trapping(gsr, syn):
+    """Reference auxiliary.h:156-160: with prefiltered=true a splat that fails the frustum test makes the kernel
+    printf + __trap(), i.e. the caller promises it culled already and the process dies if it did not. The C ABI
+    accepts the flag for signature parity and SKIPS such a splat (include/gsr.h): same frame, radii
+    and gradients as prefiltered=false, the context stays alive."""
+    sc = _build(syn, 4000, SMALL, mult=2.0, frac_behind=0.3, frac_offscreen=0.3)
+    s0 = gsr.capi.Settings.from_camera(sc.cam)
+    s1 = gsr.capi.Settings.from_camera(sc.cam)
+    s1.prefiltered = True
+    kw = dict(colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    a = gsr.forward(s0, sc.means3D, sc.opacities, **kw)
+    b = gsr.forward(s1, sc.means3D, sc.opacities, **kw)
+    torch.cuda.synchronize()
+    assert int((a.radii == 0).sum()) > 500                      # there ARE culled splats
+    assert torch.equal(a.radii, b.radii) and torch.equal(a.color, b.color) and torch.equal(a.depth, b.depth)
+    assert a.num_rendered == b.num_rendered
+    ga, gb = gsr.backward(a, sc.dL_dpix), gsr.backward(b, sc.dL_dpix)
+    assert rel_err(gb.dL_dmeans3D.cpu().numpy(), ga.dL_dmeans3D.cpu().numpy()) < 1e-5
+    r0 = gsr.visible_filter(s0, sc.means3D, sc.scales, sc.rotations)
+    r1 = gsr.visible_filter(s1, sc.means3D, sc.scales, sc.rotations)
+    assert torch.equal(r0, r1)
+    _, f = oracle.forward_scene(sc)
+    np.testing.assert_array_equal(b.radii.cpu().numpy(), f.radii)
+
+
 def test_mark_visible_and_visible_filter(gsr, syn):
     sc = _build(syn, 20000, syn.TUM1, mult=2.0, Tcw=pose(), frac_behind=0.3, frac_offscreen=0.3)
     s = gsr.capi.Settings.from_camera(sc.cam)
@@ -181,9 +219,13 @@ def test_workspace_path_matches_callback_path_and_flags_overflow(gsr, syn):
     assert n == st.num_rendered and ovf
 
 
-def test_properties_at_baseline_size(gsr, syn):
-    """BASELINE.json metric size (1M splats, 1200x680): size-independent properties only."""
-    sc = _build(syn, 1_000_000, syn.REPLICA)
+@pytest.mark.parametrize("P,camname", [(1_000_000, "replica"), (2_000_000, "scannet")])
+def test_properties_at_baseline_size(gsr, syn, P, camname):
+    """BASELINE.json metric size (1M splats, 1200x680) and the config-5 size (2M+ splats on the ScanNet camera,
+    640x480: ~6.5 splats per pixel-area unit more than the headline): size-independent properties only."""
+    camd = syn.CAMERAS[camname]
+    Hh, Ww = camd["height"], camd["width"]
+    sc = _build(syn, P, camd)
     s = gsr.capi.Settings.from_camera(sc.cam)
     st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
     d = gsr.debug_export(st)
@@ -195,7 +237,7 @@ def test_properties_at_baseline_size(gsr, syn):
     r = d["ranges"].astype(np.int64)
     assert int((r[:, 1] - r[:, 0]).sum()) == st.num_rendered
     assert np.array_equal(np.sort(np.unique(d["point_list"])), np.nonzero(st.radii.cpu().numpy() > 0)[0])
-    T0 = d["final_T"].reshape(680, 1200)
+    T0 = d["final_T"].reshape(Hh, Ww)
     assert np.isfinite(st.color.cpu().numpy()).all() and T0.min() >= 0 and T0.max() <= 1
     # background linearity: C(bg) = C(0) + T_final * bg
     bg = np.array([0.25, 0.5, 0.75], np.float32)
@@ -344,12 +386,17 @@ def test_large_frame_more_than_8192_tiles(gsr, syn):
     np.testing.assert_array_equal(d["point_list"], f.stages["point_list"])
     mc, md = o.margins(f)
     ok = mc >= EPS_MARGIN
-    assert (~ok).mean() < 1e-2
+    assert (~ok).mean() <= 2e-3
     col = st.color.cpu().numpy()
     assert np.abs(col - f.color)[:, ok].max() <= TOL * max(1.0, float(np.abs(f.color).max()))
     g_in = sc.dL_dpix * ok[None]
     b = o.backward(g_in)
     gr = gsr.backward(st, g_in)
+    worst, name = {}, "4k-frame"
     for n in ("dL_dmeans3D", "dL_dopacity", "dL_dcolors", "dL_dscales", "dL_drotations"):
-        e = rel_err(getattr(gr, n).cpu().numpy(), getattr(b, n))
+        got, ref = getattr(gr, n).cpu().numpy(), getattr(b, n)
+        e, m = rel_err(got, ref), mixed_err(got, ref)
+        worst[n] = (e, m)
         assert e <= TOL, (n, e)
+        assert m <= 1.0, (n, "element-wise bar |a-b| <= 1e-4|b| + 1e-6 max|b| exceeded by x%.2f" % m)
+    print("%s: gradients (tensor-scale rel_err, element-wise ratio):" % name, {k: "%.1e / %.2f" % v for k, v in worst.items()})

