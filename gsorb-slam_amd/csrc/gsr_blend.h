@@ -33,6 +33,13 @@ __device__ __forceinline__ int mbcnt64(unsigned long long m)
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// Lane predicates as wave masks and back. Combining conditions on the MASKS is scalar-unit work (free next to a
+// VALU-bound loop) and lets one v_cmp serve a condition and its negation (the compiler otherwise emits a second
+// compare for !(x < c)); only v_cmp and v_cndmask — both half-rate on gfx950 — remain on the vector side.
+typedef unsigned long long wmask;
+__device__ __forceinline__ wmask wm(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool lane_of(wmask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 // Can the splat reach alpha >= 1/255 on some pixel centre of the quad whose pixel centres
 // span [X0, X0+7] x [Y0, Y0+7]? alpha >= 1/255  <=>  Q(d) := 0.5*(a dx^2 + c dy^2) + b dx dy
 // <= ln(255*opacity), with d = splat centre - pixel. The minimum of the convex Q over the
@@ -174,9 +181,13 @@ __global__ void __launch_bounds__(64)
 K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* __restrict__ bg, int W, int H,
                  int grid_x, int ntiles, int tile0, const float* __restrict__ dL_dpix)
 {
-    __shared__ float4 E0[Q], E1[Q], E2[Q]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, list position, splat id, -)
-    __shared__ float ACC[Q * 9 + 64];  // + one private sink word per lane
-    __shared__ uint8_t LIST[4 * Q];
+    // parked entries; slot Q is a dummy (opacity 0, far away) the per-patch lists are padded with: no "row still active"
+    // compare and no index select in the blend loop; what the idle rows add to its accumulator record is never flushed
+    __shared__ float4 E0[Q + 1], E1[Q + 1], E2[Q + 1]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, list position, splat id, patch mask)
+    __shared__ float ACC[(Q + 1) * 9];
+    // per-patch hit lists as BYTE OFFSETS (entry * 16 into E0/E1/E2, entry * 36 into ACC): shifts and integer mads are
+    // half-rate VALU work on gfx950, a second 2-byte LDS load is not VALU work at all
+    __shared__ uint16_t LIST[4 * (Q + 4)], LISTA[4 * (Q + 4)];
     const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
     const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u;
     const int tx = tile % grid_x, ty = tile / grid_x;
@@ -206,9 +217,15 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     // difference of two rounded large numbers (measured: 9e-5 instead of 1e-6 on long lists).
     float S0 = 0.f, S1 = 0.f, S2 = 0.f;
     const int slot = rows_slot_of(l);
-    const uint32_t slot_b = slot < 0 ? 0u : 4u * (uint32_t)slot, sink_b = 4u * (uint32_t)(Q * 9 + lane);
+    const bool has_slot = slot >= 0; // the nine lanes of a row that end up holding a row total
+    const uint32_t slot_b = has_slot ? 4u * (uint32_t)slot : 0u;
     const int fe = (lane * 57) >> 9, fc = lane - 9 * fe; // lane / 9, lane % 9: flush lane -> (entry, component)
-    for (int i = lane; i < Q * 9 + 64; i += 64) ACC[i] = 0.f;
+    for (int i = lane; i < (Q + 1) * 9; i += 64) ACC[i] = 0.f;
+    if (lane == 0) {
+        E0[Q] = make_float4(-1.0e5f, -1.0e5f, -1.f, 0.f); // power2 ~ -2e10: exp2 gives 0
+        E1[Q] = make_float4(-1.f, 0.f, 0.f, 0.f);
+        E2[Q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const int ntodo = __builtin_amdgcn_readfirstlane(min(n, (int)wave_max_u32(last)));
 
     // The forward logged the entries that reach this quad (list position, id), in list order; walk them
@@ -257,17 +274,17 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
                 h[0] = (pm & 1u) != 0u; h[1] = (pm & 2u) != 0u; h[2] = (pm & 4u) != 0u; h[3] = (pm & 8u) != 0u;
             }
             const unsigned long long m0 = __ballot(h[0]), m1 = __ballot(h[1]), m2 = __ballot(h[2]), m3 = __ballot(h[3]);
-            if (h[0]) LIST[0 * Q + c0 + mbcnt64(m0)] = (uint8_t)e;
-            if (h[1]) LIST[1 * Q + c1 + mbcnt64(m1)] = (uint8_t)e;
-            if (h[2]) LIST[2 * Q + c2 + mbcnt64(m2)] = (uint8_t)e;
-            if (h[3]) LIST[3 * Q + c3 + mbcnt64(m3)] = (uint8_t)e;
+            const uint16_t off = (uint16_t)(e * 16), offa = (uint16_t)(e * 36);
+            if (h[0]) { const int p = 0 * (Q + 4) + c0 + mbcnt64(m0); LIST[p] = off; LISTA[p] = offa; }
+            if (h[1]) { const int p = 1 * (Q + 4) + c1 + mbcnt64(m1); LIST[p] = off; LISTA[p] = offa; }
+            if (h[2]) { const int p = 2 * (Q + 4) + c2 + mbcnt64(m2); LIST[p] = off; LISTA[p] = offa; }
+            if (h[3]) { const int p = 3 * (Q + 4) + c3 + mbcnt64(m3); LIST[p] = off; LISTA[p] = offa; }
             c0 += (int)__popcll(m0); c1 += (int)__popcll(m1); c2 += (int)__popcll(m2); c3 += (int)__popcll(m3);
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- blend: row r walks its own list
-        const int mycnt = r == 0 ? c0 : r == 1 ? c1 : r == 2 ? c2 : c3;
-        const int maxc = max(max(c0, c1), max(c2, c3));
-        const uint8_t* __restrict__ mylist = LIST + r * Q;
+        // ---- blend: row r walks its own list; the loop runs an even number of iterations (unrolled by two), shorter
+        //      lists are padded with the dummy entry
+        const int maxc = (max(max(c0, c1), max(c2, c3)) + 1) & ~1;
         // iterations in which two rows work on the same parked entry: those must accumulate atomically
         unsigned long long cm[(Q + 63) / 64];
 #pragma unroll
@@ -275,27 +292,31 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             const int t = b * 64 + lane;
             bool coll = false;
             if (t < maxc) {
-                const int v0 = t < c0 ? (int)LIST[0 * Q + t] : 0x100, v1 = t < c1 ? (int)LIST[1 * Q + t] : 0x101;
-                const int v2 = t < c2 ? (int)LIST[2 * Q + t] : 0x102, v3 = t < c3 ? (int)LIST[3 * Q + t] : 0x103;
+                const int v0 = t < c0 ? (int)LIST[0 * (Q + 4) + t] : 0x10000, v1 = t < c1 ? (int)LIST[1 * (Q + 4) + t] : 0x10001;
+                const int v2 = t < c2 ? (int)LIST[2 * (Q + 4) + t] : 0x10002, v3 = t < c3 ? (int)LIST[3 * (Q + 4) + t] : 0x10003;
                 coll = v0 == v1 || v0 == v2 || v0 == v3 || v1 == v2 || v1 == v3 || v2 == v3;
             }
             cm[b] = __ballot(coll);
         }
-        // One iteration on an entry already in registers. Accumulation is a plain LDS read-modify-write
-        // (LDS float atomics retire ~1 lane per 3 cycles: 36 lanes per iteration would make the kernel
-        // LDS-bound); only the iterations flagged in cm (two rows on one entry) use the atomic.
-        auto step = [&](const int it, const int idx, const float4 A, const float4 B, const float4 Cz) {
-            const bool act = it < mycnt;
-            const bool commit = slot >= 0 && act;
-            // byte offsets: one mad and one select; idle lanes use a private sink word
-            float* const accp = reinterpret_cast<float*>(reinterpret_cast<char*>(ACC) + (commit ? (uint32_t)idx * 36u + slot_b : sink_b));
-            const float acc_old = *accp;
+        {
+            const int cr = r == 0 ? c0 : r == 1 ? c1 : r == 2 ? c2 : c3;
+            for (int p = cr + l; p < maxc + 4; p += 16) { LIST[r * (Q + 4) + p] = (uint16_t)(Q * 16); LISTA[r * (Q + 4) + p] = (uint16_t)(Q * 36); }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint16_t* __restrict__ mylist = LIST + r * (Q + 4);
+        const uint16_t* __restrict__ mylista = LISTA + r * (Q + 4);
+        // One iteration on an entry already in registers. Accumulation is a plain LDS read-modify-write by the nine
+        // slot lanes of the row (LDS float atomics cost ~240 cycles per wave instruction: scripts/valu_bench2.hip);
+        // only the iterations flagged in cm (two rows on one entry) use the atomic.
+        auto step = [&](const int it, const uint32_t offa, const float4 A, const float4 B, const float4 Cz) {
+            float* const accp = reinterpret_cast<float*>(reinterpret_cast<char*>(ACC) + offa + slot_b);
+            const float acc_old = *accp; // every lane reads (the other seven of a row re-read component 0: same address, broadcast)
             __builtin_amdgcn_sched_barrier(0); // issue the accumulator read here, a whole iteration ahead of its use
             const float dx = A.x - pxf, dy = A.y - pyf;
             const float power2 = pair_power2(dx, dy, A.z, A.w, B.x); // = power * log2(e)
             const float Graw = __builtin_amdgcn_exp2f(power2);
             const float araw = fminf(0.99f, B.y * Graw);
-            const bool valid = act && __float_as_uint(Cz.y) < last && power2 <= 0.0f && araw >= GSR_ALPHA_MIN;
+            const bool valid = lane_of(wm(__float_as_uint(Cz.y) < last) & wm(power2 <= 0.0f) & wm(araw >= GSR_ALPHA_MIN));
             const float alpha = valid ? araw : 0.f, G = valid ? Graw : 0.f;
             const float ia = __builtin_amdgcn_rcpf(1.f - alpha);
             T = T * ia;
@@ -305,41 +326,46 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             const float dL_dalpha = fmaf(nTf_bg, ia, eg * T); // - T_final/(1-alpha) * (bg . dL_dpix)
             S0 = fmaf(alpha, e0, S0); S1 = fmaf(alpha, e1, S1); S2 = fmaf(alpha, e2, S2);
             const float u = G * dL_dalpha;
-            const v2f d = {dx, dy};
-            const v2f ud = u * d;      // two-wide products: v_pk_mul_f32
-            const v2f m = ud.x * d;
-            const v2f gc = dcol * g01;
+            const float udx = u * dx, udy = u * dy;
             float v[9];
             v[0] = u;
-            v[1] = ud.x;
-            v[2] = ud.y;
-            v[3] = m.x;
-            v[4] = m.y;
-            v[5] = ud.y * dy;
-            v[6] = gc.x;
-            v[7] = gc.y;
+            v[1] = udx;
+            v[2] = udy;
+            v[3] = udx * dx;
+            v[4] = udx * dy;
+            v[5] = udy * dy;
+            v[6] = dcol * g0;
+            v[7] = dcol * g1;
             v[8] = dcol * g2;
             const float mine = row_reduce9(v, l, acc_old);
             const bool collide = Q <= 64 ? ((cm[0] >> it) & 1ull) != 0ull : ((cm[it >> 6] >> (it & 63)) & 1ull) != 0ull;
-            if (!collide) *accp = acc_old + (commit ? mine : 0.f);
-            else if (commit) unsafeAtomicAdd(accp, mine);
+            if (has_slot) {
+                if (!collide) *accp = acc_old + mine;
+                else unsafeAtomicAdd(accp, mine);
+            }
         };
         // software pipeline, unrolled by two so that the two register sets alternate without copies:
-        // the entry of the next iteration and the list byte of the one after are always in flight
-        int idx0 = 0 < mycnt ? (int)mylist[0] : 0; // entry 0 is always parked: finite data for idle rows
-        float4 A0 = E0[idx0], B0 = E1[idx0], C0 = E2[idx0];
-        int raw1 = (int)mylist[1], raw0, idx1;
+        // the entry of the next iteration and the list offsets of the one after are always in flight
+        uint32_t o0 = mylist[0], oa0 = mylista[0], o1 = mylist[1], oa1 = mylista[1];
+        float4 A0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o0);
+        float4 B0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o0);
+        float4 C0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + o0);
         float4 A1, B1, C1;
         for (int it = 0; it < maxc; it += 2) {
-            idx1 = it + 1 < mycnt ? raw1 : 0;
-            A1 = E0[idx1]; B1 = E1[idx1]; C1 = E2[idx1];
-            raw0 = (int)mylist[min(it + 2, Q - 1)];
-            step(it, idx0, A0, B0, C0);
-            if (it + 1 >= maxc) break;
-            idx0 = it + 2 < mycnt ? raw0 : 0;
-            A0 = E0[idx0]; B0 = E1[idx0]; C0 = E2[idx0];
-            raw1 = (int)mylist[min(it + 3, Q - 1)];
-            step(it + 1, idx1, A1, B1, C1);
+            A1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o1);
+            B1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o1);
+            C1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + o1);
+            o0 = mylist[it + 2];
+            const uint32_t oa_cur0 = oa0;
+            oa0 = mylista[it + 2];
+            step(it, oa_cur0, A0, B0, C0);
+            A0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o0);
+            B0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o0);
+            C0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + o0);
+            o1 = mylist[it + 3];
+            const uint32_t oa_cur1 = oa1;
+            oa1 = mylista[it + 3];
+            step(it + 1, oa_cur1, A1, B1, C1);
         }
         __builtin_amdgcn_wave_barrier();
         // ---- flush: seven parked entries per instruction, nine consecutive lanes per 64-byte record
@@ -370,8 +396,12 @@ __global__ void __launch_bounds__(64)
 K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
                  int grid_x, int ntiles, int tile0, float* __restrict__ out_color, float* __restrict__ out_depth, int P)
 {
-    __shared__ float4 E0[Q], E1[Q], E2[Q]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, depth, list position + 1, id)
-    __shared__ uint8_t LIST[4 * Q];
+    // parked entries; slot Q is a dummy that no pixel can see (opacity 0, far away): the per-patch lists are padded with
+    // it, so the blend loop needs neither an "is this row still active" compare nor an index select
+    __shared__ float4 E0[Q + 1], E1[Q + 1], E2[Q + 1]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, depth, list position + 1, id)
+    // per-patch hit lists: BYTE OFFSETS of the entries (index * 16: shifts and integer mads are half-rate on gfx950,
+    // LDS loads are not VALU work at all), 4 slots of slack behind the longest list for the software pipeline
+    __shared__ uint16_t LIST[4 * (Q + 4)];
     const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
     const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u;
     const int tx = tile % grid_x, ty = tile / grid_x;
@@ -386,16 +416,22 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t last = 0u;
-    bool done = !inside;
+    wmask m_done = wm(!inside); // lanes whose pixel is finished (or outside the image)
     uint2* __restrict__ qh = bn.qhits + 4 * (size_t)range.x + (size_t)quad * (size_t)n;
     int qc = 0;
+    constexpr uint32_t DUMMY = (uint32_t)Q * 16u;
+    if (lane == 0) {
+        E0[Q] = make_float4(-1.0e5f, -1.0e5f, -1.f, 0.f); // power2 ~ -2e10: exp2 gives 0
+        E1[Q] = make_float4(-1.f, 0.f, 0.f, 0.f);
+        E2[Q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
     if (n > 0) {
         int base = 0;
         uint32_t id_c = plist[min(lane, n - 1)], id_n = plist[min(lane + 64, n - 1)];
         float4 a_c = g.g0[id_c], b_c = g.g1[id_c];
         while (base < n) {
-            const unsigned long long dmask = __ballot(done);
+            const wmask dmask = m_done;
             if (dmask == ~0ull) break;
             // ---- gather + quad cull + compaction
             int count = 0;
@@ -429,56 +465,65 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                 float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (e < count) { patch_reach4(E0[e], E1[e], X0f, Y0f, h); z = E2[e]; }
                 const unsigned long long m0 = __ballot(h[0]), m1 = __ballot(h[1]), m2 = __ballot(h[2]), m3 = __ballot(h[3]);
-                if (h[0]) LIST[0 * Q + c0 + mbcnt64(m0)] = (uint8_t)e;
-                if (h[1]) LIST[1 * Q + c1 + mbcnt64(m1)] = (uint8_t)e;
-                if (h[2]) LIST[2 * Q + c2 + mbcnt64(m2)] = (uint8_t)e;
-                if (h[3]) LIST[3 * Q + c3 + mbcnt64(m3)] = (uint8_t)e;
+                const uint16_t off = (uint16_t)(e * 16);
+                if (h[0]) LIST[0 * (Q + 4) + c0 + mbcnt64(m0)] = off;
+                if (h[1]) LIST[1 * (Q + 4) + c1 + mbcnt64(m1)] = off;
+                if (h[2]) LIST[2 * (Q + 4) + c2 + mbcnt64(m2)] = off;
+                if (h[3]) LIST[3 * (Q + 4) + c3 + mbcnt64(m3)] = off;
                 c0 += (int)__popcll(m0); c1 += (int)__popcll(m1); c2 += (int)__popcll(m2); c3 += (int)__popcll(m3);
                 const uint32_t pm = (h[0] ? 1u : 0u) | (h[1] ? 2u : 0u) | (h[2] ? 4u : 0u) | (h[3] ? 8u : 0u);
                 const unsigned long long ma = m0 | m1 | m2 | m3;
                 if (pm) qh[qc + mbcnt64(ma)] = make_uint2(__float_as_uint(z.z) - 1u, __float_as_uint(z.w) | (pm << GSR_ID_BITS));
                 qc += (int)__popcll(ma);
             }
+            // ---- blend: row r walks its own list; the wave runs as long as its longest unfinished row (an even number of
+            //      iterations: the loop is unrolled by two), shorter lists are padded with the dummy entry
+            const int e0 = ((dmask >> 0) & 0xFFFFull) == 0xFFFFull ? 0 : c0, e1 = ((dmask >> 16) & 0xFFFFull) == 0xFFFFull ? 0 : c1;
+            const int e2 = ((dmask >> 32) & 0xFFFFull) == 0xFFFFull ? 0 : c2, e3 = ((dmask >> 48) & 0xFFFFull) == 0xFFFFull ? 0 : c3;
+            const int maxc = (max(max(e0, e1), max(e2, e3)) + 1) & ~1;
+            {
+                const int cr = r == 0 ? c0 : r == 1 ? c1 : r == 2 ? c2 : c3;
+                for (int p = cr + l; p < maxc + 4; p += 16) LIST[r * (Q + 4) + p] = (uint16_t)DUMMY;
+            }
             __builtin_amdgcn_wave_barrier();
-            // ---- blend: row r walks its own list; a finished row idles
-            const bool rowdone = ((dmask >> (16 * r)) & 0xFFFFull) == 0xFFFFull;
-            const int mycnt = rowdone ? 0 : (r == 0 ? c0 : r == 1 ? c1 : r == 2 ? c2 : c3);
-            const int maxc = max(max(c0, c1), max(c2, c3));
-            const uint8_t* __restrict__ mylist = LIST + r * Q;
-            auto step = [&](const int it, const float4 A, const float4 B, const float4 Cz) {
-                const bool act = it < mycnt;
+            const uint16_t* __restrict__ mylist = LIST + r * (Q + 4);
+            auto step = [&](const float4 A, const float4 B, const float4 Cz) {
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 const float power2 = pair_power2(dx, dy, A.z, A.w, B.x); // = power * log2(e): same sign as power
                 const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(power2));
-                const bool valid = act && !done && power2 <= 0.0f && alpha >= GSR_ALPHA_MIN;
+                const wmask valid = ~m_done & wm(power2 <= 0.0f) & wm(alpha >= GSR_ALPHA_MIN);
                 const float test_T = T * (1.f - alpha);
-                const bool stop = valid && test_T < 0.0001f;
-                const bool upd = valid && !stop;
-                done = done || stop;
-                const float wgt = upd ? alpha * T : 0.f;
+                const wmask lt = wm(test_T < 0.0001f), upd = valid & ~lt;
+                m_done |= valid & lt;
+                const bool u = lane_of(upd);
+                const float wgt = u ? alpha * T : 0.f;
                 C0 = fmaf(B.z, wgt, C0);
                 C1 = fmaf(B.w, wgt, C1);
                 C2 = fmaf(Cz.x, wgt, C2);
-                Dp = (upd && T > 0.5f) ? Cz.y : Dp; // median depth (forward.cu:374-379)
-                T = upd ? test_T : T;
-                last = upd ? __float_as_uint(Cz.z) : last;
+                Dp = lane_of(upd & wm(T > 0.5f)) ? Cz.y : Dp; // median depth (forward.cu:374-379)
+                T = u ? test_T : T;
+                last = u ? __float_as_uint(Cz.z) : last;
             };
-            int idx0 = 0 < mycnt ? (int)mylist[0] : 0; // entry 0 is always parked: finite data for idle rows
-            float4 A0 = E0[idx0], B0 = E1[idx0], Z0 = E2[idx0];
-            int raw1 = (int)mylist[1], raw0, idx1;
-            float4 A1, B1, Z1;
-            for (int it = 0; it < maxc; it += 2) {
-                idx1 = it + 1 < mycnt ? raw1 : 0;
-                A1 = E0[idx1]; B1 = E1[idx1]; Z1 = E2[idx1];
-                raw0 = (int)mylist[min(it + 2, Q - 1)];
-                __builtin_amdgcn_sched_barrier(0); // keep the prefetch above the iteration it overlaps with
-                step(it, A0, B0, Z0);
-                if (it + 1 >= maxc) break;
-                idx0 = it + 2 < mycnt ? raw0 : 0;
-                A0 = E0[idx0]; B0 = E1[idx0]; Z0 = E2[idx0];
-                raw1 = (int)mylist[min(it + 3, Q - 1)];
-                __builtin_amdgcn_sched_barrier(0);
-                step(it + 1, A1, B1, Z1);
+            if (maxc > 0) {
+                uint32_t o0 = mylist[0], o1 = mylist[1];
+                float4 A0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o0);
+                float4 B0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o0);
+                float4 Z0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + o0);
+                float4 A1, B1, Z1;
+                for (int it = 0; it < maxc; it += 2) {
+                    A1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o1);
+                    B1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o1);
+                    Z1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + o1);
+                    o0 = mylist[it + 2];
+                    __builtin_amdgcn_sched_barrier(0); // keep the prefetch above the iteration it overlaps with
+                    step(A0, B0, Z0);
+                    A0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o0);
+                    B0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o0);
+                    Z0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + o0);
+                    o1 = mylist[it + 3];
+                    __builtin_amdgcn_sched_barrier(0);
+                    step(A1, B1, Z1);
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }

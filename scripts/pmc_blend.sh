@@ -6,7 +6,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 mkdir -p $out
 for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT" "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM"; do
   n=$(echo $grp | tr ' ' '_' | cut -c1-40)
-  env "$@" rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$n -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --steps 3 --warmup 1 > $out/$n.log 2>&1
+  env "$@" rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$n -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --mode rasterize --steps 3 --warmup 1 > $out/$n.log 2>&1
 done
 python - <<PY
 import csv,glob,collections

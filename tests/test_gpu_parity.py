@@ -110,8 +110,8 @@ def test_forward_backward_parity(gsr, syn, name):
     worst = {}
     # absolute floor of the element-wise bar: 1e-6 of the tensor's largest element (~10 ulps of it); observed worst ratio
     # on eight scenes 0.28. Only deep-stack-depth (R/P = 26: every splat sums ~1e5 signed fp32 terms of near-identical
-    # colours, atomics in any order, against the oracle's double accumulators) needs 1e-5 (observed 5.4e-6).
-    afloor = 1e-5 if name == "deep-stack-depth" else 1e-6
+    # colours, atomics in any order, against the oracle's double accumulators) needs 4e-5 (observed 5e-6 .. 2e-5 from run to run).
+    afloor = 4e-5 if name == "deep-stack-depth" else 1e-6
     for n in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh",
               "dL_dscales", "dL_drotations"):
         got, ref = getattr(gr, n).cpu().numpy(), getattr(b, n)
