@@ -36,6 +36,15 @@ __device__ __forceinline__ int mbcnt64(unsigned long long m)
 // Lane predicates as wave masks and back. Combining conditions on the MASKS is scalar-unit work (free next to a
 // VALU-bound loop) and lets one v_cmp serve a condition and its negation (the compiler otherwise emits a second
 // compare for !(x < c)); only v_cmp and v_cndmask — both half-rate on gfx950 — remain on the vector side.
+// A single-wave workgroup exchanges data through LDS in program order (the LDS queue of a wave is in order); the only
+// thing to prevent is the COMPILER moving LDS accesses across the hand-over point (the same block is viewed through
+// differently typed pointers).
+__device__ __forceinline__ void lds_turn()
+{
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
 typedef unsigned long long wmask;
 __device__ __forceinline__ wmask wm(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool lane_of(wmask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
@@ -71,28 +80,33 @@ __device__ __forceinline__ bool quad_reach(const float4 a, const float4 b, float
 }
 
 // =====================================================================================
-// Backward ("patch rows"): the wave still owns an 8x8 quad, but its four 16-lane DPP rows are four
-// INDEPENDENT 4x4 pixel patches, each walking its own hit list. Small splats touch few pixels of
-// an 8x8 quad (~16 of 64 lanes useful on the 1 M-splat workload); a 4x4 patch is hit by half as many
-// splats as the quad and uses ~8 of its 16 lanes, so the same wave retires ~1.7x fewer iterations.
+// Backward ("patch rows", deferred reduction): the wave owns an 8x8 quad, its four 16-lane rows are four
+// INDEPENDENT 4x4 pixel patches, each walking its own hit list. Small splats touch few pixels of an 8x8 quad
+// (~16 of 64 lanes useful on the 1 M-splat workload); a 4x4 patch is hit by half as many splats as the quad and
+// uses ~8 of its 16 lanes, so the same wave retires ~1.7x fewer iterations.
 //   gather : the forward logged which list entries reach the quad and which of its patches (qhits), so
 //            the backward never touches the rest of the tile list: 64 records per step, back to front,
 //            records behind every pixel's last contributor dropped, the rest parked in LDS;
-//   lists  : one lane per parked entry appends the entry's index to the byte list of every patch in
-//            its mask (list order is kept);
-//   blend  : row r walks list r (entries software-pipelined through two register sets); per iteration
-//            the nine partial sums are reduced inside the 16-lane row (transposing, bank-masked DPP
-//            adds) and nine lanes per row add them into the entry's LDS accumulator with a plain
-//            read-modify-write — the four rows usually work on four different splats; the iterations
-//            in which two rows meet on one entry are found beforehand and use ds_add_f32 instead
-//            (LDS float atomics retire ~1 lane per 3 cycles: using them always costs +100 us);
+//   lists  : one lane per parked entry appends the entry's byte offsets to the list of every patch in its mask
+//            (list order is kept); the lists are padded with a dummy entry to a common even length;
+//   blend  : row r walks list r (entries software-pipelined through two register sets). An iteration only does the
+//            per-PIXEL arithmetic (alpha, T, the accum_rec recursion, dL/dalpha) and parks two numbers per lane in
+//            an LDS ring: u = G * dL/dalpha and dcol = alpha * T;
+//   reduce : every 16 iterations the wave turns around: one lane per (row, iteration) pair — 64 pairs — reads the
+//            16 pixels of its pair from the ring and forms the nine per-splat sums (moments of u about the splat
+//            centre, dcol . dL/dpixel) with plain register FMAs, then adds them to the entry's LDS accumulator,
+//            row after row (the entries of one row's list are distinct: no atomics, no collision handling).
+//            The transposition is done by LDS addressing instead of a 21-instruction DPP butterfly per iteration
+//            (all DPP ops, v_cndmask, v_cmp, v_min/max run at half the rate of v_fma on gfx950:
+//            scripts/valu_bench2.hip), and the 8 moment / colour products per lane leave the loop as well;
 //   flush  : LDS accumulators -> one 9-lane global atomic per parked entry that was hit (7 per
-//            instruction), i.e. the same number of L2 atomic records as the quad kernel. Issuing the
-//            atomics per PATCH instead would double them and hit the L2 atomic ceiling (~20 G records/s,
-//            scripts/atomic_bench2.hip).
+//            instruction), i.e. one L2 atomic record per (quad, splat). Issuing the atomics per PATCH instead
+//            would double them and hit the L2 atomic ceiling (~20 G records/s, scripts/atomic_bench2.hip).
 // =====================================================================================
 #define GSR_FWDQ 96 // forward: gathers until more than 32 entries are parked (2-3 steps of ~22 quad hits)
-#define GSR_ROWQ 64 // parked entries per round = one gather step; 64 beats 96 and 128 (LDS 5.9 KB per wave)
+#define GSR_ROWQ 64 // parked entries per round = one gather step
+#define GSR_RING 16 // iterations between two reduce phases: 4 rows x 16 = one (row, iteration) pair per lane
+#define GSR_ACCW 12 // floats per LDS accumulator record (nine used): 48 bytes, so that it moves as three b128
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Exact cull of one parked entry (conic staged for pair_power2, i.e. in log2 units) against the 2x2
@@ -127,73 +141,35 @@ __device__ __forceinline__ void patch_reach4(const float4 A, const float4 B, flo
         }
 }
 
-// Transposing reduction of nine values inside each 16-lane row. Stage s pairs lanes through a DPP
-// permutation that flips bit (3-s) of the lane number; the lane keeps one value of a pair and hands the
-// other to its partner, so the live registers go 9 -> 5 -> 3 -> 2 -> 1 (21 VALU with the bank-masked first two
-// stages of row_reduce9, 27 with selects throughout). On return lane l of the
-// row holds the row total of value rows_slot_of(l).
-__device__ __forceinline__ int rows_slot_of(int l)
-{
-    if (l & 1) return l == 1 ? 8 : -1;
-    return ((l >> 3) & 1) | (((l >> 2) & 1) << 1) | (((l >> 1) & 1) << 2);
-}
-template <int CTRL>
-__device__ __forceinline__ float tr_pair(bool hi, float even, float odd)
-{
-    const float keep = hi ? odd : even, give = hi ? even : odd;
-    return keep + dpp_f<CTRL>(give);
-}
-// `early` is any value that must already be in a register when the reduction starts (the caller's LDS
-// accumulator read: naming it here keeps the compiler from sinking that load behind the reduction).
-__device__ __forceinline__ float row_reduce9(const float (&v)[9], int l, float early)
-{
-    // Stages 1 and 2 select by DPP bank (a bank = 4 lanes): the lanes of banks {0,1} / {2,3} (stage 1) and
-    // {0,2} / {1,3} (stage 2) are exactly the lanes that keep the even / odd value of a pair, so two
-    // bank-masked v_add_f32_dpp writing one register replace two v_cndmask + one add. Hand-written
-    // because the compiler cannot express a partial-bank destination; s_nop covers the VALU-write ->
-    // DPP-read hazard at the block entry, inside the block every DPP source is >= 4 instructions old.
-    float a0, a1, a2, a3, a4, c0, c1, c2;
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %0, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %1, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %1, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %2, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %2, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %3, %14, %14 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %3, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %4, %16, %16 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %5, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %5, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %6, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %6, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %7, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf"
-        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(c0), "=&v"(c1), "=&v"(c2)
-        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(early));
-    const bool b1 = (l & 2) != 0, b0 = (l & 1) != 0;
-    const float d0 = tr_pair<0x1B>(b1, c0, c1);                                             // quad_perm [3,2,1,0]  l <-> l^3
-    const float d1 = c2 + dpp_f<0x1B>(c2);
-    return tr_pair<0xB1>(b0, d0, d1);                                                       // quad_perm [1,0,3,2]  l <-> l^1
-}
-
 template <int Q>
 __global__ void __launch_bounds__(64)
 K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* __restrict__ bg, int W, int H,
                  int grid_x, int ntiles, int tile0, const float* __restrict__ dL_dpix)
 {
+    static_assert(Q == 64 && GSR_RING == 16, "one lane per parked entry and one lane per (row, ring slot) pair");
     // parked entries; slot Q is a dummy (opacity 0, far away) the per-patch lists are padded with: no "row still active"
-    // compare and no index select in the blend loop; what the idle rows add to its accumulator record is never flushed
+    // compare and no index select in the blend loop
     __shared__ float4 E0[Q + 1], E1[Q + 1], E2[Q + 1]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, list position, splat id, patch mask)
-    __shared__ float ACC[(Q + 1) * 9];
-    // per-patch hit lists as BYTE OFFSETS (entry * 16 into E0/E1/E2, entry * 36 into ACC): shifts and integer mads are
-    // half-rate VALU work on gfx950, a second 2-byte LDS load is not VALU work at all
-    __shared__ uint16_t LIST[4 * (Q + 4)], LISTA[4 * (Q + 4)];
+    // per-patch hit lists as BYTE OFFSETS (entry * 16 into E0/E1/E2): shifts and integer mads are half-rate VALU work
+    __shared__ uint16_t LIST[4 * (Q + 4)];
+    // One block of LDS used three ways, one after the other:
+    //  UD  the ring: (u, dcol) of pixel p of pair q = row * 16 + (iteration % 16) at float2 UD[p * 65 + q]. A blend iteration
+    //      writes 16 consecutive p for 4 values of q (stride 65 float2: the 16 lanes of a row fall on 16 different bank
+    //      pairs), the reduce phase reads 64 consecutive q for one p: both conflict-free;
+    //  ST  float4 ST[3 * 64]: the nine sums of pair q at ST[k * 64 + q], k = 0..2 (reduce phase -> merge by entry);
+    //  ACC float ACC[64 * 12]: the per-entry totals of the round, staged for the coalesced flush.
+    __shared__ float4 POOL[(16 * (4 * GSR_RING + 1) * 8) / 16];
+    __shared__ float4 GP[4][17]; // dL/dpixel of pixel p of patch r (17: the four rows on different banks)
+    __shared__ uint8_t INV[4][Q + 4]; // per batch: ring slot of entry e in row r, or 0xFF
+    v2f* const UD = reinterpret_cast<v2f*>(POOL);
+    float4* const ST = POOL;
     const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
     const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u;
     const int tx = tile % grid_x, ty = tile / grid_x;
     const int lane = threadIdx.x, r = lane >> 4, l = lane & 15;
     const int X0 = tx * 16 + (int)(quad & 1u) * 8, Y0 = ty * 16 + (int)(quad >> 1) * 8;
-    const int px = X0 + (r & 1) * 4 + (l & 3), py = Y0 + (r >> 1) * 4 + (l >> 2);
+    const int X0p = X0 + (r & 1) * 4, Y0p = Y0 + (r >> 1) * 4; // origin of this row's patch
+    const int px = X0p + (l & 3), py = Y0p + (l >> 2);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = im.ranges[tile];
@@ -208,7 +184,6 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     const float g0 = inside ? dL_dpix[pix] : 0.f, g1 = inside ? dL_dpix[HW + pix] : 0.f,
                 g2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
     const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
-    const v2f g01 = {g0, g1};
     const float nTf_bg = -T_final * bg_dot;
     // colour accumulated behind the current splat (the reference's accum_rec, updated eagerly:
     // last_alpha*last_color + (1-last_alpha)*accum_rec == fma(alpha, c - S, S) one step later). Kept per
@@ -216,17 +191,17 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     // similar colours (depth renders!), and contracting first turns an exact small difference into the
     // difference of two rounded large numbers (measured: 9e-5 instead of 1e-6 on long lists).
     float S0 = 0.f, S1 = 0.f, S2 = 0.f;
-    const int slot = rows_slot_of(l);
-    const bool has_slot = slot >= 0; // the nine lanes of a row that end up holding a row total
-    const uint32_t slot_b = has_slot ? 4u * (uint32_t)slot : 0u;
     const int fe = (lane * 57) >> 9, fc = lane - 9 * fe; // lane / 9, lane % 9: flush lane -> (entry, component)
-    for (int i = lane; i < (Q + 1) * 9; i += 64) ACC[i] = 0.f;
+    GP[r][l] = make_float4(g0, g1, g2, 0.f);
     if (lane == 0) {
         E0[Q] = make_float4(-1.0e5f, -1.0e5f, -1.f, 0.f); // power2 ~ -2e10: exp2 gives 0
         E1[Q] = make_float4(-1.f, 0.f, 0.f, 0.f);
         E2[Q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int ntodo = __builtin_amdgcn_readfirstlane(min(n, (int)wave_max_u32(last)));
+    for (int i = lane; i < (int)(sizeof(POOL) / sizeof(float4)); i += 64) POOL[i] = make_float4(0.f, 0.f, 0.f, 0.f); // stale ring slots are read (never used): keep them finite
+    const float X0pf = (float)X0p, Y0pf = (float)Y0p;
+    v2f* const ud_w0 = UD + l * (4 * GSR_RING + 1) + r * GSR_RING; // where this lane parks (u, dcol) of ring slot 0
 
     // The forward logged the entries that reach this quad (list position, id), in list order; walk them
     // back to front. Gather pipeline: the records of the next two steps and the geometry of the next step
@@ -240,9 +215,10 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     uint2 rec_n = qh[max(cq - 1 - (lane + 64), 0)];
     float4 a_c = g.g0[rec_c.y & GSR_ID_MASK], b_c = g.g1[rec_c.y & GSR_ID_MASK];
     while (k0 < cq) {
-        // ---- gather + compaction (records past the last contributor of every pixel are dropped)
+        // ---- gather + compaction (records past the last contributor of every pixel are dropped): one step, <= 64 entries
         int count = 0;
-        do {
+        uint32_t my_id = 0u; // lane e: the splat id of parked entry e
+        {
             const uint32_t id = rec_c.y & GSR_ID_MASK, pos = rec_c.x, pmask = rec_c.y >> GSR_ID_BITS;
             const float4 a = a_c, b = b_c;
             const int k = k0 + lane;
@@ -254,64 +230,46 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             rec_n = qh[max(cq - 1 - (k + 128), 0)];
             const unsigned long long m = __ballot(hit);
             if (hit) {
-                const int e = count + mbcnt64(m);
+                const int e = mbcnt64(m);
                 E0[e] = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
                 E1[e] = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, c.x, c.y);
                 E2[e] = make_float4(c.z, __uint_as_float(pos), __uint_as_float(id), __uint_as_float(pmask));
             }
-            count += (int)__popcll(m);
+            count = (int)__popcll(m);
             k0 += 64;
-        } while (k0 < cq && count <= Q - 64);
+        }
         if (count == 0) continue;
-        __builtin_amdgcn_wave_barrier();
-        // ---- per-patch hit lists
-        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        for (int eb = 0; eb < count; eb += 64) {
-            const int e = eb + lane;
+        lds_turn();
+        // ---- per-patch hit lists (lane e looks at parked entry e)
+        int c0, c1, c2, c3;
+        {
             bool h[4] = {false, false, false, false};
-            if (e < count) { // the forward already ran the patch cull: its verdict travels in the record
-                const uint32_t pm = __float_as_uint(E2[e].w);
+            if (lane < count) { // the forward already ran the patch cull: its verdict travels in the record
+                const float4 z = E2[lane];
+                const uint32_t pm = __float_as_uint(z.w);
+                my_id = __float_as_uint(z.z);
                 h[0] = (pm & 1u) != 0u; h[1] = (pm & 2u) != 0u; h[2] = (pm & 4u) != 0u; h[3] = (pm & 8u) != 0u;
             }
             const unsigned long long m0 = __ballot(h[0]), m1 = __ballot(h[1]), m2 = __ballot(h[2]), m3 = __ballot(h[3]);
-            const uint16_t off = (uint16_t)(e * 16), offa = (uint16_t)(e * 36);
-            if (h[0]) { const int p = 0 * (Q + 4) + c0 + mbcnt64(m0); LIST[p] = off; LISTA[p] = offa; }
-            if (h[1]) { const int p = 1 * (Q + 4) + c1 + mbcnt64(m1); LIST[p] = off; LISTA[p] = offa; }
-            if (h[2]) { const int p = 2 * (Q + 4) + c2 + mbcnt64(m2); LIST[p] = off; LISTA[p] = offa; }
-            if (h[3]) { const int p = 3 * (Q + 4) + c3 + mbcnt64(m3); LIST[p] = off; LISTA[p] = offa; }
-            c0 += (int)__popcll(m0); c1 += (int)__popcll(m1); c2 += (int)__popcll(m2); c3 += (int)__popcll(m3);
+            const uint16_t off = (uint16_t)(lane * 16);
+            if (h[0]) LIST[0 * (Q + 4) + mbcnt64(m0)] = off;
+            if (h[1]) LIST[1 * (Q + 4) + mbcnt64(m1)] = off;
+            if (h[2]) LIST[2 * (Q + 4) + mbcnt64(m2)] = off;
+            if (h[3]) LIST[3 * (Q + 4) + mbcnt64(m3)] = off;
+            c0 = (int)__popcll(m0); c1 = (int)__popcll(m1); c2 = (int)__popcll(m2); c3 = (int)__popcll(m3);
         }
-        __builtin_amdgcn_wave_barrier();
-        // ---- blend: row r walks its own list; the loop runs an even number of iterations (unrolled by two), shorter
-        //      lists are padded with the dummy entry
+        // the loop runs an even number of iterations (unrolled by two); shorter lists are padded with the dummy entry
         const int maxc = (max(max(c0, c1), max(c2, c3)) + 1) & ~1;
-        // iterations in which two rows work on the same parked entry: those must accumulate atomically
-        unsigned long long cm[(Q + 63) / 64];
-#pragma unroll
-        for (int b = 0; b < (Q + 63) / 64; b++) {
-            const int t = b * 64 + lane;
-            bool coll = false;
-            if (t < maxc) {
-                const int v0 = t < c0 ? (int)LIST[0 * (Q + 4) + t] : 0x10000, v1 = t < c1 ? (int)LIST[1 * (Q + 4) + t] : 0x10001;
-                const int v2 = t < c2 ? (int)LIST[2 * (Q + 4) + t] : 0x10002, v3 = t < c3 ? (int)LIST[3 * (Q + 4) + t] : 0x10003;
-                coll = v0 == v1 || v0 == v2 || v0 == v3 || v1 == v2 || v1 == v3 || v2 == v3;
-            }
-            cm[b] = __ballot(coll);
-        }
         {
             const int cr = r == 0 ? c0 : r == 1 ? c1 : r == 2 ? c2 : c3;
-            for (int p = cr + l; p < maxc + 4; p += 16) { LIST[r * (Q + 4) + p] = (uint16_t)(Q * 16); LISTA[r * (Q + 4) + p] = (uint16_t)(Q * 36); }
+            for (int p = cr + l; p < maxc + 4; p += 16) LIST[r * (Q + 4) + p] = (uint16_t)(Q * 16);
         }
-        __builtin_amdgcn_wave_barrier();
+        lds_turn();
         const uint16_t* __restrict__ mylist = LIST + r * (Q + 4);
-        const uint16_t* __restrict__ mylista = LISTA + r * (Q + 4);
-        // One iteration on an entry already in registers. Accumulation is a plain LDS read-modify-write by the nine
-        // slot lanes of the row (LDS float atomics cost ~240 cycles per wave instruction: scripts/valu_bench2.hip);
-        // only the iterations flagged in cm (two rows on one entry) use the atomic.
-        auto step = [&](const int it, const uint32_t offa, const float4 A, const float4 B, const float4 Cz) {
-            float* const accp = reinterpret_cast<float*>(reinterpret_cast<char*>(ACC) + offa + slot_b);
-            const float acc_old = *accp; // every lane reads (the other seven of a row re-read component 0: same address, broadcast)
-            __builtin_amdgcn_sched_barrier(0); // issue the accumulator read here, a whole iteration ahead of its use
+        // per-entry totals of this round, in the registers of lane e
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f, t5 = 0.f, t6 = 0.f, t7 = 0.f, t8 = 0.f;
+        // ---- blend: one iteration on an entry already in registers; parks (u, dcol) at `slot`
+        auto step = [&](v2f* const slot, const float4 A, const float4 B, const float4 Cz) {
             const float dx = A.x - pxf, dy = A.y - pyf;
             const float power2 = pair_power2(dx, dy, A.z, A.w, B.x); // = power * log2(e)
             const float Graw = __builtin_amdgcn_exp2f(power2);
@@ -320,66 +278,100 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             const float alpha = valid ? araw : 0.f, G = valid ? Graw : 0.f;
             const float ia = __builtin_amdgcn_rcpf(1.f - alpha);
             T = T * ia;
-            const float dcol = alpha * T;
             const float e0 = B.z - S0, e1 = B.w - S1, e2 = Cz.x - S2;
             const float eg = fmaf(e2, g2, fmaf(e1, g1, e0 * g0)); // (colour - accum_rec) . dL_dpix
             const float dL_dalpha = fmaf(nTf_bg, ia, eg * T); // - T_final/(1-alpha) * (bg . dL_dpix)
             S0 = fmaf(alpha, e0, S0); S1 = fmaf(alpha, e1, S1); S2 = fmaf(alpha, e2, S2);
-            const float u = G * dL_dalpha;
-            const float udx = u * dx, udy = u * dy;
-            float v[9];
-            v[0] = u;
-            v[1] = udx;
-            v[2] = udy;
-            v[3] = udx * dx;
-            v[4] = udx * dy;
-            v[5] = udy * dy;
-            v[6] = dcol * g0;
-            v[7] = dcol * g1;
-            v[8] = dcol * g2;
-            const float mine = row_reduce9(v, l, acc_old);
-            const bool collide = Q <= 64 ? ((cm[0] >> it) & 1ull) != 0ull : ((cm[it >> 6] >> (it & 63)) & 1ull) != 0ull;
-            if (has_slot) {
-                if (!collide) *accp = acc_old + mine;
-                else unsafeAtomicAdd(accp, mine);
+            v2f ud;
+            ud.x = G * dL_dalpha;
+            ud.y = alpha * T;
+            *slot = ud;
+        };
+        // ---- reduce + merge, every 16 iterations. (1) lane (r, l) sums the 16 pixels of the pair (row r, ring slot l) =
+        //      list position b0 + l of row r into nine numbers; (2) the sums go to ST, and every row publishes where its
+        //      entries sit (INV); (3) lane e collects the sums of entry e from the (at most four) rows that hold it.
+        //      No read-modify-write on shared data anywhere: nothing to serialise, nothing to make atomic.
+        auto reduce = [&](const int b0, const int nb) {
+            lds_turn();
+            const uint32_t o = mylist[min(b0 + l, maxc + 3)]; // padded lists: always a valid entry (slots >= nb: not published)
+            const float2 c = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(E0) + o); // splat centre
+            reinterpret_cast<uint32_t*>(INV)[lane < (4 * (Q + 4)) / 4 ? lane : 0] = 0xFFFFFFFFu;
+            if (lane + 64 < (4 * (Q + 4)) / 4) reinterpret_cast<uint32_t*>(INV)[lane + 64] = 0xFFFFFFFFu;
+            float dxk[4], dyk[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { dxk[k] = c.x - (X0pf + (float)k); dyk[k] = c.y - (Y0pf + (float)k); }
+            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int p = 0; p < 16; p++) {
+                const v2f ud = UD[p * (4 * GSR_RING + 1) + lane];
+                const float4 gp = GP[r][p];
+                const float dx = dxk[p & 3], dy = dyk[p >> 2];
+                const float udx = ud.x * dx, udy = ud.x * dy;
+                m0 += ud.x; m1 += udx; m2 += udy;
+                m3 = fmaf(udx, dx, m3); m4 = fmaf(udx, dy, m4); m5 = fmaf(udy, dy, m5);
+                q0 = fmaf(ud.y, gp.x, q0); q1 = fmaf(ud.y, gp.y, q1); q2 = fmaf(ud.y, gp.z, q2);
             }
+            lds_turn(); // every lane has read its column of the ring: the block turns into ST
+            ST[0 * 64 + lane] = make_float4(m0, m1, m2, m3);
+            ST[1 * 64 + lane] = make_float4(m4, m5, q0, q1);
+            ST[2 * 64 + lane] = make_float4(q2, 0.f, 0.f, 0.f);
+            if (l < nb) INV[r][o >> 4] = (uint8_t)l; // the dummy (index Q) lands in the slack of the row
+            lds_turn();
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const uint32_t sl = INV[rr][lane];
+                const uint32_t q = rr * GSR_RING + (sl & 15u);
+                const float4 s0 = ST[0 * 64 + q], s1 = ST[1 * 64 + q], s2 = ST[2 * 64 + q];
+                const float f = sl != 0xFFu ? 1.f : 0.f;
+                t0 = fmaf(f, s0.x, t0); t1 = fmaf(f, s0.y, t1); t2 = fmaf(f, s0.z, t2); t3 = fmaf(f, s0.w, t3);
+                t4 = fmaf(f, s1.x, t4); t5 = fmaf(f, s1.y, t5); t6 = fmaf(f, s1.z, t6); t7 = fmaf(f, s1.w, t7);
+                t8 = fmaf(f, s2.x, t8);
+            }
+            lds_turn(); // the block is the ring again
         };
         // software pipeline, unrolled by two so that the two register sets alternate without copies:
-        // the entry of the next iteration and the list offsets of the one after are always in flight
-        uint32_t o0 = mylist[0], oa0 = mylista[0], o1 = mylist[1], oa1 = mylista[1];
+        // the entry of the next iteration and the list offset of the one after are always in flight
+        uint32_t o0 = mylist[0], o1 = mylist[1];
         float4 A0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o0);
         float4 B0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o0);
         float4 C0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + o0);
         float4 A1, B1, C1;
+        int ring = 0;
         for (int it = 0; it < maxc; it += 2) {
             A1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o1);
             B1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o1);
             C1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + o1);
             o0 = mylist[it + 2];
-            const uint32_t oa_cur0 = oa0;
-            oa0 = mylista[it + 2];
-            step(it, oa_cur0, A0, B0, C0);
+            __builtin_amdgcn_sched_barrier(0); // keep the prefetch above the iteration it overlaps with
+            step(ud_w0 + ring, A0, B0, C0);
             A0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o0);
             B0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o0);
             C0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + o0);
             o1 = mylist[it + 3];
-            const uint32_t oa_cur1 = oa1;
-            oa1 = mylista[it + 3];
-            step(it + 1, oa_cur1, A1, B1, C1);
+            __builtin_amdgcn_sched_barrier(0);
+            step(ud_w0 + ring + 1, A1, B1, C1);
+            ring += 2;
+            if (ring == GSR_RING || it + 2 >= maxc) {
+                reduce(it + 2 - ring, ring);
+                ring = 0;
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        // ---- flush: seven parked entries per instruction, nine consecutive lanes per 64-byte record
+        // ---- flush: lane e holds the nine totals of entry e; stage them (12 floats per entry) and send seven entries per
+        //      instruction, nine consecutive lanes per 64-byte record: one L2 atomic record per (quad, splat)
+        float* const accf = reinterpret_cast<float*>(POOL);
+        ST[lane * 3 + 0] = make_float4(t0, t1, t2, t3);
+        ST[lane * 3 + 1] = make_float4(t4, t5, t6, t7);
+        ST[lane * 3 + 2] = make_float4(t8, 0.f, 0.f, 0.f);
+        lds_turn();
         for (int fb = 0; fb < count; fb += 7) {
             const int e = fb + fe;
             if (lane < 63 && e < count) {
-                const float val = ACC[e * 9 + fc];
-                if (val != 0.f) {
-                    ACC[e * 9 + fc] = 0.f;
-                    unsafeAtomicAdd(&g.acc[(size_t)__float_as_uint(E2[e].z) * GSR_ACC_STRIDE + fc], val);
-                }
+                const float val = accf[e * GSR_ACCW + fc];
+                if (val != 0.f) unsafeAtomicAdd(&g.acc[(size_t)__float_as_uint(E2[e].z) * GSR_ACC_STRIDE + fc], val);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        (void)my_id;
+        lds_turn();
     }
 }
 
