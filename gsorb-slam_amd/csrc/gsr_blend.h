@@ -106,6 +106,9 @@ __device__ __forceinline__ bool quad_reach(const float4 a, const float4 b, float
 #define GSR_FWDQ 96 // forward: gathers until more than 32 entries are parked (2-3 steps of ~22 quad hits)
 #define GSR_ROWQ 64 // parked entries per round = one gather step
 #define GSR_RING 16 // iterations between two reduce phases: 4 rows x 16 = one (row, iteration) pair per lane
+#ifndef GSR_BSTEP
+#define GSR_BSTEP 64 // records the backward takes per round (<= 64: one parked entry per lane)
+#endif
 #define GSR_ACCW 12 // floats per LDS accumulator record (nine used): 48 bytes, so that it moves as three b128
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -160,7 +163,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     //  ACC float ACC[64 * 12]: the per-entry totals of the round, staged for the coalesced flush.
     __shared__ float4 POOL[(16 * (4 * GSR_RING + 1) * 8) / 16];
     __shared__ float4 GP[4][17]; // dL/dpixel of pixel p of patch r (17: the four rows on different banks)
-    __shared__ uint8_t INV[4][Q + 4]; // per batch: ring slot of entry e in row r, or 0xFF
+    __shared__ uint32_t INV[Q + 4]; // per batch: byte r of word e = ring slot of entry e in row r, or 0xFF
     v2f* const UD = reinterpret_cast<v2f*>(POOL);
     float4* const ST = POOL;
     const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
@@ -212,22 +215,20 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     if (ntodo <= 0 || cq <= 0) return;
     int k0 = 0;
     uint2 rec_c = qh[max(cq - 1 - lane, 0)];
-    uint2 rec_n = qh[max(cq - 1 - (lane + 64), 0)];
-    float4 a_c = g.g0[rec_c.y & GSR_ID_MASK], b_c = g.g1[rec_c.y & GSR_ID_MASK];
+    uint2 rec_n = qh[max(cq - 1 - (lane + GSR_BSTEP), 0)];
+    float4 a_c = g.g0[rec_c.y & GSR_ID_MASK], b_c = g.g1[rec_c.y & GSR_ID_MASK], c_c = g.col[rec_c.y & GSR_ID_MASK];
     while (k0 < cq) {
         // ---- gather + compaction (records past the last contributor of every pixel are dropped): one step, <= 64 entries
         int count = 0;
         uint32_t my_id = 0u; // lane e: the splat id of parked entry e
         {
             const uint32_t id = rec_c.y & GSR_ID_MASK, pos = rec_c.x, pmask = rec_c.y >> GSR_ID_BITS;
-            const float4 a = a_c, b = b_c;
+            const float4 a = a_c, b = b_c, c = c_c; // the whole 48-byte record of the next step is in flight during this round
             const int k = k0 + lane;
-            const bool hit = k < cq && pos < (uint32_t)ntodo;
-            float4 c;
-            if (hit) c = g.col[id];
+            const bool hit = lane < GSR_BSTEP && k < cq && pos < (uint32_t)ntodo;
             rec_c = rec_n;
-            a_c = g.g0[rec_c.y & GSR_ID_MASK]; b_c = g.g1[rec_c.y & GSR_ID_MASK];
-            rec_n = qh[max(cq - 1 - (k + 128), 0)];
+            a_c = g.g0[rec_c.y & GSR_ID_MASK]; b_c = g.g1[rec_c.y & GSR_ID_MASK]; c_c = g.col[rec_c.y & GSR_ID_MASK];
+            rec_n = qh[max(cq - 1 - (k + 2 * GSR_BSTEP), 0)];
             const unsigned long long m = __ballot(hit);
             if (hit) {
                 const int e = mbcnt64(m);
@@ -236,7 +237,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
                 E2[e] = make_float4(c.z, __uint_as_float(pos), __uint_as_float(id), __uint_as_float(pmask));
             }
             count = (int)__popcll(m);
-            k0 += 64;
+            k0 += GSR_BSTEP;
         }
         if (count == 0) continue;
         lds_turn();
@@ -268,15 +269,22 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
         const uint16_t* __restrict__ mylist = LIST + r * (Q + 4);
         // per-entry totals of this round, in the registers of lane e
         float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f, t5 = 0.f, t6 = 0.f, t7 = 0.f, t8 = 0.f;
-        // ---- blend: one iteration on an entry already in registers; parks (u, dcol) at `slot`
-        auto step = [&](v2f* const slot, const float4 A, const float4 B, const float4 Cz) {
+        // ---- blend. An iteration is split in two: what does not depend on the pixel's running state (alpha and the
+        //      Gaussian weight of the entry at this pixel) and what does (T, accum_rec, dL/dalpha). The loop handles two
+        //      entries per trip and evaluates both first halves before the two second halves: a wave issues in order and
+        //      every instruction of a half depends on the one before it (exp2, min, compare, select, rcp ...), so two
+        //      independent chains in flight nearly double what one wave gets out of the SIMD — it shares it with only
+        //      two others (LDS-limited occupancy).
+        auto alpha_part = [&](const float4 A, const float4 B, const float4 Cz, float& alpha, float& G) {
             const float dx = A.x - pxf, dy = A.y - pyf;
             const float power2 = pair_power2(dx, dy, A.z, A.w, B.x); // = power * log2(e)
             const float Graw = __builtin_amdgcn_exp2f(power2);
             const float araw = fminf(0.99f, B.y * Graw);
             const bool valid = lane_of(wm(__float_as_uint(Cz.y) < last) & wm(power2 <= 0.0f) & wm(araw >= GSR_ALPHA_MIN));
-            const float alpha = valid ? araw : 0.f, G = valid ? Graw : 0.f;
-            const float ia = __builtin_amdgcn_rcpf(1.f - alpha);
+            alpha = valid ? araw : 0.f;
+            G = valid ? Graw : 0.f;
+        };
+        auto state_part = [&](v2f* const slot, const float alpha, const float G, const float ia, const float4 B, const float4 Cz) {
             T = T * ia;
             const float e0 = B.z - S0, e1 = B.w - S1, e2 = Cz.x - S2;
             const float eg = fmaf(e2, g2, fmaf(e1, g1, e0 * g0)); // (colour - accum_rec) . dL_dpix
@@ -295,67 +303,93 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             lds_turn();
             const uint32_t o = mylist[min(b0 + l, maxc + 3)]; // padded lists: always a valid entry (slots >= nb: not published)
             const float2 c = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(E0) + o); // splat centre
-            reinterpret_cast<uint32_t*>(INV)[lane < (4 * (Q + 4)) / 4 ? lane : 0] = 0xFFFFFFFFu;
-            if (lane + 64 < (4 * (Q + 4)) / 4) reinterpret_cast<uint32_t*>(INV)[lane + 64] = 0xFFFFFFFFu;
+            INV[lane] = 0xFFFFFFFFu;
+            if (lane < 4) INV[64 + lane] = 0xFFFFFFFFu;
+            // all sixteen ring reads and the first dL/dpixel reads go out before the first use: with ~3 waves per SIMD
+            // an LDS round trip per pixel would be the longest thing in this phase
+            v2f ud[16];
+#pragma unroll
+            for (int p = 0; p < 16; p++) ud[p] = UD[p * (4 * GSR_RING + 1) + lane];
+            float4 gq[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) gq[p] = GP[r][p];
+            __builtin_amdgcn_sched_barrier(0);
             float dxk[4], dyk[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) { dxk[k] = c.x - (X0pf + (float)k); dyk[k] = c.y - (Y0pf + (float)k); }
             float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
 #pragma unroll
             for (int p = 0; p < 16; p++) {
-                const v2f ud = UD[p * (4 * GSR_RING + 1) + lane];
-                const float4 gp = GP[r][p];
+                const float4 gp = gq[p & 3];
+                if (p + 4 < 16) gq[p & 3] = GP[r][p + 4];
                 const float dx = dxk[p & 3], dy = dyk[p >> 2];
-                const float udx = ud.x * dx, udy = ud.x * dy;
-                m0 += ud.x; m1 += udx; m2 += udy;
+                const float udx = ud[p].x * dx, udy = ud[p].x * dy;
+                m0 += ud[p].x; m1 += udx; m2 += udy;
                 m3 = fmaf(udx, dx, m3); m4 = fmaf(udx, dy, m4); m5 = fmaf(udy, dy, m5);
-                q0 = fmaf(ud.y, gp.x, q0); q1 = fmaf(ud.y, gp.y, q1); q2 = fmaf(ud.y, gp.z, q2);
+                q0 = fmaf(ud[p].y, gp.x, q0); q1 = fmaf(ud[p].y, gp.y, q1); q2 = fmaf(ud[p].y, gp.z, q2);
             }
             lds_turn(); // every lane has read its column of the ring: the block turns into ST
             ST[0 * 64 + lane] = make_float4(m0, m1, m2, m3);
             ST[1 * 64 + lane] = make_float4(m4, m5, q0, q1);
             ST[2 * 64 + lane] = make_float4(q2, 0.f, 0.f, 0.f);
-            if (l < nb) INV[r][o >> 4] = (uint8_t)l; // the dummy (index Q) lands in the slack of the row
+            if (l < nb) reinterpret_cast<uint8_t*>(INV)[(o >> 2) + r] = (uint8_t)l; // o >> 2 = entry * 4; the dummy (index Q) lands in the slack
             lds_turn();
+            const uint32_t inv = INV[lane]; // lane e: where entry e sits in the four rows
+            float4 s0[4], s1[4], s2[4];
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
-                const uint32_t sl = INV[rr][lane];
-                const uint32_t q = rr * GSR_RING + (sl & 15u);
-                const float4 s0 = ST[0 * 64 + q], s1 = ST[1 * 64 + q], s2 = ST[2 * 64 + q];
-                const float f = sl != 0xFFu ? 1.f : 0.f;
-                t0 = fmaf(f, s0.x, t0); t1 = fmaf(f, s0.y, t1); t2 = fmaf(f, s0.z, t2); t3 = fmaf(f, s0.w, t3);
-                t4 = fmaf(f, s1.x, t4); t5 = fmaf(f, s1.y, t5); t6 = fmaf(f, s1.z, t6); t7 = fmaf(f, s1.w, t7);
-                t8 = fmaf(f, s2.x, t8);
+                const uint32_t q = rr * GSR_RING + ((inv >> (8 * rr)) & 15u);
+                s0[rr] = ST[0 * 64 + q]; s1[rr] = ST[1 * 64 + q]; s2[rr] = ST[2 * 64 + q];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const float f = ((inv >> (8 * rr)) & 0xFFu) != 0xFFu ? 1.f : 0.f;
+                t0 = fmaf(f, s0[rr].x, t0); t1 = fmaf(f, s0[rr].y, t1); t2 = fmaf(f, s0[rr].z, t2); t3 = fmaf(f, s0[rr].w, t3);
+                t4 = fmaf(f, s1[rr].x, t4); t5 = fmaf(f, s1[rr].y, t5); t6 = fmaf(f, s1[rr].z, t6); t7 = fmaf(f, s1[rr].w, t7);
+                t8 = fmaf(f, s2[rr].x, t8);
             }
             lds_turn(); // the block is the ring again
         };
-        // software pipeline, unrolled by two so that the two register sets alternate without copies:
-        // the entry of the next iteration and the list offset of the one after are always in flight
-        uint32_t o0 = mylist[0], o1 = mylist[1];
-        float4 A0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o0);
-        float4 B0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o0);
-        float4 C0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + o0);
-        float4 A1, B1, C1;
+        // software pipeline over PAIRS of entries, unrolled by two pairs so that the register sets alternate without copies:
+        // while one pair is blended the next pair's entries and the list offsets of the pair after are in flight
+#define GSR_LOAD3(A, B, C, off) \
+        A = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + (off)); \
+        B = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + (off)); \
+        C = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + (off))
+        uint32_t o0 = mylist[0], o1 = mylist[1], o2 = mylist[2], o3 = mylist[3];
+        float4 A0, B0, C0, A1, B1, C1, A2, B2, C2, A3, B3, C3;
+        GSR_LOAD3(A0, B0, C0, o0); GSR_LOAD3(A1, B1, C1, o1);
         int ring = 0;
-        for (int it = 0; it < maxc; it += 2) {
-            A1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o1);
-            B1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o1);
-            C1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + o1);
-            o0 = mylist[it + 2];
-            __builtin_amdgcn_sched_barrier(0); // keep the prefetch above the iteration it overlaps with
-            step(ud_w0 + ring, A0, B0, C0);
-            A0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o0);
-            B0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o0);
-            C0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + o0);
-            o1 = mylist[it + 3];
-            __builtin_amdgcn_sched_barrier(0);
-            step(ud_w0 + ring + 1, A1, B1, C1);
+        auto pair = [&](const int it, const float4 Aa, const float4 Ba, const float4 Ca, const float4 Ab, const float4 Bb, const float4 Cb) {
+            float al0, G0, al1, G1;
+            alpha_part(Aa, Ba, Ca, al0, G0);
+            alpha_part(Ab, Bb, Cb, al1, G1);
+            const float ia0 = __builtin_amdgcn_rcpf(1.f - al0), ia1 = __builtin_amdgcn_rcpf(1.f - al1);
+            state_part(ud_w0 + ring, al0, G0, ia0, Ba, Ca);
+            state_part(ud_w0 + ring + 1, al1, G1, ia1, Bb, Cb);
             ring += 2;
             if (ring == GSR_RING || it + 2 >= maxc) {
+#ifndef GSR_EXP_NOREDUCE
                 reduce(it + 2 - ring, ring);
+#endif
                 ring = 0;
             }
+        };
+#ifdef GSR_EXP_NOLOOP
+        if (maxc == 12345)
+#endif
+        for (int it = 0; it < maxc; it += 4) {
+            GSR_LOAD3(A2, B2, C2, o2); GSR_LOAD3(A3, B3, C3, o3);
+            o0 = mylist[it + 4]; o1 = mylist[it + 5]; // the lists are padded up to maxc + 3
+            __builtin_amdgcn_sched_barrier(0); // keep the prefetch above the pair it overlaps with
+            pair(it, A0, B0, C0, A1, B1, C1);
+            if (it + 2 >= maxc) break;
+            GSR_LOAD3(A0, B0, C0, o0); GSR_LOAD3(A1, B1, C1, o1);
+            o2 = mylist[it + 6]; o3 = mylist[it + 7];
+            __builtin_amdgcn_sched_barrier(0);
+            pair(it + 2, A2, B2, C2, A3, B3, C3);
         }
+#undef GSR_LOAD3
         // ---- flush: lane e holds the nine totals of entry e; stage them (12 floats per entry) and send seven entries per
         //      instruction, nine consecutive lanes per 64-byte record: one L2 atomic record per (quad, splat)
         float* const accf = reinterpret_cast<float*>(POOL);
@@ -367,7 +401,11 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             const int e = fb + fe;
             if (lane < 63 && e < count) {
                 const float val = accf[e * GSR_ACCW + fc];
+#ifndef GSR_EXP_NOFLUSH
                 if (val != 0.f) unsafeAtomicAdd(&g.acc[(size_t)__float_as_uint(E2[e].z) * GSR_ACC_STRIDE + fc], val);
+#else
+                if (val == 123.456f) g.acc[0] = val;
+#endif
             }
         }
         (void)my_id;
