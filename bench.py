@@ -222,16 +222,15 @@ def rasterize(a, gsr, td, rank, world, dev):
     n_ev = max(a.steps, 1)
     ev = []  # per timed step: (start, stop) around the backward blend kernel, and around the forward blend
     for _ in range(n_ev):
-        e = [C.c_void_p() for _ in range(6)]
+        e = [C.c_void_p() for _ in range(4)]
         for x in e:
             hip.hipEventCreate(C.byref(x))
         ev.append(e)
-    NB, NF = 3, 6   # GSR_BWD_STAGES, GSR_FWD_STAGES (include/gsr.h)
+    NB, NF = 3, 5
     def ev_arrays(e):
         f = (C.c_void_p * (2 * NF))()
         b = (C.c_void_p * (2 * NB))()
-        f[2 * 5], f[2 * 5 + 1] = e[2], e[3]     # GSR_FWD_BLEND
-        f[2 * 4], f[2 * 4 + 1] = e[4], e[5]     # GSR_FWD_CULL
+        f[2 * 4], f[2 * 4 + 1] = e[2], e[3]     # GSR_FWD_BLEND
         b[2 * 1], b[2 * 1 + 1] = e[0], e[1]     # GSR_BWD_BLEND
         return f, b
 
@@ -276,7 +275,6 @@ def rasterize(a, gsr, td, rank, world, dev):
     if rank == 0:
         bwd_blend_ms = avg_ms(0, 1)
         fwd_blend_ms = avg_ms(2, 3)
-        fwd_cull_ms = avg_ms(4, 5)
         N = W * H
         # algorithmic bytes of the backward blend kernel per launch: 40R + 20N + 36V
         alg_bytes = 40 * R + 20 * N + 36 * V
@@ -305,7 +303,7 @@ def rasterize(a, gsr, td, rank, world, dev):
             "roofline": {"bound": "hbm", "kernel": "K_blend_bwd", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes": alg_bytes, "avg_launch_ms": bwd_blend_ms,
-                         "fwd_blend_avg_launch_ms": fwd_blend_ms, "fwd_cull_avg_launch_ms": fwd_cull_ms,
+                         "fwd_blend_avg_launch_ms": fwd_blend_ms,
                          # the kernel is VALU-issue-bound, not HBM-bound: share of the launch during
                          # which the VALU pipes were issuing, from the committed PMC summary (profiles/)
                          "valu_busy_frac": valu_busy,

@@ -88,14 +88,8 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     hipLaunchKernelGGL(gsr::K_tile_sort<false>, dim3(T), dim3(GSR_SORT_BIG_THREADS), 0, st, T, iv.ranges, gv.hdr, bv.pairs, bv.point_list);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SORT);
-    const int Tb = (f.band_y1 - f.band_y0) * f.grid_x; // tiles of the band
-    tm.begin(GSR_FWD_CULL);
-    if (Tb > 0) {
-        hipLaunchKernelGGL(gsr::K_quad_cull, dim3(Tb), dim3(256), 0, st, iv, bv, gv, f.grid_x, Tb, f.band_y0 * f.grid_x);
-        GSR_LAUNCHED();
-    }
-    tm.end(GSR_FWD_CULL);
     tm.begin(GSR_FWD_BLEND);
+    const int Tb = (f.band_y1 - f.band_y0) * f.grid_x; // tiles of the band
     if (Tb > 0)
         hipLaunchKernelGGL(gsr::K_blend_fwd<GSR_FWDQ>, dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
                            f.grid_x, Tb, f.band_y0 * f.grid_x, a->out_color, a->out_depth, P);

@@ -1,18 +1,18 @@
-// gsr_blend.h — quad cull + the two blend kernels (forward alpha compositing and its backward).
+// gsr_blend.h — the two blend kernels (forward alpha compositing and its backward).
 //
 // Mapping (wave64-first): ONE wave per 8x8 pixel quad; the four quads of a 16x16 tile are four
-// INDEPENDENT single-wave workgroups, and inside the wave the four 16-lane DPP rows are four independent
-// 4x4 pixel "patches", each with its own hit list ("patch rows").
+// INDEPENDENT single-wave workgroups that walk the same per-tile list, and inside the wave the four
+// 16-lane DPP rows are four independent 4x4 pixel "patches", each with its own hit list ("patch rows").
 //   * a workgroup is a single wave: no s_barrier anywhere; LDS holds the parked entries, the per-patch
-//     lists and (backward) the reduction ring, all written and read by the wave in program order;
+//     byte lists and (backward) the accumulators, all written and read by the wave in program order;
 //   * small splats light ~16 of the 64 lanes of a quad but ~8 of the 16 lanes of a patch, and a patch
 //     is hit by half as many splats as the quad: the wave retires ~0.6x the iterations of a
 //     one-splat-per-wave-iteration loop;
 //   * block ids are remapped so the four quads of a tile (and neighbouring tiles) run on the same XCD
 //     and share its L2 for the per-splat gathers.
-// Culling is EXACT at patch level (does the iso-alpha ellipse alpha = 1/255 intersect the rectangle of
-// pixel centres of the patch?) and happens ONCE per tile entry, in K_quad_cull, which writes per-quad lists
-// (list position, id, 4-bit patch mask); the forward walks them front to back, the backward back to front.
+// Culling is EXACT at both levels (does the iso-alpha ellipse alpha = 1/255 intersect the rectangle of
+// pixel centres of the quad / of the patch?). The forward culls and logs its verdicts (qhits: list
+// position, id, 4-bit patch mask); the backward walks the log and never culls.
 //
 // What is computed per (pixel, splat) pair is the reference's arithmetic
 // (DGR/cuda_rasterizer/forward.cu:339-391, backward.cu:470-555).
@@ -22,6 +22,7 @@
 
 namespace gsr {
 
+#define GSR_ALPHA_MIN (1.0f / 255.0f)
 // a quad-hit record keeps the splat id in the low 28 bits of .y and the 4-bit patch mask above it
 #define GSR_ID_BITS 28
 #define GSR_ID_MASK 0x0FFFFFFFu
@@ -48,6 +49,36 @@ typedef unsigned long long wmask;
 __device__ __forceinline__ wmask wm(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool lane_of(wmask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
+// Can the splat reach alpha >= 1/255 on some pixel centre of the quad whose pixel centres
+// span [X0, X0+7] x [Y0, Y0+7]? alpha >= 1/255  <=>  Q(d) := 0.5*(a dx^2 + c dy^2) + b dx dy
+// <= ln(255*opacity), with d = splat centre - pixel. The minimum of the convex Q over the
+// rectangle is attained either at d = 0 (centre inside) or on a side facing the centre,
+// where it is a clamped 1-D parabola. Conservative: the continuous rectangle contains the
+// pixel centres, the threshold carries a margin far above fp32 rounding, NaNs pass.
+__device__ __forceinline__ bool quad_reach(const float4 a, const float4 b, float X0, float Y0)
+{
+    const float op = b.y;
+    if (op < GSR_ALPHA_MIN) return false; // alpha = op*exp(power<=0) can never reach 1/255
+    const float ca = a.z, cb = a.w, cc = b.x;
+    // the construction below needs a positive-definite conic; an indefinite one (possible with cov3D_precomp:
+    // ca, cc > 0 but ca*cc <= cb^2) is not culled: the reference would still blend it (forward.cu:346-358)
+    if (!(ca > 0.f) || !(cc > 0.f) || !(ca * cc > cb * cb)) return true;
+    const float tau = __logf(255.0f * op) + 0.01f;
+    const float dxl = a.x - (X0 + 7.f), dxh = a.x - X0, dyl = a.y - (Y0 + 7.f), dyh = a.y - Y0;
+    const float dxc = fminf(fmaxf(0.f, dxl), dxh), dyc = fminf(fmaxf(0.f, dyl), dyh); // point of the range closest to 0
+    if (dxc == 0.f && dyc == 0.f) return true;
+    float q = 3.0e38f;
+    if (dxc != 0.f) { // a vertical side faces the centre: minimise over dy
+        const float dy = fminf(fmaxf(-cb * dxc * __builtin_amdgcn_rcpf(cc), dyl), dyh); // minimiser: its rounding enters q to 2nd order
+        q = fminf(q, 0.5f * (ca * dxc * dxc + cc * dy * dy) + cb * dxc * dy);
+    }
+    if (dyc != 0.f) {
+        const float dx = fminf(fmaxf(-cb * dyc * __builtin_amdgcn_rcpf(ca), dxl), dxh);
+        q = fminf(q, 0.5f * (ca * dx * dx + cc * dyc * dyc) + cb * dx * dyc);
+    }
+    return !(q > tau);
+}
+
 // =====================================================================================
 // Backward ("patch rows", deferred reduction): the wave owns an 8x8 quad, its four 16-lane rows are four
 // INDEPENDENT 4x4 pixel patches, each walking its own hit list. Small splats touch few pixels of an 8x8 quad
@@ -72,7 +103,7 @@ __device__ __forceinline__ bool lane_of(wmask m) { return __builtin_amdgcn_inver
 //            instruction), i.e. one L2 atomic record per (quad, splat). Issuing the atomics per PATCH instead
 //            would double them and hit the L2 atomic ceiling (~20 G records/s, scripts/atomic_bench2.hip).
 // =====================================================================================
-#define GSR_FWDQ 64 // forward: parked entries per round = one gather step
+#define GSR_FWDQ 96 // forward: gathers until more than 32 entries are parked (2-3 steps of ~22 quad hits)
 #define GSR_ROWQ 64 // parked entries per round = one gather step
 #define GSR_RING 16 // iterations between two reduce phases: 4 rows x 16 = one (row, iteration) pair per lane
 #ifndef GSR_BSTEP
@@ -80,6 +111,38 @@ __device__ __forceinline__ bool lane_of(wmask m) { return __builtin_amdgcn_inver
 #endif
 #define GSR_ACCW 12 // floats per LDS accumulator record (nine used): 48 bytes, so that it moves as three b128
 typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Exact cull of one parked entry (conic staged for pair_power2, i.e. in log2 units) against the 2x2
+// patches of 4x4 pixel centres of the quad at (X0, Y0); same construction and margin as quad_reach.
+// h[j*2+i]: x-half i, y-half j.
+__device__ __forceinline__ void patch_reach4(const float4 A, const float4 B, float X0, float Y0, bool (&h)[4])
+{
+    const float ca = -2.f * A.z, cb = -A.w, cc = -2.f * B.x; // log2(e) * (a, b, c)
+    const bool degenerate = !(ca > 0.f) || !(cc > 0.f) || !(ca * cc > cb * cb); // not positive definite: never culled
+    const float tau = __log2f(255.0f * B.y) + 0.0145f;
+    float dl[2], dh[2], dc[2], el[2], eh[2], ec[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        dl[i] = A.x - (X0 + 4.f * i + 3.f); dh[i] = A.x - (X0 + 4.f * i);
+        dc[i] = fminf(fmaxf(0.f, dl[i]), dh[i]);
+        el[i] = A.y - (Y0 + 4.f * i + 3.f); eh[i] = A.y - (Y0 + 4.f * i);
+        ec[i] = fminf(fmaxf(0.f, el[i]), eh[i]);
+    }
+    // minimiser of the 1-D parabola on a side; its rounding error enters q only to second order
+    const float kx = -cb * __builtin_amdgcn_rcpf(cc), ky = -cb * __builtin_amdgcn_rcpf(ca);
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float dxc = dc[i], dyc = ec[j];
+            const float dy = fminf(fmaxf(kx * dxc, el[j]), eh[j]);
+            const float qx = 0.5f * (ca * dxc * dxc + cc * dy * dy) + cb * dxc * dy;
+            const float dx = fminf(fmaxf(ky * dyc, dl[i]), dh[i]);
+            const float qy = 0.5f * (ca * dx * dx + cc * dyc * dyc) + cb * dx * dyc;
+            const float q = fminf(dxc != 0.f ? qx : 3.0e38f, dyc != 0.f ? qy : 3.0e38f);
+            h[j * 2 + i] = degenerate || (dxc == 0.f && dyc == 0.f) || !(q > tau);
+        }
+}
 
 template <int Q>
 __global__ void __launch_bounds__(64)
@@ -147,7 +210,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     // back to front. Gather pipeline: the records of the next two steps and the geometry of the next step
     // are in flight (unconditional loads from clamped, always valid addresses so that the compiler can
     // count them: the colour gather must not wait for the loads issued after it).
-    const int cq = (int)im.qdone[4 * tile + quad]; // the records the forward consumed
+    const int cq = (int)im.qcount[4 * tile + quad];
     const uint2* __restrict__ qh = bn.qhits + 4 * (size_t)range.x + (size_t)quad * (size_t)n;
     if (ntodo <= 0 || cq <= 0) return;
     int k0 = 0;
@@ -351,100 +414,21 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
 }
 
 // =====================================================================================
-// Quad cull: ONE pass over a tile's sorted list decides, exactly, which of the tile's sixteen 4x4 patches every
-// entry can reach (does the iso-alpha ellipse alpha = 1/255 meet the rectangle of the patch's pixel centres?) and
-// writes, per 8x8 quad, the compact list of the entries that reach it: (list position, splat id | 4-bit patch mask).
-// For a small splat (the alpha >= 1/255 region at most ~3.6 pixels either side of the centre: every splat of a freshly
-// initialised map) the exact test was already made ONCE PER SPLAT by K_preprocess, on the 3x3 patches around its centre
-// (the patch grid is global: tiles are 16-aligned) — here its nine bits are only shifted into the tile's frame. Larger
-// splats take the generic sixteen-patch test per tile entry (gsr_device.h: window_reach).
-// Both blend kernels walk these lists and never cull: the forward used to run the test itself, once per quad, i.e.
-// it gathered the 32-byte geometry of every tile entry four times (311 MB of gathers at 1 M splats; with the blend
-// loop disabled the kernel still took 118 of its 143 us) — now every entry is gathered once here and once per quad
-// it actually reaches (~1.4 quads).
-// One 256-thread block per tile; an entry is one thread's work; the per-quad output order is the list order
-// (ballot + cross-wave counts through LDS, one barrier per 256 entries).
-// =====================================================================================
-__global__ void __launch_bounds__(256)
-K_quad_cull(ImageView im, BinView bn, GeomView g, int grid_x, int ntiles, int tile0)
-{
-    __shared__ uint32_t CNT[2][4][4]; // [buffer][wave][quad]
-    const uint32_t tile = (uint32_t)tile0 + xcd_remap(blockIdx.x, (uint32_t)ntiles);
-    const int tx = tile % grid_x, ty = tile / grid_x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint2 range = im.ranges[tile];
-    const int n = g.hdr->overflow ? 0 : (int)(range.y - range.x);
-    const uint32_t* __restrict__ plist = bn.point_list + range.x;
-    uint2* __restrict__ qh = bn.qhits + 4 * (size_t)range.x;
-    const float X0 = (float)(tx * 16), Y0 = (float)(ty * 16);
-    uint32_t run[4] = {0u, 0u, 0u, 0u};
-    int buf = 0;
-    if (n <= 0) {
-        if (tid < 4) im.qcount[4 * tile + tid] = 0u;
-        return;
-    }
-    // Four chunks of 256 entries per pass: all their ids, then all their geometry records, are requested before the first
-    // test — a tile of the 1 M-splat frame (~750 entries) is one pass, and the three dependent round trips
-    // (range -> id -> geometry) are paid once per tile instead of once per chunk.
-    constexpr int U = 4;
-    for (int base0 = 0; base0 < n; base0 += 256 * U) {
-        uint32_t ids[U];
-        float4 ga[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) ids[u] = plist[min(base0 + 256 * u + tid, n - 1)];
-#pragma unroll
-        for (int u = 0; u < U; u++) ga[u] = g.cull[ids[u]];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int base = base0 + 256 * u;
-            if (base >= n) break; // uniform
-            const int k = base + tid;
-            const uint32_t id = ids[u];
-            const uint32_t m16 = tile_reach16(ga[u], g, id, tx, ty, k < n);
-            uint32_t pm[4];
-            unsigned long long bal[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t rows = m16 >> (8 * (q >> 1) + 2 * (q & 1)); // the quad's 2x2 patches: bits 0,1 and 4,5 from there
-                pm[q] = (rows & 3u) | ((rows >> 2) & 12u);
-                bal[q] = __ballot(pm[q] != 0u);
-                if (lane == 0) CNT[buf][wv][q] = (uint32_t)__popcll(bal[q]);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t before = 0u, total = 0u;
-#pragma unroll
-                for (int w2 = 0; w2 < 4; w2++) {
-                    const uint32_t c = CNT[buf][w2][q];
-                    before += w2 < wv ? c : 0u;
-                    total += c;
-                }
-                if (pm[q]) qh[(size_t)q * (size_t)n + run[q] + before + (uint32_t)mbcnt64(bal[q])] = make_uint2((uint32_t)k, id | (pm[q] << GSR_ID_BITS));
-                run[q] += total;
-            }
-            buf ^= 1;
-        }
-    }
-    if (tid < 4) im.qcount[4 * tile + tid] = run[tid];
-}
-
-// =====================================================================================
 // Forward ("patch rows"), same wave/row mapping as K_blend_bwd: the wave owns an 8x8 quad, its four
-// 16-lane rows are four independent 4x4 patches with their own hit lists. Per round: gather (64 records of the
-// quad's list, the whole 48-byte geometry record prefetched one round ahead), patch lists (from the recorded
-// masks), blend (row r walks list r, entries software-pipelined). A row whose 16 pixels are all done idles; the
-// wave leaves when every pixel is done and records how many records it consumed (qdone) for the backward.
+// 16-lane rows are four independent 4x4 patches with their own hit lists. Per round: gather (64 list
+// entries per step, exact quad cull, survivors compacted into LDS until more than Q-64 are parked),
+// patch lists (exact patch cull; the entry is logged for the backward as (list position, id | mask<<28)),
+// blend (row r walks list r, entries software-pipelined). A row whose 16 pixels are all done idles; the
+// wave leaves when every pixel is done.
 // =====================================================================================
 template <int Q>
 __global__ void __launch_bounds__(64)
 K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
                  int grid_x, int ntiles, int tile0, float* __restrict__ out_color, float* __restrict__ out_depth, int P)
 {
-    static_assert(Q == 64, "one gather step = one parked entry per lane");
     // parked entries; slot Q is a dummy that no pixel can see (opacity 0, far away): the per-patch lists are padded with
     // it, so the blend loop needs neither an "is this row still active" compare nor an index select
-    __shared__ float4 E0[Q + 1], E1[Q + 1], E2[Q + 1]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, depth, list position + 1, patch mask)
+    __shared__ float4 E0[Q + 1], E1[Q + 1], E2[Q + 1]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, depth, list position + 1, id)
     // per-patch hit lists: BYTE OFFSETS of the entries (index * 16: shifts and integer mads are half-rate on gfx950,
     // LDS loads are not VALU work at all), 4 slots of slack behind the longest list for the software pipeline
     __shared__ uint16_t LIST[4 * (Q + 4)];
@@ -455,16 +439,16 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
     const int X0 = tx * 16 + (int)(quad & 1u) * 8, Y0 = ty * 16 + (int)(quad >> 1) * 8;
     const int px = X0 + (r & 1) * 4 + (l & 3), py = Y0 + (r >> 1) * 4 + (l >> 2);
     const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
+    const float pxf = (float)px, pyf = (float)py, X0f = (float)X0, Y0f = (float)Y0;
     const uint2 range = im.ranges[tile];
     const int n = g.hdr->overflow ? 0 : (int)(range.y - range.x);
+    const uint32_t* __restrict__ plist = bn.point_list + range.x;
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t last = 0u;
     wmask m_done = wm(!inside); // lanes whose pixel is finished (or outside the image)
-    // K_quad_cull listed the entries that reach this quad, in list order, with their patch masks
-    const int cq = n > 0 ? (int)im.qcount[4 * tile + quad] : 0;
-    const uint2* __restrict__ qh = bn.qhits + 4 * (size_t)range.x + (size_t)quad * (size_t)n;
+    uint2* __restrict__ qh = bn.qhits + 4 * (size_t)range.x + (size_t)quad * (size_t)n;
+    int qc = 0;
     constexpr uint32_t DUMMY = (uint32_t)Q * 16u;
     if (lane == 0) {
         E0[Q] = make_float4(-1.0e5f, -1.0e5f, -1.f, 0.f); // power2 ~ -2e10: exp2 gives 0
@@ -472,40 +456,56 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
         E2[Q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    int k0 = 0;
-    if (cq > 0) {
-        // gather pipeline: the records of the next two steps and the whole 48-byte geometry record of the next step are in
-        // flight while a round blends (unconditional loads from clamped, always valid addresses)
-        uint2 rec_c = qh[min(lane, cq - 1)], rec_n = qh[min(lane + 64, cq - 1)];
-        float4 a_c = g.g0[rec_c.y & GSR_ID_MASK], b_c = g.g1[rec_c.y & GSR_ID_MASK], c_c = g.col[rec_c.y & GSR_ID_MASK];
-        while (k0 < cq) {
+    if (n > 0) {
+        int base = 0;
+        uint32_t id_c = plist[min(lane, n - 1)], id_n = plist[min(lane + 64, n - 1)];
+        float4 a_c = g.g0[id_c], b_c = g.g1[id_c];
+        while (base < n) {
             const wmask dmask = m_done;
             if (dmask == ~0ull) break;
-            // ---- park one step: lane e holds record k0 + e
-            const int count = min(64, cq - k0);
-            const uint32_t pmask = lane < count ? rec_c.y >> GSR_ID_BITS : 0u;
-            {
-                const float4 a = a_c, b = b_c, c = c_c;
-                const uint32_t pos = rec_c.x;
-                const int k = k0 + lane;
-                rec_c = rec_n;
-                a_c = g.g0[rec_c.y & GSR_ID_MASK]; b_c = g.g1[rec_c.y & GSR_ID_MASK]; c_c = g.col[rec_c.y & GSR_ID_MASK];
-                rec_n = qh[min(k + 128, cq - 1)];
-                if (lane < count) {
-                    E0[lane] = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
-                    E1[lane] = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, c.x, c.y);
-                    E2[lane] = make_float4(c.z, b.z, __uint_as_float(pos + 1u), 0.f);
+            // ---- gather + quad cull + compaction
+            int count = 0;
+            do {
+                const uint32_t id = id_c;
+                const float4 a = a_c, b = b_c;
+                const int k = base + lane;
+                const bool hit = k < n && quad_reach(a, b, X0f, Y0f);
+                float4 c;
+                if (hit) c = g.col[id];
+                id_c = id_n;
+                a_c = g.g0[id_c]; b_c = g.g1[id_c];
+                id_n = plist[min(k + 128, n - 1)];
+                const unsigned long long m = __ballot(hit);
+                if (hit) {
+                    const int e = count + mbcnt64(m);
+                    E0[e] = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
+                    E1[e] = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, c.x, c.y);
+                    E2[e] = make_float4(c.z, b.z, __uint_as_float((uint32_t)k + 1u), __uint_as_float(id));
                 }
-                k0 += 64;
+                count += (int)__popcll(m);
+                base += 64;
+            } while (base < n && count <= Q - 64);
+            if (count == 0) continue;
+            __builtin_amdgcn_wave_barrier();
+            // ---- per-patch hit lists + the log for the backward
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            for (int eb = 0; eb < count; eb += 64) {
+                const int e = eb + lane;
+                bool h[4] = {false, false, false, false};
+                float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < count) { patch_reach4(E0[e], E1[e], X0f, Y0f, h); z = E2[e]; }
+                const unsigned long long m0 = __ballot(h[0]), m1 = __ballot(h[1]), m2 = __ballot(h[2]), m3 = __ballot(h[3]);
+                const uint16_t off = (uint16_t)(e * 16);
+                if (h[0]) LIST[0 * (Q + 4) + c0 + mbcnt64(m0)] = off;
+                if (h[1]) LIST[1 * (Q + 4) + c1 + mbcnt64(m1)] = off;
+                if (h[2]) LIST[2 * (Q + 4) + c2 + mbcnt64(m2)] = off;
+                if (h[3]) LIST[3 * (Q + 4) + c3 + mbcnt64(m3)] = off;
+                c0 += (int)__popcll(m0); c1 += (int)__popcll(m1); c2 += (int)__popcll(m2); c3 += (int)__popcll(m3);
+                const uint32_t pm = (h[0] ? 1u : 0u) | (h[1] ? 2u : 0u) | (h[2] ? 4u : 0u) | (h[3] ? 8u : 0u);
+                const unsigned long long ma = m0 | m1 | m2 | m3;
+                if (pm) qh[qc + mbcnt64(ma)] = make_uint2(__float_as_uint(z.z) - 1u, __float_as_uint(z.w) | (pm << GSR_ID_BITS));
+                qc += (int)__popcll(ma);
             }
-            // ---- per-patch hit lists from the recorded masks
-            const wmask m0 = wm((pmask & 1u) != 0u), m1 = wm((pmask & 2u) != 0u), m2 = wm((pmask & 4u) != 0u), m3 = wm((pmask & 8u) != 0u);
-            const uint16_t off = (uint16_t)(lane * 16);
-            if (pmask & 1u) LIST[0 * (Q + 4) + mbcnt64(m0)] = off;
-            if (pmask & 2u) LIST[1 * (Q + 4) + mbcnt64(m1)] = off;
-            if (pmask & 4u) LIST[2 * (Q + 4) + mbcnt64(m2)] = off;
-            if (pmask & 8u) LIST[3 * (Q + 4) + mbcnt64(m3)] = off;
-            const int c0 = (int)__popcll(m0), c1 = (int)__popcll(m1), c2 = (int)__popcll(m2), c3 = (int)__popcll(m3);
             // ---- blend: row r walks its own list; the wave runs as long as its longest unfinished row (an even number of
             //      iterations: the loop is unrolled by two), shorter lists are padded with the dummy entry
             const int e0 = ((dmask >> 0) & 0xFFFFull) == 0xFFFFull ? 0 : c0, e1 = ((dmask >> 16) & 0xFFFFull) == 0xFFFFull ? 0 : c1;
@@ -515,7 +515,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                 const int cr = r == 0 ? c0 : r == 1 ? c1 : r == 2 ? c2 : c3;
                 for (int p = cr + l; p < maxc + 4; p += 16) LIST[r * (Q + 4) + p] = (uint16_t)DUMMY;
             }
-            lds_turn();
+            __builtin_amdgcn_wave_barrier();
             const uint16_t* __restrict__ mylist = LIST + r * (Q + 4);
             auto step = [&](const float4 A, const float4 B, const float4 Cz) {
                 const float dx = A.x - pxf, dy = A.y - pyf;
@@ -555,10 +555,10 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                     step(A1, B1, Z1);
                 }
             }
-            lds_turn();
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    if (lane == 0) im.qdone[4 * tile + quad] = (uint32_t)min(k0, cq); // the backward starts from here
+    if (lane == 0) im.qcount[4 * tile + quad] = (uint32_t)qc;
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
         im.final_T[pix] = T;

@@ -2,7 +2,7 @@
 //
 // Data layout in HBM (all sub-arrays 256-byte aligned inside caller-owned blobs):
 //
-//   geometry blob  (gsr_geom_bytes(P)), 144 B per splat:
+//   geometry blob  (gsr_geom_bytes(P)), 128 B per splat:
 //     GeomHeader                         256 B   {num_rendered, overflow, capacity of the binning blob}
 //     rec  48 B[P]  the per-splat record the blend kernels gather, interleaved so that it costs one L2 line:
 //          g0  {x, y, conic_a, conic_b}            pixel centre + half of the conic
@@ -10,18 +10,15 @@
 //          col {r, g, b, clamp-flags}              colour the blend uses (SH result or copy of colors_precomp)
 //     slots uint4[P]     bin record for the fill pass: rank in the splat's class counter (TileRec / Cls4Rec),
 //                        depth bits, band-clipped tile rectangle
-//     cull float4[P]     {px, py, patch-reach word, -}: what K_quad_cull gathers per tile entry (a random 16-byte
-//                        gather moves a quarter of the bytes of a 48-byte record that straddles 128-byte lines)
 //     acc  float[P][16]  backward accumulators, one 64-byte line per splat (48-byte records straddle lines and
 //                        the L2 atomic rate drops from 20 to 13 G records/s): moments of u = G*dL/dalpha
 //                        {sum u, u*dx, u*dy, u*dx^2, u*dx*dy, u*dy^2}, dcolor.rgb, 7 unused
 //   image blob     (gsr_image_bytes(W,H)):
 //     final_T f32[N], n_contrib u32[N], ranges uint2[T], tiles TileRec[T] + cls4 Cls4Rec[T] + tier2 flag (cleared
-//     by one memset per frame), run4 u32[T][256], anchor u32[T][128], qcount u32[4T], qdone u32[4T]
+//     by one memset per frame), run4 u32[T][256], anchor u32[T][128], qcount u32[4T]
 //   binning blob   (gsr_binning_bytes(capacity)), 44 B per tile instance:
 //     pairs u64[R] (depth bits << 32 | splat id, grouped per tile), point_list u32[R],
-//     qhits uint2[4R] (per 8x8 quad: the list entries that can reach it, with their 4x4-patch masks; written by
-//     K_quad_cull, walked front to back by the forward blend and back to front by the backward blend)
+//     qhits uint2[4R] (the forward's log of quad hits for the backward)
 //
 // The reference keeps 79 B/splat + 24 B/instance + radix-sort temporaries (rasterizer_impl.h:21-65).
 #pragma once
@@ -100,7 +97,6 @@ struct GeomView {
     float4* col;
 #endif
     uint4* slots; // {rank in the class counter, depth bits, x0 | y0 << 16, x1 | y1 << 16} (band-clipped tile rectangle; x1 == x0: not binned)
-    float4* cull; // {px, py, reach word (col.w), -}: the 16 bytes K_quad_cull gathers per tile entry of a small splat
     float* acc;
 };
 struct ImageView {
@@ -112,8 +108,7 @@ struct ImageView {
     uint32_t* tier2;  // [64] word 0: some splat used the second tier this frame
     uint32_t* run4;   // [T][GSR_RUN4] second-tier run offsets
     uint32_t* anchor; // [T][GSR_ANCHOR_ROW] absolute run starts per (anchor, class, covered tile)
-    uint32_t* qcount; // [4*T] quad-hit records K_quad_cull wrote per 8x8 quad
-    uint32_t* qdone;  // [4*T] how many of them the forward blend consumed before every pixel of the quad was done
+    uint32_t* qcount; // [4*T] quad-hit records the forward blend wrote per 8x8 quad
 };
 struct BinView {
     uint64_t* pairs;
@@ -139,7 +134,6 @@ __host__ __device__ inline size_t geom_layout(char* base, int P, GeomView* v)
     g.col = (float4*)(base + off); off = gsr_align_up(off + Pz * 16);
 #endif
     g.slots = (uint4*)(base + off); off = gsr_align_up(off + Pz * 16);
-    g.cull = (float4*)(base + off); off = gsr_align_up(off + Pz * 16);
     g.acc = (float*)(base + off); off = gsr_align_up(off + Pz * GSR_ACC_STRIDE * 4);
     if (v) *v = g;
     return off;
@@ -160,7 +154,6 @@ __host__ __device__ inline size_t image_layout(char* base, int W, int H, ImageVi
     g.run4 = (uint32_t*)(base + off); off = gsr_align_up(off + T * GSR_RUN4 * 4);
     g.anchor = (uint32_t*)(base + off); off = gsr_align_up(off + T * GSR_ANCHOR_ROW * 4);
     g.qcount = (uint32_t*)(base + off); off = gsr_align_up(off + T * 16);
-    g.qdone = (uint32_t*)(base + off); off = gsr_align_up(off + T * 16);
     if (v) *v = g;
     return off;
 }
@@ -210,131 +203,6 @@ __device__ __forceinline__ float pair_power2(float dx, float dy, float ca2, floa
 {
     const float t = fmaf(ca2, dx, cb2 * dy);
     return fmaf(t, dx, (cc2 * dy) * dy);
-}
-
-// ---------------------------------------------------------------------------------
-// Exact patch reach (shared by K_preprocess, once per small splat, and K_quad_cull, per tile entry of a large one).
-// ---------------------------------------------------------------------------------
-#define GSR_ALPHA_MIN (1.0f / 255.0f)
-// Exact reach of one splat over a WINDOW of NW x NW patches (4x4 pixels each) whose first patch has its pixel centres
-// at (wx, wy) .. (wx + 3, wy + 3): bit (j * NW + i) of the result = the iso-alpha ellipse alpha = 1/255 meets patch (i, j).
-// alpha >= 1/255  <=>  Q(d) := 0.5*(a dx^2 + c dy^2) + b dx dy <= log2(255*opacity) in log2 units, d = centre - pixel.
-// The minimum of the convex Q over a rectangle is attained at d = 0 (centre inside), or on a side facing the centre,
-// where it is a 1-D parabola clamped to the side. Conservative: the continuous rectangle contains the pixel centres,
-// the threshold carries a margin far above fp32 rounding, NaNs pass. Everything that depends on one axis only is
-// hoisted out of the NW x NW loop.
-struct ReachSetup {
-    float ax, ay, hca, hcc, cb, kx, ky, tau;
-    bool pd, never, small;
-};
-__device__ __forceinline__ ReachSetup reach_setup(float px, float py, float conic_a, float conic_b, float conic_c, float op)
-{
-    ReachSetup s;
-    const float ca = conic_a * GSR_LOG2E, cb = conic_b * GSR_LOG2E, cc = conic_c * GSR_LOG2E;
-    const float det = ca * cc - cb * cb;
-    // the construction needs a positive-definite conic; an indefinite one (possible with cov3D_precomp) is never culled:
-    // the reference would still blend it (forward.cu:346-358)
-    s.pd = ca > 0.f && cc > 0.f && det > 0.f;
-    s.never = !(op >= GSR_ALPHA_MIN) && op == op; // alpha = op * exp(power <= 0) can never reach 1/255
-    s.ax = px; s.ay = py; s.hca = 0.5f * ca; s.hcc = 0.5f * cc; s.cb = cb;
-    s.kx = -cb * __builtin_amdgcn_rcpf(cc); s.ky = -cb * __builtin_amdgcn_rcpf(ca);
-    s.tau = __log2f(255.0f * op) + 0.0145f;
-    // half extents of the ellipse Q <= tau: ex^2 = 2 tau cc / det, ey^2 = 2 tau ca / det; "small": both below ~7.6 pixels,
-    // so that the ellipse cannot leave the 5x5 patches around the patch that holds its centre (SinglePixel-initialised
-    // splats reach 2.2 .. 6.3 pixels)
-    const float lim = 64.0f * 0.9f * det;
-    s.small = s.pd && 2.f * s.tau * cc <= lim && 2.f * s.tau * ca <= lim;
-    return s;
-}
-template <int NW>
-__device__ __forceinline__ uint32_t window_reach(const ReachSetup& s, float wx, float wy)
-{
-    float dl[NW], dh[NW], el[NW], eh[NW], Ax[NW], Bx[NW], Kx[NW], Ay[NW], By[NW], Ky[NW];
-    uint32_t zc = 0u, zr = 0u; // columns / rows whose range contains the centre coordinate
-#pragma unroll
-    for (int i = 0; i < NW; i++) {
-        dl[i] = s.ax - (wx + 4.f * i + 3.f); dh[i] = s.ax - (wx + 4.f * i);
-        const float dc = fminf(fmaxf(0.f, dl[i]), dh[i]); // point of the range closest to 0
-        Ax[i] = dc != 0.f ? s.hca * dc * dc : 3.0e38f;    // a side faces the centre only if the centre is outside the range
-        Bx[i] = s.cb * dc; Kx[i] = s.kx * dc;
-        zc |= dc == 0.f ? 1u << i : 0u;
-        el[i] = s.ay - (wy + 4.f * i + 3.f); eh[i] = s.ay - (wy + 4.f * i);
-        const float ec = fminf(fmaxf(0.f, el[i]), eh[i]);
-        Ay[i] = ec != 0.f ? s.hcc * ec * ec : 3.0e38f;
-        By[i] = s.cb * ec; Ky[i] = s.ky * ec;
-        zr |= ec == 0.f ? 1u << i : 0u;
-    }
-    uint32_t mask = 0u;
-#pragma unroll
-    for (int j = 0; j < NW; j++) {
-        if (zr & (1u << j)) mask |= zc << (j * NW); // centre inside the patch rectangle
-#pragma unroll
-        for (int i = 0; i < NW; i++) {
-            const float dy = fminf(fmaxf(Kx[i], el[j]), eh[j]);            // minimiser on the vertical side x = dc_i
-            const float qx = fmaf(dy, fmaf(s.hcc, dy, Bx[i]), Ax[i]);
-            const float dx = fminf(fmaxf(Ky[j], dl[i]), dh[i]);            // minimiser on the horizontal side y = ec_j
-            const float qy = fmaf(dx, fmaf(s.hca, dx, By[j]), Ay[j]);
-            if (!(fminf(qx, qy) > s.tau)) mask |= 1u << (j * NW + i);
-        }
-    }
-    return mask;
-}
-// What K_preprocess keeps in col.w next to the three SH clamp flags (bits 0..2):
-//   bit 3 "small"  : the 25 bits below are the splat's complete patch reach
-//   bits 4..28     : reach over the 5x5 patches whose first patch is column floor(px/4) - 2, row floor(py/4) - 2
-//                    of the GLOBAL patch grid (patch column c = pixels 4c .. 4c+3)
-#define GSR_REACH_SMALL 8u
-__device__ __forceinline__ uint32_t splat_reach9(float px, float py, float conic_a, float conic_b, float conic_c, float op)
-{
-    const ReachSetup s = reach_setup(px, py, conic_a, conic_b, conic_c, op);
-    if (s.never) return GSR_REACH_SMALL; // reaches nothing
-    if (!s.small) return 0u;
-    const float wx = 4.f * (floorf(px * 0.25f) - 2.f), wy = 4.f * (floorf(py * 0.25f) - 2.f);
-    return GSR_REACH_SMALL | (window_reach<5>(s, wx, wy) << 4);
-}
-// The sixteen patches of tile (tx, ty) for one list entry: g0 = (px, py, conic a, conic b), g1 = (conic c, opacity, ..),
-// colw = the word above. The branch is wave-uniform.
-__device__ __forceinline__ uint32_t tile_reach16(const float4 rec, const GeomView& g, uint32_t id, int tx, int ty, bool valid)
-{
-    const uint32_t colw = __float_as_uint(rec.z);
-    const bool small = (colw & GSR_REACH_SMALL) != 0u;
-    uint32_t m16 = 0u;
-    {   // shift the 5x5 window into the tile's 4x4 frame
-        const uint32_t m25 = colw >> 4;
-        const int i0 = min(max((int)floorf(rec.x * 0.25f) - 2 - 4 * tx, -5), 4);
-        const int j0 = min(max((int)floorf(rec.y * 0.25f) - 2 - 4 * ty, -5), 4);
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-            const uint32_t row = (m25 >> (5 * j)) & 31u;
-            const uint32_t cols = (i0 >= 0 ? row << i0 : row >> -i0) & 0xFu;
-            const int jj = j0 + j;
-            if (jj >= 0 && jj < 4) m16 |= cols << (4 * jj);
-        }
-    }
-    // Large splats (0.9 % of the 1 M-splat frame) get the exact test here, one at a time: their record is loaded by their own
-    // lane, broadcast, and sixteen lanes test one patch each — the rest of the wave does not pay a sixteen-patch test
-    unsigned long long rem = __ballot(valid && !small);
-    if (rem != 0ull) {
-        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
-        if (valid && !small) { g0 = g.g0[id]; g1 = g.g1[id]; }
-        const int lane = (int)(threadIdx.x & 63u), p = lane & 15;
-        const float wx = (float)(16 * tx + 4 * (p & 3)), wy = (float)(16 * ty + 4 * (p >> 2));
-        while (rem != 0ull) {
-            const int j = __builtin_ctzll(rem);
-            rem &= rem - 1ull;
-            const float ax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g0.x), j));
-            const float ay = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g0.y), j));
-            const float qa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g0.z), j));
-            const float qb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g0.w), j));
-            const float qc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g1.x), j));
-            const float op = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g1.y), j));
-            const ReachSetup s = reach_setup(ax, ay, qa, qb, qc, op);
-            const bool hit = !s.never && (!s.pd || window_reach<1>(s, wx, wy) != 0u);
-            const uint32_t m = (uint32_t)__ballot(hit) & 0xFFFFu; // lanes 0..15 = patches 0..15
-            if (lane == j) m16 = m;
-        }
-    }
-    return valid ? m16 : 0u;
 }
 
 template <int CTRL>

@@ -75,7 +75,7 @@ typedef struct gsr_forward_args {
 } gsr_forward_args;
 
 /* forward stages, in launch order */
-enum { GSR_FWD_PREPROCESS = 0, GSR_FWD_SCAN, GSR_FWD_FILL, GSR_FWD_SORT, GSR_FWD_CULL, GSR_FWD_BLEND, GSR_FWD_STAGES };
+enum { GSR_FWD_PREPROCESS = 0, GSR_FWD_SCAN, GSR_FWD_FILL, GSR_FWD_SORT, GSR_FWD_BLEND, GSR_FWD_STAGES };
 /* backward stages */
 enum { GSR_BWD_CLEAR = 0, GSR_BWD_BLEND, GSR_BWD_SPLAT, GSR_BWD_STAGES };
 
