@@ -216,7 +216,9 @@ def rasterize(a, gsr, td, rank, world, dev):
     V = int((st0.radii > 0).sum())
     del st0
     ws = gsr.capi.Workspace(P, W, H, max_rendered=int(R * 1.25) + 1024, device=dev)
-    grads = gsr.capi.alloc_grads(P, 0, dev)
+    # the gradient buffers the operator wrappers pass on the scales + rotations path (torch_ext/Rasterizer.cpp): the two
+    # intermediates nobody consumes there, dL_dconic and dL_dcov3D, are NULL
+    grads = gsr.capi.alloc_grads(P, 0, dev, intermediates=False)
 
     hip = _hip()
     n_ev = max(a.steps, 1)

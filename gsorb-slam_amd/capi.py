@@ -279,9 +279,12 @@ class Grads:
     dL_drotations: torch.Tensor
 
 
-def alloc_grads(P: int, M: int, dev) -> Grads:
+def alloc_grads(P: int, M: int, dev, intermediates: bool = True) -> Grads:
+    """intermediates=False: no dL_dconic / dL_dcov3D buffers — what the operator wrappers pass on the scales + rotations
+    path, where nothing consumes them (the kernel then skips 40 bytes of stores per splat)."""
     e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-    return Grads(e(P, 3), e(P, 2, 2), e(P, 1), e(P, 3), e(P, 3), e(P, 6), e(P, M, 3), e(P, 3), e(P, 4))
+    return Grads(e(P, 3), e(P, 2, 2) if intermediates else None, e(P, 1), e(P, 3), e(P, 3), e(P, 6) if intermediates else None,
+                 e(P, M, 3), e(P, 3), e(P, 4))
 
 
 def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None, stages: int = 0, once: bool = False) -> Grads:

@@ -128,7 +128,9 @@ RasterizeGaussiansBackwardStaged(const torch::Tensor& background, const torch::T
     // except for the tensors the chosen parameterisation leaves untouched
     torch::Tensor dL_dmeans3D = torch::empty({P, 3}, fopt), dL_dmeans2D = torch::empty({P, 3}, fopt),
                   dL_dcolors = torch::empty({P, kChannels}, fopt), dL_dopacity = torch::empty({P, 1}, fopt),
-                  dL_dcov3D = torch::empty({P, 6}, fopt), dL_dsh = torch::empty({P, M, 3}, fopt),
+                  // dL_dcov3D is an intermediate of the scale / rotation path: with scales + rotations nothing consumes it
+                  // (the reference's autograd node hands it to the absent cov3Ds_precomp input), so it is not computed then
+                  dL_dcov3D = has_sr ? torch::empty({0, 6}, fopt) : torch::empty({P, 6}, fopt), dL_dsh = torch::empty({P, M, 3}, fopt),
                   dL_dscales = has_sr ? torch::empty({P, 3}, fopt) : torch::zeros({P, 3}, fopt),
                   dL_drotations = has_sr ? torch::empty({P, 4}, fopt) : torch::zeros({P, 4}, fopt);
     if (P != 0) {
@@ -147,7 +149,7 @@ RasterizeGaussiansBackwardStaged(const torch::Tensor& background, const torch::T
         a.dL_dpix = fptr(gin);
         a.dL_dmean2D = dL_dmeans2D.data_ptr<float>(); a.dL_dconic = nullptr;
         a.dL_dopacity = dL_dopacity.data_ptr<float>(); a.dL_dcolor = dL_dcolors.data_ptr<float>();
-        a.dL_dmean3D = dL_dmeans3D.data_ptr<float>(); a.dL_dcov3D = dL_dcov3D.data_ptr<float>();
+        a.dL_dmean3D = dL_dmeans3D.data_ptr<float>(); a.dL_dcov3D = has_sr ? nullptr : dL_dcov3D.data_ptr<float>();
         a.dL_dsh = M ? dL_dsh.data_ptr<float>() : nullptr;
         a.dL_dscale = has_sr ? dL_dscales.data_ptr<float>() : nullptr;
         a.dL_drot = has_sr ? dL_drotations.data_ptr<float>() : nullptr;
