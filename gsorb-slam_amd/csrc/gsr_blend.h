@@ -145,7 +145,7 @@ __device__ __forceinline__ void patch_reach4(const float4 A, const float4 B, flo
 }
 
 template <int Q>
-__global__ void __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(3, 3))) __global__ void __launch_bounds__(64)
 K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* __restrict__ bg, int W, int H,
                  int grid_x, int ntiles, int tile0, const float* __restrict__ dL_dpix)
 {
@@ -317,15 +317,27 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             float dxk[4], dyk[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) { dxk[k] = c.x - (X0pf + (float)k); dyk[k] = c.y - (Y0pf + (float)k); }
-            float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f, m5 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
+            // moments of u about the splat centre over the 4x4 patch, through its column and row sums (dx depends on the
+            // column i = p & 3 only, dy on the row j = p >> 2 only): 71 instead of 128 instructions
+            float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+            float col[4], row[4], wj[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) col[i] = (ud[i].x + ud[4 + i].x) + (ud[8 + i].x + ud[12 + i].x);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                row[j] = (ud[4 * j].x + ud[4 * j + 1].x) + (ud[4 * j + 2].x + ud[4 * j + 3].x);
+                wj[j] = fmaf(dxk[3], ud[4 * j + 3].x, fmaf(dxk[2], ud[4 * j + 2].x, fmaf(dxk[1], ud[4 * j + 1].x, dxk[0] * ud[4 * j].x)));
+            }
+            const float m0 = (row[0] + row[1]) + (row[2] + row[3]);
+            const float m1 = fmaf(dxk[3], col[3], fmaf(dxk[2], col[2], fmaf(dxk[1], col[1], dxk[0] * col[0])));
+            const float m2 = fmaf(dyk[3], row[3], fmaf(dyk[2], row[2], fmaf(dyk[1], row[1], dyk[0] * row[0])));
+            const float m3 = fmaf(dxk[3] * dxk[3], col[3], fmaf(dxk[2] * dxk[2], col[2], fmaf(dxk[1] * dxk[1], col[1], (dxk[0] * dxk[0]) * col[0])));
+            const float m4 = fmaf(dyk[3], wj[3], fmaf(dyk[2], wj[2], fmaf(dyk[1], wj[1], dyk[0] * wj[0])));
+            const float m5 = fmaf(dyk[3] * dyk[3], row[3], fmaf(dyk[2] * dyk[2], row[2], fmaf(dyk[1] * dyk[1], row[1], (dyk[0] * dyk[0]) * row[0])));
 #pragma unroll
             for (int p = 0; p < 16; p++) {
                 const float4 gp = gq[p & 3];
                 if (p + 4 < 16) gq[p & 3] = GP[r][p + 4];
-                const float dx = dxk[p & 3], dy = dyk[p >> 2];
-                const float udx = ud[p].x * dx, udy = ud[p].x * dy;
-                m0 += ud[p].x; m1 += udx; m2 += udy;
-                m3 = fmaf(udx, dx, m3); m4 = fmaf(udx, dy, m4); m5 = fmaf(udy, dy, m5);
                 q0 = fmaf(ud[p].y, gp.x, q0); q1 = fmaf(ud[p].y, gp.y, q1); q2 = fmaf(ud[p].y, gp.z, q2);
             }
             lds_turn(); // every lane has read its column of the ring: the block turns into ST
