@@ -70,9 +70,10 @@ def cpu_baseline(sc, P, W, H, budget_s=20.0):
         o.backward(sc.dL_dpix, accum_double=False)
         ts.append(time.perf_counter() - t0)
     t = float(np.median(ts)) if ts else first
+    blended, walked = o.census()   # (pixel, splat) pairs the forward blended / walked: for useful_lane_frac
     return {"value": P * W * H / t, "unit": "splats*pixels/s", "cores": cores, "kind": "port",
             "sample": f"{len(ts) or 1} fwd+bwd of the same {P}-splat {W}x{H} scene after one warm-up (median), oracle/libgsr_oracle_omp.so, "
-                      f"{t * 1e3:.0f} ms each"}
+                      f"{t * 1e3:.0f} ms each", "blended_pairs": blended, "walked_pairs": walked}
 
 
 def shard_step(a, gsr, td, rank, world, dev):
@@ -282,15 +283,31 @@ def rasterize(a, gsr, td, rank, world, dev):
         alg_bytes = 40 * R + 20 * N + 36 * V
         achieved = alg_bytes / (bwd_blend_ms * 1e-3) / 1e9
         total_alg = 152 * P + 340 * V + 128 * R + 44 * N   # whole fwd+bwd
-        valu_busy = None
         traffic = None   # HBM/fabric bytes per launch of the dominant kernel: PMC counters cannot be read live,
-        try:             # so the committed rocprofv3 --pmc summary of this same command is quoted
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        pmc = {}         # so the committed rocprofv3 --pmc summary of this same command is quoted
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
             if P == 1_000_000 and a.camera == "replica" and a.scale_mult == 1.0:
-                traffic = tj["kernels"]["K_blend_bwd"]["traffic_bytes"]
-                valu_busy = tj["kernels"]["K_blend_bwd"].get("valu_busy_frac")
+                pmc = tj["kernels"]
+                traffic = pmc["K_blend_bwd"]["traffic_bytes"]
         except Exception:
-            traffic = None
+            pmc = {}
+
+        def valu_roofline(kernel, launch_ms, body_ops):
+            """wave-level VALU instructions x 4 cycles / (1024 SIMDs x 2.4 GHz) / launch time. 4 cycles is the
+            half-rate class (v_cmp, v_cndmask, v_min/max, DPP, shifts); v_add/mul/fma issue in 2, v_exp/rcp in 8
+            (scripts/valu_bench2.hip), so this is an upper bound of the pipe occupancy."""
+            k = pmc.get(kernel)
+            if not k or "valu_instructions" not in k:
+                return None
+            vi = k["valu_instructions"]
+            d = {"kernel": kernel, "valu_insts_per_launch": vi, "cycles_per_inst": 4, "simds": 1024, "clock_ghz": 2.4,
+                 "avg_launch_ms": launch_ms, "frac": vi * 4 / (1024 * 2.4e9) / (launch_ms * 1e-3),
+                 "lds_conflict_per_lds_active": k.get("lds_conflict_frac")}
+            d["body_ops_per_pair"] = body_ops
+            return d
+        rv = valu_roofline("K_blend_bwd", bwd_blend_ms, 44)   # 33 in the per-pixel loop + 11 per pixel in the reduce phase
+        rv_f = valu_roofline("K_blend_fwd", fwd_blend_ms, 23)
         out = {
             "metric": "splats*pixels/s (fwd+bwd) @1M Gaussians 1200x680" if (P == 1_000_000 and a.camera == "replica")
                       else f"splats*pixels/s (fwd+bwd) @{P} Gaussians {W}x{H}",
@@ -306,15 +323,23 @@ def rasterize(a, gsr, td, rank, world, dev):
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes": alg_bytes, "avg_launch_ms": bwd_blend_ms,
                          "fwd_blend_avg_launch_ms": fwd_blend_ms,
-                         # the kernel is VALU-issue-bound, not HBM-bound: share of the launch during
-                         # which the VALU pipes were issuing, from the committed PMC summary (profiles/)
-                         "valu_busy_frac": valu_busy,
                          "whole_step": {"algorithmic_bytes": total_alg,
                                         "achieved": total_alg / (ms_step * 1e-3) / 1e9,
                                         "frac": total_alg / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(sc, P, W, H)
+        if rv is not None:
+            # useful_lane_frac: lane-instructions the blend arithmetic of the pairs that were actually blended needs
+            # (census of the same scene by the CPU oracle x VALU ops per pair in the loop body) / all lane slots issued
+            bp = out.get("cpu_baseline", {}).get("blended_pairs")
+            for d in (rv, rv_f):
+                if d is not None:
+                    d["blended_pairs"] = bp
+                    d["useful_lane_frac"] = None if bp is None else bp * d["body_ops_per_pair"] / (d["valu_insts_per_launch"] * 64.0)
+            out["roofline_valu"] = rv
+            if rv_f is not None:
+                out["roofline_valu"]["forward"] = rv_f
         return out
     return {}
 

@@ -476,6 +476,42 @@ void gsro_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* p
         }
 }
 
+/* Measurement instrumentation (not in the reference): how many (pixel, splat) pairs the forward of the last
+ * gsro_forward on `st` blended (passed power <= 0, alpha >= 1/255 and the stop test) and how many it evaluated
+ * (list entries walked until the pixel stopped). bench.py uses the first number for `useful_lane_frac`. */
+void gsro_blend_census(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
+                       const float* conic_opacity, const uint32_t* n_contrib, unsigned long long* blended,
+                       unsigned long long* evaluated)
+{
+    const int gx = (W + GSRO_BLOCK_X - 1) / GSRO_BLOCK_X, gy = (H + GSRO_BLOCK_Y - 1) / GSRO_BLOCK_Y;
+    unsigned long long nb = 0, ne = 0;
+#ifdef GSRO_OMP
+#pragma omp parallel for schedule(dynamic, 1) collapse(2) reduction(+ : nb, ne)
+#endif
+    for (int ty = 0; ty < gy; ty++)
+        for (int tx = 0; tx < gx; tx++) {
+            const uint32_t r0 = ranges[2 * (ty * gx + tx)];
+            for (int ly = 0; ly < GSRO_BLOCK_Y; ly++)
+                for (int lx = 0; lx < GSRO_BLOCK_X; lx++) {
+                    const int px = tx * GSRO_BLOCK_X + lx, py = ty * GSRO_BLOCK_Y + ly;
+                    if (!(px < W && py < H)) continue;
+                    const uint32_t last = n_contrib[W * py + px];
+                    ne += last;
+                    for (uint32_t k = r0; k < r0 + last; k++) { /* every valid entry up to the last contributor was blended */
+                        const uint32_t id = point_list[k];
+                        const float dx = means2D[2 * id] - (float)px, dy = means2D[2 * id + 1] - (float)py;
+                        const float* co = conic_opacity + 4 * id;
+                        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        if (power > 0.0f) continue;
+                        if (fminf(0.99f, co[3] * expf(power)) < 1.0f / 255.0f) continue;
+                        nb++;
+                    }
+                }
+        }
+    *blended = nb;
+    *evaluated = ne;
+}
+
 /* Test instrumentation (not in the reference): smallest relative distance of any
  * data-dependent branch of forward.cu:346-379 from flipping, per pixel. exp() is not
  * bit-reproducible across libm/CUDA/HIP, so a pixel whose margin is below the

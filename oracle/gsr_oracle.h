@@ -36,6 +36,9 @@ extern "C" {
 
 /* DGR/cuda_rasterizer/rasterizer_impl.cu:36-51 (getHigherMsb) */
 uint32_t gsro_higher_msb(uint32_t n);
+void gsro_blend_census(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
+                       const float* conic_opacity, const uint32_t* n_contrib, unsigned long long* blended,
+                       unsigned long long* evaluated); /* measurement only: (pixel, splat) pairs blended / walked */
 void gsro_set_threads(int n); /* OpenMP build only: size of the thread team; no-op otherwise */
 
 /* DGR/cuda_rasterizer/rasterizer_impl.cu:55-67 + auxiliary.h:139-164 */

@@ -68,6 +68,8 @@ def _load(omp: bool):
     lib.gsro_eval_sh.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4
     lib.gsro_dist2.restype = None
     lib.gsro_dist2.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    lib.gsro_blend_census.restype = None
+    lib.gsro_blend_census.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 7
     lib.gsro_set_threads.restype = None
     lib.gsro_set_threads.argtypes = [C.c_int]
     lib.gsro_higher_msb.restype = C.c_uint32
@@ -189,6 +191,16 @@ class Oracle:
             mc[:] = 1e30
             md[:] = 1e30
         return mc, md
+
+    def census(self):
+        """(blended, walked) (pixel, splat) pairs of the last forward, from the state's own arrays (no copies)."""
+        s = self._s
+        ptr = lambda idx: C.c_void_p(self.lib.gsro_stage(self.state, idx, C.byref(C.c_size_t(0))))
+        nb, ne = C.c_ulonglong(0), C.c_ulonglong(0)
+        if self._P > 0:
+            self.lib.gsro_blend_census(s.W, s.H, ptr(_STAGES["ranges"][0]), ptr(_STAGES["point_list"][0]), ptr(_STAGES["means2D"][0]),
+                                       ptr(_STAGES["conic_opacity"][0]), ptr(_STAGES["n_contrib"][0]), C.byref(nb), C.byref(ne))
+        return int(nb.value), int(ne.value)
 
     def backward(self, dL_dpix, accum_double: bool = True) -> Backward:
         P, M = self._P, self._M

@@ -1,5 +1,5 @@
 """Turns gpurun_out/prof_<tag>/ (scripts/profile_round.sh) into the committed summaries under profiles/:
-   <tag>_kernel_stats.md, <tag>_pmc.md, <tag>_bench.json and r01_traffic.json (read by bench.py)."""
+   <tag>_kernel_stats.md, <tag>_pmc.md, <tag>_bench.json and r02_traffic.json (read by bench.py)."""
 import collections
 import csv
 import glob
@@ -33,8 +33,8 @@ rows = []
 for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
     rows = list(csv.DictReader(open(f)))
 with open(os.path.join(dst, tag + "_kernel_stats.md"), "w") as o:
-    o.write("# Round 1, profile %s — %s\n\n" % (tag, note))
-    o.write("Command (MI355X box, scripts/profile_round.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 20 --warmup 5 --no-cpu`\n\n")
+    o.write("# Round %s, profile %s — %s\n\n" % (tag[1:3].lstrip("0"), tag, note))
+    o.write("Command (MI355X box, scripts/profile_round.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --mode rasterize --steps 20 --warmup 5 --no-cpu`\n\n")
     c = bench["config"]
     o.write("Workload: %d Gaussians, %dx%d, V = %d visible, R = %d tile instances; one step = gsr_forward_ws + gsr_backward.\n\n"
             % (c["splats"], c["width"], c["height"], c["visible"], c["tile_instances"]))
@@ -60,23 +60,33 @@ for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), r
         cnt[k][row["Counter_Name"]] += 1
 avg = {k: {c: v / cnt[k][c] for c, v in d.items()} for k, d in agg.items()}
 order = ["K_preprocess", "K_scan_tiles<true>", "K_fill", "K_tile_sort<true>", "K_tile_sort<false>", "K_blend_fwd", "K_blend_bwd", "K_splat_bwd"]
-sq = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
-      "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_LDS_BANK_CONFLICT"]
+sq = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY",
+      "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"]
 stats_avg = {short(x["Name"]): float(x["AverageNs"]) / 1e3 for x in rows}
 with open(os.path.join(dst, tag + "_pmc.md"), "w") as o:
-    o.write("# Round 1, profile %s — PMC counters (rocprofv3 --pmc, separate passes, --kernel-trace only)\n\n" % tag)
-    o.write("Per launch, averaged over the launches of `bench.py --no-cpu --steps 3 --warmup 1`. SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in quad-cycles (x4 = shader cycles).\n\n")
+    o.write("# Round %s, profile %s — PMC counters (rocprofv3 --pmc, separate passes, --kernel-trace only)\n\n" % (tag[1:3].lstrip("0"), tag))
+    o.write("Per launch, averaged over the launches of `bench.py --no-cpu --mode rasterize --steps 3 --warmup 1`. GRBM_GUI_ACTIVE is summed over the 8 XCDs (/8 = shader cycles of the launch). SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in quad-cycles (x4 = shader cycles).\n\n")
     o.write("| kernel | " + " | ".join(sq) + " |\n|---|" + "---|" * len(sq) + "\n")
     for k in order:
         if k in avg:
             o.write("| %s | " % k + " | ".join("%.3g" % avg[k].get(c, float("nan")) for c in sq) + " |\n")
-    o.write("\nVALU pipe occupancy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * 2.4 GHz * kernel time):\n\n")
-    for k in ("K_blend_fwd", "K_blend_bwd"):
-        if k in avg and k in stats_avg:
-            busy_us = avg[k]["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / 2.4e3
-            o.write("* %s: %.3g wave-level VALU instructions, VALU busy %.0f us of %.0f us (%.0f %%), %.2f cycles per instruction\n"
-                    % (k, avg[k]["SQ_INSTS_VALU"], busy_us, stats_avg[k], 100 * busy_us / stats_avg[k],
-                       avg[k]["SQ_ACTIVE_INST_VALU"] * 4 / avg[k]["SQ_INSTS_VALU"]))
+    o.write("\nDerived (per launch; kernel time = the rocprofv3 --stats average of the same build):\n\n")
+    o.write("| kernel | us | clock GHz (GUI_ACTIVE/8/us) | waves resident per SIMD (WAVE_CYCLES*4/cycles/1024) | VALU insts x 4 cyc / (1024 SIMD x 2.4 GHz x time) | cycles per VALU inst per wave | wave time: active / issue-stalled / waiting | LDS conflict cycles / LDS active |\n|---|---|---|---|---|---|---|---|\n")
+    for k in order:
+        if k in avg and k in stats_avg and "SQ_WAVE_CYCLES" in avg[k]:
+            a_ = avg[k]
+            us = stats_avg[k]
+            cyc = a_.get("GRBM_GUI_ACTIVE", float("nan")) / 8
+            wc = a_["SQ_WAVE_CYCLES"] * 4
+            o.write("| %s | %.1f | %.2f | %.2f | %.2f | %.1f | %.0f %% / %.0f %% / %.0f %% | %.2f |\n" % (
+                k, us, cyc / us / 1e3, wc / cyc / 1024 if cyc == cyc else float("nan"),
+                a_["SQ_INSTS_VALU"] * 4 / 1024 / 2.4e3 / us, wc / max(a_["SQ_INSTS_VALU"], 1),
+                100 * a_.get("SQ_ACTIVE_INST_ANY", float("nan")) / a_["SQ_WAVE_CYCLES"], 100 * a_["SQ_WAIT_INST_ANY"] / a_["SQ_WAVE_CYCLES"],
+                100 * a_["SQ_WAIT_ANY"] / a_["SQ_WAVE_CYCLES"],
+                a_["SQ_LDS_BANK_CONFLICT"] / a_["SQ_ACTIVE_INST_LDS"] if a_.get("SQ_ACTIVE_INST_LDS") else 0.0))
+    o.write("\nVALU instruction classes on gfx950 (scripts/valu_bench.hip, valu_bench2.hip, wave-instructions/s per SIMD at 8 waves): "
+            "v_add/mul/fma/and/mov 0.9-1.0 G (2 cycles); v_cmp, v_cndmask, v_min/max, shifts, v_mad_u32_u24, every DPP op, v_pk_* 0.5-0.58 G "
+            "(4 cycles); v_exp/rcp/log/sqrt, v_permlane*_swap 0.29 G (8 cycles); f32 MFMA 16x16x4 0.07 G (32 cycles, no overlap with VALU).\n")
     o.write("\n## L2 <-> fabric traffic\n\nFETCH_SIZE / WRITE_SIZE are reported in KB. Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 reports 1/2 of the bytes of a streaming read; traffic = 2*FETCH_SIZE + WRITE_SIZE.\n\n")
     o.write("| kernel | FETCH_SIZE KB | WRITE_SIZE KB | traffic MB (2F+W) | TCC hit rate |\n|---|---|---|---|---|\n")
     tj = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1 --no-cpu; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 bytes per launch",
@@ -88,9 +98,11 @@ with open(os.path.join(dst, tag + "_pmc.md"), "w") as o:
             tr = (2 * F + Wr) * 1024
             o.write("| %s | %.0f | %.0f | %.1f | %.2f |\n" % (k, F, Wr, tr / 1e6, hit / (hit + miss) if hit == hit else float("nan")))
             tj["kernels"][k] = {"fetch_size_kb": F, "write_size_kb": Wr, "traffic_bytes": tr}
-    for k in ("K_blend_fwd", "K_blend_bwd"):   # what actually bounds the blend kernels: VALU issue
+    for k in ("K_blend_fwd", "K_blend_bwd"):   # what bench.py's roofline_valu quotes
         if k in avg and k in stats_avg and k in tj["kernels"]:
             tj["kernels"][k]["valu_instructions"] = avg[k]["SQ_INSTS_VALU"]
-            tj["kernels"][k]["valu_busy_frac"] = avg[k]["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / 2.4e3 / stats_avg[k]
-    json.dump(tj, open(os.path.join(dst, "r01_traffic.json"), "w"), indent=1)
+            tj["kernels"][k]["profiled_launch_us"] = stats_avg[k]
+            if avg[k].get("SQ_ACTIVE_INST_LDS"):
+                tj["kernels"][k]["lds_conflict_frac"] = avg[k]["SQ_LDS_BANK_CONFLICT"] / avg[k]["SQ_ACTIVE_INST_LDS"]
+    json.dump(tj, open(os.path.join(dst, "r02_traffic.json"), "w"), indent=1)
 print("written", tag)
