@@ -22,6 +22,13 @@ def test_ssim_window_is_the_references_odd_formula(hz):
     assert w.shape == (3, 1, 11, 11) and abs(float(w[1].sum()) - 1.0) < 1e-6
     assert taps[0] < taps[-1]                      # the window is NOT symmetric: floor((x-11)/2)
     a = torch.rand(3, 40, 48)
+    # the harness applies the window as two 1-D passes: same sums as the reference's 11x11 convolution with outer(g, g)
+    b = torch.rand(3, 40, 48)
+    conv = lambda x: torch.nn.functional.conv2d(x.unsqueeze(0), w, padding=5, groups=3).squeeze(0)
+    mu1, mu2 = conv(a), conv(b)
+    s1, s2, s12 = conv(a * a) - mu1 * mu1, conv(b * b) - mu2 * mu2, conv(a * b) - mu1 * mu2
+    ref = (((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s1 + s2 + 9e-4))).mean()
+    assert abs(float(hz.ssim(a, b)) - float(ref)) < 1e-6
     assert abs(float(hz.ssim(a, a)) - 1.0) < 1e-5
     assert float(hz.ssim(a, 1 - a)) < 0.5
     m = torch.rand(3, 40, 48) > 0.5
