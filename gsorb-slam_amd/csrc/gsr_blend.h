@@ -22,7 +22,6 @@
 
 namespace gsr {
 
-#define GSR_ALPHA_MIN (1.0f / 255.0f)
 // a quad-hit record keeps the splat id in the low 28 bits of .y and the 4-bit patch mask above it
 #define GSR_ID_BITS 28
 #define GSR_ID_MASK 0x0FFFFFFFu
@@ -444,6 +443,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
     // per-patch hit lists: BYTE OFFSETS of the entries (index * 16: shifts and integer mads are half-rate on gfx950,
     // LDS loads are not VALU work at all), 4 slots of slack behind the longest list for the software pipeline
     __shared__ uint16_t LIST[4 * (Q + 4)];
+    __shared__ uint8_t PMB[Q]; // per parked entry: its 4-bit patch mask, or 0x10 = a large splat whose patches are tested when the lists are built
     const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
     const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u;
     const int tx = tile % grid_x, ty = tile / grid_x;
@@ -471,21 +471,25 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
     if (n > 0) {
         int base = 0;
         uint32_t id_c = plist[min(lane, n - 1)], id_n = plist[min(lane + 64, n - 1)];
-        float4 a_c = g.g0[id_c], b_c = g.g1[id_c];
+        float4 a_c = g.g0[id_c], b_c = g.g1[id_c], c_c = g.col[id_c]; // the whole 48-byte record, one step ahead
+        const int qcx = X0 >> 2, qcy = Y0 >> 2; // the quad's first patch in the global patch grid
         while (base < n) {
             const wmask dmask = m_done;
             if (dmask == ~0ull) break;
-            // ---- gather + quad cull + compaction
+            // ---- gather + quad cull + compaction. A small splat (K_preprocess decided its exact patch reach once, in
+            //      col.w: gsr_device.h) is culled by shifting bits; only larger ones run the exact quad test here
             int count = 0;
             do {
                 const uint32_t id = id_c;
-                const float4 a = a_c, b = b_c;
+                const float4 a = a_c, b = b_c, c = c_c;
                 const int k = base + lane;
-                const bool hit = k < n && quad_reach(a, b, X0f, Y0f);
-                float4 c;
-                if (hit) c = g.col[id];
+                const uint32_t colw = __float_as_uint(c.w);
+                const bool small = (colw & GSR_REACH_SMALL) != 0u;
+                uint32_t pm4 = quad_mask_from_word(colw, a.x, a.y, qcx, qcy);
+                if (__ballot(k < n && !small) != 0ull) pm4 = small ? pm4 : (quad_reach(a, b, X0f, Y0f) ? 0x10u : 0u); // 0x10: patches still to test
+                const bool hit = k < n && pm4 != 0u;
                 id_c = id_n;
-                a_c = g.g0[id_c]; b_c = g.g1[id_c];
+                a_c = g.g0[id_c]; b_c = g.g1[id_c]; c_c = g.col[id_c];
                 id_n = plist[min(k + 128, n - 1)];
                 const unsigned long long m = __ballot(hit);
                 if (hit) {
@@ -493,6 +497,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                     E0[e] = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
                     E1[e] = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, c.x, c.y);
                     E2[e] = make_float4(c.z, b.z, __uint_as_float((uint32_t)k + 1u), __uint_as_float(id));
+                    PMB[e] = (uint8_t)pm4;
                 }
                 count += (int)__popcll(m);
                 base += 64;
@@ -505,7 +510,14 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                 const int e = eb + lane;
                 bool h[4] = {false, false, false, false};
                 float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < count) { patch_reach4(E0[e], E1[e], X0f, Y0f, h); z = E2[e]; }
+                uint32_t pmb = 0u;
+                if (e < count) { pmb = PMB[e]; z = E2[e]; }
+                h[0] = (pmb & 1u) != 0u; h[1] = (pmb & 2u) != 0u; h[2] = (pmb & 4u) != 0u; h[3] = (pmb & 8u) != 0u;
+                if (__ballot(pmb == 0x10u) != 0ull) { // large splats: the exact patch test on the parked entry
+                    bool hx[4] = {false, false, false, false};
+                    if (pmb == 0x10u) patch_reach4(E0[e], E1[e], X0f, Y0f, hx);
+                    if (pmb == 0x10u) { h[0] = hx[0]; h[1] = hx[1]; h[2] = hx[2]; h[3] = hx[3]; }
+                }
                 const unsigned long long m0 = __ballot(h[0]), m1 = __ballot(h[1]), m2 = __ballot(h[2]), m3 = __ballot(h[3]);
                 const uint16_t off = (uint16_t)(e * 16);
                 if (h[0]) LIST[0 * (Q + 4) + c0 + mbcnt64(m0)] = off;

@@ -205,6 +205,99 @@ __device__ __forceinline__ float pair_power2(float dx, float dy, float ca2, floa
     return fmaf(t, dx, (cc2 * dy) * dy);
 }
 
+// Exact patch reach of a small splat, decided once per splat by K_preprocess; the forward blend only shifts bits.
+// ---------------------------------------------------------------------------------
+#define GSR_ALPHA_MIN (1.0f / 255.0f)
+// Exact reach of one splat over a WINDOW of NW x NW patches (4x4 pixels each) whose first patch has its pixel centres
+// at (wx, wy) .. (wx + 3, wy + 3): bit (j * NW + i) of the result = the iso-alpha ellipse alpha = 1/255 meets patch (i, j).
+// alpha >= 1/255  <=>  Q(d) := 0.5*(a dx^2 + c dy^2) + b dx dy <= log2(255*opacity) in log2 units, d = centre - pixel.
+// The minimum of the convex Q over a rectangle is attained at d = 0 (centre inside), or on a side facing the centre,
+// where it is a 1-D parabola clamped to the side. Conservative: the continuous rectangle contains the pixel centres,
+// the threshold carries a margin far above fp32 rounding, NaNs pass. Everything that depends on one axis only is
+// hoisted out of the NW x NW loop.
+struct ReachSetup {
+    float ax, ay, hca, hcc, cb, kx, ky, tau;
+    bool pd, never, small;
+};
+__device__ __forceinline__ ReachSetup reach_setup(float px, float py, float conic_a, float conic_b, float conic_c, float op)
+{
+    ReachSetup s;
+    const float ca = conic_a * GSR_LOG2E, cb = conic_b * GSR_LOG2E, cc = conic_c * GSR_LOG2E;
+    const float det = ca * cc - cb * cb;
+    // the construction needs a positive-definite conic; an indefinite one (possible with cov3D_precomp) is never culled:
+    // the reference would still blend it (forward.cu:346-358)
+    s.pd = ca > 0.f && cc > 0.f && det > 0.f;
+    s.never = !(op >= GSR_ALPHA_MIN) && op == op; // alpha = op * exp(power <= 0) can never reach 1/255
+    s.ax = px; s.ay = py; s.hca = 0.5f * ca; s.hcc = 0.5f * cc; s.cb = cb;
+    s.kx = -cb * __builtin_amdgcn_rcpf(cc); s.ky = -cb * __builtin_amdgcn_rcpf(ca);
+    s.tau = __log2f(255.0f * op) + 0.0145f;
+    // half extents of the ellipse Q <= tau: ex^2 = 2 tau cc / det, ey^2 = 2 tau ca / det; "small": both below ~7.6 pixels,
+    // so that the ellipse cannot leave the 5x5 patches around the patch that holds its centre (SinglePixel-initialised
+    // splats reach 2.2 .. 6.3 pixels)
+    const float lim = 64.0f * 0.9f * det;
+    s.small = s.pd && 2.f * s.tau * cc <= lim && 2.f * s.tau * ca <= lim;
+    return s;
+}
+template <int NW>
+__device__ __forceinline__ uint32_t window_reach(const ReachSetup& s, float wx, float wy)
+{
+    float dl[NW], dh[NW], el[NW], eh[NW], Ax[NW], Bx[NW], Kx[NW], Ay[NW], By[NW], Ky[NW];
+    uint32_t zc = 0u, zr = 0u; // columns / rows whose range contains the centre coordinate
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        dl[i] = s.ax - (wx + 4.f * i + 3.f); dh[i] = s.ax - (wx + 4.f * i);
+        const float dc = fminf(fmaxf(0.f, dl[i]), dh[i]); // point of the range closest to 0
+        Ax[i] = dc != 0.f ? s.hca * dc * dc : 3.0e38f;    // a side faces the centre only if the centre is outside the range
+        Bx[i] = s.cb * dc; Kx[i] = s.kx * dc;
+        zc |= dc == 0.f ? 1u << i : 0u;
+        el[i] = s.ay - (wy + 4.f * i + 3.f); eh[i] = s.ay - (wy + 4.f * i);
+        const float ec = fminf(fmaxf(0.f, el[i]), eh[i]);
+        Ay[i] = ec != 0.f ? s.hcc * ec * ec : 3.0e38f;
+        By[i] = s.cb * ec; Ky[i] = s.ky * ec;
+        zr |= ec == 0.f ? 1u << i : 0u;
+    }
+    uint32_t mask = 0u;
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        if (zr & (1u << j)) mask |= zc << (j * NW); // centre inside the patch rectangle
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            const float dy = fminf(fmaxf(Kx[i], el[j]), eh[j]);            // minimiser on the vertical side x = dc_i
+            const float qx = fmaf(dy, fmaf(s.hcc, dy, Bx[i]), Ax[i]);
+            const float dx = fminf(fmaxf(Ky[j], dl[i]), dh[i]);            // minimiser on the horizontal side y = ec_j
+            const float qy = fmaf(dx, fmaf(s.hca, dx, By[j]), Ay[j]);
+            if (!(fminf(qx, qy) > s.tau)) mask |= 1u << (j * NW + i);
+        }
+    }
+    return mask;
+}
+// What K_preprocess keeps in col.w next to the three SH clamp flags (bits 0..2):
+//   bit 3 "small"  : the 25 bits below are the splat's complete patch reach
+//   bits 4..28     : reach over the 5x5 patches whose first patch is column floor(px/4) - 2, row floor(py/4) - 2
+//                    of the GLOBAL patch grid (patch column c = pixels 4c .. 4c+3)
+#define GSR_REACH_SMALL 8u
+__device__ __forceinline__ uint32_t splat_reach25(float px, float py, float conic_a, float conic_b, float conic_c, float op)
+{
+    const ReachSetup s = reach_setup(px, py, conic_a, conic_b, conic_c, op);
+    if (s.never) return GSR_REACH_SMALL; // reaches nothing
+    if (!s.small) return 0u;
+    const float wx = 4.f * (floorf(px * 0.25f) - 2.f), wy = 4.f * (floorf(py * 0.25f) - 2.f);
+    return GSR_REACH_SMALL | (window_reach<5>(s, wx, wy) << 4);
+}
+// The 2x2 patches of the 8x8 quad whose first patch is (qcx, qcy) of the global patch grid, from a small splat's word:
+// bit (j * 2 + i) = patch (qcx + i, qcy + j).
+__device__ __forceinline__ uint32_t quad_mask_from_word(uint32_t colw, float px, float py, int qcx, int qcy)
+{
+    const uint32_t m = colw >> 4;
+    const int sh = qcx - (int)floorf(px * 0.25f) + 3; // = first window column of the quad + 1: the 5-bit row is shifted up by one
+    const int j0 = qcy - (int)floorf(py * 0.25f) + 2; // first window row of the quad
+    const uint32_t r0 = (uint32_t)j0 < 5u ? (m >> (5 * j0)) & 31u : 0u;
+    const uint32_t r1 = (uint32_t)(j0 + 1) < 5u ? (m >> (5 * (j0 + 1))) & 31u : 0u;
+    const uint32_t c0 = (uint32_t)sh <= 5u ? ((r0 << 1) >> sh) & 3u : 0u;
+    const uint32_t c1 = (uint32_t)sh <= 5u ? ((r1 << 1) >> sh) & 3u : 0u;
+    return c0 | (c1 << 2);
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v)
 {

@@ -81,8 +81,11 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
         const uint32_t flags = (r < 0 ? 1u : 0u) | (gg < 0 ? 2u : 0u) | (b < 0 ? 4u : 0u);
         c = make_float4(fmaxf(r, 0.f), fmaxf(gg, 0.f), fmaxf(b, 0.f), __uint_as_float(flags));
     }
+    const float opac = in.opacities[idx];
+    // the exact patch reach of a small splat, once per splat instead of once per (tile entry, quad) in the blend (gsr_device.h)
+    c.w = __uint_as_float(__float_as_uint(c.w) | splat_reach25(pr.px, pr.py, pr.conic_a, pr.conic_b, pr.conic_c, opac));
     g.g0[idx] = make_float4(pr.px, pr.py, pr.conic_a, pr.conic_b);
-    g.g1[idx] = make_float4(pr.conic_c, in.opacities[idx], pr.p_view.z, __int_as_float(pr.radius));
+    g.g1[idx] = make_float4(pr.conic_c, opac, pr.p_view.z, __int_as_float(pr.radius));
     g.col[idx] = c;
     if (radii_out) radii_out[idx] = pr.radius;
     // count the splat into its tiles: ONE returning atomic for a rectangle of at most 2x2 tiles (see TileRec)
