@@ -11,10 +11,12 @@
 //   K_tile_sort    per tile  : bitonic sort of the tile's segment in LDS -> point_list
 //                              ((depth, id) ascending == the reference's stable radix order)
 //   K_blend_fwd    per quad  : front-to-back alpha blend, one wave per 8x8 quad, four independent 4x4 patch
-//                              rows per wave, exact culling, logs its hits for the backward (gsr_blend.h)
+//                              rows per wave, exact culling (small splats: bit shifts on the reach word K_preprocess
+//                              left in col.w), logs its hits for the backward (gsr_blend.h)
 // Backward (replaces rasterizer_impl.cu:405-498):
-//   K_blend_bwd    per quad  : back-to-front walk of the forward's log, in-row DPP reduction, LDS merge, one
-//                              9-lane atomic per (quad, splat) into the per-splat accumulator (gsr_blend.h)
+//   K_blend_bwd    per quad  : back-to-front walk of the forward's log; the per-pixel loop parks (u, dcol) in an LDS
+//                              ring, every 16 iterations one lane per (row, iteration) pair forms the nine sums and
+//                              lane e merges the sums of entry e; one 9-lane atomic per (quad, splat) (gsr_blend.h)
 //   K_splat_bwd    per splat : conic/mean2D/colour gradients -> mean3D, cov3D, scale, rot, SH
 //
 // No global sort and no (tile | depth) keys: per-tile counting replaces the reference's 64-bit radix sort of

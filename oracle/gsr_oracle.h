@@ -11,9 +11,14 @@
  * cooperative_groups) and is unbuildable in this image; it ships no tests or
  * golden vectors. This restatement is therefore pinned only (a) on the
  * sub-functions the reference also ships as importable Python
- * (utils/sh_utils.py eval_sh, utils/graphics_utils.py getProjectionMatrix /
- * geom_transform_points — fixtures under tests/golden/ref_utils.npz) and
- * (b) against an independent fp64 autograd restatement (tests/spec_fp64.py).
+ * (utils/sh_utils.py eval_sh / RGB2SH / SH2RGB, utils/graphics_utils.py
+ * getProjectionMatrix / geom_transform_points, utils/image_utils.py psnr,
+ * scripts/eval_ate.py — fixtures under tests/golden/ref_utils.npz and
+ * ref_eval.npz, each with the script that imported the reference to make it),
+ * (b) against an independent fp64 autograd restatement (tests/spec_fp64.py,
+ * nine scenes incl. cov3D_precomp and SH degrees 1-3) and (c) against closed
+ * forms worked out by hand from forward.cu / backward.cu on a two-splat scene
+ * (tests/test_oracle_known_answers.py).
  * Whole-pipeline parity with the CUDA binary is "parity unpinned".
  *
  * Every function cites the reference file:line it follows. Paths are
