@@ -71,15 +71,36 @@ gsr::SplatInputs splat_inputs(const float* means3D, const float* scales, const f
     return in;
 }
 
+#ifndef GSR_FILL_WX
+#define GSR_FILL_WX 8
+#endif
+// launch shape of the two binning passes: one workgroup per splat range x tile window
+struct BinGrid {
+    int rows, per, wx, nwin, twmax;
+    dim3 grid;
+};
+BinGrid bin_grid(int P, int T, int wx, int window)
+{
+    BinGrid b;
+    b.rows = bin_rows(P);
+    b.per = (P + b.rows - 1) / b.rows;
+    b.wx = wx;
+    const int wy = (T + wx * window - 1) / (wx * window);
+    b.nwin = wx * wy;
+    b.grid = dim3(b.rows * wx, wy);
+    b.twmax = ((T + b.nwin - 1) / b.nwin + 2) & ~1; // even: the staged keys behind the per-tile words stay 8-byte aligned
+    return b;
+}
+
 int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView& iv, const BinView& bv,
                  const FrameParams& f, hipStream_t st)
 {
     const int P = a->P, T = f.grid_x * f.grid_y;
     const StageTimer tm{a->profile_events, st};
     tm.begin(GSR_FWD_FILL);
-    hipLaunchKernelGGL(gsr::K_anchor_table, dim3(T), dim3(GSR_ANCHOR_ROW), 0, st, T, f.grid_x, iv.tiles, iv.tier2, iv.run4, iv.anchor);
-    GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_fill, dim3(blocks256(P)), dim3(256), 0, st, P, f.grid_x, gv, iv.tiles, iv.anchor, bv.pairs);
+    const BinGrid bg = bin_grid(P, T, GSR_FILL_WX, GSR_BIN_WINDOW);
+    hipLaunchKernelGGL(gsr::K_bin_fill, bg.grid, dim3(GSR_BIN_THREADS), (size_t)bg.twmax * 4, st, P, bg.per, T, f.grid_x, bg.wx, bg.nwin, gv,
+                       iv.binmat, iv.tile_start, bv.pairs);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_FILL);
     tm.begin(GSR_FWD_SORT);
@@ -113,13 +134,14 @@ int forward_head(const gsr_forward_args* a, char* geom, char* image, hipStream_t
                                              a->projmatrix, a->cam_pos);
     const StageTimer tm{a->profile_events, st};
     tm.begin(GSR_FWD_PREPROCESS);
-    GSR_HIP(hipMemsetAsync(iv->tiles, 0, (size_t)T * (sizeof(TileRec) + sizeof(Cls4Rec)) + 256, st)); // tiles, cls4, tier2
-    hipLaunchKernelGGL(gsr::K_preprocess, dim3(blocks256(P)), dim3(256), 0, st, f, in, a->radii, *gv, iv->tiles, iv->cls4, iv->tier2);
+    hipLaunchKernelGGL(gsr::K_preprocess, dim3(blocks256(P)), dim3(256), 0, st, f, in, a->radii, *gv);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_PREPROCESS);
     tm.begin(GSR_FWD_SCAN);
-    hipLaunchKernelGGL(gsr::K_tile_runs, dim3((T + 15) / 16), dim3(256), 0, st, T, f.grid_x, iv->tiles, iv->cls4, iv->tier2, iv->run4);
-    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, T, iv->tiles, iv->ranges, gv->hdr, capacity);
+    const BinGrid bg = bin_grid(P, T, 1, GSR_BIN_WINDOW);
+    hipLaunchKernelGGL(gsr::K_bin_count, bg.grid, dim3(GSR_BIN_THREADS), (size_t)bg.twmax * 4, st, P, bg.per, T, f.grid_x, bg.wx, bg.nwin, *gv, iv->binmat);
+    hipLaunchKernelGGL(gsr::K_bin_colscan, dim3((T + 31) / 32), dim3(1024), 0, st, bg.rows, T, iv->binmat, iv->tile_cnt);
+    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, T, iv->tile_cnt, 1, iv->tile_start, 1, iv->ranges, gv->hdr, capacity);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SCAN);
     *fo = f;
@@ -384,14 +406,14 @@ int gsr_dist2(int P, const float* points, float* mean_dists, char* workspace, si
     gsr::knn_layout(workspace, P, &k);
     const int bits = gsr::knn_bucket_bits(P), nb = 1 << bits, shift = 30 - bits;
     const int nbox = (P + GSR_KNN_BOX - 1) / GSR_KNN_BOX;
-    GSR_HIP(hipMemsetAsync(k.buckets, 0, (size_t)nb * sizeof(TileRec), st));
+    GSR_HIP(hipMemsetAsync(k.buckets, 0, (size_t)nb * sizeof(gsr::BucketRec), st));
     hipLaunchKernelGGL(gsr::K_knn_init, dim3(1), dim3(64), 0, st, k.bbox);
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_knn_bbox, dim3(std::min(blocks256(P), 1024)), dim3(256), 0, st, P, points, k.bbox);
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_knn_code, dim3(blocks256(P)), dim3(256), 0, st, P, shift, points, k.bbox, k.buckets, k.code, k.slot);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, nb, k.buckets, k.ranges, k.hdr, 0xFFFFFFFFu);
+    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, nb, &k.buckets->cnt, 16, &k.buckets->start, 16, k.ranges, k.hdr, 0xFFFFFFFFu);
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_knn_fill, dim3(blocks256(P)), dim3(256), 0, st, P, shift, k.code, k.slot, k.buckets, k.pairs);
     GSR_LAUNCHED();

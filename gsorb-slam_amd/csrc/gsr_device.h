@@ -8,14 +8,13 @@
 //          g0  {x, y, conic_a, conic_b}            pixel centre + half of the conic
 //          g1  {conic_c, opacity, depth, radius}   radius stored as int bits (0: culled)
 //          col {r, g, b, clamp-flags}              colour the blend uses (SH result or copy of colors_precomp)
-//     slots uint4[P]     bin record for the fill pass: rank in the splat's class counter (TileRec / Cls4Rec),
-//                        depth bits, band-clipped tile rectangle
+//     slots uint4[P]     bin record for the count and fill passes: tile count, depth bits, band-clipped tile rectangle
 //     acc  float[P][16]  backward accumulators, one 64-byte line per splat (48-byte records straddle lines and
 //                        the L2 atomic rate drops from 20 to 13 G records/s): moments of u = G*dL/dalpha
 //                        {sum u, u*dx, u*dy, u*dx^2, u*dx*dy, u*dy^2}, dcolor.rgb, 7 unused
 //   image blob     (gsr_image_bytes(W,H)):
-//     final_T f32[N], n_contrib u32[N], ranges uint2[T], tiles TileRec[T] + cls4 Cls4Rec[T] + tier2 flag (cleared
-//     by one memset per frame), run4 u32[T][256], anchor u32[T][128], qcount u32[4T]
+//     final_T f32[N], n_contrib u32[N], ranges uint2[T], tile_cnt u32[T], tile_start u32[T],
+//     binmat u32[GSR_BIN_ROWS][T] (the count matrix of the binning, below), qcount u32[4T]
 //   binning blob   (gsr_binning_bytes(capacity)), 44 B per tile instance:
 //     pairs u64[R] (depth bits << 32 | splat id, grouped per tile), point_list u32[R],
 //     qhits uint2[4R] (the forward's log of quad hits for the backward)
@@ -39,50 +38,37 @@ struct GeomHeader {
 };
 static_assert(sizeof(GeomHeader) == 256, "header is one aligned slot");
 
-// Per-tile binning record, padded to its own 64-byte line: device-scope atomics on
-// counters that share a line serialise (measured 12 vs 23 G atomics/s on MI355X), and the chip
-// retires only ~20 G device-scope atomics/s in total, so the count pass is built to issue as few
-// as possible: a splat whose tile rectangle is at most 2x2 (almost all of a freshly initialised map) is counted with ONE
-// returning atomic on the class counter cls[(w-1) + 2*(h-1)] of its top-left ("anchor") tile, and
-// the value returned is its rank in that class. The scan kernel lays every tile's list segment out
-// as nine runs — one per (class, anchor) that covers the tile:
-//     run 0: 1x1 at t | 1: 2x1 at t | 2: 2x1 at t-(1,0) | 3: 1x2 at t | 4: 1x2 at t-(0,1)
-//     5: 2x2 at t | 6: 2x2 at t-(1,0) | 7: 2x2 at t-(0,1) | 8: 2x2 at t-(1,1)
-// run 0 starts at `start`, runs 1..8 at start + off[0..7]; the fill pass writes the splat at run start + rank
-// in each of its tiles with no further atomic. Larger rectangles are counted per tile in cnt_big and
-// take slots from cur_big in the fill pass.
-// (cnt_small is the plain per-bucket counter of the k-NN path, which shares the scan and sort kernels.)
-struct TileRec {
-    uint32_t cnt_small, cnt_big, start, cur_big;
-    uint32_t cls[4];
-    uint32_t off[8];
-};
-static_assert(sizeof(TileRec) == 64, "one cache line per tile");
-// Second tier of the same scheme for rectangles up to 4x4 tiles that are not <= 2x2 (fat splats): class
-// counter c[(w-1) + 4*(h-1)] of the anchor tile, again one returning atomic per splat. A tile is covered
-// by up to 16 anchors (dx, dy in 0..3 to its upper left) x the classes wide/high enough to reach it: its
-// runs are laid out behind the nine first-tier runs, run4[(dy*4+dx)*16 + class] = offset from `start`.
-// `tier2` (one word per frame, next to the records) tells the run kernel whether any such splat exists.
-struct Cls4Rec {
-    uint32_t c[16];
-};
-static_assert(sizeof(Cls4Rec) == 64, "one cache line per tile");
-#define GSR_RUN4 256
-// Anchor table: what the fill pass reads. Row A holds, for every class (w, h <= 4) anchored at tile A and every
-// tile (dx, dy) of its rectangle, the absolute list position where that (class, anchor) run starts in tile
-// A + (dx, dy): entry anchor_base(w, h) + dy*w + dx (100 entries, rows padded to 128). One or two cache
-// lines per splat instead of two scattered gathers per (splat, tile).
-#define GSR_ANCHOR_ROW 128
-__host__ __device__ constexpr int anchor_base(int w, int h) { return 5 * h * (h - 1) + h * w * (w - 1) / 2; }
+// Tile binning is a two-level counting sort without a single global atomic (the chip retires only ~20 G
+// device-scope atomics/s, an LDS atomic costs ~7 ns of one CU: scripts/valu_bench2.hip). The splats are cut into
+// `rows` contiguous ranges, one workgroup each:
+//   K_bin_count    the workgroup histograms the tiles its splats cover in LDS and writes the histogram as row b
+//                  of the count matrix binmat[rows][T]
+//   K_bin_colscan  exclusive scan down every column (binmat[b][t] = instances of tile t in rows < b), column
+//                  total -> tile_cnt[t]
+//   K_scan_tiles   tile_cnt -> tile_start, ranges, num_rendered, overflow
+//   K_bin_fill     the same workgroup over the same splats: every (splat, tile) takes its slot from an LDS cursor
+//                  that starts at tile_start[t] + binmat[b][t] (returning LDS atomic) and its key goes there
+// The matrix has at most GSR_BIN_ROWS rows, so the image blob's size depends on the resolution only. Frames of
+// more than GSR_BIN_WINDOW tiles are histogrammed in windows of that many tiles (grid.y = windows); the fill pass
+// always works in (a multiple of) eight windows, one per XCD.
+#define GSR_BIN_ROWS 512
+#define GSR_BIN_THREADS 1024
+#define GSR_BIN_WINDOW 16384 // tiles per window: 64 KB of LDS
+__host__ __device__ inline int bin_rows(int P)
+{
+    // 4096 splats per range: 256 ranges at 1 M splats (measured fill / column scan: 28.5 / 6.7 us; 512 ranges 32.1 / 9.3, 128 ranges 32.7 / 5.1)
+#define GSR_BIN_SPLATS 4096
+    int r = (P + GSR_BIN_SPLATS - 1) / GSR_BIN_SPLATS;
+    if (r > 128) r = (r + 255) & ~255; // whole rounds of the 256 CUs
+    return r < 1 ? 1 : (r > GSR_BIN_ROWS ? GSR_BIN_ROWS : r);
+}
 
 // The per-splat records the blend kernels gather are interleaved (GSR_GSTRIDE float4 per splat): a random
 // gather pulls a whole 128-byte L2 line per touched address, so g0, g1 and col of one splat share a line
 // (48-byte records). Measured at 1 M splats, forward / backward blend: separate arrays 182 / 294 us,
 // stride 2 (g0,g1) 172 / 289, stride 3 169 / 288, stride 4 (64-B records) 168 / 289 but slower per-splat
 // kernels (step 0.703 vs 0.696 ms).
-#ifndef GSR_GSTRIDE
 #define GSR_GSTRIDE 3
-#endif
 struct Strided4 {
     float4* p;
     __host__ __device__ float4& operator[](size_t i) const { return p[GSR_GSTRIDE * i]; }
@@ -91,23 +77,17 @@ struct GeomView {
     GeomHeader* hdr;
     Strided4 g0;
     Strided4 g1;
-#if GSR_GSTRIDE >= 3
     Strided4 col;
-#else
-    float4* col;
-#endif
-    uint4* slots; // {rank in the class counter, depth bits, x0 | y0 << 16, x1 | y1 << 16} (band-clipped tile rectangle; x1 == x0: not binned)
+    uint4* slots; // {tiles covered, depth bits, x0 | y0 << 16, x1 | y1 << 16} (band-clipped tile rectangle; 0 tiles: not binned)
     float* acc;
 };
 struct ImageView {
     float* final_T;
     uint32_t* n_contrib;
     uint2* ranges;
-    TileRec* tiles;
-    Cls4Rec* cls4;    // [T] second-tier class counters, directly behind `tiles` (one memset clears both + tier2)
-    uint32_t* tier2;  // [64] word 0: some splat used the second tier this frame
-    uint32_t* run4;   // [T][GSR_RUN4] second-tier run offsets
-    uint32_t* anchor; // [T][GSR_ANCHOR_ROW] absolute run starts per (anchor, class, covered tile)
+    uint32_t* tile_cnt;   // [T] instances per tile
+    uint32_t* tile_start; // [T] where the tile's list segment starts
+    uint32_t* binmat;     // [GSR_BIN_ROWS][T] count matrix (after K_bin_colscan: exclusive column prefixes)
     uint32_t* qcount; // [4*T] quad-hit records the forward blend wrote per 8x8 quad
 };
 struct BinView {
@@ -126,13 +106,8 @@ __host__ __device__ inline size_t geom_layout(char* base, int P, GeomView* v)
     g.hdr = (GeomHeader*)(base + off); off = gsr_align_up(off + sizeof(GeomHeader));
     g.g0.p = (float4*)(base + off);
     g.g1.p = g.g0.p + 1;
-#if GSR_GSTRIDE >= 3
     g.col.p = g.g0.p + 2;
     off = gsr_align_up(off + Pz * 16 * GSR_GSTRIDE);
-#else
-    off = gsr_align_up(off + Pz * 32);
-    g.col = (float4*)(base + off); off = gsr_align_up(off + Pz * 16);
-#endif
     g.slots = (uint4*)(base + off); off = gsr_align_up(off + Pz * 16);
     g.acc = (float*)(base + off); off = gsr_align_up(off + Pz * GSR_ACC_STRIDE * 4);
     if (v) *v = g;
@@ -148,11 +123,9 @@ __host__ __device__ inline size_t image_layout(char* base, int W, int H, ImageVi
     g.final_T = (float*)(base + off); off = gsr_align_up(off + N * 4);
     g.n_contrib = (uint32_t*)(base + off); off = gsr_align_up(off + N * 4);
     g.ranges = (uint2*)(base + off); off = gsr_align_up(off + T * 8);
-    g.tiles = (TileRec*)(base + off); off = off + T * sizeof(TileRec);
-    g.cls4 = (Cls4Rec*)(base + off); off = off + T * sizeof(Cls4Rec);
-    g.tier2 = (uint32_t*)(base + off); off = gsr_align_up(off + 256);
-    g.run4 = (uint32_t*)(base + off); off = gsr_align_up(off + T * GSR_RUN4 * 4);
-    g.anchor = (uint32_t*)(base + off); off = gsr_align_up(off + T * GSR_ANCHOR_ROW * 4);
+    g.tile_cnt = (uint32_t*)(base + off); off = gsr_align_up(off + T * 4);
+    g.tile_start = (uint32_t*)(base + off); off = gsr_align_up(off + T * 4);
+    g.binmat = (uint32_t*)(base + off); off = gsr_align_up(off + T * GSR_BIN_ROWS * 4);
     g.qcount = (uint32_t*)(base + off); off = gsr_align_up(off + T * 16);
     if (v) *v = g;
     return off;

@@ -2,12 +2,12 @@
 // Gaussian-splat rasterizer. Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off.
 //
 // Forward  (replaces rasterizer_impl.cu:199-345 of the reference's DGR tree):
-//   K_preprocess   per splat : project, cull, radius, tile rectangle, colour; ONE count atomic per splat on the
-//                              (class, anchor) counter of its tile rectangle (gsr_device.h: TileRec, Cls4Rec)
-//   K_tile_runs    per tile  : the (class, anchor) runs that cover a tile -> its count and run offsets
+//   K_preprocess   per splat : project, cull, radius, tile rectangle, colour, reach word
+//   K_bin_count    per range : LDS histogram of the tiles a contiguous range of splats covers -> one row of the
+//                              count matrix (gsr_device.h)
+//   K_bin_colscan  per column: exclusive scan down the matrix columns, column totals = tile counts
 //   K_scan_tiles   1 block   : counts -> segment starts, ranges, num_rendered, overflow flag
-//   K_anchor_table per anchor: absolute run starts per (anchor, class, covered tile)
-//   K_fill         per splat : (depth bits<<32 | id) at run start + rank in each of its tiles (no atomics)
+//   K_bin_fill     per range : (depth bits<<32 | id) into the list slot an LDS cursor hands out (no global atomics)
 //   K_tile_sort    per tile  : bitonic sort of the tile's segment in LDS -> point_list
 //                              ((depth, id) ascending == the reference's stable radix order)
 //   K_blend_fwd    per quad  : front-to-back alpha blend, one wave per 8x8 quad, four independent 4x4 patch
@@ -55,8 +55,7 @@ __device__ __forceinline__ void load_cov3d(const SplatInputs& in, const FramePar
 }
 
 __global__ void __launch_bounds__(256)
-K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomView g,
-             TileRec* __restrict__ tiles, Cls4Rec* __restrict__ cls4, uint32_t* __restrict__ tier2)
+K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomView g)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= f.P) return;
@@ -90,24 +89,11 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
     g.g1[idx] = make_float4(pr.conic_c, opac, pr.p_view.z, __int_as_float(pr.radius));
     g.col[idx] = c;
     if (radii_out) radii_out[idx] = pr.radius;
-    // count the splat into its tiles: ONE returning atomic for a rectangle of at most 2x2 tiles (see TileRec)
-    pr.y0 = max(pr.y0, f.band_y0); pr.y1 = max(pr.y0, min(pr.y1, f.band_y1)); // only the band's tile rows are binned
-    const int w = pr.x1 - pr.x0, h = pr.y1 - pr.y0;
-    const uint32_t zbits = __float_as_uint(pr.p_view.z);
-    const uint32_t r0 = (uint32_t)pr.x0 | ((uint32_t)pr.y0 << 16), r1 = (uint32_t)pr.x1 | ((uint32_t)pr.y1 << 16);
-    if (w * h == 0) { g.slots[idx] = make_uint4(0u, 0u, 0u, 0u); return; }
-    if (w <= 2 && h <= 2) {
-        const uint32_t rank = atomicAdd(&tiles[pr.y0 * f.grid_x + pr.x0].cls[(w - 1) + 2 * (h - 1)], 1u);
-        g.slots[idx] = make_uint4(rank, zbits, r0, r1);
-    } else if (w <= 4 && h <= 4) { // second tier: still one atomic
-        const uint32_t rank = atomicAdd(&cls4[pr.y0 * f.grid_x + pr.x0].c[(w - 1) + 4 * (h - 1)], 1u);
-        g.slots[idx] = make_uint4(rank, zbits, r0, r1);
-        tier2[0] = 1u;
-    } else {
-        g.slots[idx] = make_uint4(0u, zbits, r0, r1);
-        for (int y = pr.y0; y < pr.y1; y++)
-            for (int x = pr.x0; x < pr.x1; x++) atomicAdd(&tiles[y * f.grid_x + x].cnt_big, 1u);
-    }
+    // the bin record of the count and fill passes; only the band's tile rows are binned
+    pr.y0 = max(pr.y0, f.band_y0); pr.y1 = max(pr.y0, min(pr.y1, f.band_y1));
+    const uint32_t ntl = (uint32_t)((pr.x1 - pr.x0) * (pr.y1 - pr.y0));
+    g.slots[idx] = make_uint4(ntl, __float_as_uint(pr.p_view.z), (uint32_t)pr.x0 | ((uint32_t)pr.y0 << 16),
+                              (uint32_t)pr.x1 | ((uint32_t)pr.y1 << 16));
 }
 
 __global__ void __launch_bounds__(256)
@@ -134,91 +120,143 @@ K_mark_visible(int P, const float* __restrict__ means3D, const float* __restrict
 // ===================================================================================
 // tile binning
 // ===================================================================================
-// Per tile, 16 lanes per tile: cnt_small and the run offsets of its list segment.
-//   first tier (TileRec): the nine (class, anchor) runs that cover the tile, off[j] = where run j+1 starts
-//   relative to the segment start (lane 0 of the group);
-//   second tier (Cls4Rec), only when some splat used it this frame: one lane per anchor (dx, dy) up-left of
-//   the tile sums the classes of its anchor that reach the tile, a 16-lane shuffle scan orders the anchors,
-//   and each lane writes the run offsets of its anchor behind the first-tier runs.
-// The one-block scan below then only reads two counters per tile.
-__global__ void __launch_bounds__(256)
-K_tile_runs(int T, int grid_x, TileRec* __restrict__ tiles, const Cls4Rec* __restrict__ cls4,
-            const uint32_t* __restrict__ tier2, uint32_t* __restrict__ run4)
+// The two passes over the splats (gsr_device.h) share the walk: one workgroup per contiguous range of `per` splats
+// and tile window; a rectangle of up to 16 tiles is walked by its own lane, larger ones are taken one at a time by
+// the whole wave (a fat splat would otherwise hold 63 lanes idle for its whole walk). hit(window tile, key) is
+// called for every (splat, tile of the window).
+struct BinWindow {
+    int brow, t0, tw, wy0, wy1;
+};
+__device__ __forceinline__ BinWindow bin_window(int T, int grid_x, int wx, int nwin)
 {
-    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), nb = threadIdx.x & 15, dx = nb & 3, dy = nb >> 2;
-    if (i >= T) return; // whole 16-lane groups leave together
-    const int ty = i / grid_x, tx = i - ty * grid_x;
-    uint32_t o1 = 0;
-    if (nb == 0) {
-        const bool L = tx > 0, U = ty > 0;
-        const uint4 me = *reinterpret_cast<const uint4*>(tiles[i].cls);
-        const uint4 le = L ? *reinterpret_cast<const uint4*>(tiles[i - 1].cls) : make_uint4(0u, 0u, 0u, 0u);
-        const uint4 up = U ? *reinterpret_cast<const uint4*>(tiles[i - grid_x].cls) : make_uint4(0u, 0u, 0u, 0u);
-        const uint32_t ul = (L && U) ? tiles[i - grid_x - 1].cls[3] : 0u;
-        const uint32_t c[9] = {me.x, me.y, le.y, me.z, up.z, me.w, le.w, up.w, ul};
-        uint32_t o = c[0];
-        uint32_t off[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) { off[j] = o; o += c[j + 1]; }
-        uint4* const dst = reinterpret_cast<uint4*>(tiles[i].off);
-        dst[0] = make_uint4(off[0], off[1], off[2], off[3]);
-        dst[1] = make_uint4(off[4], off[5], off[6], off[7]);
-        o1 = o;
-    }
-    o1 = (uint32_t)__shfl((int)o1, 0, 16);
-    uint32_t total = 0;
-    if (tier2[0]) {
-        const bool have = tx >= dx && ty >= dy;
-        uint32_t cnt[16];
-        uint32_t sum = 0;
-        const uint4* const src = reinterpret_cast<const uint4*>(cls4[have ? i - dy * grid_x - dx : i].c);
-        const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-        const uint32_t raw[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-#pragma unroll
-        for (int c = 0; c < 16; c++) {
-            const int w = (c & 3) + 1, h = (c >> 2) + 1;
-            cnt[c] = (have && w > dx && h > dy && !(w <= 2 && h <= 2)) ? raw[c] : 0u;
-            sum += cnt[c];
+    // consecutive workgroup ids go to consecutive XCDs: with wx = 8 all workgroups of one XCD work on the same eighth of the tiles
+    BinWindow w;
+    const int wi = blockIdx.x % wx + wx * blockIdx.y;
+    w.brow = blockIdx.x / wx;
+    w.t0 = (int)((int64_t)T * wi / nwin);
+    w.tw = (int)((int64_t)T * (wi + 1) / nwin) - w.t0;
+    w.wy0 = w.t0 / grid_x; w.wy1 = (w.t0 + w.tw + grid_x - 1) / grid_x; // tile rows the window touches
+    return w;
+}
+template <typename Hit>
+__device__ __forceinline__ void bin_walk(int P, int per, int grid_x, const BinWindow& w, const uint4* __restrict__ slots, Hit hit)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = w.brow * per, e = min(P, b + per);
+    // whole waves make the same number of trips. (Loading the records of several trips ahead was measured slower: 29 -> 32 us.)
+    for (int base = b; base < e; base += GSR_BIN_THREADS) {
+        const int idx = base + tid;
+        const uint4 br = idx < e ? slots[idx] : make_uint4(0u, 0u, 0u, 0u);
+        const int x0 = (int)(br.z & 0xFFFFu), y0 = (int)(br.z >> 16), x1 = (int)(br.w & 0xFFFFu), y1 = (int)(br.w >> 16);
+        const uint64_t key = ((uint64_t)br.y << 32) | (uint32_t)idx;
+        const bool wide = br.x > 16u && y0 < w.wy1 && y1 > w.wy0;
+        if (br.x != 0u && br.x <= 16u)
+            for (int y = max(y0, w.wy0); y < min(y1, w.wy1); y++)
+                for (int x = x0; x < x1; x++) {
+                    const int t = y * grid_x + x - w.t0;
+                    if ((uint32_t)t < (uint32_t)w.tw) hit(t, key);
+                }
+        uint64_t todo = __ballot(wide);
+        while (todo) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int fx0 = __shfl(x0, l, 64), fy0 = __shfl(y0, l, 64), fw = __shfl(x1, l, 64) - fx0;
+            const int n = __shfl((int)br.x, l, 64);
+            const uint64_t fkey = ((uint64_t)(uint32_t)__shfl((int)br.y, l, 64) << 32) | (uint32_t)(base + (tid & ~63) + l);
+            for (int k = lane; k < n; k += 64) {
+                const int dy = k / fw;
+                const int t = (fy0 + dy) * grid_x + fx0 + (k - dy * fw) - w.t0;
+                if ((uint32_t)t < (uint32_t)w.tw) hit(t, fkey);
+            }
         }
-        uint32_t inc = sum; // inclusive scan over the 16 anchors of the tile
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 16);
-            if (nb >= off) inc += o;
-        }
-        total = (uint32_t)__shfl((int)inc, 15, 16);
-        uint32_t o = o1 + inc - sum; // behind the first-tier runs
-        uint32_t* const row = run4 + (size_t)i * GSR_RUN4 + nb * 16;
-#pragma unroll
-        for (int c = 0; c < 16; c++) { row[c] = o; o += cnt[c]; }
     }
-    if (nb == 0) tiles[i].cnt_small = o1 + total;
+}
+__device__ __forceinline__ uint32_t lds_take(uint32_t* p)
+{
+    return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// Count pass: histogram of the window's tiles in LDS -> the range's row of the count matrix.
+__global__ void __launch_bounds__(GSR_BIN_THREADS)
+K_bin_count(int P, int per, int T, int grid_x, int wx, int nwin, GeomView g, uint32_t* __restrict__ binmat)
+{
+    extern __shared__ uint32_t s_bin[];
+    const BinWindow w = bin_window(T, grid_x, wx, nwin);
+    for (int t = threadIdx.x; t < w.tw; t += GSR_BIN_THREADS) s_bin[t] = 0u;
+    __syncthreads();
+    bin_walk(P, per, grid_x, w, g.slots, [&](int t, uint64_t) { (void)lds_take(&s_bin[t]); });
+    __syncthreads();
+    uint32_t* const row = binmat + (size_t)w.brow * T + w.t0;
+    for (int t = threadIdx.x; t < w.tw; t += GSR_BIN_THREADS) row[t] = s_bin[t];
 }
 
-// One block: per-tile counts (cnt_small, cnt_big) -> list segments (start, cursor of the big splats),
-// ranges, num_rendered and the overflow flag. Shared with the k-NN path (buckets instead of tiles).
-__global__ void __launch_bounds__(1024)
-K_scan_tiles(int T, TileRec* __restrict__ tiles, uint2* __restrict__ ranges,
-             GeomHeader* __restrict__ hdr, uint32_t capacity)
+// Fill pass: the LDS words start as the range's cursors (segment start of the tile + instances of earlier ranges);
+// every (splat, tile) takes its slot with a returning LDS atomic and stores its key there. (Sorting the keys of a
+// workgroup by tile in LDS first, so that a wave stores to as few lines as possible, was measured slower — 36.6 vs
+// 28.5 us at 1 M splats: the pass is bound by the latency of its few dependent phases, not by L2 transactions.)
+__global__ void __launch_bounds__(GSR_BIN_THREADS)
+K_bin_fill(int P, int per, int T, int grid_x, int wx, int nwin, GeomView g, const uint32_t* __restrict__ binmat,
+           const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ pairs)
 {
-    auto counts = [&](int i, uint32_t& cs, uint32_t& cb) { cs = tiles[i].cnt_small; cb = tiles[i].cnt_big; };
+    extern __shared__ uint32_t s_bin[];
+    if (g.hdr->overflow) return;
+    const BinWindow w = bin_window(T, grid_x, wx, nwin);
+    const uint32_t* const row = binmat + (size_t)w.brow * T + w.t0;
+    for (int t = threadIdx.x; t < w.tw; t += GSR_BIN_THREADS) s_bin[t] = tile_start[w.t0 + t] + row[t];
+    __syncthreads();
+    bin_walk(P, per, grid_x, w, g.slots, [&](int t, uint64_t key) { pairs[lds_take(&s_bin[t])] = key; });
+}
+
+// Exclusive scan down the columns of the count matrix, in place; column totals -> tile_cnt. One workgroup takes
+// 32 tiles x 32 row groups (a wave reads two 128-byte row segments per load), every thread keeps its <= 16 rows
+// in registers between the two passes.
+__global__ void __launch_bounds__(1024)
+K_bin_colscan(int rows, int T, uint32_t* __restrict__ binmat, uint32_t* __restrict__ tile_cnt)
+{
+    __shared__ uint32_t part[32][33];
+    static_assert(GSR_BIN_ROWS <= 32 * 16, "rows per thread");
+    const int c = threadIdx.x & 31, q = threadIdx.x >> 5, t = blockIdx.x * 32 + c;
+    const int rper = (rows + 31) / 32, r0 = q * rper, r1 = min(rows, r0 + rper);
+    uint32_t v[16];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        v[j] = (t < T && r0 + j < r1) ? binmat[(size_t)(r0 + j) * T + t] : 0u;
+        sum += v[j];
+    }
+    part[q][c] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int k = 0; k < q; k++) run += part[k][c];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (t < T && r0 + j < r1) binmat[(size_t)(r0 + j) * T + t] = run;
+        run += v[j];
+    }
+    if (q == 31 && t < T) tile_cnt[t] = run;
+}
+
+// One block: per-tile counts -> list segments (start), ranges, num_rendered and the overflow flag. Shared with the
+// k-NN path (buckets instead of tiles; its counters sit in padded records, hence the strides, in words).
+__global__ void __launch_bounds__(1024)
+K_scan_tiles(int T, const uint32_t* __restrict__ cnt, int cnt_stride, uint32_t* __restrict__ start, int start_stride,
+             uint2* __restrict__ ranges, GeomHeader* __restrict__ hdr, uint32_t capacity)
+{
     // each thread owns `per` consecutive tiles (its counts stay in registers when per <= 8), the block
     // scan is one shuffle scan per wave plus one over the 16 wave totals: two barriers in all
     __shared__ uint32_t wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int per = (T + 1023) / 1024;
     const int b = tid * per, e = min(T, b + per);
-    uint32_t ks[8], kb[8];
+    uint32_t ks[8];
     uint32_t s = 0;
     if (per <= 8) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            ks[j] = kb[j] = 0u;
-            if (j < per && b + j < e) counts(b + j, ks[j], kb[j]);
-            s += ks[j] + kb[j];
+            ks[j] = (j < per && b + j < e) ? cnt[(size_t)(b + j) * cnt_stride] : 0u;
+            s += ks[j];
         }
     } else {
-        for (int i = b; i < e; i++) { uint32_t cs, cb; counts(i, cs, cb); s += cs + cb; }
+        for (int i = b; i < e; i++) s += cnt[(size_t)i * cnt_stride];
     }
     uint32_t inc = s; // inclusive scan inside the wave
 #pragma unroll
@@ -236,53 +274,23 @@ K_scan_tiles(int T, TileRec* __restrict__ tiles, uint2* __restrict__ ranges,
         total += x;
     }
     uint32_t run = wbase + inc - s;
-    auto emit = [&](int i, uint32_t cs, uint32_t cb) {
-        const uint32_t c = cs + cb;
+    auto emit = [&](int i, uint32_t c) {
         ranges[i] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u); // empty tiles read (0,0) like the reference's memset
-        tiles[i].start = run;
-        tiles[i].cur_big = run + cs;
+        start[(size_t)i * start_stride] = run;
         run += c;
     };
     if (per <= 8) {
 #pragma unroll
         for (int j = 0; j < 8; j++)
-            if (j < per && b + j < e) emit(b + j, ks[j], kb[j]);
+            if (j < per && b + j < e) emit(b + j, ks[j]);
     } else {
-        for (int i = b; i < e; i++) { uint32_t cs, cb; counts(i, cs, cb); emit(i, cs, cb); }
+        for (int i = b; i < e; i++) emit(i, cnt[(size_t)i * cnt_stride]);
     }
     if (tid == 0) {
-
         hdr->num_rendered = total;
         hdr->overflow = total > capacity ? 1u : 0u;
         hdr->capacity = capacity;
     }
-}
-
-// After the scan: the anchor table (gsr_device.h). One block per anchor tile, one thread per entry.
-__global__ void __launch_bounds__(GSR_ANCHOR_ROW)
-K_anchor_table(int T, int grid_x, const TileRec* __restrict__ tiles, const uint32_t* __restrict__ tier2,
-               const uint32_t* __restrict__ run4, uint32_t* __restrict__ anchor)
-{
-    const int A = blockIdx.x, e = threadIdx.x;
-    if (e >= 100) return;
-    int w = 1, h = 1; // decode e -> class (w, h) and tile (dx, dy) of its rectangle
-#pragma unroll
-    for (int hh = 1; hh <= 4; hh++)
-#pragma unroll
-        for (int ww = 1; ww <= 4; ww++)
-            if (e >= anchor_base(ww, hh)) { w = ww; h = hh; }
-    const int k = e - anchor_base(w, h), dx = k % w, dy = k / w;
-    const bool first_tier = w <= 2 && h <= 2;
-    if (!first_tier && !tier2[0]) return;
-    const int ax = A % grid_x, t = A + dy * grid_x + dx;
-    if (ax + dx >= grid_x || t >= T) return; // no rectangle of this class is anchored here
-    uint32_t pos = tiles[t].start;
-    if (first_tier) {
-        const int c2 = (w - 1) + 2 * (h - 1);
-        const int run = (c2 == 0 ? 0 : c2 == 1 ? 1 : c2 == 2 ? 3 : 5) + (c2 == 3 ? dx + 2 * dy : dx + dy);
-        if (run) pos += tiles[t].off[run - 1];
-    } else pos += run4[(size_t)t * GSR_RUN4 + (dy * 4 + dx) * 16 + (w - 1) + 4 * (h - 1)];
-    anchor[(size_t)A * GSR_ANCHOR_ROW + e] = pos;
 }
 
 // the forward's capacity guess was too small: switch the header to the exact capacity before the tail re-runs
@@ -290,29 +298,6 @@ __global__ void K_set_capacity(GeomHeader* hdr, uint32_t capacity)
 {
     hdr->capacity = capacity;
     hdr->overflow = hdr->num_rendered > capacity ? 1u : 0u;
-}
-
-__global__ void __launch_bounds__(256)
-K_fill(int P, int grid_x, GeomView g, TileRec* __restrict__ tiles, const uint32_t* __restrict__ anchor,
-       uint64_t* __restrict__ pairs)
-{
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P || g.hdr->overflow) return;
-    const uint4 br = g.slots[idx]; // everything this pass needs, written by K_preprocess
-    const int x0 = (int)(br.z & 0xFFFFu), y0 = (int)(br.z >> 16), x1 = (int)(br.w & 0xFFFFu), y1 = (int)(br.w >> 16);
-    const uint64_t key = ((uint64_t)br.y << 32) | (uint32_t)idx;
-    const int w = x1 - x0, h = y1 - y0;
-    if (w * h == 0) return;
-    if (w <= 4 && h <= 4) { // the rank was taken when the splat was counted: no atomics, one table row per splat
-        const uint32_t* __restrict__ row = anchor + (size_t)(y0 * grid_x + x0) * GSR_ANCHOR_ROW + anchor_base(w, h);
-        const int ntl = w * h;
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            if (k < ntl) pairs[row[k] + br.x] = key;
-    } else {
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) pairs[atomicAdd(&tiles[y * grid_x + x].cur_big, 1u)] = key;
-    }
 }
 
 // All-ascending bitonic network ("flip" then "disperse" stages): every compare-exchange

@@ -26,10 +26,18 @@ namespace gsr {
 
 #define GSR_KNN_BOX 1024
 
+// Bucket counter padded to its own 64-byte line: device-scope atomics on counters that share a line serialise
+// (measured 12 vs 23 G atomics/s on MI355X).
+struct BucketRec {
+    uint32_t cnt, start;
+    uint32_t pad[14];
+};
+static_assert(sizeof(BucketRec) == 64, "one line per bucket");
+
 struct KnnView {
     GeomHeader* hdr;
     uint32_t* bbox;     // [6] ordered-uint min xyz, max xyz
-    TileRec* buckets;   // [nb]
+    BucketRec* buckets; // [nb]
     uint2* ranges;      // [nb]
     uint64_t* pairs;    // [P]
     uint32_t* order;    // [P] Morton-sorted point indices
@@ -52,7 +60,7 @@ __host__ __device__ inline size_t knn_layout(char* base, int P, KnnView* v)
     KnnView k;
     k.hdr = (GeomHeader*)(base + off); off = gsr_align_up(off + sizeof(GeomHeader));
     k.bbox = (uint32_t*)(base + off); off = gsr_align_up(off + 32);
-    k.buckets = (TileRec*)(base + off); off = gsr_align_up(off + nb * sizeof(TileRec));
+    k.buckets = (BucketRec*)(base + off); off = gsr_align_up(off + nb * sizeof(BucketRec));
     k.ranges = (uint2*)(base + off); off = gsr_align_up(off + nb * 8);
     k.pairs = (uint64_t*)(base + off); off = gsr_align_up(off + Pz * 8);
     k.order = (uint32_t*)(base + off); off = gsr_align_up(off + Pz * 4);
@@ -115,7 +123,7 @@ __device__ __forceinline__ uint32_t morton_axis(float c, float lo, float hi)
 
 __global__ void __launch_bounds__(256)
 K_knn_code(int P, int bucket_shift, const float* __restrict__ pts, const uint32_t* __restrict__ bbox,
-           TileRec* __restrict__ buckets, uint32_t* __restrict__ code, uint32_t* __restrict__ slot)
+           BucketRec* __restrict__ buckets, uint32_t* __restrict__ code, uint32_t* __restrict__ slot)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
@@ -123,12 +131,12 @@ K_knn_code(int P, int bucket_shift, const float* __restrict__ pts, const uint32_
     const uint32_t c = morton_axis(x, ord2f(bbox[0]), ord2f(bbox[3])) | (morton_axis(y, ord2f(bbox[1]), ord2f(bbox[4])) << 1) |
                        (morton_axis(z, ord2f(bbox[2]), ord2f(bbox[5])) << 2);
     code[i] = c;
-    slot[i] = atomicAdd(&buckets[c >> bucket_shift].cnt_small, 1u);
+    slot[i] = atomicAdd(&buckets[c >> bucket_shift].cnt, 1u);
 }
 
 __global__ void __launch_bounds__(256)
 K_knn_fill(int P, int bucket_shift, const uint32_t* __restrict__ code, const uint32_t* __restrict__ slot,
-           const TileRec* __restrict__ buckets, uint64_t* __restrict__ pairs)
+           const BucketRec* __restrict__ buckets, uint64_t* __restrict__ pairs)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;

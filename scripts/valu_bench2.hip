@@ -86,6 +86,12 @@ DEFK(k_ds_rmw, "ds_read_b32 v40, %16", "v_add_f32 %0, %0, %9", "v_add_f32 %1, %1
      "v_add_f32 v40, v40, %9", "ds_write_b32 %16, v40", "v_add_f32 %5, %5, %9", "v_add_f32 %6, %6, %9")
 DEFK(k_ds_add_f32, "ds_add_f32 %16, %12", "v_add_f32 %0, %0, %9", "v_add_f32 %1, %1, %9", "v_add_f32 %2, %2, %9",
      "v_add_f32 %3, %3, %9", "v_add_f32 %4, %4, %9", "v_add_f32 %5, %5, %9", "v_add_f32 %6, %6, %9")
+DEFK(k_ds_add_u32, "ds_add_u32 %16, %16", "v_add_f32 %0, %0, %9", "v_add_f32 %1, %1, %9", "v_add_f32 %2, %2, %9",
+     "v_add_f32 %3, %3, %9", "v_add_f32 %4, %4, %9", "v_add_f32 %5, %5, %9", "v_add_f32 %6, %6, %9")
+DEFK(k_ds_add_rtn_u32, "ds_add_rtn_u32 v40, %16, %16", "v_add_f32 %0, %0, %9", "v_add_f32 %1, %1, %9", "v_add_f32 %2, %2, %9",
+     "v_add_f32 %3, %3, %9", "v_add_f32 %4, %4, %9", "v_add_f32 %5, %5, %9", "s_waitcnt lgkmcnt(0)")
+DEFK(k_ds_add_rtn_u32_x4, "ds_add_rtn_u32 v40, %16, %16", "ds_add_rtn_u32 v41, %16, %16 offset:1024", "ds_add_rtn_u32 v42, %16, %16 offset:2048", "ds_add_rtn_u32 v43, %16, %16 offset:3072",
+     "v_add_f32 %3, %3, %9", "v_add_f32 %4, %4, %9", "v_add_f32 %5, %5, %9", "s_waitcnt lgkmcnt(0)")
 DEFK(k_ds_swizzle, "ds_swizzle_b32 v40, %12 offset:swizzle(SWAP,8)", "v_add_f32 %0, %0, %9", "v_add_f32 %1, %1, %9", "v_add_f32 %2, %2, %9",
      "ds_swizzle_b32 v41, %13 offset:swizzle(SWAP,4)", "v_add_f32 %4, %4, %9", "v_add_f32 %5, %5, %9", "s_waitcnt lgkmcnt(0)")
 DEFK(k_ds_bpermute, "ds_bpermute_b32 v40, %16, %12", "v_add_f32 %0, %0, %9", "v_add_f32 %1, %1, %9", "v_add_f32 %2, %2, %9",
@@ -119,7 +125,8 @@ int main()
         E("baseline: 7 v_add + s_nop per 8", k_adds_only7),
         E("s_and vcc; cnd vcc; 2 add; cnd vcc; 3 add", k_salu_vcc_cnd), E("s_and s[]; cnd_e64; 2 add; cnd_e64; 3 add", k_salu_s_cnd),
         E("v_cmp vcc; cnd vcc; 2 add; cnd vcc; 3 add", k_cmp_vcc_cnd2),
-        E("2 ds_read_b128 + 5 add + wait", k_ds_read_b128), E("ds_read_b32;2 add;wait;add;ds_write;2 add", k_ds_rmw), E("ds_add_f32 + 7 add", k_ds_add_f32),
+        E("2 ds_read_b128 + 5 add + wait", k_ds_read_b128), E("ds_read_b32;2 add;wait;add;ds_write;2 add", k_ds_rmw), E("ds_add_f32 + 7 add", k_ds_add_f32), E("ds_add_u32 + 7 add", k_ds_add_u32), E("ds_add_rtn_u32 + 6 add + wait", k_ds_add_rtn_u32),
+        E("4 ds_add_rtn_u32 + 3 add + wait", k_ds_add_rtn_u32_x4),
         E("2 ds_swizzle + 5 add + wait", k_ds_swizzle), E("2 ds_bpermute + 5 add + wait", k_ds_bpermute),
         E("1 mfma16x16x4f32 + 7 add", k_mfma_16x16x4), E("8 mfma16x16x4f32", k_mfma_only), E("1 mfma4x4x1_16b + 7 add", k_mfma_4x4),
     };

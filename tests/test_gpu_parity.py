@@ -404,3 +404,21 @@ def test_large_frame_more_than_8192_tiles(gsr, syn):
         assert e <= TOL, (n, e)
         assert m <= 1.0, (n, "element-wise bar |a-b| <= 1e-4|b| + 1e-6 max|b| exceeded by x%.2f" % m)
     print("%s: gradients (tensor-scale rel_err, element-wise ratio):" % name, {k: "%.1e / %.2f" % v for k, v in worst.items()})
+
+
+@pytest.mark.gpu
+def test_huge_frame_more_than_131072_tiles(gsr, syn):
+    """8192x4112 = 512x257 = 131584 tiles: the count pass histograms the frame in nine LDS windows and the fill pass in
+    sixteen (two per XCD), with splats from one tile to thousands of tiles wide. Integer stages bit-exact."""
+    cam = syn.make_camera(8192, 4112, 4000.0, 4000.0)
+    sc = syn.make_scene(30000, cam, seed=11, scale_mult=5.0, frac_offscreen=0.1)
+    sc.scales[::97] *= 40.0  # a few splats that cover hundreds of tile rows
+    o, f = oracle.forward_scene(sc, omp=True)
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    d = gsr.debug_export(st)
+    assert st.num_rendered == f.num_rendered
+    np.testing.assert_array_equal(st.radii.cpu().numpy(), f.radii)
+    np.testing.assert_array_equal(d["ranges"], f.stages["ranges"])
+    np.testing.assert_array_equal(d["point_list"], f.stages["point_list"])
+    assert (f.stages["ranges"][:, 1] - f.stages["ranges"][:, 0]).max() > 0
