@@ -406,10 +406,50 @@ __device__ __forceinline__ void lds_sort(uint64_t* s, int cap)
     }
 }
 
-// Two instantiations share the tiles: SMALL sorts tiles of <= 1024 entries with ONE wave (16 keys per lane
-// and trip, 8 KB of LDS, no s_barrier), the other takes the longer lists with 256 threads and 32 KB; each
-// skips the other's tiles.
+// Wave-wide inclusive scan / reduction in eight DPP instructions (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then
+// row_bcast15 / row_bcast31 across rows) instead of six dependent ds_bpermute round trips per __shfl scan.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWS, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) // inclusive
+{
+    v += dpp_u<0x111, 0xf>(0u, v);
+    v += dpp_u<0x112, 0xf>(0u, v);
+    v += dpp_u<0x114, 0xf>(0u, v);
+    v += dpp_u<0x118, 0xf>(0u, v);
+    v += dpp_u<0x142, 0xa>(0u, v); // lane 15 of rows 0, 2 -> rows 1, 3
+    v += dpp_u<0x143, 0xc>(0u, v); // lane 31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) // the result, in every lane
+{
+    v = min(v, dpp_u<0x111, 0xf>(v, v)); v = min(v, dpp_u<0x112, 0xf>(v, v));
+    v = min(v, dpp_u<0x114, 0xf>(v, v)); v = min(v, dpp_u<0x118, 0xf>(v, v));
+    v = min(v, dpp_u<0x142, 0xa>(v, v)); v = min(v, dpp_u<0x143, 0xc>(v, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v)
+{
+    v = max(v, dpp_u<0x111, 0xf>(v, v)); v = max(v, dpp_u<0x112, 0xf>(v, v));
+    v = max(v, dpp_u<0x114, 0xf>(v, v)); v = max(v, dpp_u<0x118, 0xf>(v, v));
+    v = max(v, dpp_u<0x142, 0xa>(v, v)); v = max(v, dpp_u<0x143, 0xc>(v, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Two instantiations share the tiles: SMALL sorts tiles of <= 1024 entries with ONE wave (16 keys per lane,
+// no s_barrier), the other takes the longer lists with 256 threads; each skips the other's tiles.
+//
+// A list that fits LDS is bucket-sorted first: the high word of a key (depth bits, or Morton code on the k-NN path)
+// maps monotonically to one of CAP bins spread over the list's own [min, max], a returning LDS atomic counts the
+// bin and ranks the key inside it, a scan turns counts into bin starts, and every key finds its final place as
+// bin start + the number of smaller keys (full 64-bit compare) in its bin. With depths spread over the tile's
+// range a bin holds one or two keys and the whole sort is ~7 LDS operations per key, against 30 LDS operations and
+// 27 compare-exchanges per key of the bitonic network; a list whose keys crowd into few bins (sum of squared bin
+// counts > 8 n: the ranking loops would cost more than the network) falls back to the network.
 #define GSR_SORT_SMALL 1024
+#define GSR_SORT_MATES 16 // keys of a lane that look at their bin-mates together (measured 4 / 8 / 16: 25.0 / 25.9 / 23.9 us)
 #define GSR_SORT_G 4              // 16 keys per thread and trip
 #define GSR_SORT_SMALL_THREADS 64
 #define GSR_SORT_BIG_THREADS 256  // 1024 threads per 4096-key tile measured no faster
@@ -418,14 +458,128 @@ __global__ void __launch_bounds__(SMALL ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_
 K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __restrict__ hdr,
             uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list)
 {
-    __shared__ uint64_t s[SMALL ? GSR_SORT_SMALL : GSR_SORT_CAP];
+    constexpr int NT = SMALL ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS, CAP = SMALL ? GSR_SORT_SMALL : GSR_SORT_CAP;
+    constexpr int EPT = CAP / NT, LOGCAP = SMALL ? 10 : 12;
+    static_assert(EPT == 16 && (1 << LOGCAP) == CAP, "sixteen keys and sixteen bins per thread");
+    __shared__ uint64_t s[CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t h[CAP + 4];
+    __shared__ uint32_t red[3][NT / 64];
     const uint32_t tile = xcd_remap(blockIdx.x, ntiles);
     if (hdr->overflow) return;
     const uint2 r = ranges[tile];
     const int n = (int)(r.y - r.x);
     if (n == 0 || (n <= GSR_SORT_SMALL) != SMALL) return;
     uint64_t* seg = pairs + r.x;
-    if (n <= GSR_SORT_CAP) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (n <= CAP) {
+        // Straight-line code: a load inside a divergent branch is waited for inside that branch, sixteen branches would be
+        // sixteen serial round trips. Loads use clamped addresses and selects, only stores are predicated.
+        uint64_t k[EPT];
+        uint32_t dmin = ~0u, dmax = 0u;
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            const int i = j * NT + tid;
+            const uint64_t v = seg[min(i, n - 1)];
+            k[j] = i < n ? v : ~0ull; // padding keys: above every real key
+            dmin = min(dmin, (uint32_t)(k[j] >> 32));
+            dmax = max(dmax, i < n ? (uint32_t)(v >> 32) : 0u);
+            h[i] = 0u;
+        }
+        dmin = wave_min_u32(dmin);
+        dmax = wave_max_dpp(dmax);
+        if (!SMALL) {
+            if (lane == 0) { red[0][wv] = dmin; red[1][wv] = dmax; }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NT / 64; q++) { dmin = min(dmin, red[0][q]); dmax = max(dmax, red[1][q]); }
+        }
+        sort_sync<SMALL>();
+        const int shift = max(0, 32 - __clz((int)(dmax - dmin)) - LOGCAP); // (dmax - dmin) >> shift < CAP
+        uint32_t bin[EPT], rnk[EPT]; // rank of the key inside its bin, in arrival order
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            const bool valid = j * NT + tid < n;
+            bin[j] = valid ? ((uint32_t)(k[j] >> 32) - dmin) >> shift : (uint32_t)(CAP + (lane & 3)); // padding: four spare words
+            rnk[j] = __hip_atomic_fetch_add(&h[bin[j]], valid ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        sort_sync<SMALL>();
+        // counts -> bin starts: every thread owns sixteen consecutive bins
+        uint32_t c[EPT];
+#pragma unroll
+        for (int q = 0; q < EPT / 4; q++) {
+            const uint4 v = reinterpret_cast<const uint4*>(h)[tid * (EPT / 4) + q];
+            c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+        }
+        uint32_t sum = 0, sq = 0;
+#pragma unroll
+        for (int j = 0; j < EPT; j++) { sum += c[j]; sq += c[j] * c[j]; }
+        const uint32_t inc = wave_scan_add(sum);
+        sq = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add(sq), 63);
+        uint32_t run = inc - sum;
+        if (!SMALL) {
+            if (lane == 63) red[0][wv] = inc;
+            if (lane == 0) red[2][wv] = sq;
+            __syncthreads();
+            sq = 0;
+#pragma unroll
+            for (int q = 0; q < NT / 64; q++) { if (q < wv) run += red[0][q]; sq += red[2][q]; }
+        }
+        if (sq <= 8u * (uint32_t)n) {
+#pragma unroll
+            for (int q = 0; q < EPT / 4; q++) { // bin start | count << 16: one random read per key instead of two
+                uint4 v;
+                v.x = run | (c[4 * q] << 16); run += c[4 * q]; v.y = run | (c[4 * q + 1] << 16); run += c[4 * q + 1];
+                v.z = run | (c[4 * q + 2] << 16); run += c[4 * q + 2]; v.w = run | (c[4 * q + 3] << 16); run += c[4 * q + 3];
+                reinterpret_cast<uint4*>(h)[tid * (EPT / 4) + q] = v;
+            }
+            sort_sync<SMALL>();
+            uint32_t sb[EPT]; // bin start | keys of the bin below this one << 16
+#pragma unroll
+            for (int j = 0; j < EPT; j++) {
+                const bool valid = j * NT + tid < n;
+                const uint32_t sc = h[bin[j]];
+                sb[j] = sc & 0xFFFFu;
+                if (valid) s[sb[j] + rnk[j]] = k[j];
+                rnk[j] = valid ? rnk[j] | (sc & 0xFFFF0000u) : 0u; // rank | bin count << 16 (padding: the spare words hold anything)
+            }
+            sort_sync<SMALL>();
+            // rank inside the bin = the number of smaller keys among the OTHER keys of the bin (most bins hold one key: nothing
+            // to do). The keys of a lane step through their bin-mates together: the reads of one step are issued back to
+            // back and waited for once; a key without a further mate reads word 0 (a broadcast, no bank conflict).
+#pragma unroll
+            for (int j0 = 0; j0 < EPT; j0 += GSR_SORT_MATES) {
+                for (uint32_t q = 1;; q++) {
+                    bool more = false;
+#pragma unroll
+                    for (int j = j0; j < j0 + GSR_SORT_MATES; j++) more |= q < (rnk[j] >> 16);
+                    if (!__builtin_amdgcn_ballot_w64(more)) break;
+                    uint64_t mate[GSR_SORT_MATES];
+#pragma unroll
+                    for (int j = j0; j < j0 + GSR_SORT_MATES; j++) {
+                        const uint32_t cnt = rnk[j] >> 16;
+                        uint32_t o = (rnk[j] & 0xFFFFu) + q;
+                        o = o >= cnt ? o - cnt : o;
+                        mate[j - j0] = s[q < cnt ? (sb[j] & 0xFFFFu) + o : 0u];
+                    }
+#pragma unroll
+                    for (int j = j0; j < j0 + GSR_SORT_MATES; j++) sb[j] += (q < (rnk[j] >> 16) && mate[j - j0] < k[j]) ? 0x10000u : 0u;
+                }
+            }
+            // ids to their places in LDS, then out in order (the counts in h are dead: every lane read them before the barrier above)
+#pragma unroll
+            for (int j = 0; j < EPT; j++)
+                if (j * NT + tid < n) h[(sb[j] & 0xFFFFu) + (sb[j] >> 16)] = (uint32_t)k[j];
+            sort_sync<SMALL>();
+#pragma unroll
+            for (int j = 0; j < EPT; j++) {
+                const uint32_t id = h[j * NT + tid];
+                if (j * NT + tid < n) point_list[r.x + j * NT + tid] = id;
+            }
+            return;
+        }
+        sort_sync<SMALL>();
+    }
+    if (n <= CAP) { // crowded bins: the bitonic network
         int n2 = 1 << GSR_SORT_G;
         while (n2 < n) n2 <<= 1;
         for (int i = threadIdx.x; i < n2; i += blockDim.x) s[swz(i)] = i < n ? seg[i] : ~0ull;

@@ -1,6 +1,6 @@
 #!/bin/bash
-# per-kernel average durations of one bench run (rocprofv3 --kernel-trace --stats)
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kst && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu --mode rasterize "$@" > /tmp/kst.log 2>&1
+# per-kernel average durations of one bench run (timeout 300 rocprofv3 --kernel-trace --stats)
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kst && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu --mode rasterize "$@" > /tmp/kst.log 2>&1
 python - <<PY
 import csv,glob
 f=glob.glob("/tmp/kst/**/*kernel_stats.csv",recursive=True)[0]
