@@ -422,3 +422,34 @@ def test_huge_frame_more_than_131072_tiles(gsr, syn):
     np.testing.assert_array_equal(d["ranges"], f.stages["ranges"])
     np.testing.assert_array_equal(d["point_list"], f.stages["point_list"])
     assert (f.stages["ranges"][:, 1] - f.stages["ranges"][:, 0]).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["planes", "wall+outlier", "all-equal"])
+def test_sort_order_with_depth_ties_and_crowded_bins(gsr, syn, layout):
+    """The tile sort bins keys over the tile's own depth range and ranks inside a bin; lists whose depths crowd into few
+    bins take the bitonic network instead. Exact depth ties (order by splat id, like the reference's stable radix sort),
+    a thin wall plus one far outlier (everything in two bins) and a single depth for the whole map: point_list bit-exact."""
+    cam = syn.make_camera(320, 240, 240.0, 240.0)
+    sc = syn.make_scene(60000, cam, seed=21, scale_mult=1.5)
+    rng = np.random.default_rng(5)
+    z = sc.means3D[:, 2].copy()
+    if layout == "planes":
+        z = np.float32(1.0) + np.float32(0.5) * rng.integers(0, 3, len(z)).astype(np.float32)
+    elif layout == "wall+outlier":
+        z = (2.0 + 1e-4 * rng.random(len(z))).astype(np.float32)
+        z[::50] = 40.0
+    else:
+        z[:] = 1.5
+    scale = z / sc.means3D[:, 2]  # keep every splat on its pixel ray: same tiles, new depth
+    sc.means3D = (sc.means3D * scale[:, None]).astype(np.float32)
+    sc.means3D[:, 2] = z
+    o, f = oracle.forward_scene(sc, omp=True)
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    d = gsr.debug_export(st)
+    assert st.num_rendered == f.num_rendered
+    lens = f.stages["ranges"][:, 1] - f.stages["ranges"][:, 0]
+    assert lens.max() > 1024 and (lens[lens > 0] <= 1024).any()  # both sort kernels run
+    np.testing.assert_array_equal(d["ranges"], f.stages["ranges"])
+    np.testing.assert_array_equal(d["point_list"], f.stages["point_list"])
