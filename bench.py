@@ -163,6 +163,9 @@ def main():
                     help="rasterize: the headline fwd+bwd line only; shard-step: only the sharded mapping/tracking step; all: both")
     ap.add_argument("--shard-steps", type=int, default=20, help="timed iterations of each shard_step loop")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--splat-order", choices=["map", "tile"], default="map",
+                    help="experiment: 'tile' hands the splats over sorted by the 16x16 tile of their projected centre "
+                         "(what a spatially coherent map order would buy the gathers); 'map' = the headline workload")
     ap.add_argument("--scale-mult", type=float, default=1.0, help="splat size multiplier (1 = the headline workload; >1: fatter splats, for experiments)")
     a = ap.parse_args()
 
@@ -204,6 +207,14 @@ def rasterize(a, gsr, td, rank, world, dev):
     cam = syn.make_camera(**syn.CAMERAS[a.camera])
     W, H = cam.width, cam.height
     sc = syn.make_scene(P, cam, seed=rank, scale_mult=a.scale_mult)  # each rank: its own scene shard
+    if a.splat_order == "tile":
+        import numpy as np
+        u = sc.means3D[:, 0] / sc.means3D[:, 2] * cam.fx + cam.width / 2
+        v = sc.means3D[:, 1] / sc.means3D[:, 2] * cam.fy + cam.height / 2
+        key = (np.clip(v // 16, 0, 4095).astype(np.int64) << 12) | np.clip(u // 16, 0, 4095).astype(np.int64)
+        perm = np.argsort(key, kind="stable")
+        for n in ("means3D", "opacities", "colors", "scales", "rotations"):
+            setattr(sc, n, np.ascontiguousarray(getattr(sc, n)[perm]))
     s = gsr.capi.Settings.from_camera(cam, device=dev)
     t = lambda x: torch.as_tensor(x, dtype=torch.float32, device=dev).contiguous()
     ins = dict(means3D=t(sc.means3D), opacities=t(sc.opacities), colors=t(sc.colors), shs=None,
