@@ -163,6 +163,9 @@ def main():
                     help="rasterize: the headline fwd+bwd line only; shard-step: only the sharded mapping/tracking step; all: both")
     ap.add_argument("--shard-steps", type=int, default=20, help="timed iterations of each shard_step loop")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--depth-layout", choices=["uniform", "two-walls"], default="uniform",
+                    help="experiment: 'two-walls' moves every splat along its pixel ray onto one of two thin depth slabs "
+                         "(1.5 m and 4 m, 2 cm thick): every tile list has two depth clusters, the tile sort's hard case")
     ap.add_argument("--splat-order", choices=["map", "tile"], default="map",
                     help="experiment: 'tile' hands the splats over sorted by the 16x16 tile of their projected centre "
                          "(what a spatially coherent map order would buy the gathers); 'map' = the headline workload")
@@ -207,6 +210,11 @@ def rasterize(a, gsr, td, rank, world, dev):
     cam = syn.make_camera(**syn.CAMERAS[a.camera])
     W, H = cam.width, cam.height
     sc = syn.make_scene(P, cam, seed=rank, scale_mult=a.scale_mult)  # each rank: its own scene shard
+    if a.depth_layout == "two-walls":
+        import numpy as np
+        rng = np.random.default_rng(3)
+        z = np.where(rng.random(P) < 0.5, 1.5, 4.0) + 0.02 * rng.random(P)
+        sc.means3D = (sc.means3D * (z / sc.means3D[:, 2])[:, None]).astype(np.float32)
     if a.splat_order == "tile":
         import numpy as np
         u = sc.means3D[:, 0] / sc.means3D[:, 2] * cam.fx + cam.width / 2

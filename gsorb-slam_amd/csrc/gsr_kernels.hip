@@ -446,8 +446,10 @@ __device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v)
 // bin and ranks the key inside it, a scan turns counts into bin starts, and every key finds its final place as
 // bin start + the number of smaller keys (full 64-bit compare) in its bin. With depths spread over the tile's
 // range a bin holds one or two keys and the whole sort is ~7 LDS operations per key, against 30 LDS operations and
-// 27 compare-exchanges per key of the bitonic network; a list whose keys crowd into few bins (sum of squared bin
-// counts > 8 n: the ranking loops would cost more than the network) falls back to the network.
+// 27 compare-exchanges per key of the bitonic network. A list whose keys crowd into few bins (sum of squared bin
+// counts > 8 n: the ranking loops would cost more than the network — two surfaces in one tile, a far outlier) is
+// binned a second time with equalised bins (every non-empty bin cut into sub-bins in proportion to its count), and
+// only if that does not spread the keys either (exact depth ties) the list is sorted by the network.
 #define GSR_SORT_SMALL 1024
 #define GSR_SORT_MATES 16 // keys of a lane that look at their bin-mates together (measured 4 / 8 / 16: 25.0 / 25.9 / 23.9 us)
 #define GSR_SORT_G 4              // 16 keys per thread and trip
@@ -463,7 +465,7 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
     static_assert(EPT == 16 && (1 << LOGCAP) == CAP, "sixteen keys and sixteen bins per thread");
     __shared__ uint64_t s[CAP];
     __shared__ __attribute__((aligned(16))) uint32_t h[CAP + 4];
-    __shared__ uint32_t red[3][NT / 64];
+    __shared__ uint32_t red[9][NT / 64];
     const uint32_t tile = xcd_remap(blockIdx.x, ntiles);
     if (hdr->overflow) return;
     const uint2 r = ranges[tile];
@@ -503,28 +505,70 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
             rnk[j] = __hip_atomic_fetch_add(&h[bin[j]], valid ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         sort_sync<SMALL>();
-        // counts -> bin starts: every thread owns sixteen consecutive bins
-        uint32_t c[EPT];
+        // counts -> bin starts: every thread owns sixteen consecutive bins. SLOT: which words of `red` a call may use
+        // (every call its own: no barrier needed between the calls)
+        auto block_sums = [&](const uint32_t v, const int slot, uint32_t& before, uint32_t& total) {
+            const uint32_t inc = wave_scan_add(v);
+            before = inc - v;
+            total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            if (!SMALL) {
+                if (lane == 63) red[slot][wv] = inc;
+                __syncthreads();
+                total = 0;
 #pragma unroll
-        for (int q = 0; q < EPT / 4; q++) {
-            const uint4 v = reinterpret_cast<const uint4*>(h)[tid * (EPT / 4) + q];
-            c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+                for (int q = 0; q < NT / 64; q++) { if (q < wv) before += red[slot][q]; total += red[slot][q]; }
+            }
+        };
+        uint32_t c[EPT], run, sq, nz;
+        auto scan_counts = [&](const uint32_t* arr, const int slot) {
+#pragma unroll
+            for (int q = 0; q < EPT / 4; q++) {
+                const uint4 v = reinterpret_cast<const uint4*>(arr)[tid * (EPT / 4) + q];
+                c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+            }
+            uint32_t sum = 0, sq_own = 0, nz_own = 0, t;
+#pragma unroll
+            for (int j = 0; j < EPT; j++) { sum += c[j]; sq_own += c[j] * c[j]; nz_own += c[j] ? 1u : 0u; }
+            block_sums(sum, slot, run, t);
+            block_sums(sq_own, slot + 1, t, sq);
+            block_sums(nz_own, slot + 2, t, nz);
+        };
+        scan_counts(h, 2);
+        bool crowded = sq > 8u * (uint32_t)n;
+        if (crowded && shift > 0) {
+            // The depths crowd into few of the equal-width bins (two surfaces in one tile, a far outlier). Second attempt with
+            // equalised bins: every non-empty bin is cut into a number of sub-bins proportional to its count, CAP in all,
+            // and the keys are binned again by their position inside the old bin. Still monotone in the depth bits.
+            uint32_t* const h2 = reinterpret_cast<uint32_t*>(s); // the keys are in registers: s is free until they are placed
+            const float share = (float)((uint32_t)CAP - nz) / (float)n * 0.999f;
+            uint32_t nsub[EPT], tot = 0, first, t;
+#pragma unroll
+            for (int j = 0; j < EPT; j++) { nsub[j] = c[j] ? 1u + (uint32_t)((float)c[j] * share) : 0u; tot += nsub[j]; }
+            block_sums(tot, 5, first, t);
+#pragma unroll
+            for (int q = 0; q < EPT / 4; q++) { // first sub-bin | sub-bins << 16
+                uint4 v;
+                v.x = first | (nsub[4 * q] << 16); first += nsub[4 * q]; v.y = first | (nsub[4 * q + 1] << 16); first += nsub[4 * q + 1];
+                v.z = first | (nsub[4 * q + 2] << 16); first += nsub[4 * q + 2]; v.w = first | (nsub[4 * q + 3] << 16); first += nsub[4 * q + 3];
+                reinterpret_cast<uint4*>(h)[tid * (EPT / 4) + q] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < EPT; j++) h2[j * NT + tid] = 0u;
+            sort_sync<SMALL>();
+            const int down = max(0, shift - 16), frac = min(shift, 16); // position inside the old bin, in 16 bits
+#pragma unroll
+            for (int j = 0; j < EPT; j++) {
+                const bool valid = j * NT + tid < n;
+                const uint32_t m = h[min(bin[j], (uint32_t)CAP - 1u)];
+                const uint32_t inside = (((uint32_t)(k[j] >> 32) - dmin) - (bin[j] << shift)) >> down;
+                bin[j] = valid ? (m & 0xFFFFu) + ((inside * (m >> 16)) >> frac) : (uint32_t)(CAP + (lane & 3));
+                rnk[j] = __hip_atomic_fetch_add(&h2[bin[j]], valid ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            sort_sync<SMALL>();
+            scan_counts(h2, 6);
+            crowded = sq > 8u * (uint32_t)n;
         }
-        uint32_t sum = 0, sq = 0;
-#pragma unroll
-        for (int j = 0; j < EPT; j++) { sum += c[j]; sq += c[j] * c[j]; }
-        const uint32_t inc = wave_scan_add(sum);
-        sq = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add(sq), 63);
-        uint32_t run = inc - sum;
-        if (!SMALL) {
-            if (lane == 63) red[0][wv] = inc;
-            if (lane == 0) red[2][wv] = sq;
-            __syncthreads();
-            sq = 0;
-#pragma unroll
-            for (int q = 0; q < NT / 64; q++) { if (q < wv) run += red[0][q]; sq += red[2][q]; }
-        }
-        if (sq <= 8u * (uint32_t)n) {
+        if (!crowded) {
 #pragma unroll
             for (int q = 0; q < EPT / 4; q++) { // bin start | count << 16: one random read per key instead of two
                 uint4 v;

@@ -425,11 +425,12 @@ def test_huge_frame_more_than_131072_tiles(gsr, syn):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("layout", ["planes", "wall+outlier", "all-equal"])
+@pytest.mark.parametrize("layout", ["planes", "wall+outlier", "two-slabs", "all-equal"])
 def test_sort_order_with_depth_ties_and_crowded_bins(gsr, syn, layout):
     """The tile sort bins keys over the tile's own depth range and ranks inside a bin; lists whose depths crowd into few
     bins take the bitonic network instead. Exact depth ties (order by splat id, like the reference's stable radix sort),
-    a thin wall plus one far outlier (everything in two bins) and a single depth for the whole map: point_list bit-exact."""
+    a thin wall plus one far outlier (everything in two bins), two 2-cm slabs (the equalised second binning succeeds) and a
+    single depth for the whole map: point_list bit-exact."""
     cam = syn.make_camera(320, 240, 240.0, 240.0)
     sc = syn.make_scene(60000, cam, seed=21, scale_mult=1.5)
     rng = np.random.default_rng(5)
@@ -439,6 +440,8 @@ def test_sort_order_with_depth_ties_and_crowded_bins(gsr, syn, layout):
     elif layout == "wall+outlier":
         z = (2.0 + 1e-4 * rng.random(len(z))).astype(np.float32)
         z[::50] = 40.0
+    elif layout == "two-slabs":
+        z = (np.where(rng.random(len(z)) < 0.5, 1.5, 4.0) + 0.02 * rng.random(len(z))).astype(np.float32)
     else:
         z[:] = 1.5
     scale = z / sc.means3D[:, 2]  # keep every splat on its pixel ray: same tiles, new depth
