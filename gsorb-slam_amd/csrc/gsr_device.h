@@ -30,6 +30,14 @@
 #define GSR_ALIGN 256
 #define GSR_ACC_STRIDE 16 // floats; 9 used
 
+// Tile-sort size classes (gsr_kernels.hip): one wave sorts lists of <= GSR_SORT_SMALL keys in LDS, 256 threads those of
+// <= GSR_SORT_CAP, longer lists go through a bucket sort in global scratch. K_scan_tiles queues the tiles of the two
+// upper classes so that their kernels launch a handful of workgroups instead of one per tile.
+#define GSR_SORT_SMALL 1024
+#define GSR_SORT_CAP 4096
+#define GSR_SORTQ_HEAD 64 // words before the two tile queues: [0] tiles in the middle class, [1] tiles in the long class
+
+
 struct GeomHeader {
     uint32_t num_rendered;
     uint32_t overflow;
@@ -88,6 +96,7 @@ struct ImageView {
     uint32_t* tile_cnt;   // [T] instances per tile
     uint32_t* tile_start; // [T] where the tile's list segment starts
     uint32_t* binmat;     // [GSR_BIN_ROWS][T] count matrix (after K_bin_colscan: exclusive column prefixes)
+    uint32_t* sortq;  // [GSR_SORTQ_HEAD + 2T] queues of the tiles with more than GSR_SORT_SMALL / GSR_SORT_CAP list entries
     uint32_t* qcount; // [4*T] quad-hit records the forward blend wrote per 8x8 quad
 };
 struct BinView {
@@ -126,6 +135,7 @@ __host__ __device__ inline size_t image_layout(char* base, int W, int H, ImageVi
     g.tile_cnt = (uint32_t*)(base + off); off = gsr_align_up(off + T * 4);
     g.tile_start = (uint32_t*)(base + off); off = gsr_align_up(off + T * 4);
     g.binmat = (uint32_t*)(base + off); off = gsr_align_up(off + T * GSR_BIN_ROWS * 4);
+    g.sortq = (uint32_t*)(base + off); off = gsr_align_up(off + (GSR_SORTQ_HEAD + 2 * T) * 4);
     g.qcount = (uint32_t*)(base + off); off = gsr_align_up(off + T * 16);
     if (v) *v = g;
     return off;
@@ -269,6 +279,38 @@ __device__ __forceinline__ uint32_t quad_mask_from_word(uint32_t colw, float px,
     const uint32_t c0 = (uint32_t)sh <= 5u ? ((r0 << 1) >> sh) & 3u : 0u;
     const uint32_t c1 = (uint32_t)sh <= 5u ? ((r1 << 1) >> sh) & 3u : 0u;
     return c0 | (c1 << 2);
+}
+
+// Wave-wide inclusive scan / reduction in eight DPP instructions (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then
+// row_bcast15 / row_bcast31 across rows) instead of six dependent ds_bpermute round trips per __shfl scan.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWS, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) // inclusive
+{
+    v += dpp_u<0x111, 0xf>(0u, v);
+    v += dpp_u<0x112, 0xf>(0u, v);
+    v += dpp_u<0x114, 0xf>(0u, v);
+    v += dpp_u<0x118, 0xf>(0u, v);
+    v += dpp_u<0x142, 0xa>(0u, v); // lane 15 of rows 0, 2 -> rows 1, 3
+    v += dpp_u<0x143, 0xc>(0u, v); // lane 31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) // the result, in every lane
+{
+    v = min(v, dpp_u<0x111, 0xf>(v, v)); v = min(v, dpp_u<0x112, 0xf>(v, v));
+    v = min(v, dpp_u<0x114, 0xf>(v, v)); v = min(v, dpp_u<0x118, 0xf>(v, v));
+    v = min(v, dpp_u<0x142, 0xa>(v, v)); v = min(v, dpp_u<0x143, 0xc>(v, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v)
+{
+    v = max(v, dpp_u<0x111, 0xf>(v, v)); v = max(v, dpp_u<0x112, 0xf>(v, v));
+    v = max(v, dpp_u<0x114, 0xf>(v, v)); v = max(v, dpp_u<0x118, 0xf>(v, v));
+    v = max(v, dpp_u<0x142, 0xa>(v, v)); v = max(v, dpp_u<0x143, 0xc>(v, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 template <int CTRL>

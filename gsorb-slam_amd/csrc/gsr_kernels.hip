@@ -239,7 +239,7 @@ K_bin_colscan(int rows, int T, uint32_t* __restrict__ binmat, uint32_t* __restri
 // k-NN path (buckets instead of tiles; its counters sit in padded records, hence the strides, in words).
 __global__ void __launch_bounds__(1024)
 K_scan_tiles(int T, const uint32_t* __restrict__ cnt, int cnt_stride, uint32_t* __restrict__ start, int start_stride,
-             uint2* __restrict__ ranges, GeomHeader* __restrict__ hdr, uint32_t capacity)
+             uint2* __restrict__ ranges, GeomHeader* __restrict__ hdr, uint32_t capacity, uint32_t* __restrict__ sortq)
 {
     // each thread owns `per` consecutive tiles (its counts stay in registers when per <= 8), the block
     // scan is one shuffle scan per wave plus one over the 16 wave totals: two barriers in all
@@ -291,6 +291,34 @@ K_scan_tiles(int T, const uint32_t* __restrict__ cnt, int cnt_stride, uint32_t* 
         hdr->overflow = total > capacity ? 1u : 0u;
         hdr->capacity = capacity;
     }
+    if (!sortq) return;
+    // queues of the tiles whose lists do not fit the one-wave sort (gsr_device.h): the same scan over two more counts
+    __shared__ uint32_t qsum[2][16];
+    auto for_own = [&](auto fn) {
+        if (per <= 8) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (j < per && b + j < e) fn(b + j, ks[j]);
+        } else {
+            for (int i = b; i < e; i++) fn(i, cnt[(size_t)i * cnt_stride]);
+        }
+    };
+    uint32_t nmid = 0, nlong = 0;
+    for_own([&](int, uint32_t c) { nmid += (c > GSR_SORT_SMALL && c <= GSR_SORT_CAP) ? 1u : 0u; nlong += c > GSR_SORT_CAP ? 1u : 0u; });
+    const uint32_t imid = wave_scan_add(nmid), ilong = wave_scan_add(nlong);
+    if (lane == 63) { qsum[0][wv] = imid; qsum[1][wv] = ilong; }
+    __syncthreads();
+    uint32_t omid = imid - nmid, olong = ilong - nlong, tmid = 0, tlong = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (j < wv) { omid += qsum[0][j]; olong += qsum[1][j]; }
+        tmid += qsum[0][j]; tlong += qsum[1][j];
+    }
+    for_own([&](int i, uint32_t c) {
+        if (c > GSR_SORT_SMALL && c <= GSR_SORT_CAP) sortq[GSR_SORTQ_HEAD + omid++] = (uint32_t)i;
+        if (c > GSR_SORT_CAP) sortq[GSR_SORTQ_HEAD + T + olong++] = (uint32_t)i;
+    });
+    if (tid == 0) { sortq[0] = tmid; sortq[1] = tlong; }
 }
 
 // the forward's capacity guess was too small: switch the header to the exact capacity before the tail re-runs
@@ -302,7 +330,6 @@ __global__ void K_set_capacity(GeomHeader* hdr, uint32_t capacity)
 
 // All-ascending bitonic network ("flip" then "disperse" stages): every compare-exchange
 // keeps the smaller key at the lower index, so virtual +inf padding above n never moves.
-#define GSR_SORT_CAP 4096
 __device__ __forceinline__ void cex(uint64_t& a, uint64_t& b)
 {
     if (a > b) { const uint64_t t = a; a = b; b = t; }
@@ -323,6 +350,11 @@ __device__ __forceinline__ void cex(uint64_t& a, uint64_t& b)
 // the K addresses of a group are one swizzled base XOR per-trip constants.
 __device__ __forceinline__ int swz(int i) { return i ^ ((i >> 5) & 31) ^ ((i >> 10) & 31); }
 
+// a one-wave sort may be one of several waves of its workgroup (K_tile_sort_all): it counts its own lanes only
+template <bool ONEWAVE>
+__device__ __forceinline__ int sort_tid() { return ONEWAVE ? (int)(threadIdx.x & 63u) : (int)threadIdx.x; }
+template <bool ONEWAVE>
+__device__ __forceinline__ int sort_nt() { return ONEWAVE ? 64 : (int)blockDim.x; }
 template <bool ONEWAVE>
 __device__ __forceinline__ void sort_sync()
 {
@@ -348,7 +380,7 @@ __device__ __forceinline__ void lds_disperse_from(uint64_t* s, int cap, int lj)
     constexpr int K = 1 << G;
     while (lj >= 0) {
         const int low = lj - G + 1 > 0 ? lj - G + 1 : 0, nb = lj - low + 1;
-        for (int grp = threadIdx.x; grp < cap / K; grp += blockDim.x) {
+        for (int grp = sort_tid<ONEWAVE>(); grp < cap / K; grp += sort_nt<ONEWAVE>()) {
             const int x = swz(((grp >> low) << (low + G)) | (grp & ((1 << low) - 1)));
             uint64_t r[K];
 #pragma unroll
@@ -366,7 +398,7 @@ template <int G, bool ONEWAVE>
 __device__ __forceinline__ void lds_sort(uint64_t* s, int cap)
 {
     constexpr int K = 1 << G, H = K / 2;
-    for (int grp = threadIdx.x; grp < cap / K; grp += blockDim.x) { // stages k = 2 .. K inside the group
+    for (int grp = sort_tid<ONEWAVE>(); grp < cap / K; grp += sort_nt<ONEWAVE>()) { // stages k = 2 .. K inside the group
         uint64_t r[K];
 #pragma unroll
         for (int q = 0; q < K; q++) r[q] = s[swz(grp * K) ^ q]; // q < 32: swz(q) = q
@@ -383,7 +415,7 @@ __device__ __forceinline__ void lds_sort(uint64_t* s, int cap)
     sort_sync<ONEWAVE>();
     for (int k = 2 * K, lk = G + 1; k <= cap; k <<= 1, lk++) {
         const int low = lk - G; // the group spans bits low .. lk-1
-        for (int grp = threadIdx.x; grp < cap / K; grp += blockDim.x) {
+        for (int grp = sort_tid<ONEWAVE>(); grp < cap / K; grp += sort_nt<ONEWAVE>()) {
             const int xl = ((grp >> low) << lk) | (grp & ((1 << low) - 1));
             // mirror image of x in its block of k: base + k-1 - offset; its field bits are all ones, so
             // "minus m << low" is an XOR as well
@@ -406,38 +438,6 @@ __device__ __forceinline__ void lds_sort(uint64_t* s, int cap)
     }
 }
 
-// Wave-wide inclusive scan / reduction in eight DPP instructions (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then
-// row_bcast15 / row_bcast31 across rows) instead of six dependent ds_bpermute round trips per __shfl scan.
-template <int CTRL, int ROWS>
-__device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWS, 0xf, false);
-}
-__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) // inclusive
-{
-    v += dpp_u<0x111, 0xf>(0u, v);
-    v += dpp_u<0x112, 0xf>(0u, v);
-    v += dpp_u<0x114, 0xf>(0u, v);
-    v += dpp_u<0x118, 0xf>(0u, v);
-    v += dpp_u<0x142, 0xa>(0u, v); // lane 15 of rows 0, 2 -> rows 1, 3
-    v += dpp_u<0x143, 0xc>(0u, v); // lane 31 -> rows 2, 3
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) // the result, in every lane
-{
-    v = min(v, dpp_u<0x111, 0xf>(v, v)); v = min(v, dpp_u<0x112, 0xf>(v, v));
-    v = min(v, dpp_u<0x114, 0xf>(v, v)); v = min(v, dpp_u<0x118, 0xf>(v, v));
-    v = min(v, dpp_u<0x142, 0xa>(v, v)); v = min(v, dpp_u<0x143, 0xc>(v, v));
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-__device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v)
-{
-    v = max(v, dpp_u<0x111, 0xf>(v, v)); v = max(v, dpp_u<0x112, 0xf>(v, v));
-    v = max(v, dpp_u<0x114, 0xf>(v, v)); v = max(v, dpp_u<0x118, 0xf>(v, v));
-    v = max(v, dpp_u<0x142, 0xa>(v, v)); v = max(v, dpp_u<0x143, 0xc>(v, v));
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 // Two instantiations share the tiles: SMALL sorts tiles of <= 1024 entries with ONE wave (16 keys per lane,
 // no s_barrier), the other takes the longer lists with 256 threads; each skips the other's tiles.
 //
@@ -450,29 +450,29 @@ __device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v)
 // counts > 8 n: the ranking loops would cost more than the network — two surfaces in one tile, a far outlier) is
 // binned a second time with equalised bins (every non-empty bin cut into sub-bins in proportion to its count), and
 // only if that does not spread the keys either (exact depth ties) the list is sorted by the network.
-#define GSR_SORT_SMALL 1024
 #define GSR_SORT_MATES 16 // keys of a lane that look at their bin-mates together (measured 4 / 8 / 16: 25.0 / 25.9 / 23.9 us)
 #define GSR_SORT_G 4              // 16 keys per thread and trip
 #define GSR_SORT_SMALL_THREADS 64
 #define GSR_SORT_BIG_THREADS 256  // 1024 threads per 4096-key tile measured no faster
 template <bool SMALL>
-__global__ void __launch_bounds__(SMALL ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS)
-K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __restrict__ hdr,
-            uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list)
+struct SortShared {
+    static constexpr int NT = SMALL ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS, CAP = SMALL ? GSR_SORT_SMALL : GSR_SORT_CAP;
+    uint64_t s[CAP];
+    __attribute__((aligned(16))) uint32_t h[CAP + 4];
+    uint32_t red[9][NT / 64];
+};
+template <bool SMALL>
+__device__ __forceinline__ void sort_tile(SortShared<SMALL>& sh, const uint2 r, uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list)
 {
-    constexpr int NT = SMALL ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS, CAP = SMALL ? GSR_SORT_SMALL : GSR_SORT_CAP;
+    constexpr int NT = SortShared<SMALL>::NT, CAP = SortShared<SMALL>::CAP;
     constexpr int EPT = CAP / NT, LOGCAP = SMALL ? 10 : 12;
     static_assert(EPT == 16 && (1 << LOGCAP) == CAP, "sixteen keys and sixteen bins per thread");
-    __shared__ uint64_t s[CAP];
-    __shared__ __attribute__((aligned(16))) uint32_t h[CAP + 4];
-    __shared__ uint32_t red[9][NT / 64];
-    const uint32_t tile = xcd_remap(blockIdx.x, ntiles);
-    if (hdr->overflow) return;
-    const uint2 r = ranges[tile];
+    uint64_t* const s = sh.s;
+    uint32_t* const h = sh.h;
+    auto& red = sh.red;
     const int n = (int)(r.y - r.x);
-    if (n == 0 || (n <= GSR_SORT_SMALL) != SMALL) return;
     uint64_t* seg = pairs + r.x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = sort_tid<SMALL>(), lane = tid & 63, wv = tid >> 6;
     if (n <= CAP) {
         // Straight-line code: a load inside a divergent branch is waited for inside that branch, sixteen branches would be
         // sixteen serial round trips. Loads use clamped addresses and selects, only stores are predicated.
@@ -626,10 +626,10 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
     if (n <= CAP) { // crowded bins: the bitonic network
         int n2 = 1 << GSR_SORT_G;
         while (n2 < n) n2 <<= 1;
-        for (int i = threadIdx.x; i < n2; i += blockDim.x) s[swz(i)] = i < n ? seg[i] : ~0ull;
+        for (int i = tid; i < n2; i += sort_nt<SMALL>()) s[swz(i)] = i < n ? seg[i] : ~0ull;
         sort_sync<SMALL>();
         lds_sort<GSR_SORT_G, SMALL>(s, n2);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) point_list[r.x + i] = (uint32_t)s[swz(i)];
+        for (int i = tid; i < n; i += sort_nt<SMALL>()) point_list[r.x + i] = (uint32_t)s[swz(i)];
         return;
     }
     // oversize tile: chunk-local stages in LDS, long-stride stages in global memory
@@ -639,14 +639,14 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
     for (int c = 0; c < nchunks; c++) {
         const long base = (long)c * GSR_SORT_CAP;
         if (base >= n) break;
-        for (int i = threadIdx.x; i < GSR_SORT_CAP; i += blockDim.x) s[swz(i)] = base + i < n ? seg[base + i] : ~0ull;
+        for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<SMALL>()) s[swz(i)] = base + i < n ? seg[base + i] : ~0ull;
         __syncthreads();
         lds_sort<GSR_SORT_G, false>(s, GSR_SORT_CAP);
-        for (int i = threadIdx.x; i < GSR_SORT_CAP; i += blockDim.x) if (base + i < n) seg[base + i] = s[swz(i)];
+        for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<SMALL>()) if (base + i < n) seg[base + i] = s[swz(i)];
         __syncthreads();
     }
     for (long k = 2L * GSR_SORT_CAP; k <= n2; k <<= 1) {
-        for (long i = threadIdx.x; i < n2 / 2; i += blockDim.x) { // flip in global memory
+        for (long i = tid; i < n2 / 2; i += sort_nt<SMALL>()) { // flip in global memory
             const long blk = i / (k >> 1), off = i % (k >> 1);
             const long lo = blk * k + off, hi = blk * k + (k - 1 - off);
             if (hi < n) { uint64_t a = seg[lo], b = seg[hi]; if (a > b) { seg[lo] = b; seg[hi] = a; } }
@@ -654,7 +654,7 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
         __syncthreads();
         long j = k >> 2;
         for (; j >= GSR_SORT_CAP; j >>= 1) { // disperse with stride >= chunk: global memory
-            for (long i = threadIdx.x; i < n2 / 2; i += blockDim.x) {
+            for (long i = tid; i < n2 / 2; i += sort_nt<SMALL>()) {
                 const long lo = (i / j) * 2 * j + (i % j), hi = lo + j;
                 if (hi < n) { uint64_t a = seg[lo], b = seg[hi]; if (a > b) { seg[lo] = b; seg[hi] = a; } }
             }
@@ -663,14 +663,225 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
         for (int c = 0; c < nchunks; c++) { // remaining strides are chunk-local
             const long base = (long)c * GSR_SORT_CAP;
             if (base >= n) break;
-            for (int i = threadIdx.x; i < GSR_SORT_CAP; i += blockDim.x) s[swz(i)] = base + i < n ? seg[base + i] : ~0ull;
+            for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<SMALL>()) s[swz(i)] = base + i < n ? seg[base + i] : ~0ull;
             __syncthreads();
             lds_disperse_from<GSR_SORT_G, false>(s, GSR_SORT_CAP, 11); // strides 2048 ... 1 (GSR_SORT_CAP / 2 = 2^11)
-            for (int i = threadIdx.x; i < GSR_SORT_CAP; i += blockDim.x) if (base + i < n) seg[base + i] = s[swz(i)];
+            for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<SMALL>()) if (base + i < n) seg[base + i] = s[swz(i)];
             __syncthreads();
         }
     }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) point_list[r.x + i] = (uint32_t)seg[i];
+    for (int i = tid; i < n; i += sort_nt<SMALL>()) point_list[r.x + i] = (uint32_t)seg[i];
+}
+
+// Launch modes: one workgroup per tile (sortq == nullptr: the k-NN path, and always for SMALL), or a fixed grid that
+// walks K_scan_tiles's queue of the tiles in the middle class — a frame without such tiles (the 1 M-splat headline
+// frame has none) then costs a few hundred empty workgroups instead of one per tile.
+template <bool SMALL>
+__global__ void __launch_bounds__(SMALL ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS)
+K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __restrict__ hdr,
+            uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list, const uint32_t* __restrict__ sortq)
+{
+    __shared__ SortShared<SMALL> sh;
+    if (hdr->overflow) return;
+    if constexpr (!SMALL) {
+        if (sortq) {
+            const uint32_t cnt = sortq[0];
+            for (uint32_t t = blockIdx.x; t < cnt; t += gridDim.x) {
+                sort_tile<false>(sh, ranges[sortq[GSR_SORTQ_HEAD + t]], pairs, point_list);
+                __syncthreads();
+            }
+            return;
+        }
+    }
+    const uint2 r = ranges[xcd_remap(blockIdx.x, ntiles)];
+    const int n = (int)(r.y - r.x);
+    if (n == 0 || (n <= GSR_SORT_SMALL) != SMALL) return;
+    sort_tile<SMALL>(sh, r, pairs, point_list);
+}
+
+// Lists longer than GSR_SORT_CAP: the same bucket sort with the keys in global scratch instead of LDS (the tile's own
+// share of the quad-hit log, which the forward blend fills only later). 256 threads per list, eight keys per thread
+// in flight; bins in LDS. Passes: min/max, count, [equalise + count again], scatter by bin, rank among bin-mates.
+// Crowded lists (exact depth ties) fall back to the bitonic network in global memory (sort_tile).
+#define GSR_SORT_LONG_BINS 8192
+__device__ __forceinline__ void sort_long_list(SortShared<false>& sh, const uint2 r, uint64_t* __restrict__ pairs,
+                                               uint32_t* __restrict__ point_list, uint2* __restrict__ qhits)
+{
+    constexpr int NT = GSR_SORT_BIG_THREADS, NB = GSR_SORT_LONG_BINS, BPT = NB / NT, LOGNB = 13, U = 8;
+    static_assert((1 << LOGNB) == NB && BPT % 4 == 0, "whole uint4 of bins per thread");
+    static_assert(sizeof(sh.s) >= NB * sizeof(uint32_t), "the bins live in the network's key array");
+    uint32_t* const hb = reinterpret_cast<uint32_t*>(sh.s);
+    auto& red = sh.red; // (the network fallback uses them only for lists that fit LDS)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int slot = 0; // every block_sums call of a list its own words of `red`; lists are separated by barriers
+    auto block_sums = [&](const uint32_t v, uint32_t& before, uint32_t& total) {
+        const uint32_t inc = wave_scan_add(v);
+        if (lane == 63) red[slot][wv] = inc;
+        __syncthreads();
+        before = inc - v; total = 0;
+#pragma unroll
+        for (int q = 0; q < NT / 64; q++) { if (q < wv) before += red[slot][q]; total += red[slot][q]; }
+        slot++;
+    };
+    {
+        const int n = (int)(r.y - r.x);
+        const uint64_t* __restrict__ seg = pairs + r.x;
+        uint64_t* const temp = reinterpret_cast<uint64_t*>(qhits + 4 * (size_t)r.x); // [n] keys by bin
+        uint32_t* const map = reinterpret_cast<uint32_t*>(temp + n);                  // [NB] equalisation map (32 KB <= 24 n bytes)
+        slot = 0;
+        // ---- min / max of the depth words
+        uint32_t dmin = ~0u, dmax = 0u;
+        for (int i0 = 0; i0 < n; i0 += NT * U) {
+            uint64_t k[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) k[u] = seg[min(i0 + u * NT + tid, n - 1)];
+#pragma unroll
+            for (int u = 0; u < U; u++) { dmin = min(dmin, (uint32_t)(k[u] >> 32)); dmax = max(dmax, (uint32_t)(k[u] >> 32)); }
+        }
+        dmin = wave_min_u32(dmin); dmax = wave_max_dpp(dmax);
+        if (lane == 0) { red[6][wv] = dmin; red[7][wv] = dmax; }
+        for (int b = tid; b < NB; b += NT) hb[b] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NT / 64; q++) { dmin = min(dmin, red[6][q]); dmax = max(dmax, red[7][q]); }
+        const int shift = max(0, 32 - __clz((int)(dmax - dmin)) - LOGNB);
+        const int down = max(0, shift - 16), frac = min(shift, 16);
+        bool equalised = false;
+        auto bin_of = [&](const uint64_t key) -> uint32_t {
+            const uint32_t rel = (uint32_t)(key >> 32) - dmin, b = rel >> shift;
+            if (!equalised) return b;
+            const uint32_t m = map[b];
+            return (m & 0xFFFFu) + ((((rel - (b << shift)) >> down) * (m >> 16)) >> frac);
+        };
+        auto count_keys = [&]() {
+            for (int i0 = 0; i0 < n; i0 += NT * U) {
+                uint64_t k[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) k[u] = seg[min(i0 + u * NT + tid, n - 1)];
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (i0 + u * NT + tid < n) (void)lds_take(&hb[bin_of(k[u])]);
+            }
+            __syncthreads();
+        };
+        uint32_t c[BPT], run, sq, nz;
+        auto scan_counts = [&]() {
+#pragma unroll
+            for (int q = 0; q < BPT / 4; q++) {
+                const uint4 v = reinterpret_cast<const uint4*>(hb)[tid * (BPT / 4) + q];
+                c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+            }
+            uint32_t sum = 0, sq_own = 0, nz_own = 0, x;
+#pragma unroll
+            for (int j = 0; j < BPT; j++) { sum += c[j]; sq_own += c[j] * c[j]; nz_own += c[j] ? 1u : 0u; }
+            block_sums(sum, run, x);
+            block_sums(sq_own, x, sq);
+            block_sums(nz_own, x, nz);
+        };
+        count_keys();
+        scan_counts();
+        bool crowded = sq > 8u * (uint32_t)n;
+        if (crowded && shift > 0) { // second binning with equalised bins (see sort_tile)
+            const float share = (float)((uint32_t)NB - nz) / (float)n * 0.999f;
+            uint32_t nsub[BPT], tot = 0, first, x;
+#pragma unroll
+            for (int j = 0; j < BPT; j++) { nsub[j] = c[j] ? 1u + (uint32_t)((float)c[j] * share) : 0u; tot += nsub[j]; }
+            slot = 3;
+            block_sums(tot, first, x);
+#pragma unroll
+            for (int j = 0; j < BPT; j++) { map[tid * BPT + j] = first | (nsub[j] << 16); first += nsub[j]; }
+            __syncthreads(); // every thread has read its counts
+            for (int b = tid; b < NB; b += NT) hb[b] = 0u;
+            __syncthreads(); // ... and the map is visible to the workgroup
+            equalised = true;
+            count_keys();
+            slot = 0;
+            scan_counts();
+            crowded = sq > 8u * (uint32_t)n;
+        }
+        if (crowded) { // exact ties: the network, in place in the list segment
+            __syncthreads();
+            sort_tile<false>(sh, r, pairs, point_list);
+            __syncthreads();
+            return;
+        }
+        __syncthreads(); // every thread has read its counts: the words turn into cursors
+#pragma unroll
+        for (int j = 0; j < BPT; j++) { hb[tid * BPT + j] = run; run += c[j]; }
+        __syncthreads();
+        // ---- keys to their bins (afterwards hb[b] = end of bin b = start of bin b + 1)
+        for (int i0 = 0; i0 < n; i0 += NT * U) {
+            uint64_t k[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) k[u] = seg[min(i0 + u * NT + tid, n - 1)];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (i0 + u * NT + tid < n) temp[lds_take(&hb[bin_of(k[u])])] = k[u];
+        }
+        __syncthreads();
+        // ---- rank among the bin-mates, ids out
+        for (int i0 = 0; i0 < n; i0 += NT * U) {
+            uint64_t k[U];
+            uint32_t s0[U], e0[U], below[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) k[u] = temp[min(i0 + u * NT + tid, n - 1)];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t b = bin_of(k[u]);
+                s0[u] = b ? hb[b - 1] : 0u; e0[u] = hb[b]; below[u] = 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                for (uint32_t q = s0[u]; q < e0[u]; q++) below[u] += temp[q] < k[u] ? 1u : 0u;
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (i0 + u * NT + tid < n) point_list[r.x + s0[u] + below[u]] = (uint32_t)k[u];
+        }
+        __syncthreads();
+    }
+}
+
+// The rasterizer's sort: ONE launch for the three size classes (an empty kernel in the stream costs 4-5 us here: three
+// launches of which two usually have nothing to do were 9 us of a 520 us step). The first workgroups walk the queues
+// of the long and the middle class, the others sort four short lists each, one per wave.
+#define GSR_SORT_ALL_LONG 128
+#define GSR_SORT_ALL_MID 512
+__global__ void __launch_bounds__(GSR_SORT_BIG_THREADS)
+K_tile_sort_all(int T, const uint2* __restrict__ ranges, const GeomHeader* __restrict__ hdr, uint64_t* __restrict__ pairs,
+                uint32_t* __restrict__ point_list, uint2* __restrict__ qhits, const uint32_t* __restrict__ sortq)
+{
+    union Shared {
+        SortShared<true> small[GSR_SORT_BIG_THREADS / 64];
+        SortShared<false> big;
+    };
+    __shared__ Shared sh;
+    if (hdr->overflow) return;
+    int b = blockIdx.x;
+    if (b < GSR_SORT_ALL_LONG) {
+        const uint32_t cnt = sortq[1];
+        for (uint32_t t = b; t < cnt; t += GSR_SORT_ALL_LONG) {
+            sort_long_list(sh.big, ranges[sortq[GSR_SORTQ_HEAD + T + t]], pairs, point_list, qhits);
+            __syncthreads();
+        }
+        return;
+    }
+    b -= GSR_SORT_ALL_LONG;
+    if (b < GSR_SORT_ALL_MID) {
+        const uint32_t cnt = sortq[0];
+        for (uint32_t t = b; t < cnt; t += GSR_SORT_ALL_MID) {
+            sort_tile<false>(sh.big, ranges[sortq[GSR_SORTQ_HEAD + t]], pairs, point_list);
+            __syncthreads();
+        }
+        return;
+    }
+    b -= GSR_SORT_ALL_MID;
+    const int wv = (int)(threadIdx.x >> 6), per = GSR_SORT_BIG_THREADS / 64, nsmall = (T + per - 1) / per;
+    const int tile = (int)xcd_remap((uint32_t)b, (uint32_t)nsmall) * per + wv;
+    if (tile >= T) return;
+    const uint2 r = ranges[tile];
+    const int n = (int)(r.y - r.x);
+    if (n == 0 || n > GSR_SORT_SMALL) return;
+    sort_tile<true>(sh.small[wv], r, pairs, point_list);
 }
 
 // blending kernels (K_blend_fwd, K_blend_bwd)

@@ -425,17 +425,22 @@ def test_huge_frame_more_than_131072_tiles(gsr, syn):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("layout", ["planes", "wall+outlier", "two-slabs", "all-equal"])
-def test_sort_order_with_depth_ties_and_crowded_bins(gsr, syn, layout):
+@pytest.mark.parametrize("frame", ["lists-to-4096", "lists-over-4096"])
+@pytest.mark.parametrize("layout", ["uniform", "planes", "wall+outlier", "two-slabs", "all-equal"])
+def test_sort_order_with_depth_ties_and_crowded_bins(gsr, syn, layout, frame):
     """The tile sort bins keys over the tile's own depth range and ranks inside a bin; lists whose depths crowd into few
-    bins take the bitonic network instead. Exact depth ties (order by splat id, like the reference's stable radix sort),
-    a thin wall plus one far outlier (everything in two bins), two 2-cm slabs (the equalised second binning succeeds) and a
-    single depth for the whole map: point_list bit-exact."""
-    cam = syn.make_camera(320, 240, 240.0, 240.0)
+    bins are binned again with equalised bins, and only then take the bitonic network. Exact depth ties (order by splat
+    id, like the reference's stable radix sort), a thin wall plus one far outlier (everything in two bins), two 2-cm
+    slabs (the equalised second binning succeeds) and a single depth for the whole map, on a frame whose lists use the
+    one-wave and the 256-thread LDS sorts and on one whose lists exceed 4096 entries (bucket sort through global
+    scratch): point_list bit-exact."""
+    cam = syn.make_camera(320, 240, 240.0, 240.0) if frame == "lists-to-4096" else syn.make_camera(128, 96, 96.0, 96.0)
     sc = syn.make_scene(60000, cam, seed=21, scale_mult=1.5)
     rng = np.random.default_rng(5)
     z = sc.means3D[:, 2].copy()
-    if layout == "planes":
+    if layout == "uniform":
+        pass
+    elif layout == "planes":
         z = np.float32(1.0) + np.float32(0.5) * rng.integers(0, 3, len(z)).astype(np.float32)
     elif layout == "wall+outlier":
         z = (2.0 + 1e-4 * rng.random(len(z))).astype(np.float32)
@@ -453,6 +458,11 @@ def test_sort_order_with_depth_ties_and_crowded_bins(gsr, syn, layout):
     d = gsr.debug_export(st)
     assert st.num_rendered == f.num_rendered
     lens = f.stages["ranges"][:, 1] - f.stages["ranges"][:, 0]
-    assert lens.max() > 1024 and (lens[lens > 0] <= 1024).any()  # both sort kernels run
+    if layout == "uniform":
+        pass  # control: the scene's own depths (its lists are shorter: splat size follows depth)
+    elif frame == "lists-to-4096":
+        assert lens.max() > 1024 and (lens[lens > 0] <= 1024).any()  # both LDS sort kernels run
+    else:
+        assert (lens > 4096).sum() > 8
     np.testing.assert_array_equal(d["ranges"], f.stages["ranges"])
     np.testing.assert_array_equal(d["point_list"], f.stages["point_list"])
