@@ -237,6 +237,8 @@ K_bin_colscan(int rows, int T, uint32_t* __restrict__ binmat, uint32_t* __restri
 
 // One block: per-tile counts -> list segments (start), ranges, num_rendered and the overflow flag. Shared with the
 // k-NN path (buckets instead of tiles; its counters sit in padded records, hence the strides, in words).
+// (Measured and dropped: letting the last workgroup of K_bin_colscan run this scan — the device-scope release / acquire
+// fences of the hand-over cost 45 us, the separate launch 5.)
 __global__ void __launch_bounds__(1024)
 K_scan_tiles(int T, const uint32_t* __restrict__ cnt, int cnt_stride, uint32_t* __restrict__ start, int start_stride,
              uint2* __restrict__ ranges, GeomHeader* __restrict__ hdr, uint32_t capacity, uint32_t* __restrict__ sortq)
