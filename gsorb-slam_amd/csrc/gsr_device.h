@@ -229,12 +229,12 @@ __device__ __forceinline__ uint32_t window_reach(const ReachSetup& s, float wx, 
 #pragma unroll
     for (int i = 0; i < NW; i++) {
         dl[i] = s.ax - (wx + 4.f * i + 3.f); dh[i] = s.ax - (wx + 4.f * i);
-        const float dc = fminf(fmaxf(0.f, dl[i]), dh[i]); // point of the range closest to 0
+        const float dc = __builtin_amdgcn_fmed3f(0.f, dl[i], dh[i]); // point of the range closest to 0 (one v_med3 instead of max + min; a NaN gives the lower end, like the pair did)
         Ax[i] = dc != 0.f ? s.hca * dc * dc : 3.0e38f;    // a side faces the centre only if the centre is outside the range
         Bx[i] = s.cb * dc; Kx[i] = s.kx * dc;
         zc |= dc == 0.f ? 1u << i : 0u;
         el[i] = s.ay - (wy + 4.f * i + 3.f); eh[i] = s.ay - (wy + 4.f * i);
-        const float ec = fminf(fmaxf(0.f, el[i]), eh[i]);
+        const float ec = __builtin_amdgcn_fmed3f(0.f, el[i], eh[i]);
         Ay[i] = ec != 0.f ? s.hcc * ec * ec : 3.0e38f;
         By[i] = s.cb * ec; Ky[i] = s.ky * ec;
         zr |= ec == 0.f ? 1u << i : 0u;
@@ -245,9 +245,9 @@ __device__ __forceinline__ uint32_t window_reach(const ReachSetup& s, float wx, 
         if (zr & (1u << j)) mask |= zc << (j * NW); // centre inside the patch rectangle
 #pragma unroll
         for (int i = 0; i < NW; i++) {
-            const float dy = fminf(fmaxf(Kx[i], el[j]), eh[j]);            // minimiser on the vertical side x = dc_i
+            const float dy = __builtin_amdgcn_fmed3f(Kx[i], el[j], eh[j]);         // minimiser on the vertical side x = dc_i
             const float qx = fmaf(dy, fmaf(s.hcc, dy, Bx[i]), Ax[i]);
-            const float dx = fminf(fmaxf(Ky[j], dl[i]), dh[i]);            // minimiser on the horizontal side y = ec_j
+            const float dx = __builtin_amdgcn_fmed3f(Ky[j], dl[i], dh[i]);         // minimiser on the horizontal side y = ec_j
             const float qy = fmaf(dx, fmaf(s.hca, dx, By[j]), Ay[j]);
             if (!(fminf(qx, qy) > s.tau)) mask |= 1u << (j * NW + i);
         }
