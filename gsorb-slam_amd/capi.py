@@ -17,7 +17,8 @@ _LIB = None
 
 EXPORTS = ["gsr_forward", "gsr_forward_ws", "gsr_ws_status", "gsr_backward", "gsr_mark_visible",
            "gsr_visible_filter", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
-           "gsr_debug_export", "gsr_acc_view", "gsr_knn_bytes", "gsr_dist2", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
+           "gsr_debug_export", "gsr_acc_view", "gsr_knn_bytes", "gsr_dist2", "gsr_ssim_partials", "gsr_ssim_forward", "gsr_ssim_backward",
+           "gsr_adam_step", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
 
 
 def library_path() -> str:
@@ -102,6 +103,16 @@ def lib():
     L.gsr_knn_bytes.argtypes = [C.c_int]
     L.gsr_dist2.restype = C.c_int
     L.gsr_dist2.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.gsr_ssim_partials.restype = C.c_size_t
+    L.gsr_ssim_partials.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.gsr_ssim_forward.restype = C.c_int
+    L.gsr_ssim_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gsr_ssim_backward.restype = C.c_int
+    L.gsr_ssim_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p,
+                                    C.c_void_p, C.c_void_p]
+    L.gsr_adam_step.restype = C.c_int
+    L.gsr_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
+                                C.c_int, C.c_void_p]
     L.gsr_error_string.restype = C.c_char_p
     L.gsr_error_string.argtypes = [C.c_int]
     L.gsr_last_hip_error.restype = C.c_char_p
@@ -386,6 +397,78 @@ def dist2(points, workspace=None):
         with torch.cuda.device(dev):
             _check(L.gsr_dist2(P, _p(p), _p(out), _p(ws), ws.numel(), _stream()))
     return out
+
+
+# ---- fused SSIM and Adam (include/gsr.h) ---------------------------------------------------------
+class _FusedSSIM(torch.autograd.Function):
+    """mean SSIM of img1 vs img2 ([C,H,W] float32 on the GPU) with an 11-tap separable window; gradient w.r.t. img1."""
+
+    @staticmethod
+    def forward(ctx, img1, img2, taps):
+        L = lib()
+        img1, img2 = img1.contiguous(), img2.contiguous()
+        Cc, H, W = (int(x) for x in img1.shape)
+        tp = (C.c_float * 11)(*[float(x) for x in taps])
+        partial = torch.empty((int(L.gsr_ssim_partials(Cc, H, W)),), dtype=torch.float32, device=img1.device)
+        need = img1.requires_grad
+        dmaps = torch.empty((3, Cc, H, W), dtype=torch.float32, device=img1.device) if need else None
+        with torch.cuda.device(img1.device):
+            _check(L.gsr_ssim_forward(_p(img1), _p(img2), Cc, H, W, tp, _p(partial), _p(dmaps) if need else None, _stream()))
+        ctx.save_for_backward(img1, img2, dmaps if need else img1)
+        ctx.taps, ctx.need = tp, need
+        return partial.sum() / float(Cc * H * W)
+
+    @staticmethod
+    def backward(ctx, grad):
+        img1, img2, dmaps = ctx.saved_tensors
+        if not ctx.need:
+            return None, None, None
+        Cc, H, W = (int(x) for x in img1.shape)
+        g = grad.to(torch.float32).contiguous()
+        out = torch.empty_like(img1)
+        with torch.cuda.device(img1.device):
+            _check(lib().gsr_ssim_backward(_p(img1), _p(img2), _p(dmaps), Cc, H, W, ctx.taps, _p(g), _p(out), _stream()))
+        return out, None, None
+
+
+def ssim_mean(img1, img2, taps):
+    """Fused mean-SSIM (reference Utils.cc:77-100) of two [C,H,W] GPU images; differentiable w.r.t. img1 only
+    (the mapping and tracking losses compare a render with a fixed frame)."""
+    if img2.requires_grad:
+        raise GsrError("ssim_mean: only the first image may require a gradient")
+    return _FusedSSIM.apply(_f32(img1, img1.device) if img1.dtype != torch.float32 else img1, img2.to(torch.float32), tuple(taps))
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(lr, betas, eps) — no weight decay, no amsgrad, as src/Gaussian.cc:144-175 configures the reference's
+    optimisers — with the per-tensor update in one HIP kernel. Same param_groups / state layout (step, exp_avg,
+    exp_avg_sq), so the reference's optimiser-state surgery on pruning and concatenation works unchanged."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        L = lib()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise GsrError("FusedAdam: parameters must be contiguous float32 GPU tensors")
+                st = self.state[p]
+                if "exp_avg" not in st:
+                    st["step"] = torch.zeros((), dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                if "step" not in st:
+                    st["step"] = torch.zeros((), dtype=torch.float32)
+                st["step"] += 1
+                g = p.grad.contiguous()
+                with torch.cuda.device(p.device):
+                    _check(L.gsr_adam_step(_p(p), _p(g), _p(st["exp_avg"]), _p(st["exp_avg_sq"]), p.numel(), float(group["lr"]), float(b1),
+                                           float(b2), float(group["eps"]), int(st["step"]), _stream()))
 
 
 def acc_view(st: ForwardState) -> torch.Tensor:

@@ -4,6 +4,7 @@
 #include "../../include/gsr.h"
 #include "gsr_kernels.hip"
 #include "gsr_knn.h"
+#include "gsr_train.h"
 
 #include <string.h>
 #include <algorithm>
@@ -423,6 +424,53 @@ int gsr_dist2(int P, const float* points, float* mean_dists, char* workspace, si
     hipLaunchKernelGGL(gsr::K_knn_boxes, dim3(nbox), dim3(256), 0, st, P, points, k.order, k.spts, k.boxes);
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_knn_search, dim3(blocks256(P)), dim3(256), 0, st, P, nbox, k.spts, k.boxes, mean_dists);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+size_t gsr_ssim_partials(int C, int H, int W)
+{
+    if (C <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)C * ((H + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE) * ((W + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE);
+}
+
+int gsr_ssim_forward(const float* img1, const float* img2, int C, int H, int W, const float* taps11, float* partial,
+                     float* dmaps, void* stream)
+{
+    if (!img1 || !img2 || !taps11 || !partial || C <= 0 || C > 65535 || H <= 0 || W <= 0) return GSR_EINVAL;
+    gsr::SsimTaps t;
+    for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
+    const dim3 grid((W + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, (H + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, C);
+    hipLaunchKernelGGL(gsr::K_ssim_fwd, grid, dim3(GSR_SSIM_TILE * GSR_SSIM_TILE), 0, (hipStream_t)stream, img1, img2, H, W, t, partial, dmaps);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_ssim_backward(const float* img1, const float* img2, const float* dmaps, int C, int H, int W, const float* taps11,
+                      const float* dL_dmean, float* dL_dimg1, void* stream)
+{
+    if (!img1 || !img2 || !dmaps || !taps11 || !dL_dmean || !dL_dimg1 || C <= 0 || C > 65535 || H <= 0 || W <= 0) return GSR_EINVAL;
+    gsr::SsimTaps t;
+    for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
+    const dim3 grid((W + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, (H + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, C);
+    hipLaunchKernelGGL(gsr::K_ssim_bwd, grid, dim3(GSR_SSIM_TILE * GSR_SSIM_TILE), 0, (hipStream_t)stream, img1, img2, dmaps, H, W, t, dL_dmean, dL_dimg1);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
+                  double beta2, double eps, int step, void* stream)
+{
+    if (n == 0) return GSR_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return GSR_EINVAL;
+    // the bias corrections in double, like the Python scalars of torch.optim.Adam
+    // (and 1 - beta as well: 1.f - 0.999f is 1.3e-5 off the float nearest to 0.001)
+    const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1), sqrt_bc2 = (float)std::sqrt(bc2);
+    const size_t blocks = (n + 1023) / 1024;
+    if (blocks > 0x7FFFFFFFu) return GSR_EINVAL;
+    hipLaunchKernelGGL(gsr::K_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1),
+                       (float)beta2, (float)(1.0 - beta2), (float)eps, step_size, sqrt_bc2);
     GSR_LAUNCHED();
     return GSR_OK;
 }

@@ -1,0 +1,165 @@
+// gsr_train.h — the two non-rasterizer hot spots of a mapping iteration, fused:
+//
+//   SSIM   reference: ORB_SLAM2::ssim, src/Utils.cc:77-100 — five depthwise 11x11 convolutions (mu1, mu2, E[x^2],
+//          E[y^2], E[xy]) plus a dozen elementwise passes through libtorch, and the same again backwards: 2.2 ms of a
+//          6.0 ms mapping iteration at 1200x680 through MIOpen. Here: one kernel forwards (tile + halo in LDS, the
+//          separable window as a row pass and a column pass, the SSIM map, its three partial derivatives w.r.t. the
+//          window sums of the FIRST image) and one backwards (the transposed window over the three derivative maps).
+//          The window is whatever 11 taps the caller passes (the reference's is asymmetric: harness.py:_ssim_taps).
+//   Adam   reference: torch::optim::Adam, src/Gaussian.cc:144-175 (eps 1e-15, no weight decay, no amsgrad) — libtorch
+//          runs it as ~12 elementwise passes per parameter tensor (0.6 ms per step at 1 M Gaussians); here one pass.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gsr {
+
+#define GSR_SSIM_TILE 16
+#define GSR_SSIM_R 5 // window radius: 11 taps
+#define GSR_SSIM_HALO (GSR_SSIM_TILE + 2 * GSR_SSIM_R)
+struct SsimTaps {
+    float g[2 * GSR_SSIM_R + 1];
+};
+
+// zero-padded "same" cross-correlation, like conv2d(padding = 5): out[y][x] = sum_k sum_l g[k] g[l] in[y + k - 5][x + l - 5]
+__global__ void __launch_bounds__(GSR_SSIM_TILE* GSR_SSIM_TILE)
+K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W, SsimTaps taps,
+           float* __restrict__ partial, float* __restrict__ dmaps)
+{
+    constexpr int TS = GSR_SSIM_TILE, HS = GSR_SSIM_HALO, R = GSR_SSIM_R;
+    __shared__ float a[HS][HS + 1], b[HS][HS + 1];
+    __shared__ float h[5][HS][TS + 1];
+    __shared__ float wsum[TS * TS / 64];
+    const int tid = threadIdx.x, tx = tid % TS, ty = tid / TS;
+    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS, c = blockIdx.z;
+    const size_t plane = (size_t)H * W;
+    const float* __restrict__ p1 = img1 + c * plane;
+    const float* __restrict__ p2 = img2 + c * plane;
+    for (int i = tid; i < HS * HS; i += TS * TS) {
+        const int y = i / HS, x = i - y * HS, gy = y0 + y - R, gx = x0 + x - R;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        a[y][x] = in ? p1[(size_t)gy * W + gx] : 0.f;
+        b[y][x] = in ? p2[(size_t)gy * W + gx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < HS * TS; i += TS * TS) { // row pass: five window sums per (halo row, column)
+        const int y = i / TS, x = i - y * TS;
+        float s1 = 0.f, s2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+#pragma unroll
+        for (int k = 0; k <= 2 * R; k++) {
+            const float p = a[y][x + k], q = b[y][x + k], g = taps.g[k];
+            s1 = fmaf(g, p, s1); s2 = fmaf(g, q, s2);
+            s11 = fmaf(g, p * p, s11); s22 = fmaf(g, q * q, s22); s12 = fmaf(g, p * q, s12);
+        }
+        h[0][y][x] = s1; h[1][y][x] = s2; h[2][y][x] = s11; h[3][y][x] = s22; h[4][y][x] = s12;
+    }
+    __syncthreads();
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k <= 2 * R; k++) {
+        const float g = taps.g[k];
+#pragma unroll
+        for (int q = 0; q < 5; q++) v[q] = fmaf(g, h[q][ty + k][tx], v[q]);
+    }
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const float mu1 = v[0], mu2 = v[1], mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+    const float s1 = v[2] - mu1_sq, s2 = v[3] - mu2_sq, s12 = v[4] - mu12;
+    const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cc = mu1_sq + mu2_sq + C1, D = s1 + s2 + C2;
+    const float inv = 1.f / (Cc * D), m = (A * B) * inv;
+    const int gx = x0 + tx, gy = y0 + ty;
+    const bool inside = gx < W && gy < H;
+    if (inside && dmaps) {
+        // d(map)/d(mu1), d(map)/d(E[x^2]), d(map)/d(E[xy]) with s1 = E[x^2] - mu1^2, s12 = E[xy] - mu1 mu2
+        const size_t o = c * plane + (size_t)gy * W + gx, N = (size_t)gridDim.z * plane;
+        dmaps[o] = 2.f * mu2 * (B - A) * inv - 2.f * mu1 * m * (1.f / Cc - 1.f / D);
+        dmaps[N + o] = -m / D;
+        dmaps[2 * N + o] = 2.f * A * inv;
+    }
+    float sum = inside ? m : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if ((tid & 63) == 0) wsum[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) { // one partial per workgroup, summed by the caller: a deterministic total
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < TS * TS / 64; q++) t += wsum[q];
+        partial[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+// dL/dimg1 = scale * ( corrT(dmu1) + 2 img1 corrT(dE11) + img2 corrT(dE12) ), corrT = the transposed window:
+// out[x] = sum_k g[k] d[x - k + 5]; scale = *dL_dmean / (C H W)
+__global__ void __launch_bounds__(GSR_SSIM_TILE* GSR_SSIM_TILE)
+K_ssim_bwd(const float* __restrict__ img1, const float* __restrict__ img2, const float* __restrict__ dmaps, int H, int W,
+           SsimTaps taps, const float* __restrict__ dL_dmean, float* __restrict__ dL_dimg1)
+{
+    constexpr int TS = GSR_SSIM_TILE, HS = GSR_SSIM_HALO, R = GSR_SSIM_R;
+    __shared__ float d[3][HS][HS + 1];
+    __shared__ float h[3][HS][TS + 1];
+    const int tid = threadIdx.x, tx = tid % TS, ty = tid / TS;
+    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS, c = blockIdx.z;
+    const size_t plane = (size_t)H * W, N = (size_t)gridDim.z * plane;
+    for (int i = tid; i < HS * HS; i += TS * TS) {
+        const int y = i / HS, x = i - y * HS, gy = y0 + y - R, gx = x0 + x - R;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const size_t o = c * plane + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+#pragma unroll
+        for (int q = 0; q < 3; q++) d[q][y][x] = in ? dmaps[q * N + o] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < HS * TS; i += TS * TS) {
+        const int y = i / TS, x = i - y * TS;
+        float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k <= 2 * R; k++) {
+            const float g = taps.g[2 * R - k]; // transposed: tap k meets d[x - k + 5] = halo column x + (10 - k)
+#pragma unroll
+            for (int q = 0; q < 3; q++) s[q] = fmaf(g, d[q][y][x + k], s[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) h[q][y][x] = s[q];
+    }
+    __syncthreads();
+    float v[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k <= 2 * R; k++) {
+        const float g = taps.g[2 * R - k];
+#pragma unroll
+        for (int q = 0; q < 3; q++) v[q] = fmaf(g, h[q][ty + k][tx], v[q]);
+    }
+    const int gx = x0 + tx, gy = y0 + ty;
+    if (gx < W && gy < H) {
+        const size_t o = c * plane + (size_t)gy * W + gx;
+        const float scale = dL_dmean[0] / (float)N;
+        dL_dimg1[o] = scale * (v[0] + 2.f * img1[o] * v[1] + img2[o] * v[2]);
+    }
+}
+
+// torch.optim.Adam's single-tensor update (no weight decay, no amsgrad, not maximising):
+//   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ void __launch_bounds__(256)
+K_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+       float w1 /* 1 - beta1 */, float b2, float w2 /* 1 - beta2 */, float eps, float step_size, float sqrt_bias2)
+{
+    const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    auto one = [&](float& pp, const float gg, float& mm, float& vv) {
+        mm = fmaf(w1, gg - mm, mm);                    // exp_avg.lerp_(grad, 1 - beta1)
+        vv = fmaf(w2 * gg, gg, vv * b2);             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        const float denom = sqrtf(vv) / sqrt_bias2 + eps;
+        pp = fmaf(-step_size, mm / denom, pp);        // param.addcdiv_(exp_avg, denom, value = -step_size)
+    };
+    if (i4 + 4 <= n && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                         reinterpret_cast<uintptr_t>(v)) & 15u) == 0u) {
+        float4 P = *reinterpret_cast<float4*>(p + i4), M = *reinterpret_cast<float4*>(m + i4), V = *reinterpret_cast<float4*>(v + i4);
+        const float4 G = *reinterpret_cast<const float4*>(g + i4);
+        one(P.x, G.x, M.x, V.x); one(P.y, G.y, M.y, V.y); one(P.z, G.z, M.z, V.z); one(P.w, G.w, M.w, V.w);
+        *reinterpret_cast<float4*>(p + i4) = P; *reinterpret_cast<float4*>(m + i4) = M; *reinterpret_cast<float4*>(v + i4) = V;
+    } else {
+        for (size_t i = i4; i < n && i < i4 + 4; i++) one(p[i], g[i], m[i], v[i]);
+    }
+}
+
+} // namespace gsr

@@ -94,10 +94,30 @@ def _ssim_taps(window_size=11, sigma=1.5, device="cpu"):
     return g / g.sum()
 
 
+def _capi():
+    """The C-ABI wrappers (fused SSIM / Adam kernels); using them raises ImportError when the HIP library is not built."""
+    from . import capi
+    return capi
+
+
+_TAPS = None
+
+
 def ssim(img1, img2):
     """Utils.cc:77-100. The reference convolves with the 11x11 window outer(g, g) (ssim_window above); the window is
-    separable, so the same sums are formed by an 11x1 and a 1x11 pass — 22 taps instead of 121 per pixel (the 11x11
-    depthwise convolution was 55 % of the GPU time of a mapping iteration at 1200x680)."""
+    separable, so the same sums are formed by an 11x1 and a 1x11 pass. On the GPU the whole loss — five window sums, the
+    SSIM map, its mean, and the backward — is two HIP kernels (csrc/gsr_train.h: the convolutions through MIOpen were
+    2.2 ms of a 6.0 ms mapping iteration at 1200x680); CPU tensors (the oracle-driven test loops) take the torch path."""
+    global _TAPS
+    if img1.is_cuda:
+        if _TAPS is None:
+            _TAPS = [float(x) for x in _ssim_taps(11, 1.5, "cpu")]
+        return _capi().ssim_mean(img1, img2.detach(), _TAPS)
+    return ssim_torch(img1, img2)
+
+
+def ssim_torch(img1, img2):
+    """The same loss through torch convolutions (CPU loops; the fp32 reference the fused kernels are tested against)."""
     C1, C2 = 0.01 * 0.01, 0.03 * 0.03
     ch = img1.shape[0]
     g = _ssim_taps(11, 1.5, img1.device)
@@ -111,6 +131,14 @@ def ssim(img1, img2):
     s12 = conv(img1 * img2) - mu12
     m = ((2.0 * mu12 + C1) * (2.0 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
     return m.mean()
+
+
+def _adam(groups, device):
+    """Adam as Gaussian.cc:144-175 configures it (eps 1e-15). GPU parameters: the fused one-kernel-per-tensor step
+    (capi.FusedAdam, same state layout); CPU parameters (oracle-driven test loops): torch.optim.Adam."""
+    if torch.device(device).type == "cuda":
+        return _capi().FusedAdam(groups, lr=0.0, eps=1e-15)
+    return torch.optim.Adam(groups, lr=0.0, eps=1e-15)
 
 
 # ---- pose parameterisation (include/Utils.h:56-77, Utils.cc:170-179) ----------------------------
@@ -198,7 +226,7 @@ class GaussianMap:
             for n, t in zip(self.NAMES, new):
                 setattr(self, n, t.requires_grad_(True))
             groups = [{"params": [getattr(self, n)], "lr": lr} for n, lr in zip(self.NAMES, self._lrs())]
-            self.opt = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+            self.opt = _adam(groups, self.device)
             return
         for gi, (n, t) in enumerate(zip(self.NAMES, new)):       # CatTensorToOptimizer, Gaussian.cc:236-258
             old = getattr(self, n)
@@ -233,8 +261,8 @@ class GaussianMap:
         self.cam_quat = rot_to_quat(Tcw[:3, :3].cpu()).reshape(4, 1).to(self.device).requires_grad_(True)
         self.cam_trans = Tcw[:3, 3].clone().reshape(3, 1).requires_grad_(True)
         # both groups use lrCamQuat, like the reference (Gaussian.cc:149-150)
-        self.opt_pose = torch.optim.Adam([{"params": [self.cam_quat], "lr": self.cfg.lr_cam_quat},
-                                          {"params": [self.cam_trans], "lr": self.cfg.lr_cam_quat}], lr=0.0, eps=1e-15)
+        self.opt_pose = _adam([{"params": [self.cam_quat], "lr": self.cfg.lr_cam_quat},
+                               {"params": [self.cam_trans], "lr": self.cfg.lr_cam_quat}], self.device)
         return Tcw
 
 

@@ -190,6 +190,25 @@ size_t gsr_knn_bytes(int P);
 int gsr_dist2(int P, const float* points /* [P,3] */, float* mean_dists /* [P] */, char* workspace,
               size_t workspace_bytes, void* stream);
 
+/* ---- the two non-rasterizer hot spots of a mapping iteration, fused ---------------------------
+ * SSIM (reference ORB_SLAM2::ssim, src/Utils.cc:77-100: five depthwise 11x11 convolutions + elementwise passes through
+ * libtorch, and their autograd): mean over [C,H,W] of the SSIM map of img1 vs img2 with the 11-tap separable window
+ * `taps11` (host pointer; zero padding like conv2d(padding=5)) and its gradient w.r.t. img1.
+ *   gsr_ssim_forward  writes one partial sum of the map per workgroup (gsr_ssim_partials of them; the caller adds them
+ *                     up and divides by C*H*W) and, if dmaps != NULL, the three derivative maps [3,C,H,W] the backward needs
+ *   gsr_ssim_backward dL_dimg1 [C,H,W] = (*dL_dmean / (C*H*W)) * d(sum of the map)/d(img1); dL_dmean is a DEVICE scalar
+ * Adam (reference torch::optim::Adam as src/Gaussian.cc:144-175 configures it: no weight decay, no amsgrad): one
+ * in-place step of one parameter tensor, `step` = the 1-based step count of that tensor; the hyper-parameters are doubles,
+ * like the Python / C++ scalars the reference passes (1 - beta and the bias corrections are formed in double). Never
+ * allocate, never sync. */
+size_t gsr_ssim_partials(int C, int H, int W);
+int gsr_ssim_forward(const float* img1, const float* img2, int C, int H, int W, const float* taps11,
+                     float* partial, float* dmaps, void* stream);
+int gsr_ssim_backward(const float* img1, const float* img2, const float* dmaps, int C, int H, int W,
+                      const float* taps11, const float* dL_dmean, float* dL_dimg1, void* stream);
+int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
+                  double beta1, double beta2, double eps, int step, void* stream);
+
 /* Workspace sizes: replace required<GeometryState/ImageState/BinningState>
  * (rasterizer_impl.h:67-73). */
 size_t gsr_geom_bytes(int P);

@@ -1,0 +1,91 @@
+"""the fused SSIM and Adam kernels (csrc/gsr_train.h) against plain PyTorch fp32 references of the
+same operations — the torch-convolution SSIM of harness.ssim_torch (Utils.cc:77-100, the reference's asymmetric window)
+and torch.optim.Adam as Gaussian.cc:144-175 configures it."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hz(gsr):
+    return __import__("gsorb_slam_amd.harness", fromlist=["x"])
+
+
+@pytest.mark.parametrize("shape", [(3, 37, 53), (1, 16, 16), (3, 5, 200), (3, 680, 1200)])
+def test_fused_ssim_matches_the_torch_convolutions(gsr, hz, shape):
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(shape, generator=g).cuda()
+    b = (a + 0.2 * torch.randn(shape, generator=g).cuda()).clamp(0, 1)
+    a1, a2 = a.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    ref = hz.ssim_torch(a1, b)
+    got = hz.ssim(a2, b)
+    assert got.is_cuda and abs(float(got.detach()) - float(ref.detach())) <= 2e-6 * max(1.0, abs(float(ref.detach())))
+    w = 0.37
+    (w * (1.0 - ref)).backward()
+    (w * (1.0 - got)).backward()
+    scale = float(a1.grad.abs().max())
+    assert scale > 0
+    assert float((a2.grad - a1.grad).abs().max()) <= 2e-5 * scale       # tolerance: fp32 summation order (121 taps x 5 sums)
+    # no gradient requested: no derivative maps, same value
+    with torch.no_grad():
+        assert abs(float(hz.ssim(a, b)) - float(ref.detach())) <= 2e-6
+
+
+def test_fused_ssim_uses_the_window_it_is_given(gsr, hz):
+    """A symmetric and the reference's asymmetric 11-tap window give different losses; each matches its own convolution."""
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.rand((3, 40, 44), generator=g).cuda(), torch.rand((3, 40, 44), generator=g).cuda()
+    taps_ref = [float(x) for x in hz._ssim_taps(11, 1.5, "cpu")]
+    sym = torch.tensor([np.exp(-((x - 5) ** 2) / (2 * 1.5 ** 2)) for x in range(11)], dtype=torch.float32)
+    sym = [float(x) for x in sym / sym.sum()]
+    assert taps_ref != taps_ref[::-1]
+    v_ref, v_sym = float(gsr.capi.ssim_mean(a, b, taps_ref)), float(gsr.capi.ssim_mean(a, b, sym))
+    assert abs(v_ref - float(hz.ssim_torch(a, b))) <= 2e-6 and abs(v_ref - v_sym) > 1e-5
+
+
+def test_fused_adam_matches_torch_adam_over_several_steps(gsr):
+    g = torch.Generator().manual_seed(11)
+    shapes = [(1000, 3), (1001, 1), (7,), (4, 1), (12345, 4)]
+    lrs = [1e-4, 2.5e-3, 1e-3, 4e-4, 5e-2]
+    init = [torch.randn(s, generator=g).cuda() for s in shapes]
+    pa = [t.clone().requires_grad_(True) for t in init]
+    pb = [t.clone().requires_grad_(True) for t in init]
+    oa = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(pa, lrs)], lr=0.0, eps=1e-15)
+    ob = gsr.capi.FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(pb, lrs)], lr=0.0, eps=1e-15)
+    for it in range(6):
+        grads = [torch.randn(s, generator=g).cuda() * (10.0 ** (it % 3 - 1)) for s in shapes]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        if it == 3:
+            pa[2].grad = pb[2].grad = None            # a parameter without a gradient keeps its step count
+        oa.step(); ob.step()
+    for p, q in zip(pa, pb):
+        d = (p - q).abs().max()
+        assert float(d) <= 2e-6 * float(p.abs().max()), float(d)
+        sa, sb = oa.state[p], ob.state[q]
+        assert float(sa["step"]) == float(sb["step"])
+        assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-12)
+        assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+
+
+def test_harness_map_uses_the_fused_optimiser_and_keeps_state_through_surgery(gsr, hz):
+    m = hz.GaussianMap(hz.Config(), 300.0, 300.0, device="cuda")
+    pts = torch.rand(500, 3) + torch.tensor([0.0, 0.0, 1.0])
+    m.add_points(pts, torch.rand(500, 3))
+    assert isinstance(m.opt, gsr.capi.FusedAdam)
+    for n in m.NAMES:
+        getattr(m, n).grad = torch.randn_like(getattr(m, n))
+    m.opt.step()
+    before = m.opt.state[m.xyz]["exp_avg"].clone()
+    m.add_points(pts[:50] + 0.01, torch.rand(50, 3))                     # CatTensorToOptimizer
+    st = m.opt.state[m.xyz]
+    assert st["exp_avg"].shape[0] == 550 and torch.equal(st["exp_avg"][:500], before) and float(st["exp_avg"][500:].abs().max()) == 0
+    keep_mask = torch.zeros(550, dtype=torch.bool, device="cuda"); keep_mask[::2] = True
+    m.prune(keep_mask)                                                   # PruneOptimizer
+    assert m.opt.state[m.xyz]["exp_avg"].shape[0] == 275
+    for n in m.NAMES:
+        getattr(m, n).grad = torch.randn_like(getattr(m, n))
+    m.opt.step()
+    assert float(m.opt.state[m.xyz]["step"]) == 2
