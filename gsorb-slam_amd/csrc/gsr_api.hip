@@ -458,6 +458,15 @@ int gsr_ssim_backward(const float* img1, const float* img2, const float* dmaps, 
     return GSR_OK;
 }
 
+int gsr_pose_grad(const float* means3D, const float* dL_dmeans_cam, size_t n, float* partial, void* stream)
+{
+    static_assert(GSR_POSE_PARTIALS == GSR_POSE_BLOCKS, "header and kernel agree on the number of partial rows");
+    if (!partial || (n > 0 && (!means3D || !dL_dmeans_cam))) return GSR_EINVAL;
+    hipLaunchKernelGGL(gsr::K_pose_grad, dim3(GSR_POSE_BLOCKS), dim3(256), 0, (hipStream_t)stream, means3D, dL_dmeans_cam, n, partial);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
 int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
                   double beta2, double eps, int step, void* stream)
 {

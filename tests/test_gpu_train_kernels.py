@@ -89,3 +89,25 @@ def test_harness_map_uses_the_fused_optimiser_and_keeps_state_through_surgery(gs
         getattr(m, n).grad = torch.randn_like(getattr(m, n))
     m.opt.step()
     assert float(m.opt.state[m.xyz]["step"]) == 2
+
+
+def test_to_camera_pose_gradient_matches_autograd_through_the_product(gsr):
+    """N1 of the verdict's table: dL/dTcw through mc = X R^T + t. The fused reduction against autograd through the plain
+    product (what the reference does, Render.cc:750-752), in float64 for the comparison's reference."""
+    g = torch.Generator().manual_seed(2)
+    n = 300_001
+    X = (torch.randn((n, 3), generator=g) * 2).cuda()
+    T = torch.eye(4); T[:3, :3] = torch.linalg.qr(torch.randn((3, 3), generator=g))[0]; T[:3, 3] = torch.randn(3, generator=g)
+    T = T.cuda()
+    w = torch.randn((n, 3), generator=g).cuda()
+    Ta, Xa = T.clone().requires_grad_(True), X.clone().requires_grad_(True)
+    mc = gsr.capi.to_camera(Ta, Xa)
+    (mc * w).sum().backward()
+    Tb, Xb = T.double().clone().requires_grad_(True), X.double().clone().requires_grad_(True)
+    ref = Xb @ Tb[:3, :3].t() + Tb[:3, 3]
+    (ref * w.double()).sum().backward()
+    assert float((mc.double() - ref).abs().max()) <= 1e-5
+    assert float((Xa.grad.double() - Xb.grad).abs().max()) <= 1e-5
+    scale = float(Tb.grad.abs().max())
+    assert float((Ta.grad.double() - Tb.grad).abs().max()) <= 2e-5 * scale   # fp32 sums of 3e5 terms
+    assert float(Ta.grad[3].abs().max()) == 0.0
