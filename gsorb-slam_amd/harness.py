@@ -71,13 +71,16 @@ def _dgr():
 
 # ---- losses (Utils.cc:39-100) -----------------------------------------------------------
 def l1_mapping(a, b, mask=None):
+    """Utils.cc:39-56: mean |a - b|, over the masked elements if a mask is given. The reference selects them
+    (masked_select: a device->host sync for the count); the same mean is sum(where(mask, d, 0)) / count(mask) without one.
+    An empty mask gives NaN, like the mean of an empty selection."""
     d = torch.abs(a - b)
-    return d.mean() if mask is None else d.masked_select(mask).mean()
+    return d.mean() if mask is None else torch.where(mask, d, torch.zeros_like(d)).sum() / mask.sum()
 
 
 def l1_tracking(a, b, mask=None):
     d = torch.abs(a - b)
-    return d.sum() if mask is None else d.masked_select(mask).sum()
+    return d.sum() if mask is None else torch.where(mask, d, torch.zeros_like(d)).sum()
 
 
 def ssim_window(window_size=11, sigma=1.5, channel=3, device="cpu"):
@@ -356,15 +359,20 @@ class SlamRenderer:
         valid_sur = (fr.depth > 0) & (rdepth[1] > 0.99)
         image_loss = c.lam * l1_mapping(rimage, fr.rgb) + (1 - c.lam) * (1.0 - ssim(rimage, fr.rgb))
         depth_loss = l1_mapping(rdepth[0], fr.depth, valid.detach())
-        sur_loss = l1_mapping(rsur[0], fr.depth, valid_sur.detach()) if bool(valid_sur.any()) else rimage.sum() * 0
+        # (no surface pixel: the reference skips the term; here it is an exact zero with a zero gradient, without asking the host)
+        n_sur = valid_sur.sum()
+        sur_loss = torch.where(valid_sur.detach(), torch.abs(rsur[0] - fr.depth), torch.zeros_like(fr.depth)).sum() / n_sur.clamp_min(1)
         max_scalar = 0.1 * g.scene_radius
         sc = torch.exp(g.log_scales)
-        big = torch.where(sc > max_scalar)[0]
-        sel = sc.index_select(0, big)
-        mx, mn = (sel.max(1)[0], sel.min(1)[0]) if sel.numel() else (sc.sum(1)[:0], sc.sum(1)[:0])
-        over, spread, cnt = self._reduce_regularisers((mx - max_scalar).sum(), (mx - mn).sum(), float(mx.numel()))
+        # Render.cc:449-462 gathers the rows of every scale COMPONENT above the limit (torch::where(...)[0]: a row with two
+        # oversized axes counts twice) and takes max / min of those rows. The same sums with the multiplicity as a weight,
+        # without the index list (nonzero: another host sync)
+        w = (sc > max_scalar).sum(1).to(sc.dtype)
+        mx, mn = sc.max(1)[0], sc.min(1)[0]
+        over, spread, cnt = self._reduce_regularisers((w * (mx - max_scalar)).sum(), (w * (mx - mn)).sum(), w.sum())
+        cnt = torch.as_tensor(cnt, dtype=sc.dtype, device=sc.device)
         reg_scalar = over
-        reg_long = spread / cnt if cnt > 0 else spread * 0          # mean over the oversized splats (Render.cc:455-462)
+        reg_long = torch.where(cnt > 0, spread / cnt.clamp_min(1), torch.zeros_like(spread))   # mean over the oversized splats
         return (c.im_weight_mapping * image_loss + c.depth_weight_mapping * depth_loss + c.sur_depth_weight_mapping * sur_loss
                 + c.reg_long_weight * reg_long + c.reg_scalar_weight * reg_scalar)
 

@@ -136,7 +136,7 @@ def make_sharded_mapper(harness_mod):
             return rgb, sur, torch.cat([depth, sil], 0)
 
         def _reduce_regularisers(self, sum_over, sum_spread, count):
-            tot = self.comp.all_reduce_scalars([float(sum_over.detach()), float(sum_spread.detach()), count])
+            tot = self.comp.all_reduce_scalars([float(sum_over.detach()), float(sum_spread.detach()), float(count)])
             # value = whole-map total, gradient = this shard's part
             over = sum_over + (tot[0] - float(sum_over.detach()))
             spread = sum_spread + (tot[1] - float(sum_spread.detach()))

@@ -36,6 +36,31 @@ def test_ssim_window_is_the_references_odd_formula(hz):
     assert torch.allclose(hz.l1_mapping(a, 1 - a), torch.abs(2 * a - 1).mean())
 
 
+def test_sync_free_losses_equal_the_selecting_forms(hz):
+    """The reference selects the masked elements / the rows of oversized scale components (masked_select,
+    torch::where(...)[0]: host syncs); the harness forms the same sums with masks and multiplicities."""
+    g = torch.Generator().manual_seed(9)
+    a, b = torch.rand((3, 20, 30), generator=g), torch.rand((3, 20, 30), generator=g)
+    b[0, 3, 4] = float("nan")                                   # a NaN under the mask must not leak
+    mask = torch.rand((3, 20, 30), generator=g) > 0.4
+    mask[0, 3, 4] = False
+    d = torch.abs(a - b)
+    assert torch.allclose(hz.l1_mapping(a, b, mask), d.masked_select(mask).mean(), rtol=1e-6)
+    assert torch.allclose(hz.l1_tracking(a, b, mask), d.masked_select(mask).sum(), rtol=1e-6)
+    assert torch.isnan(hz.l1_mapping(a, b, torch.zeros_like(mask)))
+    # scale regularisers (Render.cc:449-462): rows gathered once per oversized COMPONENT
+    sc = torch.rand((200, 3), generator=g)
+    lim = 0.6
+    big = torch.where(sc > lim)[0]
+    sel = sc.index_select(0, big)
+    ref_over, ref_spread, ref_cnt = (sel.max(1)[0] - lim).sum(), (sel.max(1)[0] - sel.min(1)[0]).sum(), float(sel.shape[0])
+    w = (sc > lim).sum(1).to(sc.dtype)
+    mx, mn = sc.max(1)[0], sc.min(1)[0]
+    assert torch.allclose((w * (mx - lim)).sum(), ref_over, rtol=1e-6)
+    assert torch.allclose((w * (mx - mn)).sum(), ref_spread, rtol=1e-6)
+    assert float(w.sum()) == ref_cnt and ref_cnt > 200          # some rows count twice or three times
+
+
 def test_pose_parameterisation_round_trip(hz):
     for th, t in ((0.3, (0.1, -0.2, 0.3)), (2.9, (1, 2, 3)), (-1.2, (0, 0, 0))):
         T = torch.tensor(pose(th, t), dtype=torch.float32)
