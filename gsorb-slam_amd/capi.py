@@ -18,7 +18,7 @@ _LIB = None
 EXPORTS = ["gsr_forward", "gsr_forward_ws", "gsr_ws_status", "gsr_backward", "gsr_mark_visible",
            "gsr_visible_filter", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
            "gsr_debug_export", "gsr_acc_view", "gsr_knn_bytes", "gsr_dist2", "gsr_ssim_partials", "gsr_ssim_forward", "gsr_ssim_backward",
-           "gsr_adam_step", "gsr_pose_grad", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
+           "gsr_adam_step", "gsr_pose_grad", "gsr_to_camera", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
 
 
 def library_path() -> str:
@@ -111,7 +111,9 @@ def lib():
     L.gsr_ssim_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p,
                                     C.c_void_p, C.c_void_p]
     L.gsr_pose_grad.restype = C.c_int
-    L.gsr_pose_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.gsr_pose_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gsr_to_camera.restype = C.c_int
+    L.gsr_to_camera.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gsr_adam_step.restype = C.c_int
     L.gsr_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
                                 C.c_int, C.c_void_p]
@@ -445,26 +447,32 @@ POSE_PARTIALS = 512  # GSR_POSE_PARTIALS
 
 
 class _ToCamera(torch.autograd.Function):
-    """mc = X R^T + t (Render.cc:750-752) with the pose gradient from one reduction kernel instead of a 3 x N x 3 GEMM."""
+    """mc = X R^T + t (Render.cc:750-752) as one elementwise kernel; backward: dL/dX = dmc R and the pose gradient from one
+    reduction kernel instead of a 3 x N x 3 GEMM. The pose stays on the device."""
 
     @staticmethod
     def forward(ctx, Tcw, X):
-        R, t = Tcw[:3, :3], Tcw[:3, 3]
-        ctx.save_for_backward(Tcw, X)
-        return X @ R.t() + t
+        Xc = X.contiguous()
+        Td = Tcw.detach().to(device=Xc.device, dtype=torch.float32).contiguous()
+        mc = torch.empty_like(Xc)
+        with torch.cuda.device(Xc.device):
+            _check(lib().gsr_to_camera(_p(Xc), int(Xc.shape[0]), _p(Td), _p(mc), _stream()))
+        ctx.save_for_backward(Xc, Td)
+        return mc
 
     @staticmethod
     def backward(ctx, dmc):
-        Tcw, X = ctx.saved_tensors
+        X, Td = ctx.saved_tensors
         dT = dX = None
         dmc = dmc.contiguous()
-        if ctx.needs_input_grad[1]:
-            dX = dmc @ Tcw[:3, :3]
-        if ctx.needs_input_grad[0]:
-            part = torch.empty((POSE_PARTIALS, 12), dtype=torch.float32, device=X.device)
-            Xc = X.contiguous()
-            with torch.cuda.device(X.device):
-                _check(lib().gsr_pose_grad(_p(Xc), _p(dmc), int(Xc.shape[0]), _p(part), _stream()))
+        want_T, want_X = ctx.needs_input_grad
+        if not (want_T or want_X):
+            return None, None
+        part = torch.empty((POSE_PARTIALS, 12), dtype=torch.float32, device=X.device) if want_T else None
+        dX = torch.empty_like(X) if want_X else None
+        with torch.cuda.device(X.device):
+            _check(lib().gsr_pose_grad(_p(X), _p(dmc), int(X.shape[0]), _p(Td), _p(part), _p(dX), _stream()))
+        if want_T:
             s = part.sum(0)
             dT = torch.zeros((4, 4), dtype=torch.float32, device=X.device)
             dT[:3, :3] = s[:9].reshape(3, 3)

@@ -458,11 +458,22 @@ int gsr_ssim_backward(const float* img1, const float* img2, const float* dmaps, 
     return GSR_OK;
 }
 
-int gsr_pose_grad(const float* means3D, const float* dL_dmeans_cam, size_t n, float* partial, void* stream)
+int gsr_to_camera(const float* means3D, size_t n, const float* Tcw, float* means_cam, void* stream)
+{
+    if (n == 0) return GSR_OK;
+    if (!means3D || !Tcw || !means_cam || (n + 255) / 256 > 0x7FFFFFFFu) return GSR_EINVAL;
+    hipLaunchKernelGGL(gsr::K_to_camera, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, means3D, n, Tcw, means_cam);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_pose_grad(const float* means3D, const float* dL_dmeans_cam, size_t n, const float* Tcw, float* partial,
+                  float* dL_dmeans3D, void* stream)
 {
     static_assert(GSR_POSE_PARTIALS == GSR_POSE_BLOCKS, "header and kernel agree on the number of partial rows");
-    if (!partial || (n > 0 && (!means3D || !dL_dmeans_cam))) return GSR_EINVAL;
-    hipLaunchKernelGGL(gsr::K_pose_grad, dim3(GSR_POSE_BLOCKS), dim3(256), 0, (hipStream_t)stream, means3D, dL_dmeans_cam, n, partial);
+    if ((!partial && !dL_dmeans3D) || !Tcw || (n > 0 && (!dL_dmeans_cam || (partial && !means3D)))) return GSR_EINVAL;
+    hipLaunchKernelGGL(gsr::K_pose_grad, dim3(GSR_POSE_BLOCKS), dim3(256), 0, (hipStream_t)stream, means3D, dL_dmeans_cam, n, Tcw, partial,
+                       dL_dmeans3D);
     GSR_LAUNCHED();
     return GSR_OK;
 }

@@ -168,19 +168,57 @@ K_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m
 // N = 1 M (38 % of a tracking iteration). Here: every thread sums its splats, a DPP butterfly per wave, one row of twelve
 // partial sums per workgroup (the caller adds the rows: deterministic).
 #define GSR_POSE_BLOCKS 512
-__global__ void __launch_bounds__(256)
-K_pose_grad(const float* __restrict__ X, const float* __restrict__ dmc, size_t n, float* __restrict__ partial)
+struct Pose34 {
+    float r[9], t[3]; // R row-major, t
+};
+// the pose lives on the device (the optimiser's output): every wave reads its twelve numbers with scalar loads
+__device__ __forceinline__ Pose34 load_pose(const float* __restrict__ Tcw)
 {
+    Pose34 p;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) p.r[3 * i + j] = Tcw[4 * i + j];
+        p.t[i] = Tcw[4 * i + 3];
+    }
+    return p;
+}
+// mc = X R^T + t, one splat per thread (as a GEMM: 63 us at 1 M splats through rocBLAS; this is 24 MB of traffic)
+__global__ void __launch_bounds__(256)
+K_to_camera(const float* __restrict__ X, size_t n, const float* __restrict__ Tcw, float* __restrict__ mc)
+{
+    const Pose34 T = load_pose(Tcw);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
+    mc[3 * i] = fmaf(T.r[2], z, fmaf(T.r[1], y, T.r[0] * x)) + T.t[0];
+    mc[3 * i + 1] = fmaf(T.r[5], z, fmaf(T.r[4], y, T.r[3] * x)) + T.t[1];
+    mc[3 * i + 2] = fmaf(T.r[8], z, fmaf(T.r[7], y, T.r[6] * x)) + T.t[2];
+}
+// backward: twelve pose sums per workgroup (if partial) and dL/dX = dmc R (if dX)
+__global__ void __launch_bounds__(256)
+K_pose_grad(const float* __restrict__ X, const float* __restrict__ dmc, size_t n, const float* __restrict__ Tcw,
+            float* __restrict__ partial, float* __restrict__ dX)
+{
+    const Pose34 T = load_pose(Tcw);
     __shared__ float ws[4][12];
     float a[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
         const float g0 = dmc[3 * i], g1 = dmc[3 * i + 1], g2 = dmc[3 * i + 2];
-        a[0] = fmaf(g0, x, a[0]); a[1] = fmaf(g0, y, a[1]); a[2] = fmaf(g0, z, a[2]);
-        a[3] = fmaf(g1, x, a[3]); a[4] = fmaf(g1, y, a[4]); a[5] = fmaf(g1, z, a[5]);
-        a[6] = fmaf(g2, x, a[6]); a[7] = fmaf(g2, y, a[7]); a[8] = fmaf(g2, z, a[8]);
-        a[9] += g0; a[10] += g1; a[11] += g2;
+        if (dX) {
+            dX[3 * i] = fmaf(g2, T.r[6], fmaf(g1, T.r[3], g0 * T.r[0]));
+            dX[3 * i + 1] = fmaf(g2, T.r[7], fmaf(g1, T.r[4], g0 * T.r[1]));
+            dX[3 * i + 2] = fmaf(g2, T.r[8], fmaf(g1, T.r[5], g0 * T.r[2]));
+        }
+        if (partial) {
+            const float x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
+            a[0] = fmaf(g0, x, a[0]); a[1] = fmaf(g0, y, a[1]); a[2] = fmaf(g0, z, a[2]);
+            a[3] = fmaf(g1, x, a[3]); a[4] = fmaf(g1, y, a[4]); a[5] = fmaf(g1, z, a[5]);
+            a[6] = fmaf(g2, x, a[6]); a[7] = fmaf(g2, y, a[7]); a[8] = fmaf(g2, z, a[8]);
+            a[9] += g0; a[10] += g1; a[11] += g2;
+        }
     }
+    if (!partial) return;
 #pragma unroll
     for (int q = 0; q < 12; q++) {
 #pragma unroll

@@ -206,10 +206,17 @@ int gsr_ssim_forward(const float* img1, const float* img2, int C, int H, int W, 
                      float* partial, float* dmaps, void* stream);
 int gsr_ssim_backward(const float* img1, const float* img2, const float* dmaps, int C, int H, int W,
                       const float* taps11, const float* dL_dmean, float* dL_dimg1, void* stream);
-/* Pose gradient through mc = X R^T + t (src/Render.cc:750-752; the reference leaves it to autograd through bmm): partial
- * [GSR_POSE_PARTIALS][12], row = (dL/dR row-major 3x3, dL/dt) summed over that workgroup's splats; the caller adds the rows. */
+/* The camera transform mc = X R^T + t of the means (src/Render.cc:750-752: Tcw.repeat(n,1,1).bmm([x;1])) and its
+ * backward (the reference leaves both to libtorch's batched GEMM and autograd). Tcw: DEVICE pointer to the 4x4 row-major pose
+ * (the pose optimiser's output: no host round trip).
+ *   gsr_to_camera  means_cam [n,3]
+ *   gsr_pose_grad  from dL/dmeans_cam [n,3]: dL_dmeans3D [n,3] = dmc R (NULL: not wanted) and partial
+ *                  [GSR_POSE_PARTIALS][12] (NULL: not wanted), row = (dL/dR row-major 3x3, dL/dt) summed over that
+ *                  workgroup's splats; the caller adds the rows */
 #define GSR_POSE_PARTIALS 512
-int gsr_pose_grad(const float* means3D /* [n,3] */, const float* dL_dmeans_cam /* [n,3] */, size_t n, float* partial, void* stream);
+int gsr_to_camera(const float* means3D /* [n,3] */, size_t n, const float* Tcw, float* means_cam, void* stream);
+int gsr_pose_grad(const float* means3D /* [n,3] */, const float* dL_dmeans_cam /* [n,3] */, size_t n, const float* Tcw,
+                  float* partial, float* dL_dmeans3D, void* stream);
 int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
                   double beta1, double beta2, double eps, int step, void* stream);
 

@@ -143,16 +143,20 @@ def test_tracking_mapping_loop_on_hip_matches_the_same_loop_on_the_oracle(gsr, s
     # enters or leaves it whole, and one pixel is ~1e-3 of the total — observed 1.4e-3 / 3.2e-3, bar 1e-2.
     # The FIRST mapping loop starts from bit-identical states: 1e-4 (observed 2.5e-6). The later loops inherit the
     # divergence of the 300 .. 600 Adam steps before them (observed 6e-4 / 1.3e-3): 3e-3.
-    assert rep["map_curve_rel"][0] <= 1e-4 and max(rep["map_curve_rel"]) <= 3e-3 and max(rep["track_curve_rel"]) <= 1e-2, rep
+    # Both runs are chaotic in the last digits (float atomics in the HIP backward, and since the harness moved its losses,
+    # optimiser and pose gradient to fused kernels the two sides no longer share those roundings either): over seven runs
+    # of this test the later mapping loops spread 2.5e-4 .. 1.6e-3 and the tracking curves 2.4e-3 .. 6.0e-3 — bars at
+    # about three times the worst seen.
+    assert rep["map_curve_rel"][0] <= 1e-4 and max(rep["map_curve_rel"]) <= 5e-3 and max(rep["track_curve_rel"]) <= 2e-2, rep
     # whole curves: 95 % of the iterations agree closely. The maximum is reported, not asserted: the reference's mapping
     # loss is discontinuous too (a scale that crosses 0.1 * scene radius enters the regularisers whole, Render.cc:455-462),
     # and the two runs may cross such a threshold one iteration apart (observed: one 90 % spike in 300 iterations).
     assert max(rep["map_curve_rel_all_q95"]) <= 5e-3 and max(rep["track_curve_rel_all_q95"]) <= 5e-2, rep
-    assert all(a == b for a, b in rep["track_len"]), rep
+    assert all(abs(a - b) <= 2 for a, b in rep["track_len"]), rep    # the early-exit test (|loss change| < 1e-3) may fire an iteration apart
     assert max(dt) < 1e-3 and max(dR) < 1e-3, rep                     # final poses agree: < 1 mm, < 1 mrad
     assert rep["ate_hip_vs_oracle_m"] < 1e-3, rep                    # ATE between the two runs below 1 mm
     assert abs(rep["ate_hip_vs_gt_m"] - rep["ate_oracle_vs_gt_m"]) < 1e-3, rep
     assert all(e < 0.5 * e0 for e, e0 in zip(errk, err0)), rep        # and tracking actually tracks
-    assert rep["psnr_hip_vs_oracle_db"] > 50.0, rep
+    assert rep["psnr_hip_vs_oracle_db"] > 48.0, rep                   # observed 52.7 .. 68.7 dB over seven runs
     assert abs(rep["psnr_hip_vs_observation_db"] - rep["psnr_oracle_vs_observation_db"]) < 0.1, rep
     assert hip["n"] == ora["n"] == P
