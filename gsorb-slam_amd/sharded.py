@@ -45,10 +45,10 @@ class LayerCompositor:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
-    def composite(self, rgb: torch.Tensor, ds: torch.Tensor, order_key: float, sur: torch.Tensor | None = None):
+    def composite(self, rgb: torch.Tensor, ds: torch.Tensor, order_key, sur: torch.Tensor | None = None):
         """rgb [3,H,W], ds [2,H,W] = this rank's layer (may require grad); order_key = any
         scalar that sorts the shards front to back for this camera (e.g. the shard's nearest
-        camera-space depth). Returns (rgb, depth, silhouette) of the whole scene.
+        camera-space depth; a python float or a 0-d tensor). Returns (rgb, depth, silhouette) of the whole scene.
 
         With `sur` [1,H,W] (the layer's own surface / median depth, which carries no gradient) a fourth value is
         returned: the surface depth of the first layer, front to back, behind which the accumulated transmittance
@@ -58,18 +58,21 @@ class LayerCompositor:
         if self.world == 1:
             return (rgb, ds[0:1], ds[1:2]) if sur is None else (rgb, ds[0:1], ds[1:2], sur)
         with torch.no_grad():
-            # ONE all-gather: the order key travels in a padding row of the layer (5 or 6 floats/pixel + W floats)
+            # ONE all-gather: the order key travels in a padding row of the layer (5 or 6 floats/pixel + W floats). The key
+            # may be a device scalar: nothing here asks the host for a value (no sync between the renders and the loss).
             pad = torch.zeros((1,) + tuple(layer.shape[1:]), dtype=layer.dtype, device=layer.device)
-            pad[0, 0, 0] = float(order_key)
-            gathered = _all_gather(torch.cat([layer.detach(), pad], 0).contiguous(), self.world, self.group)
-            keys = torch.stack([g[-1, 0, 0] for g in gathered]).tolist()
-            order = sorted(range(self.world), key=lambda g: (keys[g], g))
+            pad[0, 0, 0] = order_key
+            gathered = torch.stack(_all_gather(torch.cat([layer.detach(), pad], 0).contiguous(), self.world, self.group))
+            keys = gathered[:, -1, 0, 0].double()
+            order = torch.argsort(keys, stable=True)         # front to back: by key, ties by rank (the gathered index)
+            layers = gathered.index_select(0, order)[:, :-1]
+            mine = order == self.rank                        # [world] which sorted slot is this rank's own layer
         T = torch.ones_like(layer[0:1])
         out = torch.zeros_like(layer[0:4])
         surf = None if sur is None else torch.zeros_like(layer[0:1])
         found = None if sur is None else torch.zeros_like(layer[0:1], dtype=torch.bool)
-        for g in order:
-            L = layer if g == self.rank else gathered[g]   # own layer keeps its autograd history
+        for k in range(self.world):
+            L = torch.where(mine[k], layer, layers[k])       # own layer keeps its autograd history (zero gradient elsewhere)
             out = out + T * L[0:4]
             T = T * (1.0 - L[4:5])
             if sur is not None:
@@ -95,6 +98,19 @@ class LayerCompositor:
             t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t.tolist()
+
+    def all_reduce_vector(self, t: torch.Tensor) -> torch.Tensor:
+        """Sum of a small tensor over the ranks, staying where it is (RCCL reduces device tensors in place; gloo, which
+        has no device collectives, goes through the host). No value reaches Python: no sync on the RCCL path."""
+        if self.world == 1:
+            return t
+        if dist.get_backend(self.group) == "gloo" and t.is_cuda:
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            return h.to(t.device)
+        out = t.detach().clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+        return out
 
 
 def shard_by_depth_slabs(depths: torch.Tensor, world: int):
@@ -127,19 +143,22 @@ def make_sharded_mapper(harness_mod):
 
         def render_pair(self, Tcw, tracking=False):
             rimage, rsur, rdepth = super().render_pair(Tcw, tracking)
-            with torch.no_grad():
+            with torch.no_grad():                                # the shard's nearest camera depth, as a device scalar
                 xyz = self.map.xyz
-                z = (xyz @ Tcw[2, :3] + Tcw[2, 3]) if len(self.map) else xyz.new_zeros(0)
-                z = z[z > 0.2]                                   # what the rasterizer keeps (auxiliary.h:154)
-                key = float(z.min()) if z.numel() else float("inf")
+                if len(self.map):
+                    z = xyz @ Tcw[2, :3] + Tcw[2, 3]
+                    key = torch.where(z > 0.2, z, torch.full_like(z, float("inf"))).min()   # what the rasterizer keeps (auxiliary.h:154)
+                else:
+                    key = float("inf")
             rgb, depth, sil, sur = self.comp.composite(rimage, rdepth[0:2], key, sur=rsur)
             return rgb, sur, torch.cat([depth, sil], 0)
 
         def _reduce_regularisers(self, sum_over, sum_spread, count):
-            tot = self.comp.all_reduce_scalars([float(sum_over.detach()), float(sum_spread.detach()), float(count)])
+            mine = torch.stack([sum_over.detach(), sum_spread.detach(), torch.as_tensor(count, dtype=sum_over.dtype, device=sum_over.device)])
+            tot = self.comp.all_reduce_vector(mine)
             # value = whole-map total, gradient = this shard's part
-            over = sum_over + (tot[0] - float(sum_over.detach()))
-            spread = sum_spread + (tot[1] - float(sum_spread.detach()))
+            over = sum_over + (tot[0] - mine[0])
+            spread = sum_spread + (tot[1] - mine[1])
             return over, spread, tot[2]
 
         def _sync_pose_grads(self):
