@@ -14,7 +14,8 @@
 //                        {sum u, u*dx, u*dy, u*dx^2, u*dx*dy, u*dy^2}, dcolor.rgb, 7 unused
 //   image blob     (gsr_image_bytes(W,H)):
 //     final_T f32[N], n_contrib u32[N], ranges uint2[T], tile_cnt u32[T], tile_start u32[T],
-//     binmat u32[GSR_BIN_ROWS][T] (the count matrix of the binning, below), qcount u32[4T]
+//     binmat u32[GSR_BIN_ROWS][T] (the count matrix of the binning, below), sortq u32[64 + 2T] (queues of the tiles
+//     with long lists for the sort), qcount u32[4T]
 //   binning blob   (gsr_binning_bytes(capacity)), 44 B per tile instance:
 //     pairs u64[R] (depth bits << 32 | splat id, grouped per tile), point_list u32[R],
 //     qhits uint2[4R] (the forward's log of quad hits for the backward)

@@ -6,10 +6,14 @@
 //   K_bin_count    per range : LDS histogram of the tiles a contiguous range of splats covers -> one row of the
 //                              count matrix (gsr_device.h)
 //   K_bin_colscan  per column: exclusive scan down the matrix columns, column totals = tile counts
-//   K_scan_tiles   1 block   : counts -> segment starts, ranges, num_rendered, overflow flag
+//   K_scan_tiles   1 block   : counts -> segment starts, ranges, num_rendered, overflow flag, queues of the tiles with
+//                              more than 1024 / 4096 list entries
 //   K_bin_fill     per range : (depth bits<<32 | id) into the list slot an LDS cursor hands out (no global atomics)
-//   K_tile_sort    per tile  : bitonic sort of the tile's segment in LDS -> point_list
+//   K_tile_sort_all per tile : one launch: bucket sort by depth in LDS with exact in-bin ranking (one wave per short
+//                              list, 256 threads for the queued longer ones, lists over 4096 through global scratch),
+//                              bitonic network only for lists of tied depths -> point_list
 //                              ((depth, id) ascending == the reference's stable radix order)
+//                              (K_tile_sort<SMALL>: the same code launched per bucket by the k-NN path)
 //   K_blend_fwd    per quad  : front-to-back alpha blend, one wave per 8x8 quad, four independent 4x4 patch
 //                              rows per wave, exact culling (small splats: bit shifts on the reach word K_preprocess
 //                              left in col.w), logs its hits for the backward (gsr_blend.h)

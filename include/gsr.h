@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 1
+#define GSR_ABI_VERSION 2 /* 2: blob layouts of round 2 (sizes through gsr_*_bytes only), fused loop kernels */
 
 #define GSR_OK 0
 #define GSR_EINVAL (-1)    /* bad argument combination (NULL where data is required, sizes < 0 …) */
