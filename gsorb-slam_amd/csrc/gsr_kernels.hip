@@ -180,6 +180,8 @@ __device__ __forceinline__ uint32_t lds_take(uint32_t* p)
     return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // Count pass: histogram of the window's tiles in LDS -> the range's row of the count matrix.
+// (Measured and dropped: K_preprocess and this pass in one launch, 1024-thread workgroups projecting four splats per
+// thread and counting as they go — 38 us against 28.5 + 7.5 us for the two launches.)
 __global__ void __launch_bounds__(GSR_BIN_THREADS)
 K_bin_count(int P, int per, int T, int grid_x, int wx, int nwin, GeomView g, uint32_t* __restrict__ binmat)
 {
