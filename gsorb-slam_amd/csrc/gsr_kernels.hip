@@ -782,7 +782,10 @@ __device__ __forceinline__ void sort_long_list(SortShared<false>& sh, const uint
             }
             uint32_t sum = 0, sq_own = 0, nz_own = 0, x;
 #pragma unroll
-            for (int j = 0; j < BPT; j++) { sum += c[j]; sq_own += c[j] * c[j]; nz_own += c[j] ? 1u : 0u; }
+            for (int j = 0; j < BPT; j++) { // (saturating: a list of 10^5 tied keys must not wrap the sum of squares)
+                const uint32_t cc = min(c[j], 65535u);
+                sum += c[j]; sq_own = min(sq_own + min(cc * cc, 0x7FFFFFu), 0x7FFFFFu); nz_own += c[j] ? 1u : 0u;
+            }
             block_sums(sum, run, x);
             block_sums(sq_own, x, sq);
             block_sums(nz_own, x, nz);

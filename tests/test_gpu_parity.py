@@ -466,3 +466,22 @@ def test_sort_order_with_depth_ties_and_crowded_bins(gsr, syn, layout, frame):
         assert (lens > 4096).sum() > 8
     np.testing.assert_array_equal(d["ranges"], f.stages["ranges"])
     np.testing.assert_array_equal(d["point_list"], f.stages["point_list"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["uniform", "all-equal"])
+def test_one_tile_with_a_hundred_thousand_entries(gsr, syn, layout):
+    """A 16x16 frame: every splat lands in the single tile. 120 k list entries go through the global-scratch bucket sort
+    (15 keys per bin on average), and with one depth for the whole map through the bitonic network in global memory."""
+    cam = syn.make_camera(16, 16, 12.0, 12.0)
+    sc = syn.make_scene(120000, cam, seed=8, scale_mult=2.0)
+    if layout == "all-equal":
+        sc.means3D = (sc.means3D * (np.float32(1.5) / sc.means3D[:, 2])[:, None]).astype(np.float32)
+        sc.means3D[:, 2] = 1.5
+    o, f = oracle.forward_scene(sc, omp=True)
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    d = gsr.debug_export(st)
+    assert st.num_rendered == f.num_rendered and f.num_rendered > 100000
+    np.testing.assert_array_equal(d["ranges"], f.stages["ranges"])
+    np.testing.assert_array_equal(d["point_list"], f.stages["point_list"])
