@@ -18,7 +18,7 @@ _LIB = None
 EXPORTS = ["gsr_forward", "gsr_forward_ws", "gsr_ws_status", "gsr_backward", "gsr_mark_visible",
            "gsr_visible_filter", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
            "gsr_debug_export", "gsr_acc_view", "gsr_knn_bytes", "gsr_dist2", "gsr_ssim_partials", "gsr_ssim_forward", "gsr_ssim_backward",
-           "gsr_adam_step", "gsr_pose_grad", "gsr_to_camera", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
+           "gsr_adam_step", "gsr_pose_grad", "gsr_to_camera", "gsr_pose_from_quat", "gsr_pose_from_quat_backward", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
 
 
 def library_path() -> str:
@@ -114,6 +114,10 @@ def lib():
     L.gsr_pose_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gsr_to_camera.restype = C.c_int
     L.gsr_to_camera.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gsr_pose_from_quat.restype = C.c_int
+    L.gsr_pose_from_quat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gsr_pose_from_quat_backward.restype = C.c_int
+    L.gsr_pose_from_quat_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gsr_adam_step.restype = C.c_int
     L.gsr_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
                                 C.c_int, C.c_void_p]
@@ -483,6 +487,33 @@ class _ToCamera(torch.autograd.Function):
 def to_camera(Tcw, X):
     """Camera-frame means [n,3] of world-frame means X under the pose Tcw [4,4] (float32, GPU); differentiable in both."""
     return _ToCamera.apply(Tcw, X)
+
+
+class _Rt2T(torch.autograd.Function):
+    """Tcw [4,4] from an un-normalised quaternion (r,x,y,z) [4,1] and a translation [3,1] (include/Utils.h:56-77)."""
+
+    @staticmethod
+    def forward(ctx, quat, trans):
+        q, t = quat.contiguous(), trans.contiguous()
+        T = torch.empty((4, 4), dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            _check(lib().gsr_pose_from_quat(_p(q), _p(t), _p(T), _stream()))
+        ctx.save_for_backward(q)
+        ctx.shapes = (quat.shape, trans.shape)
+        return T
+
+    @staticmethod
+    def backward(ctx, dT):
+        (q,) = ctx.saved_tensors
+        dq = torch.empty((4,), dtype=torch.float32, device=q.device)
+        dt = torch.empty((3,), dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            _check(lib().gsr_pose_from_quat_backward(_p(q), _p(dT.contiguous()), _p(dq), _p(dt), _stream()))
+        return dq.reshape(ctx.shapes[0]), dt.reshape(ctx.shapes[1])
+
+
+def rt2T(quat, trans):
+    return _Rt2T.apply(quat, trans)
 
 
 class FusedAdam(torch.optim.Optimizer):

@@ -478,6 +478,22 @@ int gsr_pose_grad(const float* means3D, const float* dL_dmeans_cam, size_t n, co
     return GSR_OK;
 }
 
+int gsr_pose_from_quat(const float* quat, const float* trans, float* Tcw, void* stream)
+{
+    if (!quat || !trans || !Tcw) return GSR_EINVAL;
+    hipLaunchKernelGGL(gsr::K_rt2T, dim3(1), dim3(64), 0, (hipStream_t)stream, quat, trans, Tcw);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_pose_from_quat_backward(const float* quat, const float* dL_dTcw, float* dL_dquat, float* dL_dtrans, void* stream)
+{
+    if (!quat || !dL_dTcw || !dL_dquat || !dL_dtrans) return GSR_EINVAL;
+    hipLaunchKernelGGL(gsr::K_rt2T_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, quat, dL_dTcw, dL_dquat, dL_dtrans);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
 int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
                   double beta2, double eps, int step, void* stream)
 {

@@ -232,4 +232,34 @@ K_pose_grad(const float* __restrict__ X, const float* __restrict__ dmc, size_t n
     if (threadIdx.x < 12) partial[blockIdx.x * 12 + threadIdx.x] = (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]);
 }
 
+// Pose from the optimiser's parameters, rt2T of the reference (include/Utils.h:56-77, src/Utils.cc:170-179): an
+// un-normalised quaternion (r, x, y, z) and a translation -> the 4x4 row-major Tcw, and its backward. In libtorch this
+// is ~40 scalar-tensor kernels forwards and ~80 backwards per tracking iteration (0.4 ms of launches); one thread does it.
+__global__ void K_rt2T(const float* __restrict__ quat, const float* __restrict__ trans, float* __restrict__ T)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float n = sqrtf(quat[0] * quat[0] + quat[1] * quat[1] + quat[2] * quat[2] + quat[3] * quat[3]);
+    const float r = quat[0] / n, x = quat[1] / n, y = quat[2] / n, z = quat[3] / n;
+    T[0] = 1.f - 2.f * (y * y + z * z); T[1] = 2.f * (x * y - r * z); T[2] = 2.f * (x * z + r * y); T[3] = trans[0];
+    T[4] = 2.f * (x * y + r * z); T[5] = 1.f - 2.f * (x * x + z * z); T[6] = 2.f * (y * z - r * x); T[7] = trans[1];
+    T[8] = 2.f * (x * z - r * y); T[9] = 2.f * (y * z + r * x); T[10] = 1.f - 2.f * (x * x + y * y); T[11] = trans[2];
+    T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+}
+__global__ void K_rt2T_bwd(const float* __restrict__ quat, const float* __restrict__ dT, float* __restrict__ dquat, float* __restrict__ dtrans)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float n = sqrtf(quat[0] * quat[0] + quat[1] * quat[1] + quat[2] * quat[2] + quat[3] * quat[3]);
+    const float r = quat[0] / n, x = quat[1] / n, y = quat[2] / n, z = quat[3] / n;
+    const float G00 = dT[0], G01 = dT[1], G02 = dT[2], G10 = dT[4], G11 = dT[5], G12 = dT[6], G20 = dT[8], G21 = dT[9], G22 = dT[10];
+    // d/d(unit quaternion)
+    const float dr = 2.f * (-z * G01 + y * G02 + z * G10 - x * G12 - y * G20 + x * G21);
+    const float dx = 2.f * (y * G01 + z * G02 + y * G10 - 2.f * x * G11 - r * G12 + z * G20 + r * G21 - 2.f * x * G22);
+    const float dy = 2.f * (-2.f * y * G00 + x * G01 + r * G02 + x * G10 + z * G12 - r * G20 + z * G21 - 2.f * y * G22);
+    const float dz = 2.f * (-2.f * z * G00 - r * G01 + x * G02 + r * G10 - 2.f * z * G11 + y * G12 + x * G20 + y * G21);
+    // through q / |q|
+    const float dot = r * dr + x * dx + y * dy + z * dz;
+    dquat[0] = (dr - r * dot) / n; dquat[1] = (dx - x * dot) / n; dquat[2] = (dy - y * dot) / n; dquat[3] = (dz - z * dot) / n;
+    dtrans[0] = dT[3]; dtrans[1] = dT[7]; dtrans[2] = dT[11];
+}
+
 } // namespace gsr

@@ -146,7 +146,10 @@ def _adam(groups, device):
 
 # ---- pose parameterisation (include/Utils.h:56-77, Utils.cc:170-179) ----------------------------
 def rt2T(quat, trans):
-    """quat [4,1] un-normalised (r,x,y,z), trans [3,1] -> Tcw [4,4]."""
+    """quat [4,1] un-normalised (r,x,y,z), trans [3,1] -> Tcw [4,4]. GPU parameters: one kernel forwards, one backwards
+    (csrc/gsr_train.h: the same formulas; as scalar-tensor arithmetic it is ~120 launches per tracking iteration)."""
+    if quat.is_cuda and quat.dtype == torch.float32 and trans.dtype == torch.float32:
+        return _capi().rt2T(quat, trans)
     q = quat.reshape(4)
     q = q / torch.sqrt((q * q).sum())
     r, x, y, z = q[0], q[1], q[2], q[3]

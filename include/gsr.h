@@ -217,6 +217,10 @@ int gsr_ssim_backward(const float* img1, const float* img2, const float* dmaps, 
 int gsr_to_camera(const float* means3D /* [n,3] */, size_t n, const float* Tcw, float* means_cam, void* stream);
 int gsr_pose_grad(const float* means3D /* [n,3] */, const float* dL_dmeans_cam /* [n,3] */, size_t n, const float* Tcw,
                   float* partial, float* dL_dmeans3D, void* stream);
+/* rt2T (reference include/Utils.h:56-77, src/Utils.cc:170-179): un-normalised quaternion (r,x,y,z) [4] and translation [3]
+ * -> Tcw [4,4] row-major, and the backward from dL/dTcw [4,4]. All pointers are device pointers. */
+int gsr_pose_from_quat(const float* quat, const float* trans, float* Tcw, void* stream);
+int gsr_pose_from_quat_backward(const float* quat, const float* dL_dTcw, float* dL_dquat, float* dL_dtrans, void* stream);
 int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
                   double beta1, double beta2, double eps, int step, void* stream);
 

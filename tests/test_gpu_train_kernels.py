@@ -111,3 +111,20 @@ def test_to_camera_pose_gradient_matches_autograd_through_the_product(gsr):
     scale = float(Tb.grad.abs().max())
     assert float((Ta.grad.double() - Tb.grad).abs().max()) <= 2e-5 * scale   # fp32 sums of 3e5 terms
     assert float(Ta.grad[3].abs().max()) == 0.0
+
+
+def test_rt2T_kernel_matches_the_tensor_formulas_and_their_autograd(gsr, hz):
+    g = torch.Generator().manual_seed(4)
+    for _ in range(5):
+        q = (torch.randn((4, 1), generator=g) * 1.7)
+        t = torch.randn((3, 1), generator=g)
+        w = torch.randn((4, 4), generator=g)
+        qa, ta = q.double().clone().requires_grad_(True), t.double().clone().requires_grad_(True)
+        Ta = hz.rt2T(qa, ta)                                   # CPU double: the tensor formulas (include/Utils.h:56-77)
+        (Ta * w.double()).sum().backward()
+        qb, tb = q.cuda().requires_grad_(True), t.cuda().requires_grad_(True)
+        Tb = hz.rt2T(qb, tb)
+        (Tb * w.cuda()).sum().backward()
+        assert float((Tb.cpu().double() - Ta).abs().max()) <= 1e-6
+        assert float((qb.grad.cpu().double() - qa.grad).abs().max()) <= 1e-5 * max(1.0, float(qa.grad.abs().max()))
+        assert float((tb.grad.cpu().double() - ta.grad).abs().max()) <= 1e-6
