@@ -146,7 +146,7 @@ def make_sharded_mapper(harness_mod):
             with torch.no_grad():                                # the shard's nearest camera depth, as a device scalar
                 xyz = self.map.xyz
                 if len(self.map):
-                    z = xyz @ Tcw[2, :3] + Tcw[2, 3]
+                    z = (xyz * Tcw[2, :3]).sum(1) + Tcw[2, 3]      # (as a matrix-vector product rocBLAS takes 0.7 ms at 1 M rows)
                     key = torch.where(z > 0.2, z, torch.full_like(z, float("inf"))).min()   # what the rasterizer keeps (auxiliary.h:154)
                 else:
                     key = float("inf")
