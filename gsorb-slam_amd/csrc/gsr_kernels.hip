@@ -856,8 +856,8 @@ __device__ __forceinline__ void sort_long_list(SortShared<false>& sh, const uint
 // The rasterizer's sort: ONE launch for the three size classes (an empty kernel in the stream costs 4-5 us here: three
 // launches of which two usually have nothing to do were 9 us of a 520 us step). The first workgroups walk the queues
 // of the long and the middle class, the others sort four short lists each, one per wave.
-#define GSR_SORT_ALL_LONG 128
-#define GSR_SORT_ALL_MID 512
+#define GSR_SORT_ALL_LONG 768
+#define GSR_SORT_ALL_MID 768
 __global__ void __launch_bounds__(GSR_SORT_BIG_THREADS)
 K_tile_sort_all(int T, const uint2* __restrict__ ranges, const GeomHeader* __restrict__ hdr, uint64_t* __restrict__ pairs,
                 uint32_t* __restrict__ point_list, uint2* __restrict__ qhits, const uint32_t* __restrict__ sortq)
