@@ -842,9 +842,19 @@ __device__ __forceinline__ void sort_long_list(SortShared<false>& sh, const uint
                 const uint32_t b = bin_of(k[u]);
                 s0[u] = b ? hb[b - 1] : 0u; e0[u] = hb[b]; below[u] = 0u;
             }
+            // all U keys of a thread step through their bins together: U independent loads per step instead of one
+            // dependent global round trip per step and key (that was most of this path's time)
+            for (uint32_t q = 0;; q++) {
+                bool more = false;
 #pragma unroll
-            for (int u = 0; u < U; u++)
-                for (uint32_t q = s0[u]; q < e0[u]; q++) below[u] += temp[q] < k[u] ? 1u : 0u;
+                for (int u = 0; u < U; u++) more |= s0[u] + q < e0[u];
+                if (!__builtin_amdgcn_ballot_w64(more)) break;
+                uint64_t mate[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) mate[u] = temp[s0[u] + q < e0[u] ? s0[u] + q : 0u];
+#pragma unroll
+                for (int u = 0; u < U; u++) below[u] += (s0[u] + q < e0[u] && mate[u] < k[u]) ? 1u : 0u;
+            }
 #pragma unroll
             for (int u = 0; u < U; u++)
                 if (i0 + u * NT + tid < n) point_list[r.x + s0[u] + below[u]] = (uint32_t)k[u];
