@@ -17,7 +17,8 @@
  * ref_eval.npz, each with the script that imported the reference to make it),
  * (b) against an independent fp64 autograd restatement (tests/spec_fp64.py,
  * nine scenes incl. cov3D_precomp and SH degrees 1-3) and (c) against closed
- * forms worked out by hand from forward.cu / backward.cu on a two-splat scene
+ * forms worked out by hand from forward.cu / backward.cu on a two-splat scene,
+ * plus finite differences of the forward formulas for the per-splat backward
  * (tests/test_oracle_known_answers.py).
  * Whole-pipeline parity with the CUDA binary is "parity unpinned".
  *

@@ -135,3 +135,83 @@ def test_two_splat_scene_worked_out_by_hand(syn):
         np.testing.assert_allclose(b.dL_dmeans2D[k][:2],
                                    [dG * (-gdx * p["con"][0] - gdy * p["con"][1]) * 0.5 * W,
                                     dG * (-gdy * p["con"][2] - gdx * p["con"][1]) * 0.5 * H], rtol=1e-5, atol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Second scene: rotated, anisotropic splats. The per-splat backward (computeCov2DCUDA backward.cu:148-334, computeCov3D
+# backward :340-396, preprocessCUDA :399-424) is pinned to the FORWARD formulas read off the reference: the loss at one
+# pixel is written out in float64 straight from forward.cu, and its central finite differences with respect to every
+# input are the expected gradients. No code is shared with the oracle, the fp64 spec or the kernels.
+# ---------------------------------------------------------------------------------------------------------------------
+def _rot_matrix(q):
+    """forward.cu:118-148 computeCov3D: glm fills the matrix column by column, M = S * R, Sigma = transpose(M) * M, which
+    is R_std S^2 R_std^T with the standard rotation matrix of (r, x, y, z) — q is used as given, NOT normalised (:128)."""
+    r, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],
+                     [2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)],
+                     [2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]])
+
+
+def _pixel_loss(means, scales, quats, opac, cols, px, py, g):
+    """L = g . C(px, py): forward.cu:74-116 (cov2D), :190-232 (projection, conic), :339-398 (blend); identity view,
+    fx = fy = 16 on a 32x32 image (tan_fov = 1), front-to-back order by depth."""
+    order = np.argsort(means[:, 2], kind="stable")
+    T, C = 1.0, np.zeros(3)
+    for k in order:
+        m, s, q = means[k], scales[k], quats[k]
+        R = _rot_matrix(q)
+        Sigma = R @ np.diag(s * s) @ R.T
+        tx, ty, tz = m
+        lim = 1.3 * 1.0                                                      # forward.cu:86-91 clamp of t.x/t.z (inactive here)
+        assert abs(tx / tz) < lim and abs(ty / tz) < lim
+        J = np.array([[FX / tz, 0, -FX * tx / tz ** 2], [0, FY / tz, -FY * ty / tz ** 2]])
+        cov = J @ Sigma @ J.T + 0.3 * np.eye(2)
+        det = cov[0, 0] * cov[1, 1] - cov[0, 1] ** 2
+        con = np.array([cov[1, 1], -cov[0, 1], cov[0, 0]]) / det
+        pix = np.array([((tx / (tz + 1e-7) + 1.0) * W - 1.0) * 0.5, ((ty / (tz + 1e-7) + 1.0) * H - 1.0) * 0.5])
+        d = pix - np.array([px, py], float)
+        power = -0.5 * (con[0] * d[0] ** 2 + con[2] * d[1] ** 2) - con[1] * d[0] * d[1]
+        alpha = min(0.99, opac[k] * math.exp(power))
+        assert power <= 0 and alpha >= 1.0 / 255.0 and alpha < 0.99 and T * (1 - alpha) >= 1e-4   # smooth regime only
+        C = C + cols[k] * alpha * T
+        T *= 1 - alpha
+    return float(g @ (C + T * BG))
+
+
+def test_per_splat_backward_against_finite_differences_of_the_forward_formulas(syn):
+    cam = syn.make_camera(W, H, FX, FY, bg=tuple(BG))
+    means = np.array([[0.05, -0.1, 2.0], [0.3, 0.1, 3.5]])
+    scales = np.array([[0.30, 0.20, 0.25], [0.45, 0.6, 0.35]])
+    quats = np.array([[0.9, 0.1, -0.2, 0.3], [0.7, -0.4, 0.3, 0.5]])        # deliberately NOT unit length
+    opac = np.array([0.8, 0.6])
+    cols = np.stack([CA, CB])
+    px, py, g = 17, 14, np.array([0.7, -0.3, 0.5])
+    f32 = lambda a: np.asarray(a, np.float32)
+    o = oracle.Oracle()
+    f = o.forward(means3D=f32(means), opacities=f32(opac).reshape(-1, 1), cam=cam, colors=f32(cols), scales=f32(scales), rotations=f32(quats))
+    L0 = _pixel_loss(means, scales, quats, opac, cols, px, py, g)
+    assert abs(float(g @ f.color[:, py, px].astype(np.float64)) - L0) < 2e-6
+    dL = np.zeros((3, H, W), np.float32)
+    dL[:, py, px] = g
+    b = o.backward(dL)
+
+    def fd(arr, k, j, h=1e-6):
+        args = dict(means=means.copy(), scales=scales.copy(), quats=quats.copy(), opac=opac.copy(), cols=cols.copy())
+        lo, hi = {n: v.copy() for n, v in args.items()}, {n: v.copy() for n, v in args.items()}
+        if arr == "opac":
+            lo[arr][k] -= h; hi[arr][k] += h
+        else:
+            lo[arr][k, j] -= h; hi[arr][k, j] += h
+        return (_pixel_loss(px=px, py=py, g=g, **hi) - _pixel_loss(px=px, py=py, g=g, **lo)) / (2 * h)
+
+    for k in range(2):
+        exp_mean = np.array([fd("means", k, j) for j in range(3)])
+        exp_scale = np.array([fd("scales", k, j) for j in range(3)])
+        exp_rot = np.array([fd("quats", k, j) for j in range(4)])
+        exp_col = np.array([fd("cols", k, j) for j in range(3)])
+        exp_op = fd("opac", k, 0)
+        for got, exp, name in ((b.dL_dmeans3D[k], exp_mean, "mean3D"), (b.dL_dscales[k], exp_scale, "scale"),
+                               (b.dL_drotations[k], exp_rot, "rotation"), (b.dL_dcolors[k], exp_col, "colour"),
+                               (b.dL_dopacity[k].ravel(), np.array([exp_op]), "opacity")):
+            scale = max(1e-6, float(np.abs(exp).max()))
+            assert float(np.abs(np.asarray(got, np.float64).ravel() - exp).max()) <= 2e-4 * scale, (k, name, got, exp)
