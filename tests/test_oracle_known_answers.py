@@ -215,3 +215,67 @@ def test_per_splat_backward_against_finite_differences_of_the_forward_formulas(s
                                (b.dL_dopacity[k].ravel(), np.array([exp_op]), "opacity")):
             scale = max(1e-6, float(np.abs(exp).max()))
             assert float(np.abs(np.asarray(got, np.float64).ravel() - exp).max()) <= 2e-4 * scale, (k, name, got, exp)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Third scene: view-dependent colours. computeColorFromSH (forward.cu:20-71) written out by hand for degree 2 — basis
+# constants as printed in auxiliary.h:21-38 — with the +0.5 shift and the clamp at zero; its backward (backward.cu:24-140,
+# incl. the direction normalisation dnormvdv, :13-22... and the clamp rule: a clamped channel passes no gradient) and the
+# extra mean gradient through the view direction (:399-424) are pinned by finite differences of this forward text.
+# ---------------------------------------------------------------------------------------------------------------------
+_C0, _C1 = 0.28209479177387814, 0.4886025119029199
+_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+
+
+def _sh_colour(sh, mean, campos):
+    d = mean - campos
+    x, y, z = d / np.linalg.norm(d)
+    c = _C0 * sh[0] - _C1 * y * sh[1] + _C1 * z * sh[2] - _C1 * x * sh[3]
+    c = c + _C2[0] * x * y * sh[4] + _C2[1] * y * z * sh[5] + _C2[2] * (2 * z * z - x * x - y * y) * sh[6] \
+          + _C2[3] * x * z * sh[7] + _C2[4] * (x * x - y * y) * sh[8]
+    return np.maximum(c + 0.5, 0.0)
+
+
+def test_sh_colour_backward_against_finite_differences_of_the_forward_formulas(syn):
+    cam = syn.make_camera(W, H, FX, FY, bg=tuple(BG))
+    cam.sh_degree = 2
+    campos = np.asarray(cam.campos, np.float64)
+    means = np.array([[0.05, -0.1, 2.0], [0.3, 0.1, 3.5]])
+    scales = np.array([[0.30, 0.20, 0.25], [0.45, 0.6, 0.35]])
+    quats = np.array([[0.9, 0.1, -0.2, 0.3], [0.7, -0.4, 0.3, 0.5]])
+    quats = quats / np.linalg.norm(quats, axis=1, keepdims=True)
+    opac = np.array([0.8, 0.6])
+    rng = np.random.default_rng(6)
+    shs = rng.normal(0, 0.35, (2, 9, 3))
+    shs[0, 0] = [1.2, 0.3, -2.5]          # the blue channel of splat 0 clamps at zero: no gradient through it
+    px, py, g = 17, 14, np.array([0.7, -0.3, 0.5])
+    f32 = lambda a: np.asarray(a, np.float32)
+
+    def loss(means_, shs_):
+        cols = np.stack([_sh_colour(shs_[k], means_[k], campos) for k in range(2)])
+        return _pixel_loss(means_, scales, quats, opac, cols, px, py, g), cols
+
+    L0, cols0 = loss(means, shs)
+    assert cols0[0, 2] == 0.0 and (cols0[0, :2] > 0).all() and (cols0[1] > 0).all()
+    o = oracle.Oracle()
+    f = o.forward(means3D=f32(means), opacities=f32(opac).reshape(-1, 1), cam=cam, shs=f32(shs), scales=f32(scales), rotations=f32(quats))
+    assert abs(float(g @ f.color[:, py, px].astype(np.float64)) - L0) < 2e-6
+    np.testing.assert_array_equal(f.stages["clamped"].reshape(2, 3), [[0, 0, 1], [0, 0, 0]])
+    dL = np.zeros((3, H, W), np.float32)
+    dL[:, py, px] = g
+    b = o.backward(dL)
+    h = 1e-6
+    exp_sh = np.zeros_like(shs)
+    for idx in np.ndindex(*shs.shape):
+        lo, hi = shs.copy(), shs.copy()
+        lo[idx] -= h; hi[idx] += h
+        exp_sh[idx] = (loss(means, hi)[0] - loss(means, lo)[0]) / (2 * h)
+    exp_mean = np.zeros_like(means)
+    for idx in np.ndindex(*means.shape):
+        lo, hi = means.copy(), means.copy()
+        lo[idx] -= h; hi[idx] += h
+        exp_mean[idx] = (loss(hi, shs)[0] - loss(lo, shs)[0]) / (2 * h)
+    got_sh = np.asarray(b.dL_dsh, np.float64)[:, :9]
+    assert float(np.abs(got_sh - exp_sh).max()) <= 2e-4 * float(np.abs(exp_sh).max())
+    assert float(np.abs(got_sh[0, :, 2]).max()) == 0.0                       # the clamped channel
+    assert float(np.abs(np.asarray(b.dL_dmeans3D, np.float64) - exp_mean).max()) <= 2e-4 * float(np.abs(exp_mean).max())
