@@ -279,3 +279,66 @@ def test_sh_colour_backward_against_finite_differences_of_the_forward_formulas(s
     assert float(np.abs(got_sh - exp_sh).max()) <= 2e-4 * float(np.abs(exp_sh).max())
     assert float(np.abs(got_sh[0, :, 2]).max()) == 0.0                       # the clamped channel
     assert float(np.abs(np.asarray(b.dL_dmeans3D, np.float64) - exp_mean).max()) <= 2e-4 * float(np.abs(exp_mean).max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Fourth scene: a rotated, translated camera and covariances given directly (cov3D_precomp). Pins the view-matrix
+# convention of computeCov2D (forward.cu:74-116: t = view * mean, T = W * J with glm's column-major W, cov = T^T Vrk T —
+# i.e. J R_cw Sigma R_cw^T J^T) and the 6-vector layout (xx, xy, xz, yy, yz, zz) of cov3D and of its gradient (an
+# off-diagonal entry stands for both symmetric elements, backward.cu:200-215).
+# ---------------------------------------------------------------------------------------------------------------------
+def test_rotated_camera_and_precomputed_covariances_against_finite_differences(syn):
+    a, bq = 0.15, -0.1
+    Ry = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+    Rx = np.array([[1, 0, 0], [0, math.cos(bq), -math.sin(bq)], [0, math.sin(bq), math.cos(bq)]])
+    Rcw, tcw = Ry @ Rx, np.array([0.1, -0.05, 0.3])
+    Tcw = np.eye(4)
+    Tcw[:3, :3], Tcw[:3, 3] = Rcw, tcw
+    cam = syn.make_camera(W, H, FX, FY, Tcw=Tcw, bg=tuple(BG))
+    means = np.array([[0.1, -0.15, 2.2], [-0.2, 0.2, 3.0]])
+    rng = np.random.default_rng(12)
+    A = rng.normal(0, 0.25, (2, 3, 3))
+    Sig = np.stack([m @ m.T + 0.02 * np.eye(3) for m in A])
+    cov6 = np.stack([[S[0, 0], S[0, 1], S[0, 2], S[1, 1], S[1, 2], S[2, 2]] for S in Sig])
+    opac, cols = np.array([0.75, 0.65]), np.stack([CA, CB])
+    px, py, g = 16, 15, np.array([0.7, -0.3, 0.5])
+
+    def loss(means_, cov6_):
+        T, C = 1.0, np.zeros(3)
+        cam_pts = means_ @ Rcw.T + tcw
+        for k in np.argsort(cam_pts[:, 2], kind="stable"):
+            tx, ty, tz = cam_pts[k]
+            c = cov6_[k]
+            S = np.array([[c[0], c[1], c[2]], [c[1], c[3], c[4]], [c[2], c[4], c[5]]])
+            J = np.array([[FX / tz, 0, -FX * tx / tz ** 2], [0, FY / tz, -FY * ty / tz ** 2]])
+            cov = J @ Rcw @ S @ Rcw.T @ J.T + 0.3 * np.eye(2)
+            det = cov[0, 0] * cov[1, 1] - cov[0, 1] ** 2
+            con = np.array([cov[1, 1], -cov[0, 1], cov[0, 0]]) / det
+            pix = np.array([((tx / (tz + 1e-7) + 1.0) * W - 1.0) * 0.5, ((ty / (tz + 1e-7) + 1.0) * H - 1.0) * 0.5])
+            d = pix - np.array([px, py], float)
+            power = -0.5 * (con[0] * d[0] ** 2 + con[2] * d[1] ** 2) - con[1] * d[0] * d[1]
+            alpha = min(0.99, opac[k] * math.exp(power))
+            assert power <= 0 and 1.0 / 255.0 <= alpha < 0.99 and T * (1 - alpha) >= 1e-4
+            C = C + cols[k] * alpha * T
+            T *= 1 - alpha
+        return float(g @ (C + T * BG))
+
+    f32 = lambda x: np.asarray(x, np.float32)
+    o = oracle.Oracle()
+    f = o.forward(means3D=f32(means), opacities=f32(opac).reshape(-1, 1), cam=cam, colors=f32(cols), cov3D_precomp=f32(cov6))
+    assert abs(float(g @ f.color[:, py, px].astype(np.float64)) - loss(means, cov6)) < 2e-6
+    dL = np.zeros((3, H, W), np.float32)
+    dL[:, py, px] = g
+    b = o.backward(dL)
+    h = 1e-6
+    exp_cov, exp_mean = np.zeros_like(cov6), np.zeros_like(means)
+    for idx in np.ndindex(*cov6.shape):
+        lo, hi = cov6.copy(), cov6.copy()
+        lo[idx] -= h; hi[idx] += h
+        exp_cov[idx] = (loss(means, hi) - loss(means, lo)) / (2 * h)
+    for idx in np.ndindex(*means.shape):
+        lo, hi = means.copy(), means.copy()
+        lo[idx] -= h; hi[idx] += h
+        exp_mean[idx] = (loss(hi, cov6) - loss(lo, cov6)) / (2 * h)
+    assert float(np.abs(np.asarray(b.dL_dcov3D, np.float64) - exp_cov).max()) <= 2e-4 * float(np.abs(exp_cov).max())
+    assert float(np.abs(np.asarray(b.dL_dmeans3D, np.float64) - exp_mean).max()) <= 2e-4 * float(np.abs(exp_mean).max())
