@@ -342,3 +342,45 @@ def test_rotated_camera_and_precomputed_covariances_against_finite_differences(s
         exp_mean[idx] = (loss(hi, cov6) - loss(lo, cov6)) / (2 * h)
     assert float(np.abs(np.asarray(b.dL_dcov3D, np.float64) - exp_cov).max()) <= 2e-4 * float(np.abs(exp_cov).max())
     assert float(np.abs(np.asarray(b.dL_dmeans3D, np.float64) - exp_mean).max()) <= 2e-4 * float(np.abs(exp_mean).max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Fifth scene: the 0.99 clamp and early termination (forward.cu:356-364): a stack of four large co-axial splats. The first
+# saturates (alpha = 0.99), the second is half transparent, the third would push T below 1e-4 — the pixel is DONE before
+# blending it, it does not count as a contributor, and the fourth is never looked at. Backward (backward.cu:476-557): only
+# the contributors receive gradients, and the clamp is transparent to dL/dopacity (straight-through: :555).
+# ---------------------------------------------------------------------------------------------------------------------
+def test_alpha_clamp_and_early_termination_worked_out_by_hand(syn):
+    cam = syn.make_camera(W, H, FX, FY, bg=tuple(BG))
+    zs = np.array([2.0, 2.5, 3.0, 3.5])
+    means = np.stack([np.zeros(4), np.zeros(4), zs], 1)
+    scales = np.full((4, 3), 2.0) * (zs / 2.0)[:, None]            # the same 2D footprint for all four: cov = 256.3
+    quats = np.tile([1.0, 0, 0, 0], (4, 1))
+    opac = np.array([1.0, 0.5, 1.0, 0.9])
+    cols = np.array([[1.0, 0.5, 0.25], [0.2, 0.4, 0.9], [0.6, 0.1, 0.3], [0.9, 0.9, 0.1]])
+    px, py, g = 15, 16, np.array([0.7, -0.3, 0.5])
+    cov = (FX / 2.0) ** 2 * 2.0 ** 2 + 0.3                         # 256.3 on both axes, no off-diagonal
+    G = math.exp(-0.5 * (0.5 ** 2 + 0.5 ** 2) / cov)               # pixel centre 15.5: d = (0.5, -0.5)
+    a1, a2, a3 = min(0.99, 1.0 * G), 0.5 * G, min(0.99, 1.0 * G)
+    assert a1 == 0.99 and a3 == 0.99
+    T1 = 1.0 - a1
+    T2 = T1 * (1.0 - a2)
+    assert T2 * (1.0 - a3) < 1e-4 * 0.6 and T1 * (1 - a2) > 1e-4 * 10   # far from the knife edge in either direction
+    C = cols[0] * a1 + cols[1] * a2 * T1 + BG * T2
+    f32 = lambda a: np.asarray(a, np.float32)
+    o = oracle.Oracle()
+    f = o.forward(means3D=f32(means), opacities=f32(opac).reshape(-1, 1), cam=cam, colors=f32(cols), scales=f32(scales), rotations=f32(quats))
+    np.testing.assert_allclose(f.color[:, py, px], C, rtol=3e-6)
+    assert abs(f.stages["final_T"].reshape(H, W)[py, px] - T2) < 1e-8
+    assert f.stages["n_contrib"].reshape(H, W)[py, px] == 2
+    assert f.depth[0, py, px] == 2.0                                # T = 1 > 0.5 only when the first splat arrives
+    dL = np.zeros((3, H, W), np.float32)
+    dL[:, py, px] = g
+    b = o.backward(dL)
+    assert float(np.abs(b.dL_dcolors[2:]).max()) == 0.0 and float(np.abs(b.dL_dopacity[2:]).max()) == 0.0
+    assert float(np.abs(b.dL_dmeans3D[2:]).max()) == 0.0
+    np.testing.assert_allclose(b.dL_dcolors[0], a1 * 1.0 * g, rtol=3e-6)
+    np.testing.assert_allclose(b.dL_dcolors[1], a2 * T1 * g, rtol=3e-6)
+    dA2 = (cols[1] @ g) * T1 - T2 / (1 - a2) * (BG @ g)
+    dA1 = ((cols[0] - a2 * cols[1]) @ g) * 1.0 - T2 / (1 - a1) * (BG @ g)
+    np.testing.assert_allclose(b.dL_dopacity.ravel()[:2], [G * dA1, G * dA2], rtol=2e-5)   # the clamp passes the gradient
