@@ -180,9 +180,19 @@ def main():
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        # RCCL ("nccl") is the backend of every real run. GSR_BENCH_BACKEND=gloo exists so that the N > 1 code path can
+        # be exercised on a box with fewer GPUs than ranks (ranks then share devices: `local_rank % device_count`);
+        # its numbers mean nothing.
+        backend = os.environ.get("GSR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            td.init_process_group(backend)
+    ndev = max(torch.cuda.device_count(), 1)
+    if world > 1 and os.environ.get("GSR_BENCH_BACKEND", "nccl") == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {ndev} GPU(s) visible")
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
 
     gsr = entry.load_package()
     gsr.lib()  # fails loudly if the HIP extension is missing
