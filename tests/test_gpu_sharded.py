@@ -212,3 +212,31 @@ def test_two_gpus_rccl_drive_the_hip_backends():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (RCCL); the same path runs over gloo on one GPU in the test above")
     _run("nccl")
+
+
+@pytest.mark.gpu
+def test_bench_runs_its_multi_rank_branch_with_two_ranks():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), here with both ranks on
+    whatever GPUs exist and gloo instead of RCCL (GSR_BENCH_BACKEND): rendezvous, per-rank scenes, barriers, the
+    max-over-ranks timing, and `shard_step` with its layer all-gather and all-reduces all execute; one JSON line from rank 0."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GSR_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--splats", "40000", "--camera", "tum",
+           "--steps", "5", "--warmup", "2", "--shard-steps", "3"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "scene-shard x2" and "cpu_baseline" not in d
+    ss = d["shard_step"]
+    assert ss["rccl_ranks"] == 2 and ss["splats_per_rank"] == 20000 and ss["mapping_ms_per_iter"] > 0 and ss["tracking_ms_per_iter"] > 0
