@@ -523,6 +523,9 @@ void gsro_render_margins(int W, int H, const uint32_t* ranges, const uint32_t* p
                          float* margin_depth)
 {
     const int gx = (W + GSRO_BLOCK_X - 1) / GSRO_BLOCK_X, gy = (H + GSRO_BLOCK_Y - 1) / GSRO_BLOCK_Y;
+#ifdef GSRO_OMP
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+#endif
     for (int ty = 0; ty < gy; ty++)
         for (int tx = 0; tx < gx; tx++) {
             const uint32_t r0 = ranges[2 * (ty * gx + tx)], r1 = ranges[2 * (ty * gx + tx) + 1];
