@@ -105,14 +105,16 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     GSR_LAUNCHED();
     tm.end(GSR_FWD_FILL);
     tm.begin(GSR_FWD_SORT);
-    hipLaunchKernelGGL(gsr::K_tile_sort_all, dim3(GSR_SORT_ALL_LONG + GSR_SORT_ALL_MID + (T + 3) / 4), dim3(GSR_SORT_BIG_THREADS), 0, st, T, iv.ranges, gv.hdr,
-                       bv.pairs, bv.point_list, bv.qhits, iv.sortq);
+    hipLaunchKernelGGL(gsr::K_tile_sort_short, dim3(T), dim3(GSR_SORT_BIG_THREADS), 0, st, T, f.grid_x, iv.ranges, gv, bv.pairs, bv.point_list,
+                       bv.qhits, iv.qcount);
+    hipLaunchKernelGGL(gsr::K_tile_sort_long, dim3(GSR_SORT_ALL_LONG + GSR_SORT_ALL_MID), dim3(GSR_SORT_BIG_THREADS), 0, st, T, f.grid_x, iv.ranges, gv,
+                       bv.pairs, bv.point_list, bv.qhits, iv.sortq, iv.qcount);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SORT);
     tm.begin(GSR_FWD_BLEND);
     const int Tb = (f.band_y1 - f.band_y0) * f.grid_x; // tiles of the band
     if (Tb > 0)
-        hipLaunchKernelGGL(gsr::K_blend_fwd<GSR_FWDQ>, dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
+        hipLaunchKernelGGL(gsr::K_blend_fwd<GSR_ROWQ>, dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
                            f.grid_x, Tb, f.band_y0 * f.grid_x, a->out_color, a->out_depth, P);
     else // an empty band launches no blend kernel: clear the backward accumulators here
         GSR_HIP(hipMemsetAsync(gv.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
@@ -417,9 +419,9 @@ int gsr_dist2(int P, const float* points, float* mean_dists, char* workspace, si
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_knn_fill, dim3(blocks256(P)), dim3(256), 0, st, P, shift, k.code, k.slot, k.buckets, k.pairs);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_tile_sort<true>, dim3(nb), dim3(GSR_SORT_SMALL_THREADS), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(gsr::K_tile_sort<GSR_SORT_WAVE>, dim3(nb), dim3(GSR_SORT_SMALL_THREADS), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order, (const uint32_t*)nullptr);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_tile_sort<false>, dim3(nb), dim3(256), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(gsr::K_tile_sort<GSR_SORT_BLOCK>, dim3(nb), dim3(256), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order, (const uint32_t*)nullptr);
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_knn_boxes, dim3(nbox), dim3(256), 0, st, P, points, k.order, k.spts, k.boxes);
     GSR_LAUNCHED();

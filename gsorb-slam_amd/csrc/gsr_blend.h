@@ -102,7 +102,6 @@ __device__ __forceinline__ bool quad_reach(const float4 a, const float4 b, float
 //            instruction), i.e. one L2 atomic record per (quad, splat). Issuing the atomics per PATCH instead
 //            would double them and hit the L2 atomic ceiling (~20 G records/s, scripts/atomic_bench2.hip).
 // =====================================================================================
-#define GSR_FWDQ 96 // forward: gathers until more than 32 entries are parked (2-3 steps of ~22 quad hits)
 #define GSR_ROWQ 64 // parked entries per round = one gather step
 #define GSR_RING 16 // iterations between two reduce phases: 4 rows x 16 = one (row, iteration) pair per lane
 #ifndef GSR_BSTEP
@@ -163,6 +162,10 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     __shared__ float4 POOL[(16 * (4 * GSR_RING + 1) * 8) / 16];
     __shared__ float4 GP[4][17]; // dL/dpixel of pixel p of patch r (17: the four rows on different banks)
     __shared__ uint32_t INV[Q + 4]; // per batch: byte r of word e = ring slot of entry e in row r, or 0xFF
+#ifdef GSR_EXP_LDSPAD // occupancy experiment: more LDS per wave, fewer waves per SIMD
+    __shared__ uint32_t PADX[GSR_EXP_LDSPAD];
+    if (W == -1) PADX[threadIdx.x] = 1u;
+#endif
     v2f* const UD = reinterpret_cast<v2f*>(POOL);
     float4* const ST = POOL;
     const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
@@ -209,7 +212,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     // back to front. Gather pipeline: the records of the next two steps and the geometry of the next step
     // are in flight (unconditional loads from clamped, always valid addresses so that the compiler can
     // count them: the colour gather must not wait for the loads issued after it).
-    const int cq = (int)im.qcount[4 * tile + quad];
+    const int cq = (int)im.qdone[4 * tile + quad]; // the records the forward took: every contributor is among them
     const uint2* __restrict__ qh = bn.qhits + 4 * (size_t)range.x + (size_t)quad * (size_t)n;
     if (ntodo <= 0 || cq <= 0) return;
     int k0 = 0;
@@ -426,24 +429,25 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
 
 // =====================================================================================
 // Forward ("patch rows"), same wave/row mapping as K_blend_bwd: the wave owns an 8x8 quad, its four
-// 16-lane rows are four independent 4x4 patches with their own hit lists. Per round: gather (64 list
-// entries per step, exact quad cull, survivors compacted into LDS until more than Q-64 are parked),
-// patch lists (exact patch cull; the entry is logged for the backward as (list position, id | mask<<28)),
-// blend (row r walks list r, entries software-pipelined). A row whose 16 pixels are all done idles; the
-// wave leaves when every pixel is done.
+// 16-lane rows are four independent 4x4 patches with their own hit lists. The quad's list of hits (list
+// position, id | patch mask) was cut by the tile sort (gsr_kernels.hip: emit_quad_lists); per round the
+// wave takes 64 of them, front to back: gather (records two steps ahead, the whole 48-byte record one
+// step ahead; every record is a hit: no culling here), patch lists from the masks, blend (row r walks
+// list r, entries software-pipelined). A row whose 16 pixels are all done idles; the wave leaves when
+// every pixel is done and notes how many records it took (qdone): the backward starts there.
 // =====================================================================================
 template <int Q>
 __global__ void __launch_bounds__(64)
 K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
                  int grid_x, int ntiles, int tile0, float* __restrict__ out_color, float* __restrict__ out_depth, int P)
 {
+    static_assert(Q == 64, "one parked entry per lane");
     // parked entries; slot Q is a dummy that no pixel can see (opacity 0, far away): the per-patch lists are padded with
     // it, so the blend loop needs neither an "is this row still active" compare nor an index select
     __shared__ float4 E0[Q + 1], E1[Q + 1], E2[Q + 1]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, depth, list position + 1, id)
     // per-patch hit lists: BYTE OFFSETS of the entries (index * 16: shifts and integer mads are half-rate on gfx950,
     // LDS loads are not VALU work at all), 4 slots of slack behind the longest list for the software pipeline
     __shared__ uint16_t LIST[4 * (Q + 4)];
-    __shared__ uint8_t PMB[Q]; // per parked entry: its 4-bit patch mask, or 0x10 = a large splat whose patches are tested when the lists are built
     const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
     const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u;
     const int tx = tile % grid_x, ty = tile / grid_x;
@@ -451,16 +455,15 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
     const int X0 = tx * 16 + (int)(quad & 1u) * 8, Y0 = ty * 16 + (int)(quad >> 1) * 8;
     const int px = X0 + (r & 1) * 4 + (l & 3), py = Y0 + (r >> 1) * 4 + (l >> 2);
     const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py, X0f = (float)X0, Y0f = (float)Y0;
+    const float pxf = (float)px, pyf = (float)py;
     const uint2 range = im.ranges[tile];
     const int n = g.hdr->overflow ? 0 : (int)(range.y - range.x);
-    const uint32_t* __restrict__ plist = bn.point_list + range.x;
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t last = 0u;
     wmask m_done = wm(!inside); // lanes whose pixel is finished (or outside the image)
-    uint2* __restrict__ qh = bn.qhits + 4 * (size_t)range.x + (size_t)quad * (size_t)n;
-    int qc = 0;
+    const int cq = n > 0 ? (int)im.qcount[4 * tile + quad] : 0;
+    const uint2* __restrict__ qh = bn.qhits + 4 * (size_t)range.x + (size_t)quad * (size_t)n;
     constexpr uint32_t DUMMY = (uint32_t)Q * 16u;
     if (lane == 0) {
         E0[Q] = make_float4(-1.0e5f, -1.0e5f, -1.f, 0.f); // power2 ~ -2e10: exp2 gives 0
@@ -468,67 +471,43 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
         E2[Q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    if (n > 0) {
-        int base = 0;
-        uint32_t id_c = plist[min(lane, n - 1)], id_n = plist[min(lane + 64, n - 1)];
-        float4 a_c = g.g0[id_c], b_c = g.g1[id_c], c_c = g.col[id_c]; // the whole 48-byte record, one step ahead
-        const int qcx = X0 >> 2, qcy = Y0 >> 2; // the quad's first patch in the global patch grid
-        while (base < n) {
+    int k0 = 0;
+    if (cq > 0) {
+        // unconditional loads from clamped, always valid addresses: the compiler can count them, and the gathers of the next
+        // step do not wait for the loads issued after them
+        uint2 rec_c = qh[min(lane, cq - 1)], rec_n = qh[min(lane + 64, cq - 1)];
+        float4 a_c = g.g0[rec_c.y & GSR_ID_MASK], b_c = g.g1[rec_c.y & GSR_ID_MASK], c_c = g.col[rec_c.y & GSR_ID_MASK];
+        while (k0 < cq) {
             const wmask dmask = m_done;
             if (dmask == ~0ull) break;
-            // ---- gather + quad cull + compaction. A small splat (K_preprocess decided its exact patch reach once, in
-            //      col.w: gsr_device.h) is culled by shifting bits; only larger ones run the exact quad test here
-            int count = 0;
-            do {
-                const uint32_t id = id_c;
+            // ---- gather: one step, <= 64 entries, entry e in the LDS slot of lane e
+            const int count = min(64, cq - k0);
+            uint32_t pm = 0u;
+            {
+                const uint2 rec = rec_c;
                 const float4 a = a_c, b = b_c, c = c_c;
-                const int k = base + lane;
-                const uint32_t colw = __float_as_uint(c.w);
-                const bool small = (colw & GSR_REACH_SMALL) != 0u;
-                uint32_t pm4 = quad_mask_from_word(colw, a.x, a.y, qcx, qcy);
-                if (__ballot(k < n && !small) != 0ull) pm4 = small ? pm4 : (quad_reach(a, b, X0f, Y0f) ? 0x10u : 0u); // 0x10: patches still to test
-                const bool hit = k < n && pm4 != 0u;
-                id_c = id_n;
-                a_c = g.g0[id_c]; b_c = g.g1[id_c]; c_c = g.col[id_c];
-                id_n = plist[min(k + 128, n - 1)];
-                const unsigned long long m = __ballot(hit);
-                if (hit) {
-                    const int e = count + mbcnt64(m);
-                    E0[e] = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
-                    E1[e] = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, c.x, c.y);
-                    E2[e] = make_float4(c.z, b.z, __uint_as_float((uint32_t)k + 1u), __uint_as_float(id));
-                    PMB[e] = (uint8_t)pm4;
+                rec_c = rec_n;
+                a_c = g.g0[rec_c.y & GSR_ID_MASK]; b_c = g.g1[rec_c.y & GSR_ID_MASK]; c_c = g.col[rec_c.y & GSR_ID_MASK];
+                rec_n = qh[min(k0 + lane + 128, cq - 1)];
+                if (lane < count) {
+                    E0[lane] = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
+                    E1[lane] = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, c.x, c.y);
+                    E2[lane] = make_float4(c.z, b.z, __uint_as_float(rec.x + 1u), __uint_as_float(rec.y & GSR_ID_MASK));
+                    pm = rec.y >> GSR_ID_BITS;
                 }
-                count += (int)__popcll(m);
-                base += 64;
-            } while (base < n && count <= Q - 64);
-            if (count == 0) continue;
-            __builtin_amdgcn_wave_barrier();
-            // ---- per-patch hit lists + the log for the backward
-            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-            for (int eb = 0; eb < count; eb += 64) {
-                const int e = eb + lane;
-                bool h[4] = {false, false, false, false};
-                float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                uint32_t pmb = 0u;
-                if (e < count) { pmb = PMB[e]; z = E2[e]; }
-                h[0] = (pmb & 1u) != 0u; h[1] = (pmb & 2u) != 0u; h[2] = (pmb & 4u) != 0u; h[3] = (pmb & 8u) != 0u;
-                if (__ballot(pmb == 0x10u) != 0ull) { // large splats: the exact patch test on the parked entry
-                    bool hx[4] = {false, false, false, false};
-                    if (pmb == 0x10u) patch_reach4(E0[e], E1[e], X0f, Y0f, hx);
-                    if (pmb == 0x10u) { h[0] = hx[0]; h[1] = hx[1]; h[2] = hx[2]; h[3] = hx[3]; }
-                }
-                const unsigned long long m0 = __ballot(h[0]), m1 = __ballot(h[1]), m2 = __ballot(h[2]), m3 = __ballot(h[3]);
-                const uint16_t off = (uint16_t)(e * 16);
-                if (h[0]) LIST[0 * (Q + 4) + c0 + mbcnt64(m0)] = off;
-                if (h[1]) LIST[1 * (Q + 4) + c1 + mbcnt64(m1)] = off;
-                if (h[2]) LIST[2 * (Q + 4) + c2 + mbcnt64(m2)] = off;
-                if (h[3]) LIST[3 * (Q + 4) + c3 + mbcnt64(m3)] = off;
-                c0 += (int)__popcll(m0); c1 += (int)__popcll(m1); c2 += (int)__popcll(m2); c3 += (int)__popcll(m3);
-                const uint32_t pm = (h[0] ? 1u : 0u) | (h[1] ? 2u : 0u) | (h[2] ? 4u : 0u) | (h[3] ? 8u : 0u);
-                const unsigned long long ma = m0 | m1 | m2 | m3;
-                if (pm) qh[qc + mbcnt64(ma)] = make_uint2(__float_as_uint(z.z) - 1u, __float_as_uint(z.w) | (pm << GSR_ID_BITS));
-                qc += (int)__popcll(ma);
+                k0 += 64;
+            }
+            // ---- per-patch hit lists (lane e looks at parked entry e; its patch mask came with the record)
+            int c0, c1, c2, c3;
+            {
+                const bool h0 = (pm & 1u) != 0u, h1 = (pm & 2u) != 0u, h2 = (pm & 4u) != 0u, h3 = (pm & 8u) != 0u;
+                const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+                const uint16_t off = (uint16_t)(lane * 16);
+                if (h0) LIST[0 * (Q + 4) + mbcnt64(m0)] = off;
+                if (h1) LIST[1 * (Q + 4) + mbcnt64(m1)] = off;
+                if (h2) LIST[2 * (Q + 4) + mbcnt64(m2)] = off;
+                if (h3) LIST[3 * (Q + 4) + mbcnt64(m3)] = off;
+                c0 = (int)__popcll(m0); c1 = (int)__popcll(m1); c2 = (int)__popcll(m2); c3 = (int)__popcll(m3);
             }
             // ---- blend: row r walks its own list; the wave runs as long as its longest unfinished row (an even number of
             //      iterations: the loop is unrolled by two), shorter lists are padded with the dummy entry
@@ -539,7 +518,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                 const int cr = r == 0 ? c0 : r == 1 ? c1 : r == 2 ? c2 : c3;
                 for (int p = cr + l; p < maxc + 4; p += 16) LIST[r * (Q + 4) + p] = (uint16_t)DUMMY;
             }
-            __builtin_amdgcn_wave_barrier();
+            lds_turn();
             const uint16_t* __restrict__ mylist = LIST + r * (Q + 4);
             auto step = [&](const float4 A, const float4 B, const float4 Cz) {
                 const float dx = A.x - pxf, dy = A.y - pyf;
@@ -579,10 +558,10 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                     step(A1, B1, Z1);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
+            lds_turn();
         }
     }
-    if (lane == 0) im.qcount[4 * tile + quad] = (uint32_t)qc;
+    if (lane == 0) im.qdone[4 * tile + quad] = (uint32_t)min(k0, cq);
     if (inside) {
         const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
         im.final_T[pix] = T;

@@ -2,12 +2,14 @@
 //
 // Data layout in HBM (all sub-arrays 256-byte aligned inside caller-owned blobs):
 //
-//   geometry blob  (gsr_geom_bytes(P)), 128 B per splat:
+//   geometry blob  (gsr_geom_bytes(P)), 136 B per splat:
 //     GeomHeader                         256 B   {num_rendered, overflow, capacity of the binning blob}
 //     rec  48 B[P]  the per-splat record the blend kernels gather, interleaved so that it costs one L2 line:
 //          g0  {x, y, conic_a, conic_b}            pixel centre + half of the conic
 //          g1  {conic_c, opacity, depth, radius}   radius stored as int bits (0: culled)
 //          col {r, g, b, clamp-flags}              colour the blend uses (SH result or copy of colors_precomp)
+//     reach uint2[P]     what culls the splat against the 4x4 patches of a tile, dense (8 bytes: one gather per tile instance
+//                        by the tile sort): {reach word (below), centre's patch column | patch row << 16 (int16 each)}
 //     slots uint4[P]     bin record for the count and fill passes: tile count, depth bits, band-clipped tile rectangle
 //     acc  float[P][16]  backward accumulators, one 64-byte line per splat (48-byte records straddle lines and
 //                        the L2 atomic rate drops from 20 to 13 G records/s): moments of u = G*dL/dalpha
@@ -15,10 +17,11 @@
 //   image blob     (gsr_image_bytes(W,H)):
 //     final_T f32[N], n_contrib u32[N], ranges uint2[T], tile_cnt u32[T], tile_start u32[T],
 //     binmat u32[GSR_BIN_ROWS][T] (the count matrix of the binning, below), sortq u32[64 + 2T] (queues of the tiles
-//     with long lists for the sort), qcount u32[4T]
+//     with long lists for the sort), qcount u32[4T], qdone u32[4T]
 //   binning blob   (gsr_binning_bytes(capacity)), 44 B per tile instance:
 //     pairs u64[R] (depth bits << 32 | splat id, grouped per tile), point_list u32[R],
-//     qhits uint2[4R] (the forward's log of quad hits for the backward)
+//     qhits uint2[4R] (per 8x8 quad: the tile-list entries that reach it, with their 4-bit patch masks; written by the
+//                      tile sort, walked front to back by the forward blend and back to front by the backward)
 //
 // The reference keeps 79 B/splat + 24 B/instance + radix-sort temporaries (rasterizer_impl.h:21-65).
 #pragma once
@@ -87,6 +90,7 @@ struct GeomView {
     Strided4 g0;
     Strided4 g1;
     Strided4 col;
+    uint2* reach; // {reach word: bit 3 small, bits 4..28 the 5x5 patch window; (int16) floor(px/4) | (int16) floor(py/4) << 16}
     uint4* slots; // {tiles covered, depth bits, x0 | y0 << 16, x1 | y1 << 16} (band-clipped tile rectangle; 0 tiles: not binned)
     float* acc;
 };
@@ -98,13 +102,14 @@ struct ImageView {
     uint32_t* tile_start; // [T] where the tile's list segment starts
     uint32_t* binmat;     // [GSR_BIN_ROWS][T] count matrix (after K_bin_colscan: exclusive column prefixes)
     uint32_t* sortq;  // [GSR_SORTQ_HEAD + 2T] queues of the tiles with more than GSR_SORT_SMALL / GSR_SORT_CAP list entries
-    uint32_t* qcount; // [4*T] quad-hit records the forward blend wrote per 8x8 quad
+    uint32_t* qcount; // [4*T] quad-hit records per 8x8 quad (written by the tile sort)
+    uint32_t* qdone;  // [4*T] how many of them the forward blend consumed before every pixel of the quad was done
 };
 struct BinView {
     uint64_t* pairs;
     uint32_t* point_list;
-    uint2* qhits;     // [4*R] (list position, splat id) of every list entry that can reach a quad, in list order;
-                      // the quad q of a tile with range [x, x+n) owns qhits[4x + q*n .. 4x + (q+1)*n)
+    uint2* qhits;     // [4*R] (list position, splat id | 4-bit patch mask << 28) of every list entry that can reach a quad, in
+                      // list order; the quad q of a tile with range [x, x+n) owns qhits[4x + q*n .. 4x + (q+1)*n)
 };
 
 __host__ __device__ inline size_t gsr_align_up(size_t x) { return (x + GSR_ALIGN - 1) & ~(size_t)(GSR_ALIGN - 1); }
@@ -118,6 +123,7 @@ __host__ __device__ inline size_t geom_layout(char* base, int P, GeomView* v)
     g.g1.p = g.g0.p + 1;
     g.col.p = g.g0.p + 2;
     off = gsr_align_up(off + Pz * 16 * GSR_GSTRIDE);
+    g.reach = (uint2*)(base + off); off = gsr_align_up(off + Pz * 8);
     g.slots = (uint4*)(base + off); off = gsr_align_up(off + Pz * 16);
     g.acc = (float*)(base + off); off = gsr_align_up(off + Pz * GSR_ACC_STRIDE * 4);
     if (v) *v = g;
@@ -138,6 +144,7 @@ __host__ __device__ inline size_t image_layout(char* base, int W, int H, ImageVi
     g.binmat = (uint32_t*)(base + off); off = gsr_align_up(off + T * GSR_BIN_ROWS * 4);
     g.sortq = (uint32_t*)(base + off); off = gsr_align_up(off + (GSR_SORTQ_HEAD + 2 * T) * 4);
     g.qcount = (uint32_t*)(base + off); off = gsr_align_up(off + T * 16);
+    g.qdone = (uint32_t*)(base + off); off = gsr_align_up(off + T * 16);
     if (v) *v = g;
     return off;
 }
@@ -280,6 +287,37 @@ __device__ __forceinline__ uint32_t quad_mask_from_word(uint32_t colw, float px,
     const uint32_t c0 = (uint32_t)sh <= 5u ? ((r0 << 1) >> sh) & 3u : 0u;
     const uint32_t c1 = (uint32_t)sh <= 5u ? ((r1 << 1) >> sh) & 3u : 0u;
     return c0 | (c1 << 2);
+}
+
+// The same for the 4x4 patches of a whole 16x16 tile (tx, ty): bit (j * 4 + i) = patch (4 tx + i, 4 ty + j), from the
+// splat's entry of the dense reach array (K_preprocess). Splats that are not "small" get GSR_MASK_UNTESTED.
+#define GSR_MASK_UNTESTED 0x10000u
+__device__ __forceinline__ uint2 reach_entry(uint32_t word, float px, float py)
+{
+    const int pcx = max(-32768, min(32767, (int)floorf(px * 0.25f))), pcy = max(-32768, min(32767, (int)floorf(py * 0.25f)));
+    return make_uint2(word & ~7u, ((uint32_t)pcx & 0xFFFFu) | ((uint32_t)pcy << 16));
+}
+__device__ __forceinline__ uint32_t tile_mask_from_reach(uint2 re, int tx, int ty)
+{
+    if (!(re.x & GSR_REACH_SMALL)) return GSR_MASK_UNTESTED;
+    const uint32_t m = re.x >> 4;
+    const int sx = 4 * tx - (int)(short)(re.y & 0xFFFFu) + 2; // window column / row of the tile's first patch
+    const int sy = 4 * ty - ((int)re.y >> 16) + 2;
+    uint32_t out = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int wr = sy + j;
+        const uint32_t row5 = (uint32_t)wr < 5u ? (m >> (5 * wr)) & 31u : 0u;
+        const uint32_t bits = sx >= 0 ? (sx < 5 ? row5 >> sx : 0u) : (sx > -4 ? row5 << (-sx) : 0u);
+        out |= (bits & 15u) << (4 * j);
+    }
+    return out;
+}
+// the 2x2 patches of quad q (bit 0: x half, bit 1: y half) out of a tile mask: bit (j * 2 + i)
+__device__ __forceinline__ uint32_t quad_mask_of_tile_mask(uint32_t m16, int q)
+{
+    const uint32_t lo = (m16 >> (8 * (q >> 1) + 2 * (q & 1))) & 3u, hi = (m16 >> (8 * (q >> 1) + 4 + 2 * (q & 1))) & 3u;
+    return lo | (hi << 2);
 }
 
 // Wave-wide inclusive scan / reduction in eight DPP instructions (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then

@@ -27,6 +27,7 @@
 // R instances (6 passes over 24 B/instance) by one 8 B/instance write and one LDS-resident sort per tile.
 #include "gsr_device.h"
 #include "gsr_splat_math.h"
+#include "gsr_blend.h"
 
 namespace gsr {
 
@@ -88,7 +89,8 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
     }
     const float opac = in.opacities[idx];
     // the exact patch reach of a small splat, once per splat instead of once per (tile entry, quad) in the blend (gsr_device.h)
-    c.w = __uint_as_float(__float_as_uint(c.w) | splat_reach25(pr.px, pr.py, pr.conic_a, pr.conic_b, pr.conic_c, opac));
+    const uint32_t reach = splat_reach25(pr.px, pr.py, pr.conic_a, pr.conic_b, pr.conic_c, opac);
+    g.reach[idx] = reach_entry(reach, pr.px, pr.py);
     g.g0[idx] = make_float4(pr.px, pr.py, pr.conic_a, pr.conic_b);
     g.g1[idx] = make_float4(pr.conic_c, opac, pr.p_view.z, __int_as_float(pr.radius));
     g.col[idx] = c;
@@ -463,34 +465,58 @@ __device__ __forceinline__ void lds_sort(uint64_t* s, int cap)
 #define GSR_SORT_G 4              // 16 keys per thread and trip
 #define GSR_SORT_SMALL_THREADS 64
 #define GSR_SORT_BIG_THREADS 256  // 1024 threads per 4096-key tile measured no faster
-template <bool SMALL>
+// KIND 0: one wave per list of <= 1024 keys, 16 keys per lane (the k-NN buckets); KIND 1: 256 threads per list of <= 4096 keys;
+// KIND 2: 256 threads per list of <= 1024 keys, 4 keys per thread — the rasterizer's short lists: a quarter of KIND 0's
+// registers per thread (the 16-keys-per-lane wave needs ~200 VGPRs: two waves per SIMD), four times the waves per list
+#define GSR_SORT_WAVE 0
+#define GSR_SORT_BLOCK 1
+#define GSR_SORT_BLOCK_SHORT 2
+template <int KIND>
 struct SortShared {
-    static constexpr int NT = SMALL ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS, CAP = SMALL ? GSR_SORT_SMALL : GSR_SORT_CAP;
+    static constexpr int NT = KIND == 0 ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS, CAP = KIND == 1 ? GSR_SORT_CAP : GSR_SORT_SMALL;
     uint64_t s[CAP];
     __attribute__((aligned(16))) uint32_t h[CAP + 4];
     uint32_t red[9][NT / 64];
 };
-template <bool SMALL>
-__device__ __forceinline__ void sort_tile(SortShared<SMALL>& sh, const uint2 r, uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list)
+// reach (rasterizer only): the dense per-splat reach array; every key's entry is gathered through its id as soon as the
+// key is loaded (the gathers are in flight while the list is binned and ranked) and turned into the mask of the tile's
+// patches, which is carried to the key's sorted position.
+// Returns where the sorted ids of the list can be read back besides point_list: GSR_IDS_H (sh.h[i]; the payload words,
+// if any, sit in the key array viewed as uint32_t: sort_payload(sh)[i]), GSR_IDS_S (the low words of sh.s[swz(i)]: the
+// network ran, no payload) or GSR_IDS_GLOBAL (an oversize list).
+#define GSR_IDS_H 0
+#define GSR_IDS_S 1
+#define GSR_IDS_GLOBAL 2
+template <int KIND>
+__device__ __forceinline__ uint32_t* sort_payload(SortShared<KIND>& sh) { return reinterpret_cast<uint32_t*>(sh.s); }
+template <int KIND>
+__device__ __forceinline__ int sort_tile(SortShared<KIND>& sh, const uint2 r, uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list,
+                                         const uint2* __restrict__ reach = nullptr, int tx = 0, int ty = 0)
 {
-    constexpr int NT = SortShared<SMALL>::NT, CAP = SortShared<SMALL>::CAP;
-    constexpr int EPT = CAP / NT, LOGCAP = SMALL ? 10 : 12;
-    static_assert(EPT == 16 && (1 << LOGCAP) == CAP, "sixteen keys and sixteen bins per thread");
+    constexpr int NT = SortShared<KIND>::NT, CAP = SortShared<KIND>::CAP;
+    constexpr int EPT = CAP / NT, LOGCAP = CAP == 1024 ? 10 : 12, MATES = EPT < GSR_SORT_MATES ? EPT : GSR_SORT_MATES;
+    static_assert(EPT % 4 == 0 && (1 << LOGCAP) == CAP, "whole uint4 of bins per thread");
     uint64_t* const s = sh.s;
     uint32_t* const h = sh.h;
     auto& red = sh.red;
     const int n = (int)(r.y - r.x);
     uint64_t* seg = pairs + r.x;
-    const int tid = sort_tid<SMALL>(), lane = tid & 63, wv = tid >> 6;
+    const int tid = sort_tid<KIND == 0>(), lane = tid & 63, wv = tid >> 6;
     if (n <= CAP) {
         // Straight-line code: a load inside a divergent branch is waited for inside that branch, sixteen branches would be
         // sixteen serial round trips. Loads use clamped addresses and selects, only stores are predicated.
         uint64_t k[EPT];
+        uint2 pay[EPT];
         uint32_t dmin = ~0u, dmax = 0u;
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
             const int i = j * NT + tid;
             const uint64_t v = seg[min(i, n - 1)];
+#ifdef GSR_EXP_SORT_NOGATHER
+            pay[j] = reach ? reach[r.x + min(i, n - 1)] : make_uint2(0u, 0u);
+#else
+            pay[j] = reach ? reach[(uint32_t)v] : make_uint2(0u, 0u);
+#endif
             k[j] = i < n ? v : ~0ull; // padding keys: above every real key
             dmin = min(dmin, (uint32_t)(k[j] >> 32));
             dmax = max(dmax, i < n ? (uint32_t)(v >> 32) : 0u);
@@ -498,13 +524,13 @@ __device__ __forceinline__ void sort_tile(SortShared<SMALL>& sh, const uint2 r, 
         }
         dmin = wave_min_u32(dmin);
         dmax = wave_max_dpp(dmax);
-        if (!SMALL) {
+        if (KIND != 0) {
             if (lane == 0) { red[0][wv] = dmin; red[1][wv] = dmax; }
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < NT / 64; q++) { dmin = min(dmin, red[0][q]); dmax = max(dmax, red[1][q]); }
         }
-        sort_sync<SMALL>();
+        sort_sync<KIND == 0>();
         const int shift = max(0, 32 - __clz((int)(dmax - dmin)) - LOGCAP); // (dmax - dmin) >> shift < CAP
         uint32_t bin[EPT], rnk[EPT]; // rank of the key inside its bin, in arrival order
 #pragma unroll
@@ -513,14 +539,14 @@ __device__ __forceinline__ void sort_tile(SortShared<SMALL>& sh, const uint2 r, 
             bin[j] = valid ? ((uint32_t)(k[j] >> 32) - dmin) >> shift : (uint32_t)(CAP + (lane & 3)); // padding: four spare words
             rnk[j] = __hip_atomic_fetch_add(&h[bin[j]], valid ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        sort_sync<SMALL>();
+        sort_sync<KIND == 0>();
         // counts -> bin starts: every thread owns sixteen consecutive bins. SLOT: which words of `red` a call may use
         // (every call its own: no barrier needed between the calls)
         auto block_sums = [&](const uint32_t v, const int slot, uint32_t& before, uint32_t& total) {
             const uint32_t inc = wave_scan_add(v);
             before = inc - v;
             total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            if (!SMALL) {
+            if (KIND != 0) {
                 if (lane == 63) red[slot][wv] = inc;
                 __syncthreads();
                 total = 0;
@@ -563,7 +589,7 @@ __device__ __forceinline__ void sort_tile(SortShared<SMALL>& sh, const uint2 r, 
             }
 #pragma unroll
             for (int j = 0; j < EPT; j++) h2[j * NT + tid] = 0u;
-            sort_sync<SMALL>();
+            sort_sync<KIND == 0>();
             const int down = max(0, shift - 16), frac = min(shift, 16); // position inside the old bin, in 16 bits
 #pragma unroll
             for (int j = 0; j < EPT; j++) {
@@ -573,7 +599,7 @@ __device__ __forceinline__ void sort_tile(SortShared<SMALL>& sh, const uint2 r, 
                 bin[j] = valid ? (m & 0xFFFFu) + ((inside * (m >> 16)) >> frac) : (uint32_t)(CAP + (lane & 3));
                 rnk[j] = __hip_atomic_fetch_add(&h2[bin[j]], valid ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            sort_sync<SMALL>();
+            sort_sync<KIND == 0>();
             scan_counts(h2, 6);
             crowded = sq > 8u * (uint32_t)n;
         }
@@ -585,7 +611,7 @@ __device__ __forceinline__ void sort_tile(SortShared<SMALL>& sh, const uint2 r, 
                 v.z = run | (c[4 * q + 2] << 16); run += c[4 * q + 2]; v.w = run | (c[4 * q + 3] << 16); run += c[4 * q + 3];
                 reinterpret_cast<uint4*>(h)[tid * (EPT / 4) + q] = v;
             }
-            sort_sync<SMALL>();
+            sort_sync<KIND == 0>();
             uint32_t sb[EPT]; // bin start | keys of the bin below this one << 16
 #pragma unroll
             for (int j = 0; j < EPT; j++) {
@@ -595,67 +621,76 @@ __device__ __forceinline__ void sort_tile(SortShared<SMALL>& sh, const uint2 r, 
                 if (valid) s[sb[j] + rnk[j]] = k[j];
                 rnk[j] = valid ? rnk[j] | (sc & 0xFFFF0000u) : 0u; // rank | bin count << 16 (padding: the spare words hold anything)
             }
-            sort_sync<SMALL>();
+            sort_sync<KIND == 0>();
             // rank inside the bin = the number of smaller keys among the OTHER keys of the bin (most bins hold one key: nothing
             // to do). The keys of a lane step through their bin-mates together: the reads of one step are issued back to
             // back and waited for once; a key without a further mate reads word 0 (a broadcast, no bank conflict).
 #pragma unroll
-            for (int j0 = 0; j0 < EPT; j0 += GSR_SORT_MATES) {
+            for (int j0 = 0; j0 < EPT; j0 += MATES) {
                 for (uint32_t q = 1;; q++) {
                     bool more = false;
 #pragma unroll
-                    for (int j = j0; j < j0 + GSR_SORT_MATES; j++) more |= q < (rnk[j] >> 16);
+                    for (int j = j0; j < j0 + MATES; j++) more |= q < (rnk[j] >> 16);
                     if (!__builtin_amdgcn_ballot_w64(more)) break;
-                    uint64_t mate[GSR_SORT_MATES];
+                    uint64_t mate[MATES];
 #pragma unroll
-                    for (int j = j0; j < j0 + GSR_SORT_MATES; j++) {
+                    for (int j = j0; j < j0 + MATES; j++) {
                         const uint32_t cnt = rnk[j] >> 16;
                         uint32_t o = (rnk[j] & 0xFFFFu) + q;
                         o = o >= cnt ? o - cnt : o;
                         mate[j - j0] = s[q < cnt ? (sb[j] & 0xFFFFu) + o : 0u];
                     }
 #pragma unroll
-                    for (int j = j0; j < j0 + GSR_SORT_MATES; j++) sb[j] += (q < (rnk[j] >> 16) && mate[j - j0] < k[j]) ? 0x10000u : 0u;
+                    for (int j = j0; j < j0 + MATES; j++) sb[j] += (q < (rnk[j] >> 16) && mate[j - j0] < k[j]) ? 0x10000u : 0u;
                 }
             }
-            // ids to their places in LDS, then out in order (the counts in h are dead: every lane read them before the barrier above)
+            // ids to their places in LDS, then out in order (the counts in h are dead: every lane read them before the barrier above);
+            // the payload words go to the same places of the key array, which every thread has finished reading
+            if (reach) sort_sync<KIND == 0>();
+            uint32_t* const hp = sort_payload(sh);
 #pragma unroll
             for (int j = 0; j < EPT; j++)
-                if (j * NT + tid < n) h[(sb[j] & 0xFFFFu) + (sb[j] >> 16)] = (uint32_t)k[j];
-            sort_sync<SMALL>();
+                if (j * NT + tid < n) {
+                    const uint32_t pos = (sb[j] & 0xFFFFu) + (sb[j] >> 16);
+                    h[pos] = (uint32_t)k[j];
+                    if (reach) hp[pos] = tile_mask_from_reach(pay[j], tx, ty);
+                }
+            sort_sync<KIND == 0>();
 #pragma unroll
             for (int j = 0; j < EPT; j++) {
                 const uint32_t id = h[j * NT + tid];
                 if (j * NT + tid < n) point_list[r.x + j * NT + tid] = id;
             }
-            return;
+            return GSR_IDS_H;
         }
-        sort_sync<SMALL>();
+        sort_sync<KIND == 0>();
     }
     if (n <= CAP) { // crowded bins: the bitonic network
         int n2 = 1 << GSR_SORT_G;
         while (n2 < n) n2 <<= 1;
-        for (int i = tid; i < n2; i += sort_nt<SMALL>()) s[swz(i)] = i < n ? seg[i] : ~0ull;
-        sort_sync<SMALL>();
-        lds_sort<GSR_SORT_G, SMALL>(s, n2);
-        for (int i = tid; i < n; i += sort_nt<SMALL>()) point_list[r.x + i] = (uint32_t)s[swz(i)];
-        return;
+        for (int i = tid; i < n2; i += sort_nt<KIND == 0>()) s[swz(i)] = i < n ? seg[i] : ~0ull;
+        sort_sync<KIND == 0>();
+        lds_sort<GSR_SORT_G, KIND == 0>(s, n2);
+        for (int i = tid; i < n; i += sort_nt<KIND == 0>()) point_list[r.x + i] = (uint32_t)s[swz(i)];
+        return GSR_IDS_S;
     }
     // oversize tile: chunk-local stages in LDS, long-stride stages in global memory
+    if constexpr (KIND != GSR_SORT_BLOCK) return GSR_IDS_GLOBAL; // (only the 4096-key workgroups are handed such lists)
+    else {
     long n2 = GSR_SORT_CAP;
     while (n2 < n) n2 <<= 1;
     const int nchunks = (int)(n2 / GSR_SORT_CAP);
     for (int c = 0; c < nchunks; c++) {
         const long base = (long)c * GSR_SORT_CAP;
         if (base >= n) break;
-        for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<SMALL>()) s[swz(i)] = base + i < n ? seg[base + i] : ~0ull;
+        for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<KIND == 0>()) s[swz(i)] = base + i < n ? seg[base + i] : ~0ull;
         __syncthreads();
         lds_sort<GSR_SORT_G, false>(s, GSR_SORT_CAP);
-        for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<SMALL>()) if (base + i < n) seg[base + i] = s[swz(i)];
+        for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<KIND == 0>()) if (base + i < n) seg[base + i] = s[swz(i)];
         __syncthreads();
     }
     for (long k = 2L * GSR_SORT_CAP; k <= n2; k <<= 1) {
-        for (long i = tid; i < n2 / 2; i += sort_nt<SMALL>()) { // flip in global memory
+        for (long i = tid; i < n2 / 2; i += sort_nt<KIND == 0>()) { // flip in global memory
             const long blk = i / (k >> 1), off = i % (k >> 1);
             const long lo = blk * k + off, hi = blk * k + (k - 1 - off);
             if (hi < n) { uint64_t a = seg[lo], b = seg[hi]; if (a > b) { seg[lo] = b; seg[hi] = a; } }
@@ -663,7 +698,7 @@ __device__ __forceinline__ void sort_tile(SortShared<SMALL>& sh, const uint2 r, 
         __syncthreads();
         long j = k >> 2;
         for (; j >= GSR_SORT_CAP; j >>= 1) { // disperse with stride >= chunk: global memory
-            for (long i = tid; i < n2 / 2; i += sort_nt<SMALL>()) {
+            for (long i = tid; i < n2 / 2; i += sort_nt<KIND == 0>()) {
                 const long lo = (i / j) * 2 * j + (i % j), hi = lo + j;
                 if (hi < n) { uint64_t a = seg[lo], b = seg[hi]; if (a > b) { seg[lo] = b; seg[hi] = a; } }
             }
@@ -672,31 +707,33 @@ __device__ __forceinline__ void sort_tile(SortShared<SMALL>& sh, const uint2 r, 
         for (int c = 0; c < nchunks; c++) { // remaining strides are chunk-local
             const long base = (long)c * GSR_SORT_CAP;
             if (base >= n) break;
-            for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<SMALL>()) s[swz(i)] = base + i < n ? seg[base + i] : ~0ull;
+            for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<KIND == 0>()) s[swz(i)] = base + i < n ? seg[base + i] : ~0ull;
             __syncthreads();
             lds_disperse_from<GSR_SORT_G, false>(s, GSR_SORT_CAP, 11); // strides 2048 ... 1 (GSR_SORT_CAP / 2 = 2^11)
-            for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<SMALL>()) if (base + i < n) seg[base + i] = s[swz(i)];
+            for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<KIND == 0>()) if (base + i < n) seg[base + i] = s[swz(i)];
             __syncthreads();
         }
     }
-    for (int i = tid; i < n; i += sort_nt<SMALL>()) point_list[r.x + i] = (uint32_t)seg[i];
+    for (int i = tid; i < n; i += sort_nt<KIND == 0>()) point_list[r.x + i] = (uint32_t)seg[i];
+    return GSR_IDS_GLOBAL;
+    }
 }
 
 // Launch modes: one workgroup per tile (sortq == nullptr: the k-NN path, and always for SMALL), or a fixed grid that
 // walks K_scan_tiles's queue of the tiles in the middle class — a frame without such tiles (the 1 M-splat headline
 // frame has none) then costs a few hundred empty workgroups instead of one per tile.
-template <bool SMALL>
-__global__ void __launch_bounds__(SMALL ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS)
+template <int KIND>
+__global__ void __launch_bounds__(KIND == 0 ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS)
 K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __restrict__ hdr,
             uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list, const uint32_t* __restrict__ sortq)
 {
-    __shared__ SortShared<SMALL> sh;
+    __shared__ SortShared<KIND> sh;
     if (hdr->overflow) return;
-    if constexpr (!SMALL) {
+    if constexpr (KIND != 0) {
         if (sortq) {
             const uint32_t cnt = sortq[0];
             for (uint32_t t = blockIdx.x; t < cnt; t += gridDim.x) {
-                sort_tile<false>(sh, ranges[sortq[GSR_SORTQ_HEAD + t]], pairs, point_list);
+                (void)sort_tile<KIND>(sh, ranges[sortq[GSR_SORTQ_HEAD + t]], pairs, point_list);
                 __syncthreads();
             }
             return;
@@ -704,8 +741,8 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
     }
     const uint2 r = ranges[xcd_remap(blockIdx.x, ntiles)];
     const int n = (int)(r.y - r.x);
-    if (n == 0 || (n <= GSR_SORT_SMALL) != SMALL) return;
-    sort_tile<SMALL>(sh, r, pairs, point_list);
+    if (n == 0 || (n <= GSR_SORT_SMALL) != (KIND == 0)) return;
+    (void)sort_tile<KIND>(sh, r, pairs, point_list);
 }
 
 // Lists longer than GSR_SORT_CAP: the same bucket sort with the keys in global scratch instead of LDS (the tile's own
@@ -713,7 +750,7 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
 // in flight; bins in LDS. Passes: min/max, count, [equalise + count again], scatter by bin, rank among bin-mates.
 // Crowded lists (exact depth ties) fall back to the bitonic network in global memory (sort_tile).
 #define GSR_SORT_LONG_BINS 8192
-__device__ __forceinline__ void sort_long_list(SortShared<false>& sh, const uint2 r, uint64_t* __restrict__ pairs,
+__device__ __forceinline__ void sort_long_list(SortShared<GSR_SORT_BLOCK>& sh, const uint2 r, uint64_t* __restrict__ pairs,
                                                uint32_t* __restrict__ point_list, uint2* __restrict__ qhits)
 {
     constexpr int NT = GSR_SORT_BIG_THREADS, NB = GSR_SORT_LONG_BINS, BPT = NB / NT, LOGNB = 13, U = 8;
@@ -813,7 +850,7 @@ __device__ __forceinline__ void sort_long_list(SortShared<false>& sh, const uint
         }
         if (crowded) { // exact ties: the network, in place in the list segment
             __syncthreads();
-            sort_tile<false>(sh, r, pairs, point_list);
+            (void)sort_tile<GSR_SORT_BLOCK>(sh, r, pairs, point_list);
             __syncthreads();
             return;
         }
@@ -863,53 +900,172 @@ __device__ __forceinline__ void sort_long_list(SortShared<false>& sh, const uint
     }
 }
 
-// The rasterizer's sort: ONE launch for the three size classes (an empty kernel in the stream costs 4-5 us here: three
-// launches of which two usually have nothing to do were 9 us of a 520 us step). The first workgroups walk the queues
-// of the long and the middle class, the others sort four short lists each, one per wave.
-#define GSR_SORT_ALL_LONG 768
-#define GSR_SORT_ALL_MID 768
-__global__ void __launch_bounds__(GSR_SORT_BIG_THREADS)
-K_tile_sort_all(int T, const uint2* __restrict__ ranges, const GeomHeader* __restrict__ hdr, uint64_t* __restrict__ pairs,
-                uint32_t* __restrict__ point_list, uint2* __restrict__ qhits, const uint32_t* __restrict__ sortq)
+// Quad-hit lists. The blend kernels work per 8x8 quad (one wave, four 4x4 patch rows): what they walk is not the tile
+// list but, per quad, the entries of the tile list that can reach the quad, each with the 4-bit mask of the patches it
+// reaches: (list position, id | mask << 28), in list order. The lists are cut here, by the waves that have just sorted the
+// tile. (The forward blend used to cull while it walked: every tile entry's 48-byte record gathered in each of the tile's
+// four quad-waves, 9.7 M gathers for 3.4 M quad hits at 1 M splats.) Culling is exact (gsr_device.h): the sort gathers every
+// key's 8-byte reach entry while it sorts (one gather per tile instance, overlapped with the binning and ranking),
+// shifts a small splat's reach word into the 16-bit mask of the tile's patches and carries it to the entry's sorted
+// position; only the few larger splats of a list (GSR_MASK_UNTESTED) take the closed-form quad and patch tests, all of
+// them in one batch per list.
+__device__ __forceinline__ uint32_t exact_tile_mask(const float4 a, const float4 b, const int tx, const int ty)
 {
-    union Shared {
-        SortShared<true> small[GSR_SORT_BIG_THREADS / 64];
-        SortShared<false> big;
-    };
-    __shared__ Shared sh;
-    if (hdr->overflow) return;
+    const float4 A = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
+    const float4 B = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, 0.f, 0.f);
+    uint32_t m16 = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float X0 = (float)(tx * 16 + (q & 1) * 8), Y0 = (float)(ty * 16 + (q >> 1) * 8);
+        if (quad_reach(a, b, X0, Y0)) {
+            bool h[4];
+            patch_reach4(A, B, X0, Y0, h);
+            const uint32_t sh = 8 * (q >> 1) + 2 * (q & 1);
+            m16 |= ((h[0] ? 1u : 0u) | (h[1] ? 2u : 0u)) << sh;
+            m16 |= ((h[2] ? 1u : 0u) | (h[3] ? 2u : 0u)) << (sh + 4);
+        }
+    }
+    return m16;
+}
+// ONE wave cuts the lists of quads [q0, q0 + NQ) out of entries [0, n) given by get(i) -> (id, tile mask).
+template <int NQ, typename Get>
+__device__ __forceinline__ void cut_quad_lists(Get get, const int n, const int q0, uint2* __restrict__ qh, uint32_t* __restrict__ qcount4)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    uint32_t cnt[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) cnt[q] = 0u;
+    for (int base = 0; base < n; base += 64) {
+        const int k = base + lane;
+        const uint2 e = get(min(k, n - 1));
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const uint32_t pm = k < n ? quad_mask_of_tile_mask(e.y, q0 + q) : 0u;
+            const unsigned long long m = __ballot(pm != 0u);
+            if (pm != 0u) qh[(size_t)(q0 + q) * (size_t)n + cnt[q] + (uint32_t)mbcnt64(m)] = make_uint2((uint32_t)k, e.x | (pm << GSR_ID_BITS));
+            cnt[q] += (uint32_t)__popcll(m);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+        if (lane == q) qcount4[q0 + q] = cnt[q];
+}
+// Lists whose sorted ids and mask words sit in LDS (ids[i], msk[i]; nthreads threads of the workgroup share the list):
+// the untested entries are collected (their positions in `todo`, u16), tested in one batch — one gather of the two
+// 16-byte words per such entry — and then the lists are cut: four quads by the one wave, or one quad per wave.
+template <bool ONEWAVE>
+__device__ __forceinline__ void emit_from_lds(const uint32_t* ids, uint32_t* msk, uint16_t* todo, uint32_t* counter, const int n, const int tile,
+                                              const int grid_x, const GeomView& g, uint2* __restrict__ qh, uint32_t* __restrict__ qcount4)
+{
+    const int tid = sort_tid<ONEWAVE>(), nt = sort_nt<ONEWAVE>();
+    const int tx = tile % grid_x, ty = tile / grid_x;
+    if (tid == 0) *counter = 0u;
+    sort_sync<ONEWAVE>();
+    for (int i = tid; i < n; i += nt)
+        if (msk[i] & GSR_MASK_UNTESTED) todo[lds_take(counter)] = (uint16_t)i;
+    sort_sync<ONEWAVE>();
+    const int nu = (int)*counter;
+    for (int u = tid; u < nu; u += nt) {
+        const int i = todo[u];
+        const uint32_t id = ids[i];
+        msk[i] = exact_tile_mask(g.g0[id], g.g1[id], tx, ty);
+    }
+    sort_sync<ONEWAVE>();
+    auto get = [&](int i) { return make_uint2(ids[i], msk[i]); };
+    if (ONEWAVE) cut_quad_lists<4>(get, n, 0, qh, qcount4);
+    else cut_quad_lists<1>(get, n, (int)(threadIdx.x >> 6), qh, qcount4);
+}
+// Lists without their mask words at hand (the bitonic network ran: exact depth ties; or the list went through global
+// scratch): ids read back from point_list (just written by this workgroup: made visible by the fence + barrier, read past
+// the L1), the mask recomputed from the gathered centre and reach word; wave w of the workgroup cuts quad w.
+__device__ __forceinline__ void emit_from_global(const uint2 r, const int tile, const int grid_x, const GeomView& g,
+                                                 const uint32_t* point_list, uint2* __restrict__ qhits, uint32_t* __restrict__ qcount)
+{
+    __threadfence();
+    __syncthreads();
+    const uint32_t* pl = point_list + r.x;
+    const int tx = tile % grid_x, ty = tile / grid_x;
+    cut_quad_lists<1>(
+        [&](int i) {
+            const uint32_t id = __hip_atomic_load(pl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t m = tile_mask_from_reach(g.reach[id], tx, ty);
+            if (m & GSR_MASK_UNTESTED) m = exact_tile_mask(g.g0[id], g.g1[id], tx, ty);
+            return make_uint2(id, m);
+        },
+        (int)(r.y - r.x), (int)(threadIdx.x >> 6), qhits + 4 * (size_t)r.x, qcount + 4 * (size_t)tile);
+}
+
+// The rasterizer's sort, two launches. K_tile_sort_short: one 256-thread workgroup per tile, for the lists of up to 1024
+// entries (every list of the 1 M-splat headline frame; 12 KB of LDS and ~64 VGPRs per thread: eight workgroups per CU).
+// K_tile_sort_long: a fixed grid that walks K_scan_tiles's queues of the longer lists — 256 threads bucket-sort <= 4096
+// keys in LDS, longer lists go through global scratch. Every list is cut into its four quad-hit lists right after it is
+// sorted, one quad per wave. (History: one launch for all classes saved the 4-5 us an empty kernel costs, but tied the
+// short lists to the 48 KB of LDS and the ~200 VGPRs of the 16-keys-per-lane sort: two waves per SIMD, 63 us with the
+// list cutting in; as two launches 3x us.)
+__global__ void __launch_bounds__(GSR_SORT_BIG_THREADS)
+K_tile_sort_short(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g, uint64_t* __restrict__ pairs,
+                  uint32_t* __restrict__ point_list, uint2* __restrict__ qhits, uint32_t* __restrict__ qcount)
+{
+    __shared__ SortShared<GSR_SORT_BLOCK_SHORT> sh;
+    __shared__ uint32_t counter;
+    if (g.hdr->overflow) return;
+    const int tile = (int)xcd_remap(blockIdx.x, (uint32_t)T);
+    const uint2 r = ranges[tile];
+    const int n = (int)(r.y - r.x);
+    if (n > GSR_SORT_SMALL) return; // queued for K_tile_sort_long
+    uint32_t* const qc4 = qcount + 4 * (size_t)tile;
+    if (n == 0) { // an empty tile has four empty lists
+        if (threadIdx.x < 4u) qc4[threadIdx.x] = 0u;
+        return;
+    }
+    const int where = sort_tile<GSR_SORT_BLOCK_SHORT>(sh, r, pairs, point_list, g.reach, tile % grid_x, tile / grid_x);
+    if (where == GSR_IDS_H) { // ids in h, mask words in the first 4 KB of the key array, the to-do list behind them
+        __syncthreads();
+        uint32_t* const msk = sort_payload(sh);
+        emit_from_lds<false>(sh.h, msk, reinterpret_cast<uint16_t*>(msk + GSR_SORT_SMALL), &counter, n, tile, grid_x, g, qhits + 4 * (size_t)r.x, qc4);
+    } else { // the network ran (exact depth ties)
+        emit_from_global(r, tile, grid_x, g, point_list, qhits, qcount);
+    }
+}
+
+#define GSR_SORT_ALL_LONG 256
+#define GSR_SORT_ALL_MID 512
+__global__ void __launch_bounds__(GSR_SORT_BIG_THREADS)
+K_tile_sort_long(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g, uint64_t* __restrict__ pairs,
+                 uint32_t* __restrict__ point_list, uint2* __restrict__ qhits, const uint32_t* __restrict__ sortq, uint32_t* __restrict__ qcount)
+{
+    __shared__ SortShared<GSR_SORT_BLOCK> sh;
+    __shared__ uint32_t counter;
+    if (g.hdr->overflow) return;
     int b = blockIdx.x;
     if (b < GSR_SORT_ALL_LONG) {
         const uint32_t cnt = sortq[1];
         for (uint32_t t = b; t < cnt; t += GSR_SORT_ALL_LONG) {
-            sort_long_list(sh.big, ranges[sortq[GSR_SORTQ_HEAD + T + t]], pairs, point_list, qhits);
+            const int tile = (int)sortq[GSR_SORTQ_HEAD + T + t];
+            const uint2 r = ranges[tile];
+            sort_long_list(sh, r, pairs, point_list, qhits);
+            emit_from_global(r, tile, grid_x, g, point_list, qhits, qcount); // (the sort's scratch in qhits is dead by now)
             __syncthreads();
         }
         return;
     }
     b -= GSR_SORT_ALL_LONG;
-    if (b < GSR_SORT_ALL_MID) {
-        const uint32_t cnt = sortq[0];
-        for (uint32_t t = b; t < cnt; t += GSR_SORT_ALL_MID) {
-            sort_tile<false>(sh.big, ranges[sortq[GSR_SORTQ_HEAD + t]], pairs, point_list);
+    const uint32_t cnt = sortq[0];
+    for (uint32_t t = b; t < cnt; t += GSR_SORT_ALL_MID) {
+        const int tile = (int)sortq[GSR_SORTQ_HEAD + t];
+        const uint2 r = ranges[tile];
+        const int where = sort_tile<GSR_SORT_BLOCK>(sh, r, pairs, point_list, g.reach, tile % grid_x, tile / grid_x);
+        if (where == GSR_IDS_H) { // ids in h, mask words in the first 16 KB of the key array, the to-do list behind them
             __syncthreads();
+            uint32_t* const msk = sort_payload(sh);
+            emit_from_lds<false>(sh.h, msk, reinterpret_cast<uint16_t*>(msk + GSR_SORT_CAP), &counter, (int)(r.y - r.x), tile, grid_x, g,
+                                 qhits + 4 * (size_t)r.x, qcount + 4 * (size_t)tile);
+        } else {
+            emit_from_global(r, tile, grid_x, g, point_list, qhits, qcount);
         }
-        return;
+        __syncthreads();
     }
-    b -= GSR_SORT_ALL_MID;
-    const int wv = (int)(threadIdx.x >> 6), per = GSR_SORT_BIG_THREADS / 64, nsmall = (T + per - 1) / per;
-    const int tile = (int)xcd_remap((uint32_t)b, (uint32_t)nsmall) * per + wv;
-    if (tile >= T) return;
-    const uint2 r = ranges[tile];
-    const int n = (int)(r.y - r.x);
-    if (n == 0 || n > GSR_SORT_SMALL) return;
-    sort_tile<true>(sh.small[wv], r, pairs, point_list);
 }
-
-// blending kernels (K_blend_fwd, K_blend_bwd)
-} // namespace gsr
-#include "gsr_blend.h"
-namespace gsr {
 
 // ===================================================================================
 // per-splat backward (reference K11 + K12 fused; 3D covariance recomputed, not stored)
