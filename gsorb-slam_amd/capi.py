@@ -414,11 +414,13 @@ class _FusedSSIM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img1, img2, taps):
         L = lib()
+        # (inside forward() grad mode is off: a .contiguous() COPY of a sliced / permuted render has requires_grad False,
+        # so the need for a gradient is read from the context, not from the tensor)
+        need = bool(ctx.needs_input_grad[0])
         img1, img2 = img1.contiguous(), img2.contiguous()
         Cc, H, W = (int(x) for x in img1.shape)
         tp = (C.c_float * 11)(*[float(x) for x in taps])
         partial = torch.empty((int(L.gsr_ssim_partials(Cc, H, W)),), dtype=torch.float32, device=img1.device)
-        need = img1.requires_grad
         dmaps = torch.empty((3, Cc, H, W), dtype=torch.float32, device=img1.device) if need else None
         with torch.cuda.device(img1.device):
             _check(L.gsr_ssim_forward(_p(img1), _p(img2), Cc, H, W, tp, _p(partial), _p(dmaps) if need else None, _stream()))

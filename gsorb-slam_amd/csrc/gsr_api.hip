@@ -86,6 +86,7 @@ BinGrid bin_grid(int P, int T, int wx, int window)
     b.rows = bin_rows(P);
     b.per = (P + b.rows - 1) / b.rows;
     b.wx = wx;
+    window -= 2; // the two words of slack below: a window never needs more than GSR_BIN_WINDOW words = 64 KB of LDS (T = 16384 did)
     const int wy = (T + wx * window - 1) / (wx * window);
     b.nwin = wx * wy;
     b.grid = dim3(b.rows * wx, wy);

@@ -353,6 +353,11 @@ class SlamRenderer:
     def _sync_pose_grads(self):
         """Single process: the pose gradient is already complete."""
 
+    def _replicated_term_grad_scale(self):
+        """Weight of the gradient of a loss term that every rank of a sharded run evaluates in full (the feature
+        reprojection term of track(): it depends on the pose only, not on a rank's shard). Single process: 1."""
+        return 1.0
+
     # Render.cc:420-483
     def mapping_loss(self, fr: Frame):
         g, c = self.map, self.map.cfg
@@ -362,9 +367,14 @@ class SlamRenderer:
         valid_sur = (fr.depth > 0) & (rdepth[1] > 0.99)
         image_loss = c.lam * l1_mapping(rimage, fr.rgb) + (1 - c.lam) * (1.0 - ssim(rimage, fr.rgb))
         depth_loss = l1_mapping(rdepth[0], fr.depth, valid.detach())
-        # (no surface pixel: the reference skips the term; here it is an exact zero with a zero gradient, without asking the host)
+        # DELIBERATE DEVIATION: with no surface pixel the reference's masked_select(mask).mean() over an empty selection is NaN
+        # (Utils.cc:39-44, Render.cc:455) and so is its reg_long over an empty set of oversized splats; here both terms are
+        # an exact zero with a zero gradient (and nothing asks the host), so a step that would poison Adam's moments with
+        # NaN in the reference is an ordinary step here. (strict_empty_terms=True reproduces the reference's NaN.)
         n_sur = valid_sur.sum()
         sur_loss = torch.where(valid_sur.detach(), torch.abs(rsur[0] - fr.depth), torch.zeros_like(fr.depth)).sum() / n_sur.clamp_min(1)
+        if getattr(self, "strict_empty_terms", False):
+            sur_loss = torch.where(n_sur > 0, sur_loss, torch.full_like(sur_loss, float("nan")))
         max_scalar = 0.1 * g.scene_radius
         sc = torch.exp(g.log_scales)
         # Render.cc:449-462 gathers the rows of every scale COMPONENT above the limit (torch::where(...)[0]: a row with two
@@ -376,6 +386,8 @@ class SlamRenderer:
         cnt = torch.as_tensor(cnt, dtype=sc.dtype, device=sc.device)
         reg_scalar = over
         reg_long = torch.where(cnt > 0, spread / cnt.clamp_min(1), torch.zeros_like(spread))   # mean over the oversized splats
+        if getattr(self, "strict_empty_terms", False):
+            reg_long = torch.where(cnt > 0, reg_long, torch.full_like(reg_long, float("nan")))
         return (c.im_weight_mapping * image_loss + c.depth_weight_mapping * depth_loss + c.sur_depth_weight_mapping * sur_loss
                 + c.reg_long_weight * reg_long + c.reg_scalar_weight * reg_scalar)
 
@@ -419,6 +431,11 @@ class SlamRenderer:
                 if it == int(iters / 2.0):
                     inline = werr < 5.991
                 lrpj = werr.masked_select(inline).sum()
+                # a sharded run sums the pose gradients of the ranks: a term every rank holds in full must enter each rank's
+                # gradient with weight 1/world (its VALUE is unchanged)
+                gs = self._replicated_term_grad_scale()
+                if gs != 1.0:
+                    lrpj = lrpj * gs + lrpj.detach() * (1.0 - gs)
             rimage, rsur, rdepth = self.render_pair(Tcw, tracking=True)
             certain = (rdepth[1] > 0.99) & ~torch.isnan(frame.depth)
             image_l1 = l1_tracking(rimage, frame.rgb, certain.unsqueeze(0).repeat(3, 1, 1).detach())

@@ -161,6 +161,11 @@ def make_sharded_mapper(harness_mod):
             spread = sum_spread + (tot[1] - mine[1])
             return over, spread, tot[2]
 
+        def _replicated_term_grad_scale(self):
+            # the pose gradients of the ranks are SUMMED (_sync_pose_grads): a term that does not depend on the shard
+            # (harness.track's feature reprojection error) would otherwise be counted `world` times
+            return 1.0 / self.comp.world
+
         def _sync_pose_grads(self):
             g = self.map
             if self.comp.world > 1:

@@ -413,6 +413,24 @@ def test_large_frame_more_than_8192_tiles(gsr, syn):
 
 
 @pytest.mark.gpu
+def test_frame_of_exactly_one_bin_window(gsr, syn):
+    """2048x2048 = 128x128 = 16384 tiles = exactly GSR_BIN_WINDOW: the count pass's window plus its two words of slack must
+    still fit 64 KB of LDS (it asked for 65544 bytes before the window was shortened by the slack)."""
+    cam = syn.make_camera(2048, 2048, 1500.0, 1500.0)
+    sc = syn.make_scene(40000, cam, seed=6, scale_mult=6.0, frac_offscreen=0.1)
+    o, f = oracle.forward_scene(sc, omp=True)
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    d = gsr.debug_export(st)
+    assert st.num_rendered == f.num_rendered
+    np.testing.assert_array_equal(d["ranges"], f.stages["ranges"])
+    np.testing.assert_array_equal(d["point_list"], f.stages["point_list"])
+    mc, _ = o.margins(f)
+    ok = mc >= EPS_MARGIN
+    assert np.abs(st.color.cpu().numpy() - f.color)[:, ok].max() <= TOL * max(1.0, float(np.abs(f.color).max()))
+
+
+@pytest.mark.gpu
 def test_huge_frame_more_than_131072_tiles(gsr, syn):
     """8192x4112 = 512x257 = 131584 tiles: the count pass histograms the frame in nine LDS windows and the fill pass in
     sixteen (two per XCD), with splats from one tile to thousands of tiles wide. Integer stages bit-exact."""

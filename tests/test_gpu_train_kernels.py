@@ -33,6 +33,24 @@ def test_fused_ssim_matches_the_torch_convolutions(gsr, hz, shape):
         assert abs(float(hz.ssim(a, b)) - float(ref.detach())) <= 2e-6
 
 
+def test_fused_ssim_gradient_reaches_a_non_contiguous_render(gsr, hz):
+    """A cropped / permuted render is copied by .contiguous() inside forward(), where grad mode is off: the copy has
+    requires_grad False, and the need for a gradient must come from the autograd context, not from that copy."""
+    g = torch.Generator().manual_seed(4)
+    big = torch.rand((3, 50, 70), generator=g).cuda()
+    b = torch.rand((3, 40, 60), generator=g).cuda()
+    a1, a2 = big.clone().requires_grad_(True), big.clone().requires_grad_(True)
+    crop1, crop2 = a1[:, 5:45, 3:63], a2[:, 5:45, 3:63]
+    assert not crop2.is_contiguous()
+    (1.0 - hz.ssim_torch(crop1, b)).backward()
+    (1.0 - hz.ssim(crop2, b)).backward()
+    assert a2.grad is not None and float(a2.grad.abs().max()) > 0
+    assert float((a2.grad - a1.grad).abs().max()) <= 2e-5 * float(a1.grad.abs().max())
+    hwc = torch.rand((40, 60, 3), generator=g).cuda().requires_grad_(True)     # channels-last storage, permuted view
+    (1.0 - hz.ssim(hwc.permute(2, 0, 1), b)).backward()
+    assert hwc.grad is not None and float(hwc.grad.abs().max()) > 0
+
+
 def test_fused_ssim_uses_the_window_it_is_given(gsr, hz):
     """A symmetric and the reference's asymmetric 11-tap window give different losses; each matches its own convolution."""
     g = torch.Generator().manual_seed(5)

@@ -71,6 +71,37 @@ def _target(hz, sc, OracleRasterizer, Tcw):
     return hz.Frame(rgb.clone(), sur[0].clone(), Tcw.clone())
 
 
+def _matches(Tcw, n=40, seed=9):
+    """feature matches for track(): world points in front of the camera and their pixel observations under Tcw (+ noise)."""
+    g = torch.Generator().manual_seed(seed)
+    Xc = torch.stack([torch.rand(n, generator=g) * 1.2 - 0.6, torch.rand(n, generator=g) * 0.9 - 0.45, 1.0 + 2.0 * torch.rand(n, generator=g)], 1)
+    Twc = torch.inverse(Tcw)
+    Xw = Xc @ Twc[:3, :3].t() + Twc[:3, 3]
+    K = torch.tensor([[FX, 0.0, (W - 1) / 2.0], [0.0, FY, (H - 1) / 2.0], [0.0, 0.0, 1.0]])
+    uv = (K @ (Xc / Xc[:, 2:3]).t()).t() + torch.cat([0.3 * torch.randn(n, 2, generator=g), torch.zeros(n, 1)], 1)
+    return (uv.reshape(n, 3, 1), torch.cat([Xw, torch.ones(n, 1)], 1).reshape(n, 4, 1), torch.full((n, 1), 1.0)), K
+
+
+FEATURE_WEIGHT = 20.0   # the reprojection term and the render terms pull on the pose with comparable strength
+
+
+def _record_pose_grads(g):
+    """the pose gradient the optimiser sees (after the ranks' gradients are summed), one entry per iteration"""
+    rec, init = [], g.init_camera_pose
+
+    def init_and_wrap(Tcw):                              # track() creates the pose optimiser: wrap its step() right after
+        out = init(Tcw)
+        step = g.opt_pose.step
+
+        def wrapped(*a, **k):
+            rec.append(torch.cat([g.cam_quat.grad.reshape(-1), g.cam_trans.grad.reshape(-1)]).detach().clone())
+            return step(*a, **k)
+        g.opt_pose.step = wrapped
+        return out
+    g.init_camera_pose = init_and_wrap
+    return rec
+
+
 def _tracking_loss(hz, r, frame, Tcw):
     c = r.map.cfg
     rimage, rsur, rdepth = r.render_pair(Tcw, tracking=True)
@@ -133,6 +164,16 @@ def _worker(rank, world, port, q):
         T0 = torch.tensor(pose(0.025, (0.02, -0.005, 0.03)), dtype=torch.float32)
         T_est, hist = m.track(frame, T0, iters=12)
         res.update(track_T=T_est.numpy(), track_hist=hist)
+
+        # ---- (4) the same with feature matches: the reprojection term depends on the pose only, every rank evaluates it in
+        #      full, and the summed pose gradient must contain it ONCE
+        g = _fill(hz, sc, slabs[rank])
+        m = Mapper(g, W, H, rasterizer_cls=OracleRasterizer)
+        g.cfg.feature_weight_tracking = FEATURE_WEIGHT
+        mt, K = _matches(Tcw)
+        rec = _record_pose_grads(g)
+        T_est, hist = m.track(frame, T0, iters=8, matches=mt, K=K)
+        res.update(trackm_T=T_est.numpy(), trackm_hist=hist, trackm_grad0=rec[0].numpy())
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -196,6 +237,21 @@ def _single_process_reference():
     T0 = torch.tensor(pose(0.025, (0.02, -0.005, 0.03)), dtype=torch.float32)
     T_est, hist = r.track(frame, T0, iters=12)
     ref.update(track_T=T_est.numpy(), track_hist=hist)
+    # (4) unsharded track with feature matches
+    g = _fill(hz, sc, np.arange(sc.P))
+    g.cfg.feature_weight_tracking = FEATURE_WEIGHT
+    r = hz.SlamRenderer(g, W, H, rasterizer_cls=OracleRasterizer)
+    mt, K = _matches(Tcw)
+    rec = _record_pose_grads(g)
+    T_est, hist = r.track(frame, T0, iters=8, matches=mt, K=K)
+    ref.update(trackm_T=T_est.numpy(), trackm_hist=hist, trackm_grad0=rec[0].numpy())
+    # the feature term alone (render terms switched off): its share of the pose gradient
+    g = _fill(hz, sc, np.arange(sc.P))
+    g.cfg.feature_weight_tracking, g.cfg.im_weight_tracking, g.cfg.depth_weight_tracking = FEATURE_WEIGHT, 0.0, 0.0
+    r = hz.SlamRenderer(g, W, H, rasterizer_cls=OracleRasterizer)
+    rec = _record_pose_grads(g)
+    r.track(frame, T0, iters=1, matches=mt, K=K)
+    ref.update(trackm_grad0_feature=rec[0].numpy())
     return ref
 
 
@@ -206,7 +262,7 @@ def test_two_rank_sharded_mapping_and_tracking_match_the_unsharded_harness():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=600) for _ in range(world))
+    got = dict(q.get(timeout=240) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -251,3 +307,16 @@ def test_two_rank_sharded_mapping_and_tracking_match_the_unsharded_harness():
     assert len(got[0]["track_hist"]) == len(ref["track_hist"])
     np.testing.assert_allclose(got[0]["track_hist"], ref["track_hist"], rtol=2e-2)   # the composited surface depth is approximate
     assert np.abs(got[0]["track_T"] - ref["track_T"]).max() < 2e-3
+
+    # (4) with feature matches (the term every rank holds in full enters the summed gradient once: with it counted `world`
+    #     times the second iteration's loss is already off by several percent)
+    np.testing.assert_array_equal(got[0]["trackm_T"], got[1]["trackm_T"])
+    assert len(got[0]["trackm_hist"]) == len(ref["trackm_hist"])
+    gsum, gref, gfeat = got[0]["trackm_grad0"], ref["trackm_grad0"], ref["trackm_grad0_feature"]
+    share = np.abs(gfeat).max() / scale(gref)
+    err = np.abs(gsum - gref).max() / scale(gref)
+    print("track() with matches: feature term's share of the pose gradient %.2f, summed gradient vs unsharded %.1e" % (share, err))
+    assert share > 0.2                                   # counted twice, the gradient would be off by about this much
+    assert err < 0.1 * share, (err, share)
+    np.testing.assert_allclose(got[0]["trackm_hist"], ref["trackm_hist"], rtol=2e-2)
+    assert np.abs(got[0]["trackm_T"] - ref["trackm_T"]).max() < 2e-3
