@@ -40,7 +40,8 @@ class ForwardArgs(C.Structure):
                 ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("cam_pos", C.c_void_p),
                 ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int),
                 ("out_color", C.c_void_p), ("out_depth", C.c_void_p), ("radii", C.c_void_p),
-                ("profile_events", C.POINTER(C.c_void_p)), ("band_y0", C.c_int), ("band_y1", C.c_int)]
+                ("profile_events", C.POINTER(C.c_void_p)), ("band_y0", C.c_int), ("band_y1", C.c_int),
+                ("out_ds", C.c_void_p)]
 
 
 class BackwardArgs(C.Structure):
@@ -56,7 +57,7 @@ class BackwardArgs(C.Structure):
                 ("dL_dcolor", C.c_void_p), ("dL_dmean3D", C.c_void_p), ("dL_dcov3D", C.c_void_p),
                 ("dL_dsh", C.c_void_p), ("dL_dscale", C.c_void_p), ("dL_drot", C.c_void_p),
                 ("profile_events", C.POINTER(C.c_void_p)), ("band_y0", C.c_int), ("band_y1", C.c_int),
-                ("stages", C.c_int)]
+                ("stages", C.c_int), ("dL_dds", C.c_void_p)]
 
 
 class DebugArrays(C.Structure):
@@ -196,18 +197,19 @@ class ForwardState:
     image: torch.Tensor
     ws_binning_bytes: int = 0
     band: tuple = (0, 0)
+    ds: torch.Tensor | None = None   # [2,H,W] fused depth / silhouette channels (forward(..., dual=True))
     dirty: bool = False   # a backward ran its per-splat stage without GSR_STAGE_REZERO: clear before the next one
     keep: list = field(default_factory=list)
 
 
 def _fwd_args(s: Settings, means3D, opacities, colors, shs, scales, rotations, cov3D, color, depth, radii,
-              events=None, band=(0, 0)):
+              events=None, band=(0, 0), ds=None):
     P = int(means3D.shape[0])
     M = 0 if shs is None or shs.numel() == 0 else int(shs.shape[1])
     a = ForwardArgs(P, s.sh_degree, M, _p(s.bg), s.image_width, s.image_height, _p(means3D), _p(shs), _p(colors),
                     _p(opacities), _p(scales), s.scale_modifier, _p(rotations), _p(cov3D), _p(s.viewmatrix),
                     _p(s.projmatrix), _p(s.campos), s.tanfovx, s.tanfovy, int(s.prefiltered), _p(color),
-                    _p(depth), _p(radii), events, int(band[0]), int(band[1]))
+                    _p(depth), _p(radii), events, int(band[0]), int(band[1]), _p(ds))
     return a, P, M
 
 
@@ -222,8 +224,9 @@ def _prep(s: Settings, means3D, opacities, colors, shs, scales, rotations, cov3D
 
 
 def forward(s: Settings, means3D, opacities, colors=None, shs=None, scales=None, rotations=None,
-            cov3D_precomp=None, band=(0, 0), out=None) -> ForwardState:
-    """gsr_forward with torch-owned blobs (the reference's resizeFunctional, src/Rasterizer.cu:127-134)."""
+            cov3D_precomp=None, band=(0, 0), out=None, dual: bool = False) -> ForwardState:
+    """gsr_forward with torch-owned blobs (the reference's resizeFunctional, src/Rasterizer.cu:127-134).
+    dual: also blend the depth / silhouette channels in the same pass (state.ds [2,H,W]; include/gsr.h: out_ds)."""
     L = lib()
     dev, ins = _prep(s, means3D, opacities, colors, shs, scales, rotations, cov3D_precomp)
     H, W = s.image_height, s.image_width
@@ -231,6 +234,7 @@ def forward(s: Settings, means3D, opacities, colors=None, shs=None, scales=None,
     color = out[0] if out is not None else torch.empty((3, H, W), dtype=torch.float32, device=dev)
     depth = out[1] if out is not None else torch.empty((1, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((max(P, 1),), dtype=torch.int32, device=dev)
+    ds = torch.empty((2, H, W), dtype=torch.float32, device=dev) if dual else None
     blobs = {}
 
     def mk(name):
@@ -242,11 +246,11 @@ def forward(s: Settings, means3D, opacities, colors=None, shs=None, scales=None,
 
     cbs = [mk("geom"), mk("binning"), mk("image")]
     a, P, M = _fwd_args(s, ins["means3D"], ins["opacities"], ins["colors"], ins["shs"], ins["scales"],
-                        ins["rotations"], ins["cov3D"], color, depth, radii, None, band)
+                        ins["rotations"], ins["cov3D"], color, depth, radii, None, band, ds)
     with torch.cuda.device(dev):
         R = _check(L.gsr_forward(C.byref(a), cbs[0], None, cbs[1], None, cbs[2], None, _stream()))
     return ForwardState(s, P, M, R, ins, color, depth, radii[:P], blobs["geom"], blobs["binning"],
-                        blobs["image"], band=tuple(band))
+                        blobs["image"], band=tuple(band), ds=ds)
 
 
 class Workspace:
@@ -264,6 +268,7 @@ class Workspace:
         self.color = torch.empty((3, height, width), dtype=torch.float32, device=self.device)
         self.depth = torch.empty((1, height, width), dtype=torch.float32, device=self.device)
         self.radii = torch.empty((max(P, 1),), dtype=torch.int32, device=self.device)
+        self.ds = torch.empty((2, height, width), dtype=torch.float32, device=self.device)   # fused depth / silhouette channels (dual=True)
         self.grads = None
 
     def status(self):
@@ -273,16 +278,16 @@ class Workspace:
 
 
 def forward_ws(s: Settings, ws: Workspace, means3D, opacities, colors=None, shs=None, scales=None,
-               rotations=None, cov3D_precomp=None, events=None) -> ForwardState:
+               rotations=None, cov3D_precomp=None, events=None, dual: bool = False) -> ForwardState:
     L = lib()
     dev, ins = (s.viewmatrix.device, means3D) if isinstance(means3D, dict) else \
         _prep(s, means3D, opacities, colors, shs, scales, rotations, cov3D_precomp)
     a, P, M = _fwd_args(s, ins["means3D"], ins["opacities"], ins["colors"], ins["shs"], ins["scales"],
-                        ins["rotations"], ins["cov3D"], ws.color, ws.depth, ws.radii, events)
+                        ins["rotations"], ins["cov3D"], ws.color, ws.depth, ws.radii, events, (0, 0), ws.ds if dual else None)
     assert P == ws.P and s.image_width == ws.W and s.image_height == ws.H
     _check(L.gsr_forward_ws(C.byref(a), _p(ws.geom), _p(ws.binning), ws.binning_bytes, _p(ws.image), _stream()))
     return ForwardState(s, P, M, -1, ins, ws.color, ws.depth, ws.radii[:P], ws.geom, ws.binning, ws.image,
-                        ws_binning_bytes=ws.binning_bytes)
+                        ws_binning_bytes=ws.binning_bytes, ds=ws.ds if dual else None)
 
 
 @dataclass
@@ -306,10 +311,11 @@ def alloc_grads(P: int, M: int, dev, intermediates: bool = True) -> Grads:
                  e(P, M, 3), e(P, 3), e(P, 4))
 
 
-def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None, stages: int = 0, once: bool = False) -> Grads:
+def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None, stages: int = 0, once: bool = False,
+             dL_dds=None) -> Grads:
     """gsr_backward; output shapes follow src/Rasterizer.cu:253-261. `once`: the caller runs one backward per
     forward (blend + per-splat without the re-zero of the accumulators); a later call on the same state
-    is then started with a clear."""
+    is then started with a clear. dL_dds [2,H,W]: upstream gradient of the fused depth / silhouette channels."""
     if stages == 0:
         stages = (2 | 4) if once else (2 | 4 | 8)
         if st.dirty:
@@ -318,6 +324,7 @@ def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None,
     s = st.settings
     dev = s.viewmatrix.device
     g = _f32(dL_dpix, dev)
+    gds = _f32(dL_dds, dev) if dL_dds is not None else None
     P, M = st.P, st.M
     out = grads if grads is not None else alloc_grads(P, M, dev)
     if P == 0:
@@ -331,7 +338,7 @@ def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None,
                      _p(out.dL_dmeans2D), _p(out.dL_dconic), _p(out.dL_dopacity), _p(out.dL_dcolors),
                      _p(out.dL_dmeans3D), _p(out.dL_dcov3D), _p(out.dL_dsh) if M > 0 else None,
                      _p(out.dL_dscales) if has_sr else None, _p(out.dL_drotations) if has_sr else None, events,
-                     int(st.band[0]), int(st.band[1]), int(stages))
+                     int(st.band[0]), int(st.band[1]), int(stages), _p(gds))
     if stages & 4:
         st.dirty = not (stages & 8)
     with torch.cuda.device(dev):

@@ -114,9 +114,12 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     tm.end(GSR_FWD_SORT);
     tm.begin(GSR_FWD_BLEND);
     const int Tb = (f.band_y1 - f.band_y0) * f.grid_x; // tiles of the band
-    if (Tb > 0)
-        hipLaunchKernelGGL(gsr::K_blend_fwd<GSR_ROWQ>, dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
-                           f.grid_x, Tb, f.band_y0 * f.grid_x, a->out_color, a->out_depth, P);
+    if (Tb > 0 && a->out_ds)
+        hipLaunchKernelGGL((gsr::K_blend_fwd<GSR_ROWQ, true>), dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
+                           f.grid_x, Tb, f.band_y0 * f.grid_x, a->out_color, a->out_depth, P, a->out_ds);
+    else if (Tb > 0)
+        hipLaunchKernelGGL((gsr::K_blend_fwd<GSR_ROWQ, false>), dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
+                           f.grid_x, Tb, f.band_y0 * f.grid_x, a->out_color, a->out_depth, P, (float*)nullptr);
     else // an empty band launches no blend kernel: clear the backward accumulators here
         GSR_HIP(hipMemsetAsync(gv.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
     GSR_LAUNCHED();
@@ -157,6 +160,7 @@ int forward_empty(const gsr_forward_args* a, char* geom, hipStream_t st)
     const size_t N = (size_t)a->width * a->height;
     GSR_HIP(hipMemsetAsync(a->out_color, 0, N * 3 * sizeof(float), st));
     GSR_HIP(hipMemsetAsync(a->out_depth, 0, N * sizeof(float), st));
+    if (a->out_ds) GSR_HIP(hipMemsetAsync(a->out_ds, 0, N * 2 * sizeof(float), st));
     if (geom) GSR_HIP(hipMemsetAsync(geom, 0, sizeof(GeomHeader), st));
     return GSR_OK;
 }
@@ -338,8 +342,12 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
     }
     if ((stages & GSR_STAGE_BLEND) && Tb > 0) {
         tm.begin(GSR_BWD_BLEND);
-        hipLaunchKernelGGL(gsr::K_blend_bwd<GSR_ROWQ>, dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, W, H, f.grid_x, Tb,
-                           f.band_y0 * f.grid_x, a->dL_dpix);
+        if (a->dL_dds)
+            hipLaunchKernelGGL((gsr::K_blend_bwd<GSR_ROWQ, true>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, W, H, f.grid_x, Tb,
+                               f.band_y0 * f.grid_x, a->dL_dpix, a->dL_dds);
+        else
+            hipLaunchKernelGGL((gsr::K_blend_bwd<GSR_ROWQ, false>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, W, H, f.grid_x, Tb,
+                               f.band_y0 * f.grid_x, a->dL_dpix, (const float*)nullptr);
         GSR_LAUNCHED();
         tm.end(GSR_BWD_BLEND);
     }

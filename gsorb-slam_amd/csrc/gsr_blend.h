@@ -142,15 +142,19 @@ __device__ __forceinline__ void patch_reach4(const float4 A, const float4 B, flo
         }
 }
 
-template <int Q>
+// DUAL: the fused colour + depth / silhouette render (gsr_forward_args.out_ds): two more channels ride on the same
+// alphas — the splat's view depth z and the constant 1 (what the reference renders in a second pass with colours
+// [z, 1, 0], src/Render.cc:949-981). dL_dds [2,H,W] is their upstream gradient; the z channel adds a tenth sum per
+// (quad, splat): dL/dz-colour, which K_splat_bwd folds into the mean.
+template <int Q, bool DUAL>
 __attribute__((amdgpu_waves_per_eu(3, 3))) __global__ void __launch_bounds__(64)
 K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* __restrict__ bg, int W, int H,
-                 int grid_x, int ntiles, int tile0, const float* __restrict__ dL_dpix)
+                 int grid_x, int ntiles, int tile0, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dds)
 {
     static_assert(Q == 64 && GSR_RING == 16, "one lane per parked entry and one lane per (row, ring slot) pair");
     // parked entries; slot Q is a dummy (opacity 0, far away) the per-patch lists are padded with: no "row still active"
     // compare and no index select in the blend loop
-    __shared__ float4 E0[Q + 1], E1[Q + 1], E2[Q + 1]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, list position, splat id, patch mask)
+    __shared__ float4 E0[Q + 1], E1[Q + 1], E2[Q + 1]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, list position, view depth, splat id | patch mask << 28)
     // per-patch hit lists as BYTE OFFSETS (entry * 16 into E0/E1/E2): shifts and integer mads are half-rate VALU work
     __shared__ uint16_t LIST[4 * (Q + 4)];
     // One block of LDS used three ways, one after the other:
@@ -188,6 +192,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     const uint32_t last = inside ? im.n_contrib[pix] : 0u;
     const float g0 = inside ? dL_dpix[pix] : 0.f, g1 = inside ? dL_dpix[HW + pix] : 0.f,
                 g2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
+    const float g3 = DUAL && inside ? dL_dds[pix] : 0.f, g4 = DUAL && inside ? dL_dds[HW + pix] : 0.f; // (their background is 0)
     const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
     const float nTf_bg = -T_final * bg_dot;
     // colour accumulated behind the current splat (the reference's accum_rec, updated eagerly:
@@ -195,9 +200,10 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     // channel: c - S is formed BEFORE the contraction with the pixel gradient — neighbouring splats have
     // similar colours (depth renders!), and contracting first turns an exact small difference into the
     // difference of two rounded large numbers (measured: 9e-5 instead of 1e-6 on long lists).
-    float S0 = 0.f, S1 = 0.f, S2 = 0.f;
-    const int fe = (lane * 57) >> 9, fc = lane - 9 * fe; // lane / 9, lane % 9: flush lane -> (entry, component)
-    GP[r][l] = make_float4(g0, g1, g2, 0.f);
+    float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f;
+    constexpr int NC = DUAL ? 10 : 9;                     // sums per (quad, splat) record
+    const int fe = lane / NC, fc = lane - NC * fe;        // flush lane -> (entry, component)
+    GP[r][l] = make_float4(g0, g1, g2, g3);
     if (lane == 0) {
         E0[Q] = make_float4(-1.0e5f, -1.0e5f, -1.f, 0.f); // power2 ~ -2e10: exp2 gives 0
         E1[Q] = make_float4(-1.f, 0.f, 0.f, 0.f);
@@ -236,7 +242,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
                 const int e = mbcnt64(m);
                 E0[e] = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
                 E1[e] = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, c.x, c.y);
-                E2[e] = make_float4(c.z, __uint_as_float(pos), __uint_as_float(id), __uint_as_float(pmask));
+                E2[e] = make_float4(c.z, __uint_as_float(pos), b.z, __uint_as_float(id | (pmask << GSR_ID_BITS)));
             }
             count = (int)__popcll(m);
             k0 += GSR_BSTEP;
@@ -249,8 +255,8 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             bool h[4] = {false, false, false, false};
             if (lane < count) { // the forward already ran the patch cull: its verdict travels in the record
                 const float4 z = E2[lane];
-                const uint32_t pm = __float_as_uint(z.w);
-                my_id = __float_as_uint(z.z);
+                const uint32_t pm = __float_as_uint(z.w) >> GSR_ID_BITS;
+                my_id = __float_as_uint(z.w) & GSR_ID_MASK;
                 h[0] = (pm & 1u) != 0u; h[1] = (pm & 2u) != 0u; h[2] = (pm & 4u) != 0u; h[3] = (pm & 8u) != 0u;
             }
             const unsigned long long m0 = __ballot(h[0]), m1 = __ballot(h[1]), m2 = __ballot(h[2]), m3 = __ballot(h[3]);
@@ -270,7 +276,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
         lds_turn();
         const uint16_t* __restrict__ mylist = LIST + r * (Q + 4);
         // per-entry totals of this round, in the registers of lane e
-        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f, t5 = 0.f, t6 = 0.f, t7 = 0.f, t8 = 0.f;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f, t5 = 0.f, t6 = 0.f, t7 = 0.f, t8 = 0.f, t9 = 0.f;
         // ---- blend. An iteration is split in two: what does not depend on the pixel's running state (alpha and the
         //      Gaussian weight of the entry at this pixel) and what does (T, accum_rec, dL/dalpha). The loop handles two
         //      entries per trip and evaluates both first halves before the two second halves: a wave issues in order and
@@ -289,7 +295,12 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
         auto state_part = [&](v2f* const slot, const float alpha, const float G, const float ia, const float4 B, const float4 Cz) {
             T = T * ia;
             const float e0 = B.z - S0, e1 = B.w - S1, e2 = Cz.x - S2;
-            const float eg = fmaf(e2, g2, fmaf(e1, g1, e0 * g0)); // (colour - accum_rec) . dL_dpix
+            float eg = fmaf(e2, g2, fmaf(e1, g1, e0 * g0)); // (colour - accum_rec) . dL_dpix
+            if (DUAL) { // the depth and silhouette channels: colours (z, 1)
+                const float e3 = Cz.z - S3, e4 = 1.0f - S4;
+                eg = fmaf(e4, g4, fmaf(e3, g3, eg));
+                S3 = fmaf(alpha, e3, S3); S4 = fmaf(alpha, e4, S4);
+            }
             const float dL_dalpha = fmaf(nTf_bg, ia, eg * T); // - T_final/(1-alpha) * (bg . dL_dpix)
             S0 = fmaf(alpha, e0, S0); S1 = fmaf(alpha, e1, S1); S2 = fmaf(alpha, e2, S2);
             v2f ud;
@@ -321,7 +332,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             for (int k = 0; k < 4; k++) { dxk[k] = c.x - (X0pf + (float)k); dyk[k] = c.y - (Y0pf + (float)k); }
             // moments of u about the splat centre over the 4x4 patch, through its column and row sums (dx depends on the
             // column i = p & 3 only, dy on the row j = p >> 2 only): 71 instead of 128 instructions
-            float q0 = 0.f, q1 = 0.f, q2 = 0.f;
+            float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
             float col[4], row[4], wj[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) col[i] = (ud[i].x + ud[4 + i].x) + (ud[8 + i].x + ud[12 + i].x);
@@ -341,11 +352,12 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
                 const float4 gp = gq[p & 3];
                 if (p + 4 < 16) gq[p & 3] = GP[r][p + 4];
                 q0 = fmaf(ud[p].y, gp.x, q0); q1 = fmaf(ud[p].y, gp.y, q1); q2 = fmaf(ud[p].y, gp.z, q2);
+                if (DUAL) q3 = fmaf(ud[p].y, gp.w, q3);
             }
             lds_turn(); // every lane has read its column of the ring: the block turns into ST
             ST[0 * 64 + lane] = make_float4(m0, m1, m2, m3);
             ST[1 * 64 + lane] = make_float4(m4, m5, q0, q1);
-            ST[2 * 64 + lane] = make_float4(q2, 0.f, 0.f, 0.f);
+            ST[2 * 64 + lane] = make_float4(q2, q3, 0.f, 0.f);
             if (l < nb) reinterpret_cast<uint8_t*>(INV)[(o >> 2) + r] = (uint8_t)l; // o >> 2 = entry * 4; the dummy (index Q) lands in the slack
             lds_turn();
             const uint32_t inv = INV[lane]; // lane e: where entry e sits in the four rows
@@ -361,6 +373,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
                 t0 = fmaf(f, s0[rr].x, t0); t1 = fmaf(f, s0[rr].y, t1); t2 = fmaf(f, s0[rr].z, t2); t3 = fmaf(f, s0[rr].w, t3);
                 t4 = fmaf(f, s1[rr].x, t4); t5 = fmaf(f, s1[rr].y, t5); t6 = fmaf(f, s1[rr].z, t6); t7 = fmaf(f, s1[rr].w, t7);
                 t8 = fmaf(f, s2[rr].x, t8);
+                if (DUAL) t9 = fmaf(f, s2[rr].y, t9);
             }
             lds_turn(); // the block is the ring again
         };
@@ -409,14 +422,15 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
         float* const accf = reinterpret_cast<float*>(POOL);
         ST[lane * 3 + 0] = make_float4(t0, t1, t2, t3);
         ST[lane * 3 + 1] = make_float4(t4, t5, t6, t7);
-        ST[lane * 3 + 2] = make_float4(t8, 0.f, 0.f, 0.f);
+        ST[lane * 3 + 2] = make_float4(t8, t9, 0.f, 0.f);
         lds_turn();
-        for (int fb = 0; fb < count; fb += 7) {
+        constexpr int FPER = 64 / NC; // entries per flush instruction: NC consecutive lanes per 64-byte accumulator record
+        for (int fb = 0; fb < count; fb += FPER) {
             const int e = fb + fe;
-            if (lane < 63 && e < count) {
+            if (lane < FPER * NC && e < count) {
                 const float val = accf[e * GSR_ACCW + fc];
 #ifndef GSR_EXP_NOFLUSH
-                if (val != 0.f) unsafeAtomicAdd(&g.acc[(size_t)__float_as_uint(E2[e].z) * GSR_ACC_STRIDE + fc], val);
+                if (val != 0.f) unsafeAtomicAdd(&g.acc[(size_t)(__float_as_uint(E2[e].w) & GSR_ID_MASK) * GSR_ACC_STRIDE + fc], val);
 #else
                 if (val == 123.456f) g.acc[0] = val;
 #endif
@@ -436,10 +450,11 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
 // list r, entries software-pipelined). A row whose 16 pixels are all done idles; the wave leaves when
 // every pixel is done and notes how many records it took (qdone): the backward starts there.
 // =====================================================================================
-template <int Q>
+template <int Q, bool DUAL>
 __global__ void __launch_bounds__(64)
 K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
-                 int grid_x, int ntiles, int tile0, float* __restrict__ out_color, float* __restrict__ out_depth, int P)
+                 int grid_x, int ntiles, int tile0, float* __restrict__ out_color, float* __restrict__ out_depth, int P,
+                 float* __restrict__ out_ds)
 {
     static_assert(Q == 64, "one parked entry per lane");
     // parked entries; slot Q is a dummy that no pixel can see (opacity 0, far away): the per-patch lists are padded with
@@ -459,7 +474,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
     const uint2 range = im.ranges[tile];
     const int n = g.hdr->overflow ? 0 : (int)(range.y - range.x);
 
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, C3 = 0.f, C4 = 0.f, Dp = 0.f;
     uint32_t last = 0u;
     wmask m_done = wm(!inside); // lanes whose pixel is finished (or outside the image)
     const int cq = n > 0 ? (int)im.qcount[4 * tile + quad] : 0;
@@ -533,6 +548,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                 C0 = fmaf(B.z, wgt, C0);
                 C1 = fmaf(B.w, wgt, C1);
                 C2 = fmaf(Cz.x, wgt, C2);
+                if (DUAL) { C3 = fmaf(Cz.y, wgt, C3); C4 += wgt; } // alpha-blended view depth, accumulated opacity
                 Dp = lane_of(upd & wm(T > 0.5f)) ? Cz.y : Dp; // median depth (forward.cu:374-379)
                 T = u ? test_T : T;
                 last = u ? __float_as_uint(Cz.z) : last;
@@ -570,6 +586,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
         out_color[HW + pix] = C1 + T * bg[1];
         out_color[2 * HW + pix] = C2 + T * bg[2];
         out_depth[pix] = Dp;
+        if (DUAL) { out_ds[pix] = C3; out_ds[HW + pix] = C4; }
     }
     { // The backward accumulators (64 bytes per splat) must be zero when the forward is done. Clearing them is
       // pure memory traffic and this kernel is pure VALU work, so every block clears its share here for free

@@ -1109,7 +1109,7 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o)
     }
     float* const acc = g.acc + i * GSR_ACC_STRIDE;
     const float4 q0 = reinterpret_cast<const float4*>(acc)[0], q1 = reinterpret_cast<const float4*>(acc)[1];
-    const float q8 = acc[8];
+    const float q8 = acc[8], q9 = acc[9]; // q9: dL/d(view depth as a colour) of the fused depth channel (zero without it)
     if (REZERO) { // consumed: leave the record clean for the next backward on this geometry blob
         float4* const ap = reinterpret_cast<float4*>(acc);
         ap[0] = ap[1] = ap[2] = ap[3] = make_float4(0.f, 0.f, 0.f, 0.f); // the whole 64-byte line
@@ -1182,6 +1182,9 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o)
     float3 dmean = make_float3(vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz,
                                vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz,
                                vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz);
+    // the fused depth channel blends the view depth z = vm[2] x + vm[6] y + vm[10] z + vm[14] as a colour
+    // (the reference feeds it as colors_precomp[:, 0] of its second render and lets autograd take it back to the mean)
+    dmean.x += vm[2] * q9; dmean.y += vm[6] * q9; dmean.z += vm[10] * q9;
 
     // ---- screen-space mean -> 3D mean (backward.cu:366-387) ----
     {

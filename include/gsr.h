@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 2 /* 2: blob layouts of round 2 (sizes through gsr_*_bytes only), fused loop kernels */
+#define GSR_ABI_VERSION 3 /* 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs */
 
 #define GSR_OK 0
 #define GSR_EINVAL (-1)    /* bad argument combination (NULL where data is required, sizes < 0 …) */
@@ -72,6 +72,13 @@ typedef struct gsr_forward_args {
      * every splat. 0,0 (the zero-initialised default) means the whole image. A band render is bit-identical
      * to the same rows of the full render. */
     int band_y0, band_y1;
+    /* Fused colour + depth / silhouette render (new capability; NULL = the reference's 3-channel render). GSORB-SLAM
+     * renders every view twice with the same geometry: once with the colours, once with colors_precomp = [z, 1, 0]
+     * (z = camera-frame depth) for the alpha-blended depth and the silhouette (src/Render.cc:927-981). With out_ds
+     * [2,H,W] the forward blends those two channels in the same pass: out_ds[0] = sum z_i alpha_i T_i (z_i = the
+     * splat's view-space depth, what preprocess computes anyway), out_ds[1] = sum alpha_i T_i; background 0. One
+     * preprocess / binning / sort / gather / exp / alpha / T per pair instead of two. */
+    float* out_ds;
 } gsr_forward_args;
 
 /* forward stages, in launch order */
@@ -156,6 +163,10 @@ typedef struct gsr_backward_args {
      * per-splat stage. Band sharding runs 2 on every rank, sums the accumulators across ranks
      * (gsr_acc_view + one all-reduce), then runs 4. */
     int stages;
+    /* Upstream gradient of the fused depth / silhouette channels [2,H,W] (gsr_forward_args.out_ds), or NULL. dL/dalpha
+     * then sums over all five channels; the depth channel's colour gradient (dL/dz_i) is folded into dL_dmean3D
+     * through the third row of the view matrix (z_i is a function of the mean), everything else is written as usual. */
+    const float* dL_dds;
 } gsr_backward_args;
 
 #define GSR_STAGE_CLEAR 1

@@ -1,0 +1,82 @@
+"""GPU (-m gpu): the fused colour + depth / silhouette render (include/gsr.h: gsr_forward_args.out_ds,
+gsr_backward_args.dL_dds) against what it replaces — TWO renders of the same geometry by the CPU oracle, one with the
+colours and one with colors_precomp = [z, 1, 0] (src/Render.cc:927-981), and the sum of their backward passes, the second
+one's dL/dcolour[:, 0] taken back to the mean through z = (view matrix row 2) . mean, as autograd does in the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from util import mixed_err, pose, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL, EPS_MARGIN = 1e-4, 1e-5
+
+
+def _two_oracle_renders(sc, gA, gB):
+    o, fA = oracle.forward_scene(sc, omp=True)
+    mc, _ = o.margins(fA)
+    ok = mc >= EPS_MARGIN
+    bA = o.backward(gA * ok[None])
+    z = fA.stages["depths"].astype(np.float32)                 # view-space depth of every splat, as preprocess computes it
+    colB = np.stack([z, np.ones_like(z), np.zeros_like(z)], 1).astype(np.float32)
+    o2 = oracle.Oracle(omp=True)
+    bg0 = sc.cam.bg
+    sc.cam.bg = (0.0, 0.0, 0.0)                                # the depth / silhouette channels have background 0
+    try:
+        fB = o2.forward(means3D=sc.means3D, opacities=sc.opacities, cam=sc.cam, colors=colB, scales=sc.scales, rotations=sc.rotations)
+        bB = o2.backward(gB * ok[None])
+    finally:
+        sc.cam.bg = bg0
+    vm = np.asarray(sc.cam.viewmatrix, np.float64).reshape(-1)   # column-major 4x4 as the kernels read it
+    row2 = np.array([vm[2], vm[6], vm[10]])
+    tot = {n: np.asarray(getattr(bA, n), np.float64) + np.asarray(getattr(bB, n), np.float64)
+           for n in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D")}
+    tot["dL_dmeans3D"] = tot["dL_dmeans3D"] + np.asarray(bB.dL_dcolors, np.float64)[:, 0:1] * row2[None]
+    tot["dL_dcolors"] = np.asarray(bA.dL_dcolors, np.float64)
+    return fA, fB, tot, ok
+
+
+@pytest.mark.parametrize("name", ["tum-10k", "odd-pose-bg-fat", "replica-300k"])
+def test_fused_pair_equals_two_renders(gsr, syn, name):
+    cases = {
+        "tum-10k": dict(P=10000, cam=syn.TUM1, mult=2.0),
+        "odd-pose-bg-fat": dict(P=3000, cam=dict(width=203, height=149, fx=150.0, fy=152.0), mult=4.0, Tcw=pose(), bg=(0.3, 0.5, 0.7),
+                                frac_behind=0.1, frac_offscreen=0.3),
+        "replica-300k": dict(P=300000, cam=syn.REPLICA),
+    }
+    kw = dict(cases[name])
+    cam = syn.make_camera(**kw.pop("cam"), Tcw=kw.pop("Tcw", None), bg=kw.pop("bg", (0, 0, 0)))
+    sc = syn.make_scene(kw.pop("P"), cam, seed=5, scale_mult=kw.pop("mult", 1.0), **kw)
+    rng = np.random.default_rng(7)
+    H, W = cam.height, cam.width
+    gA = sc.dL_dpix
+    gB = rng.standard_normal((3, H, W)).astype(np.float32)
+    gB[0] *= 0.3                                               # depth residuals are small next to colour residuals in the SLAM losses
+    gB[2] = 0.0
+    fA, fB, tot, ok = _two_oracle_renders(sc, gA, gB)
+
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations, dual=True)
+    plain = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    assert torch.equal(st.color, plain.color) and torch.equal(st.depth, plain.depth) and torch.equal(st.radii, plain.radii)   # the colour pass is untouched
+    ds = st.ds.cpu().numpy()
+    scale = max(1.0, float(np.abs(fB.color[0]).max()))
+    assert np.abs(ds[0] - fB.color[0])[ok].max() <= TOL * scale
+    assert np.abs(ds[1] - fB.color[1])[ok].max() <= TOL
+    assert np.abs(st.color.cpu().numpy() - fA.color)[:, ok].max() <= TOL * max(1.0, float(np.abs(fA.color).max()))
+
+    gr = gsr.backward(st, gA * ok[None], dL_dds=(gB * ok[None])[0:2])
+    torch.cuda.synchronize()
+    worst = {}
+    for n, ref in tot.items():
+        got = getattr(gr, n).cpu().numpy()
+        e, m = rel_err(got, ref), mixed_err(got, ref, afloor=2e-6)
+        worst[n] = (e, m)
+        assert e <= TOL, (n, e)
+        assert m <= 1.0, (n, m)
+    print("\n%s: fused pair vs two oracle renders (tensor-scale rel_err, element-wise ratio):" % name, {k: "%.1e / %.2f" % v for k, v in worst.items()})
+    # without dL_dds the backward is the plain one
+    g0 = gsr.backward(plain, gA * ok[None])
+    g1 = gsr.backward(st, gA * ok[None])
+    assert rel_err(g1.dL_dmeans3D.cpu().numpy(), g0.dL_dmeans3D.cpu().numpy()) < 1e-5
