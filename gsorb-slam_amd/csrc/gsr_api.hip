@@ -43,6 +43,7 @@ FrameParams frame_params(int P, int D, int M, int W, int H, float tfx, float tfy
     if (by0 == 0 && by1 == 0) by1 = f.grid_y;
     f.band_y0 = std::max(0, std::min(by0, f.grid_y));
     f.band_y1 = std::max(f.band_y0, std::min(by1, f.grid_y));
+    f.fold_depth_color = 1;
     return f;
 }
 
@@ -326,7 +327,8 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
     if (a->shs && (!a->dL_dsh || a->M <= 0 || !a->cam_pos || a->D < 0 || a->D > 3 || (a->D + 1) * (a->D + 1) > a->M)) return GSR_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int P = a->P, W = a->width, H = a->height;
-    const FrameParams f = frame_params(P, a->D, a->M, W, H, a->tan_fovx, a->tan_fovy, a->scale_modifier, a->band_y0, a->band_y1);
+    FrameParams f = frame_params(P, a->D, a->M, W, H, a->tan_fovx, a->tan_fovy, a->scale_modifier, a->band_y0, a->band_y1);
+    f.fold_depth_color = a->ds_detach_depth ? 0 : 1;
     const int T = f.grid_x * f.grid_y;
     GeomView gv; ImageView iv;
     geom_layout(a->geom_buffer, P, &gv);

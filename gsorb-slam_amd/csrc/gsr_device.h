@@ -177,6 +177,7 @@ struct FrameParams {
     float focal_x, focal_y;
     float scale_modifier;
     int band_y0, band_y1; // tile rows this call bins and blends (whole image: 0, grid_y)
+    int fold_depth_color; // backward: the fused depth channel's colour gradient goes to the mean (gsr_backward_args.ds_detach_depth == 0)
 };
 
 // ---------------------------------------------------------------------------------

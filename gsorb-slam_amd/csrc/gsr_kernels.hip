@@ -1184,7 +1184,7 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o)
                                vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz);
     // the fused depth channel blends the view depth z = vm[2] x + vm[6] y + vm[10] z + vm[14] as a colour
     // (the reference feeds it as colors_precomp[:, 0] of its second render and lets autograd take it back to the mean)
-    dmean.x += vm[2] * q9; dmean.y += vm[6] * q9; dmean.z += vm[10] * q9;
+    if (f.fold_depth_color) { dmean.x += vm[2] * q9; dmean.y += vm[6] * q9; dmean.z += vm[10] * q9; }
 
     // ---- screen-space mean -> 3D mean (backward.cu:366-387) ----
     {

@@ -74,6 +74,54 @@ class _RasterizeGaussians(torch.autograd.Function):
                 like(grad_cov3Ds_precomp, cov3Ds_precomp), None)
 
 
+class _RasterizeGaussiansPair(torch.autograd.Function):
+    """The fused pair (new capability): colours and [view depth, 1] blended in ONE pass — what GSORB-SLAM renders as two passes
+    with the same geometry (src/Render.cc:927-981, scripts/replay.py:324-325). Outputs: color [3,H,W], ds [2,H,W] (alpha-blended
+    depth, accumulated opacity; background 0), radii, depth (median). color and ds are differentiable."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                detach_depth_color):
+        dev = means3D.device
+        sh, colors_precomp, scales, rotations, cov3Ds_precomp = (_on(t, dev) for t in (
+            sh, colors_precomp, scales, rotations, cov3Ds_precomp))
+        rs = raster_settings
+        ctx.detach_depth_color = bool(detach_depth_color)
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+                rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered)
+        num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth, ds = _C.rasterize_gaussians_pair(*args)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer, opacities)
+        ctx.mark_non_differentiable(radii, depth)
+        return color, ds, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_ds, _radii, _depth):
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
+         imgBuffer, opacities) = ctx.saved_tensors
+        if grad_color is None:
+            grad_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
+        if grad_ds is None:
+            grad_ds = torch.zeros((2, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
+        stages = 7 if getattr(ctx, "backward_ran", False) else 6
+        ctx.backward_ran = True
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = _C.rasterize_gaussians_pair_backward(
+            rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_color, grad_ds, sh, rs.sh_degree, rs.campos, geomBuffer,
+            ctx.num_rendered, binningBuffer, imgBuffer, stages, ctx.detach_depth_color)
+
+        def like(g, x):
+            return None if x.numel() == 0 else g.reshape(x.shape)
+
+        return (grad_means3D, grad_means2D, like(grad_sh, sh), like(grad_colors_precomp, colors_precomp),
+                grad_opacities.reshape(opacities.shape), like(grad_scales, scales), like(grad_rotations, rotations),
+                like(grad_cov3Ds_precomp, cov3Ds_precomp), None, None)
+
+
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
     image_width: int
@@ -113,3 +161,19 @@ class GaussianRasterizer(nn.Module):
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                    cov3D_precomp, self.raster_settings)
+
+    def forward_pair(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                     cov3D_precomp=None, detach_depth_color=False):
+        """The fused pair: (color [3,H,W], ds [2,H,W], radii, depth) — see _RasterizeGaussiansPair. detach_depth_color: the depth
+        channel's colours are constants in the backward (GSORB-SLAM's tracking iterations detach their [z, 1, 0] colours)."""
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = torch.Tensor([])
+        return _RasterizeGaussiansPair.apply(means3D, means2D, empty if shs is None else shs,
+                                             empty if colors_precomp is None else colors_precomp, opacities,
+                                             empty if scales is None else scales, empty if rotations is None else rotations,
+                                             empty if cov3D_precomp is None else cov3D_precomp, self.raster_settings,
+                                             detach_depth_color)

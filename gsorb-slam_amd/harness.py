@@ -292,6 +292,7 @@ class SlamRenderer:
         self.rasterizer = (rasterizer_cls or dgr.GaussianRasterizer)(self.settings)
         self.rng = torch.Generator().manual_seed(seed)
         self.tracking_counts = self.mapping_counts = 0
+        self.fused_pair = True   # render_pair: one fused pass when the rasterizer has forward_pair (False: two passes, like the reference)
 
     @staticmethod
     def to_camera(Tcw, mean3D):
@@ -342,6 +343,14 @@ class SlamRenderer:
         # the same parameters and pose, so they are formed once here (autograd adds the two gradients: same numbers)
         xyz, rgb, q, o, s = self._params(tracking)
         mc, act = self.to_camera(Tcw, xyz), self.activations(q, o, s)
+        if self.fused_pair and hasattr(self.rasterizer, "forward_pair"):
+            # ONE pass of the rasterizer for both renders (the view matrix is the identity and the means are camera-frame:
+            # the depth channel's colour IS mc[:, 2]; tracking detaches it, like render_depth)
+            mean2D = torch.zeros_like(mc, requires_grad=True)
+            rimage, rdepth, _, rsur = self.rasterizer.forward_pair(
+                means3D=mc, means2D=mean2D, opacities=act[0], colors_precomp=rgb, scales=act[1], rotations=act[2],
+                detach_depth_color=tracking)
+            return rimage, rsur, rdepth
         rdepth, _, _ = self.render_depth(Tcw, tracking, mc=mc, act=act)
         rimage, rsur, _ = self.splat(Tcw, xyz, rgb, q, o, s, mc=mc, act=act)
         return rimage, rsur, rdepth

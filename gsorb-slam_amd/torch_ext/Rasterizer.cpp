@@ -47,13 +47,14 @@ torch::Tensor contig_f32(const torch::Tensor& t, const torch::Device& dev)
 
 } // namespace
 
+namespace {
 std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
-RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
-                       const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations,
-                       const float scale_modifier, const torch::Tensor& cov3D_precomp,
-                       const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
-                       const float tan_fovy, const int image_height, const int image_width, const torch::Tensor& sh,
-                       const int degree, const torch::Tensor& campos, const bool prefiltered, const int device_num)
+forward_impl(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
+             const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations,
+             const float scale_modifier, const torch::Tensor& cov3D_precomp,
+             const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
+             const float tan_fovy, const int image_height, const int image_width, const torch::Tensor& sh,
+             const int degree, const torch::Tensor& campos, const bool prefiltered, const int device_num, torch::Tensor* out_ds)
 {
     if (means3D.ndimension() != 2 || means3D.size(1) != 3) {
         AT_ERROR("means3D must have dimensions (num_points, 3)"); // src/Rasterizer.cu:158-160
@@ -66,6 +67,7 @@ RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& mea
     torch::Tensor out_color = torch::empty({kChannels, H, W}, fopt);
     torch::Tensor radii = torch::empty({P}, fopt.dtype(torch::kInt32));
     torch::Tensor out_depth = torch::empty({1, H, W}, fopt);
+    if (out_ds) *out_ds = torch::empty({2, H, W}, fopt);
     const auto bopt = torch::TensorOptions().device(device).dtype(torch::kByte);
     torch::Tensor geomBuffer = torch::empty({0}, bopt), binningBuffer = torch::empty({0}, bopt),
                   imgBuffer = torch::empty({0}, bopt);
@@ -91,10 +93,39 @@ RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& mea
     a.radii = P ? radii.data_ptr<int>() : nullptr;
     a.profile_events = nullptr;
     a.band_y0 = a.band_y1 = 0;
+    a.out_ds = out_ds ? out_ds->data_ptr<float>() : nullptr;
     const int rendered = gsr_forward(&a, resize_blob, &geomBuffer, resize_blob, &binningBuffer, resize_blob,
                                      &imgBuffer, current_stream(device));
     check(rendered, "RasterizeGaussiansCUDA");
     return std::make_tuple(rendered, out_color, radii, geomBuffer, binningBuffer, imgBuffer, out_depth);
+}
+} // namespace
+
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
+                       const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations,
+                       const float scale_modifier, const torch::Tensor& cov3D_precomp,
+                       const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
+                       const float tan_fovy, const int image_height, const int image_width, const torch::Tensor& sh,
+                       const int degree, const torch::Tensor& campos, const bool prefiltered, const int device_num)
+{
+    return forward_impl(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                        projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, device_num,
+                        nullptr);
+}
+
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+RasterizeGaussiansPairCUDA(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
+                           const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations,
+                           const float scale_modifier, const torch::Tensor& cov3D_precomp,
+                           const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
+                           const float tan_fovy, const int image_height, const int image_width, const torch::Tensor& sh,
+                           const int degree, const torch::Tensor& campos, const bool prefiltered, const int device_num)
+{
+    torch::Tensor ds;
+    auto r = forward_impl(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                          projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, device_num, &ds);
+    return std::tuple_cat(r, std::make_tuple(ds));
 }
 
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
@@ -108,6 +139,23 @@ RasterizeGaussiansBackwardStaged(const torch::Tensor& background, const torch::T
                                  const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
                                  const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const int stages)
 {
+    return RasterizeGaussiansPairBackward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                          viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, torch::Tensor(), sh, degree, campos,
+                                          geomBuffer, R, binningBuffer, imageBuffer, stages, false);
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor>
+RasterizeGaussiansPairBackward(const torch::Tensor& background, const torch::Tensor& means3D,
+                               const torch::Tensor& radii, const torch::Tensor& colors, const torch::Tensor& scales,
+                               const torch::Tensor& rotations, const float scale_modifier,
+                               const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+                               const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                               const torch::Tensor& dL_dout_color, const torch::Tensor& dL_dout_ds, const torch::Tensor& sh,
+                               const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
+                               const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const int stages,
+                               const bool detach_depth_color)
+{
     const int P = (int)means3D.size(0);
     const int H = (int)dL_dout_color.size(1), W = (int)dL_dout_color.size(2);
     const torch::Device device = geomBuffer.device();
@@ -119,7 +167,7 @@ RasterizeGaussiansBackwardStaged(const torch::Tensor& background, const torch::T
                         rot = contig_f32(rotations, device), cov = contig_f32(cov3D_precomp, device),
                         vm = contig_f32(viewmatrix, device), pm = contig_f32(projmatrix, device),
                         shc = contig_f32(sh, device), cp = contig_f32(campos, device),
-                        gin = contig_f32(dL_dout_color, device);
+                        gin = contig_f32(dL_dout_color, device), gds = contig_f32(dL_dout_ds, device);
     int M = 0;
     if (shc.numel() != 0) M = (int)shc.size(1);
     const bool has_sr = sc.numel() != 0 && rot.numel() != 0;
@@ -156,6 +204,8 @@ RasterizeGaussiansBackwardStaged(const torch::Tensor& background, const torch::T
         a.profile_events = nullptr;
         a.band_y0 = a.band_y1 = 0;
         a.stages = stages;
+        a.dL_dds = fptr(gds);
+        a.ds_detach_depth = detach_depth_color ? 1 : 0;
         check(gsr_backward(&a, current_stream(device)), "RasterizeGaussiansBackwardCUDA");
     }
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
@@ -310,6 +360,93 @@ torch::autograd::tensor_list _RasterizeGaussians::backward(torch::autograd::Auto
             shaped(grad_cov3Ds_precomp, cov3Ds_precomp),
             torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(),
             torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor()};
+}
+
+// ---- the fused pair (new capability): colours + [view depth, 1] in one pass -------------------------------------------
+torch::autograd::tensor_list rasterize_gaussians_pair(torch::Tensor means3D, torch::Tensor means2D, torch::Tensor sh,
+                                                      torch::Tensor colors_precomp, torch::Tensor opacities,
+                                                      torch::Tensor scales, torch::Tensor rotations,
+                                                      torch::Tensor cov3Ds_precomp, int device_num,
+                                                      GaussianRasterizationSettings s, bool detach_depth_color)
+{
+    const torch::Device device(torch::kCUDA, (c10::DeviceIndex)device_num);
+    auto dev = [&](torch::Tensor t) { return t.defined() ? t.to(device) : t; };
+    return _RasterizeGaussiansPair::apply(dev(means3D), dev(means2D), dev(sh), dev(colors_precomp), dev(opacities),
+                                          dev(scales), dev(rotations), dev(cov3Ds_precomp), dev(s.bg),
+                                          dev(s.viewmatrix), dev(s.projmatrix), dev(s.camera_center),
+                                          (int64_t)s.image_height, (int64_t)s.image_width, (double)s.tanfovx,
+                                          (double)s.tanfovy, (double)s.scale_modifier, (int64_t)s.sh_degree,
+                                          s.prefiltered, (int64_t)device_num, detach_depth_color);
+}
+
+torch::autograd::tensor_list _RasterizeGaussiansPair::forward(
+    torch::autograd::AutogradContext* ctx, torch::Tensor means3D, torch::Tensor means2D, torch::Tensor sh,
+    torch::Tensor colors_precomp, torch::Tensor opacities, torch::Tensor scales, torch::Tensor rotations,
+    torch::Tensor cov3Ds_precomp, torch::Tensor bg, torch::Tensor viewmatrix, torch::Tensor projmatrix,
+    torch::Tensor camera_center, int64_t image_height, int64_t image_width, double tanfovx, double tanfovy,
+    double scale_modifier, int64_t sh_degree, bool prefiltered, int64_t device_num, bool detach_depth_color)
+{
+    (void)means2D;
+    camera_center = camera_center.contiguous();
+    ctx->saved_data["detach_depth_color"] = detach_depth_color;
+    int num_rendered;
+    torch::Tensor color, radii, geomBuffer, binningBuffer, imgBuffer, depth, ds;
+    std::tie(num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth, ds) = RasterizeGaussiansPairCUDA(
+        bg, means3D, colors_precomp, opacities, scales, rotations, (float)scale_modifier, cov3Ds_precomp, viewmatrix,
+        projmatrix, (float)tanfovx, (float)tanfovy, (int)image_height, (int)image_width, sh, (int)sh_degree,
+        camera_center, prefiltered, (int)device_num);
+    ctx->save_for_backward({colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                            binningBuffer, imgBuffer, bg, viewmatrix, projmatrix, camera_center});
+    ctx->saved_data["num_rendered"] = num_rendered;
+    ctx->saved_data["scale_modifier"] = scale_modifier;
+    ctx->saved_data["tanfovx"] = tanfovx;
+    ctx->saved_data["tanfovy"] = tanfovy;
+    ctx->saved_data["sh_degree"] = sh_degree;
+    ctx->saved_data["opacity_shape"] = opacities.sizes().vec();
+    ctx->saved_data["H"] = image_height;
+    ctx->saved_data["W"] = image_width;
+    ctx->mark_non_differentiable({radii, depth});
+    return {color, ds, radii, depth};
+}
+
+torch::autograd::tensor_list _RasterizeGaussiansPair::backward(torch::autograd::AutogradContext* ctx,
+                                                               torch::autograd::tensor_list grad_outputs)
+{
+    const auto saved = ctx->get_saved_variables();
+    const auto &colors_precomp = saved[0], &means3D = saved[1], &scales = saved[2], &rotations = saved[3],
+               &cov3Ds_precomp = saved[4], &radii = saved[5], &sh = saved[6], &geomBuffer = saved[7],
+               &binningBuffer = saved[8], &imgBuffer = saved[9], &bg = saved[10], &viewmatrix = saved[11],
+               &projmatrix = saved[12], &camera_center = saved[13];
+    // an output the loss does not use arrives undefined: its gradient is zero
+    const torch::Tensor gcol = grad_outputs[0].defined() ? grad_outputs[0] : torch::zeros({3, ctx->saved_data["H"].toInt(), ctx->saved_data["W"].toInt()}, geomBuffer.options().dtype(torch::kFloat32));
+    const torch::Tensor gds = grad_outputs[1].defined() ? grad_outputs[1] : torch::zeros({2, gcol.size(1), gcol.size(2)}, gcol.options());
+    torch::Tensor grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+        grad_scales, grad_rotations;
+    const bool again = ctx->saved_data.count("backward_ran") != 0;
+    ctx->saved_data["backward_ran"] = true;
+    const int stages = again ? (GSR_STAGE_CLEAR | GSR_STAGE_BLEND | GSR_STAGE_SPLAT) : (GSR_STAGE_BLEND | GSR_STAGE_SPLAT);
+    std::tie(grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+             grad_scales, grad_rotations) =
+        RasterizeGaussiansPairBackward(bg, means3D, radii, colors_precomp, scales, rotations,
+                                       (float)ctx->saved_data["scale_modifier"].toDouble(), cov3Ds_precomp,
+                                       viewmatrix, projmatrix, (float)ctx->saved_data["tanfovx"].toDouble(),
+                                       (float)ctx->saved_data["tanfovy"].toDouble(), gcol, gds, sh,
+                                       (int)ctx->saved_data["sh_degree"].toInt(), camera_center, geomBuffer,
+                                       (int)ctx->saved_data["num_rendered"].toInt(), binningBuffer, imgBuffer, stages,
+                                       ctx->saved_data["detach_depth_color"].toBool());
+    auto shaped = [](const torch::Tensor& g, const torch::Tensor& like) {
+        return like.numel() == 0 ? torch::Tensor() : g.reshape(like.sizes());
+    };
+    return {grad_means3D,
+            grad_means2D,
+            shaped(grad_sh, sh),
+            shaped(grad_colors_precomp, colors_precomp),
+            grad_opacities.reshape(ctx->saved_data["opacity_shape"].toIntVector()),
+            shaped(grad_scales, scales),
+            shaped(grad_rotations, rotations),
+            shaped(grad_cov3Ds_precomp, cov3Ds_precomp),
+            torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(),
+            torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor()};
 }
 
 } // namespace ORB_SLAM2

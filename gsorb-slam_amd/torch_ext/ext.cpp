@@ -23,6 +23,19 @@ RasterizeGaussians(const torch::Tensor& background, const torch::Tensor& means3D
                                              image_width, sh, degree, campos, prefiltered, dev_index_of(means3D));
 }
 
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+RasterizeGaussiansPair(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& colors,
+                       const torch::Tensor& opacity, const torch::Tensor& scales, const torch::Tensor& rotations,
+                       const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+                       const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                       const int image_height, const int image_width, const torch::Tensor& sh, const int degree,
+                       const torch::Tensor& campos, const bool prefiltered)
+{
+    return ORB_SLAM2::RasterizeGaussiansPairCUDA(background, means3D, colors, opacity, scales, rotations, scale_modifier,
+                                                 cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height,
+                                                 image_width, sh, degree, campos, prefiltered, dev_index_of(means3D));
+}
+
 torch::Tensor FilterRadii(const torch::Tensor& means3D, const torch::Tensor& scales, const torch::Tensor& rotations,
                           const float scale_modifier, const torch::Tensor& viewmatrix,
                           const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
@@ -40,6 +53,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("rasterize_gaussians", &RasterizeGaussians);
     m.def("rasterize_gaussians_backward", &ORB_SLAM2::RasterizeGaussiansBackwardCUDA);
     m.def("rasterize_gaussians_backward_staged", &ORB_SLAM2::RasterizeGaussiansBackwardStaged);
+    m.def("rasterize_gaussians_pair", &RasterizeGaussiansPair);   // the fused colour + depth / silhouette render (Rasterizer.h)
+    m.def("rasterize_gaussians_pair_backward", &ORB_SLAM2::RasterizeGaussiansPairBackward);
     m.def("mark_visible", &ORB_SLAM2::markVisible);
     m.def("filter_radii", &FilterRadii);
     m.def("distCUDA2", [](const torch::Tensor& points) { return distCUDA2(points, points.is_cuda() ? points.device() : torch::Device(torch::kCUDA, 0)); });

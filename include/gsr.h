@@ -167,6 +167,9 @@ typedef struct gsr_backward_args {
      * then sums over all five channels; the depth channel's colour gradient (dL/dz_i) is folded into dL_dmean3D
      * through the third row of the view matrix (z_i is a function of the mean), everything else is written as usual. */
     const float* dL_dds;
+    /* non-zero: the depth channel's colour z_i is a constant for this backward (GSORB-SLAM's tracking iterations detach the
+     * [z, 1, 0] colours, src/Render.cc:949-981): its gradient is NOT folded into dL_dmean3D */
+    int ds_detach_depth;
 } gsr_backward_args;
 
 #define GSR_STAGE_CLEAR 1

@@ -123,3 +123,47 @@ def test_backward_twice_with_retain_graph(syn):
     for a, b, c in zip(g1, g2, g3):
         scale = float(a.abs().max()) + 1e-30
         assert float((a - b).abs().max()) / scale < 1e-5 and float((a - c).abs().max()) / scale < 1e-5
+
+
+@pytest.mark.parametrize("detach", [False, True])
+def test_forward_pair_equals_the_two_renders_of_the_op(syn, detach):
+    """GaussianRasterizer.forward_pair (one pass: colours + [view depth, 1]) against two calls of the op itself the way
+    GSORB-SLAM makes them (src/Render.cc:927-981: camera-frame means, identity view matrix, second render with
+    colors_precomp = [z, 1, 0] built from the means — detached in tracking iterations), through autograd."""
+    import diff_gaussian_rasterization as dgr
+    cam = syn.make_camera(320, 240, 260.0, 258.0)
+    sc = syn.make_scene(8000, cam, seed=3, scale_mult=2.5)
+    rast = dgr.GaussianRasterizer(_settings(dgr, cam))
+    g = torch.Generator().manual_seed(1)
+    gA = torch.randn((3, 240, 320), generator=g).cuda()
+    gB = (torch.randn((2, 240, 320), generator=g) * torch.tensor([0.3, 1.0]).reshape(2, 1, 1)).cuda()
+
+    def leaves():
+        t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda", requires_grad=True)
+        return t(sc.means3D), t(sc.opacities), t(sc.colors), t(sc.scales), t(sc.rotations)
+
+    # two passes
+    m, o, c, s, r = leaves()
+    z = m[:, 2:3]
+    col2 = torch.cat([z, torch.ones_like(z), torch.zeros_like(z)], 1)
+    if detach:
+        col2 = col2.detach()
+    imA, _, surA = rast(means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=o, colors_precomp=c, scales=s, rotations=r)
+    imB, _, _ = rast(means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=o, colors_precomp=col2, scales=s, rotations=r)
+    ((imA * gA).sum() + (imB[0:2] * gB).sum()).backward()
+    ref = [x.grad.clone() for x in (m, o, c, s, r)]
+    # one pass
+    m2, o2, c2, s2, r2 = leaves()
+    im, ds, radii, sur = rast.forward_pair(means3D=m2, means2D=torch.zeros_like(m2, requires_grad=True), opacities=o2, colors_precomp=c2,
+                                           scales=s2, rotations=r2, detach_depth_color=detach)
+    assert torch.equal(im, imA) and torch.equal(sur, surA)
+    assert float((ds - imB[0:2]).abs().max()) <= 1e-5 * max(1.0, float(imB[0].abs().max()))
+    ((im * gA).sum() + (ds * gB).sum()).backward()
+    for name, a, b in zip(("means3D", "opacities", "colors", "scales", "rotations"), (m2, o2, c2, s2, r2), ref):
+        err = float((a.grad - b).abs().max() / (b.abs().max() + 1e-30))
+        assert err <= 2e-5, (name, err)          # the same terms summed in another order (one accumulation instead of two)
+    # an output the loss does not use: its gradient is zero, not an error
+    m3, o3, c3, s3, r3 = leaves()
+    im3, ds3, _, _ = rast.forward_pair(means3D=m3, means2D=torch.zeros_like(m3, requires_grad=True), opacities=o3, colors_precomp=c3, scales=s3, rotations=r3)
+    (ds3 * gB).sum().backward()
+    assert float(c3.grad.abs().max()) == 0.0 and float(m3.grad.abs().max()) > 0.0
