@@ -9,16 +9,17 @@ synthetic scene whose inputs are already resident in HBM, through the C ABI
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1, headline line: weak scaling. The rasterize path itself partitions by scene shard: every rank owns
-its own 1 M-Gaussian shard (different seed) and renders it to its own layer; there is no data-path
-collective inside that timed region, only the barriers around it.
+N > 1, headline line: STRONG scaling of the rasterize path with its exchange (shard_render): the same --splats scene
+split into depth slabs over the ranks, every rank renders its slab, the layers are composited and the pose gradient
+all-reduced inside the timed region. The collective-free replica figure (every rank its own scene) is kept as
+`replica_rasterize`.
 
 `shard_step` (same JSON line, --mode all | shard-step): the step that DOES exchange data — one sharded mapping
 iteration and one sharded tracking iteration of gsorb-slam_amd/sharded.py:ShardedMapper (src/Render.cc:420-483,
 :1054-1126 with the map split into depth slabs over the ranks; BASELINE.json config 4: --splats Gaussians in
 TOTAL, strong scaling). Its timed region contains the two rasterizer forwards + backwards of the rank's shard,
-the all-gather of the layers (6 floats/pixel), the compositing, the losses, the scalar / pose-gradient
-all-reduce and the Adam step, over RCCL ("nccl") when N > 1.
+the layer compositing (all-gather of 2 floats/pixel/rank, all-reduce of 4 channels, backward all-gather of 1), the
+losses, the scalar / pose-gradient all-reduce and the Adam step, over RCCL ("nccl") when N > 1.
 
 The JSON line also carries
   roofline     : the dominant kernel (backward blend) against the HBM roofline, timed live
@@ -221,7 +222,7 @@ def shard_step(a, gsr, td, rank, world, dev):
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         dt = float(tt.item())
     track_ms = dt / max(ran["n"], 1) * 1e3
-    layer_bytes = 7 * W * H * 4    # rgb(3) + depth + silhouette + surface depth + the row that carries the order key
+    plane = W * H * 4              # sharded._CompositeFn: all-gather (silhouette, surface depth, key row), all-reduce 4 channels, backward all-gather 1
     return {"what": "one sharded mapping iteration / one sharded tracking iteration (two rasterizer fwd+bwd of the rank's depth slab, "
                     "layer all-gather, compositing, losses, scalar or pose-gradient all-reduce, Adam step) — collectives INSIDE the timed region",
             "scaling": "strong", "total_splats": a.splats, "splats_per_rank": int(len(idx)), "width": W, "height": H,
@@ -229,9 +230,75 @@ def shard_step(a, gsr, td, rank, world, dev):
             "rccl_ranks": (td.get_world_size() if world > 1 else 1),
             "mapping_ms_per_iter": map_ms, "tracking_ms_per_iter": track_ms,
             "mapping_splats_pixels_per_s": 2 * a.splats * W * H / (map_ms * 1e-3),
-            "collectives_per_mapping_iter": {"all_gather_bytes_per_rank": layer_bytes, "all_reduce_floats": 3},
-            "collectives_per_tracking_iter": {"all_gather_bytes_per_rank": layer_bytes, "all_reduce_floats": 7},
+            "collectives_per_mapping_iter": {"all_gather_bytes_sent_per_rank": 4 * plane, "all_reduce_bytes": 4 * plane, "all_reduce_floats": 3},
+            "collectives_per_tracking_iter": {"all_gather_bytes_sent_per_rank": 4 * plane, "all_reduce_bytes": 4 * plane, "all_reduce_floats": 7},
             "timed_iters": n}
+
+
+def shard_render(a, gsr, td, rank, world, dev):
+    """The rasterize path WITH its exchange, strong scaling: --splats Gaussians in total, split into depth slabs over the
+    ranks (sharded.shard_by_depth_slabs); per step every rank renders its slab (fused colour + depth / silhouette pass),
+    the layers are composited (all-gather of 2 floats/pixel/rank + one all-reduce of 4 channels), a fixed upstream
+    gradient is taken back through the composite (all-gather of 1 float/pixel/rank) and the rasterizer's backward to the
+    Gaussians and the pose, and the pose gradient is all-reduced (16 floats) — north_star: 'shards Gaussians across the
+    GPUs with an RCCL all-reduce on pose/loss gradients only'. Through the operator boundary (Python op)."""
+    syn = gsr.synthetic
+    sharded = __import__("gsorb_slam_amd.sharded", fromlist=["x"])
+    sys.path.insert(0, os.path.join(ROOT, "gsorb-slam_amd"))
+    import diff_gaussian_rasterization as dgr
+    camd = syn.CAMERAS[a.camera]
+    cam = syn.make_camera(**camd)
+    W, H = cam.width, cam.height
+    sc = syn.make_scene(a.splats, cam, seed=1234, scale_mult=a.scale_mult)      # the SAME scene on every rank
+    idx = sharded.shard_by_depth_slabs(torch.tensor(sc.means3D[:, 2]), world)[rank].numpy()
+    s = gsr.capi.Settings.from_camera(cam, device=dev)
+    rs = dgr.GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=s.tanfovx, tanfovy=s.tanfovy, bg=torch.zeros(3, device=dev),
+                                           scale_modifier=1.0, viewmatrix=s.viewmatrix, projmatrix=s.projmatrix, sh_degree=0,
+                                           campos=s.campos, prefiltered=False)
+    rast = dgr.GaussianRasterizer(raster_settings=rs)
+    comp = sharded.LayerCompositor()
+    t = lambda x: torch.as_tensor(x, dtype=torch.float32, device=dev).contiguous()
+    xyz, op, col, sca, rot = (t(x[idx]).requires_grad_(True) for x in (sc.means3D, sc.opacities, sc.colors, sc.scales, sc.rotations))
+    Tcw = torch.eye(4, device=dev, requires_grad=True)
+    g = torch.Generator().manual_seed(7)
+    G = torch.randn((5, H, W), generator=g).to(dev)
+    key = float(sc.means3D[idx, 2].min()) if len(idx) else float("inf")
+
+    def step():
+        mc = gsr.capi.to_camera(Tcw, xyz)
+        img, ds, _, sur = rast.forward_pair(means3D=mc, means2D=torch.zeros_like(mc, requires_grad=True), opacities=op, colors_precomp=col,
+                                            scales=sca, rotations=rot)
+        rgb, depth, sil, _ = comp.composite(img, ds, key, sur=sur)
+        ((rgb * G[0:3]).sum() + (depth * G[3:4]).sum() + (sil * G[4:5]).sum()).backward()
+        comp.all_reduce_pose_grad(Tcw.grad)
+        for x in (xyz, op, col, sca, rot, Tcw):
+            x.grad = None
+
+    def barrier():
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+    for _ in range(a.warmup + 10):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / max(a.steps, 1) * 1e3
+    plane = W * H * 4
+    return {"what": "sharded fwd+bwd rasterize with its exchange (see bench.py:shard_render): fused colour + depth/silhouette pass of the rank's depth slab, "
+                    "layer compositing, backward through both, pose-gradient all-reduce; collectives INSIDE the timed region",
+            "scaling": "strong", "total_splats": a.splats, "splats_per_rank": int(len(idx)), "width": W, "height": H, "ms_per_step": ms,
+            "value": a.splats * W * H / (ms * 1e-3), "unit": "splats*pixels/s",
+            "backend": (td.get_backend() if world > 1 else "none (single process)"),
+            "collective_bytes_per_rank_per_step": {"all_gather_fwd": 3 * plane * (world - 1) if world > 1 else 0, "all_reduce_fwd": 4 * plane if world > 1 else 0,
+                                                   "all_gather_bwd": plane * (world - 1) if world > 1 else 0, "all_reduce_pose": 64 if world > 1 else 0}}
 
 
 def main():
@@ -283,6 +350,19 @@ def main():
     out = {}
     if a.mode in ("all", "rasterize"):
         out = rasterize(a, gsr, td, rank, world, dev)
+        sr = shard_render(a, gsr, td, rank, world, dev)
+        if rank == 0:
+            if world > 1:
+                # N > 1: the headline value is the step that EXCHANGES data (strong scaling: the same --splats scene split over the
+                # ranks); the collective-free replica figure (every rank its own scene: linear by construction) is kept beside it
+                out["replica_rasterize"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "scaling": "weak",
+                                            "what": "every rank renders its OWN --splats scene, no collective in the timed region"}
+                out.update(value=sr["value"], ms_per_step=sr["ms_per_step"], scaling="strong")
+                out["config"]["workload"] = (f"{a.splats} Gaussians in TOTAL split into depth slabs over {world} ranks, {sr['width']}x{sr['height']}, "
+                                             "sharded fwd+bwd rasterize with layer compositing and pose-gradient all-reduce (RCCL) inside the timed region")
+                out["config"]["parallelism"] = f"scene shards (depth slabs) x{world}, strong scaling"
+                out.pop("step_ms_percentiles", None)
+            out["shard_render"] = sr
     if a.mode in ("all", "shard-step"):
         ss = shard_step(a, gsr, td, rank, world, dev)
         if a.mode == "shard-step":

@@ -8,9 +8,10 @@ and rasterizes ONLY its shard, with background 0, into a layer made of the op's 
     ds   [2,H,W]  depth / silhouette render (colors_precomp = [z,1,0],  src/Render.cc:949-981)
                   ds[0] = alpha-blended depth, ds[1] = accumulated opacity S = 1 - T_final
 
-The layers are exchanged with ONE all-gather (5 floats per pixel per rank: 16 MB at 1200x680)
-and composited front to back with the "over" operator: out = sum_g (prod_{h<g} (1 - S_h)) *
-layer_g. This is exact when the shards are depth-separable for the view (convex cells in
+The layers are composited front to back with the "over" operator: out = sum_g (prod_{h<g} (1 - S_h)) *
+layer_g. Only the silhouettes (and surface depths) are all-gathered — 2 floats per pixel per rank; every rank
+premultiplies its own layer with its prefix transmittance and ONE all-reduce sums the four channels
+(_CompositeFn below). This is exact when the shards are depth-separable for the view (convex cells in
 camera order) — SURVEY.md §8e scheme B — and otherwise an approximation whose PSNR against the
 single-GPU render must be reported, not assumed.
 
@@ -39,6 +40,85 @@ def _all_gather(tensor: torch.Tensor, world: int, group=None):
     return parts
 
 
+class _CompositeFn(torch.autograd.Function):
+    """Front-to-back "over" compositing of the ranks' layers with two small collectives instead of an all-gather of the
+    whole layers. Per pixel, with the layers ordered front to back, out = sum_k P_k L_k, P_k = prod_{h before k} (1 - S_h):
+      forward : all-gather of (silhouette S, surface depth) — 2 floats / pixel / rank — from which every rank forms ITS
+                prefix transmittance P_own; ONE all-reduce (sum) of the 4 premultiplied channels P_own * (rgb, depth);
+      backward: dL/dL_own = P_own * g needs nothing from the others; the layer's occlusion of what lies BEHIND it,
+                dL/dS_own = - sum_{k behind own} (prod_{h before k, h != own} (1 - S_h)) (g . L_k) + g_sil * prod_{h != own} (1 - S_h),
+                needs the others' g . L_k: one all-gather of 1 float / pixel / rank.
+    At 1200x680 (3.26 MB per plane): 6.5 MB x world gathered + 13 MB reduced forward, 3.3 MB x world gathered backward;
+    the all-gather of full 7-row layers it replaces moved 22.8 MB x world. No per-layer Python loop over full layers."""
+
+    @staticmethod
+    def forward(ctx, layer4, sil, sur, key, comp):
+        world, rank, group = comp.world, comp.rank, comp.group
+        dev = layer4.device
+        with torch.no_grad():
+            pad = torch.zeros((1,) + tuple(sil.shape[1:]), dtype=sil.dtype, device=dev)
+            pad[0, 0, 0] = key                                   # the order key travels in a padding row (may be a device scalar: no host sync)
+            mine = torch.cat([sil, sur if sur is not None else torch.zeros_like(sil), pad], 0).contiguous()
+            g = torch.stack(_all_gather(mine, world, group))       # [world, 3, H, W]
+            order = torch.argsort(g[:, 2, 0, 0].double(), stable=True)   # front to back: by key, ties by rank
+            S = g[:, 0].index_select(0, order)                   # [world, H, W] silhouettes, front to back
+            SU = g[:, 1].index_select(0, order)
+            pos = (order == rank).nonzero()[0, 0]                # this rank's slot in the order (device scalar)
+            one_m = 1.0 - S
+            P = torch.cumprod(torch.cat([torch.ones_like(S[:1]), one_m[:-1]], 0), 0)    # exclusive prefix transmittance per slot
+            P_own = P.index_select(0, pos.reshape(1))[0:1]       # [1,H,W]
+            contrib = (P_own * layer4).contiguous()
+            if dist.get_backend(group) == "gloo" and contrib.is_cuda:
+                h = contrib.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                out4 = h.to(dev)
+            else:
+                out4 = contrib.clone()
+                dist.all_reduce(out4, op=dist.ReduceOp.SUM, group=group)
+            T_all = P[-1:] * one_m[-1:]                          # transmittance behind the last layer
+            sil_tot = 1.0 - T_all
+            # surface depth: of the first layer, front to back, behind which the accumulated transmittance is <= 0.5
+            # (else of the last layer that has one)
+            T_after = P * one_m
+            surf = torch.zeros_like(sil)
+            found = torch.zeros_like(sil, dtype=torch.bool)
+            if sur is not None:
+                for k in range(world):
+                    has = SU[k:k + 1] > 0
+                    surf = torch.where(~found & has, SU[k:k + 1], surf)
+                    found = found | (has & (T_after[k:k + 1] <= 0.5))
+        ctx.comp = comp
+        ctx.order = order
+        ctx.save_for_backward(layer4, S, P, pos)
+        ctx.mark_non_differentiable(surf)
+        return out4, sil_tot, surf
+
+    @staticmethod
+    def backward(ctx, g4, gsil, _gsurf):
+        layer4, S, P, pos = ctx.saved_tensors
+        comp = ctx.comp
+        world, group = comp.world, comp.group
+        if g4 is None:
+            g4 = torch.zeros_like(layer4)
+        P_own = P.index_select(0, pos.reshape(1))[0:1]
+        d_layer = P_own * g4
+        c_own = (g4 * layer4).sum(0, keepdim=True).contiguous()  # g . L_own: what the layers in FRONT of this one need
+        c = torch.stack(_all_gather(c_own, world, group))[:, 0]  # [world, H, W] in RANK order
+        # back to slot order: slot k holds rank order[k]; the ranks know the order from the forward's gather (saved S is
+        # already in slot order, c is in rank order) — recover it from the saved permutation
+        c = c.index_select(0, ctx.order)
+        one_m = 1.0 - S
+        # prefix products that leave this layer out: for the slots behind it, prod_{h before k, h != own} (1 - S_h)
+        idx = torch.arange(world, device=S.device)
+        behind = (idx > pos).reshape(world, 1, 1).to(S.dtype)
+        excl = torch.where((idx == pos).reshape(world, 1, 1), torch.ones_like(one_m), one_m)     # own factor replaced by 1
+        P_excl = torch.cumprod(torch.cat([torch.ones_like(S[:1]), excl[:-1]], 0), 0)
+        dS = -(behind * P_excl * c).sum(0, keepdim=True)
+        if gsil is not None:
+            dS = dS + gsil * torch.prod(excl, 0, keepdim=True)   # d(1 - prod (1 - S_h)) / dS_own
+        return d_layer, dS, None, None, None
+
+
 class LayerCompositor:
     def __init__(self, group=None):
         self.group = group
@@ -53,34 +133,14 @@ class LayerCompositor:
         With `sur` [1,H,W] (the layer's own surface / median depth, which carries no gradient) a fourth value is
         returned: the surface depth of the first layer, front to back, behind which the accumulated transmittance
         is <= 0.5 (else of the last layer that has one) — exact when nothing translucent lies in front of that
-        layer, an approximation otherwise (each layer only knows where ITS OWN transmittance crosses 0.5)."""
-        layer = torch.cat([rgb, ds] if sur is None else [rgb, ds, sur.detach()], 0)
+        layer, an approximation otherwise (each layer only knows where ITS OWN transmittance crosses 0.5).
+
+        Exchange: _CompositeFn (an all-gather of 2 floats/pixel/rank and one all-reduce of 4 channels forward, an
+        all-gather of 1 float/pixel/rank backward)."""
         if self.world == 1:
             return (rgb, ds[0:1], ds[1:2]) if sur is None else (rgb, ds[0:1], ds[1:2], sur)
-        with torch.no_grad():
-            # ONE all-gather: the order key travels in a padding row of the layer (5 or 6 floats/pixel + W floats). The key
-            # may be a device scalar: nothing here asks the host for a value (no sync between the renders and the loss).
-            pad = torch.zeros((1,) + tuple(layer.shape[1:]), dtype=layer.dtype, device=layer.device)
-            pad[0, 0, 0] = order_key
-            gathered = torch.stack(_all_gather(torch.cat([layer.detach(), pad], 0).contiguous(), self.world, self.group))
-            keys = gathered[:, -1, 0, 0].double()
-            order = torch.argsort(keys, stable=True)         # front to back: by key, ties by rank (the gathered index)
-            layers = gathered.index_select(0, order)[:, :-1]
-            mine = order == self.rank                        # [world] which sorted slot is this rank's own layer
-        T = torch.ones_like(layer[0:1])
-        out = torch.zeros_like(layer[0:4])
-        surf = None if sur is None else torch.zeros_like(layer[0:1])
-        found = None if sur is None else torch.zeros_like(layer[0:1], dtype=torch.bool)
-        for k in range(self.world):
-            L = torch.where(mine[k], layer, layers[k])       # own layer keeps its autograd history (zero gradient elsewhere)
-            out = out + T * L[0:4]
-            T = T * (1.0 - L[4:5])
-            if sur is not None:
-                with torch.no_grad():
-                    has = L[5:6] > 0
-                    surf = torch.where(~found & has, L[5:6], surf)
-                    found = found | (has & (T <= 0.5))
-        res = (out[0:3], out[3:4], 1.0 - T)
+        out4, sil, surf = _CompositeFn.apply(torch.cat([rgb, ds[0:1]], 0), ds[1:2], None if sur is None else sur.detach(), order_key, self)
+        res = (out4[0:3], out4[3:4], sil)
         return res if sur is None else res + (surf,)
 
     def all_reduce_pose_grad(self, grad: torch.Tensor) -> torch.Tensor:
