@@ -217,8 +217,9 @@ def test_two_gpus_rccl_drive_the_hip_backends():
 @pytest.mark.gpu
 def test_bench_runs_its_multi_rank_branch_with_two_ranks():
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), here with both ranks on
-    whatever GPUs exist and gloo instead of RCCL (GSR_BENCH_BACKEND): rendezvous, per-rank scenes, barriers, the
-    max-over-ranks timing, and `shard_step` with its layer all-gather and all-reduces all execute; one JSON line from rank 0."""
+    whatever GPUs exist and gloo instead of RCCL (GSR_BENCH_BACKEND): rendezvous, barriers, the max-over-ranks timing, the
+    strong-scaling `shard_render` headline (depth slabs, layer compositing collectives, pose-gradient all-reduce), the
+    collective-free replica figure beside it, and `shard_step` all execute; one JSON line from rank 0."""
     import json
     import socket
     import subprocess
@@ -236,7 +237,11 @@ def test_bench_runs_its_multi_rank_branch_with_two_ranks():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE line
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] > 0 and d["scaling"] == "weak"
-    assert d["config"]["parallelism"] == "scene-shard x2" and "cpu_baseline" not in d
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] > 0 and d["scaling"] == "strong"
+    assert "x2" in d["config"]["parallelism"] and "cpu_baseline" not in d and "parity" not in d
+    sr = d["shard_render"]
+    assert sr["splats_per_rank"] == 20000 and sr["total_splats"] == 40000 and d["value"] == sr["value"] and d["ms_per_step"] == sr["ms_per_step"]
+    assert sr["collective_bytes_per_rank_per_step"]["all_reduce_fwd"] == 4 * 640 * 480 * 4
+    assert d["replica_rasterize"]["scaling"] == "weak" and d["replica_rasterize"]["value"] > 0
     ss = d["shard_step"]
     assert ss["rccl_ranks"] == 2 and ss["splats_per_rank"] == 20000 and ss["mapping_ms_per_iter"] > 0 and ss["tracking_ms_per_iter"] > 0
