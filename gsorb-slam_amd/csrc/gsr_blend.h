@@ -273,6 +273,15 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             const int cr = r == 0 ? c0 : r == 1 ? c1 : r == 2 ? c2 : c3;
             for (int p = cr + l; p < maxc + 4; p += 16) LIST[r * (Q + 4) + p] = (uint16_t)(Q * 16);
         }
+#ifdef GSR_EXP_ROWFILL // instrumented build (scripts/rowfill.py): how full the padded lists and the 16-slot reduce blocks are
+        if (lane == 0) {
+            atomicAdd(&g.hdr->pad[0], (uint32_t)(c0 + c1 + c2 + c3)); // list entries that do work
+            atomicAdd(&g.hdr->pad[1], (uint32_t)(4 * maxc));          // row-iterations the wave runs for them
+            atomicAdd(&g.hdr->pad[2], 1u);                            // rounds
+            atomicAdd(&g.hdr->pad[3], (uint32_t)((maxc + 15) / 16));  // reduce phases
+            atomicAdd(&g.hdr->pad[4], (uint32_t)count);               // parked entries (quad hits)
+        }
+#endif
         lds_turn();
         const uint16_t* __restrict__ mylist = LIST + r * (Q + 4);
         // per-entry totals of this round, in the registers of lane e

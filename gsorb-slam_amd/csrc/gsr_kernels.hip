@@ -297,6 +297,9 @@ K_scan_tiles(int T, const uint32_t* __restrict__ cnt, int cnt_stride, uint32_t* 
     } else {
         for (int i = b; i < e; i++) emit(i, cnt[(size_t)i * cnt_stride]);
     }
+#ifdef GSR_EXP_ROWFILL
+    if (tid < 8) hdr->pad[tid] = 0u;
+#endif
     if (tid == 0) {
         hdr->num_rendered = total;
         hdr->overflow = total > capacity ? 1u : 0u;
@@ -1018,7 +1021,15 @@ K_tile_sort_short(int T, int grid_x, const uint2* __restrict__ ranges, GeomView 
         if (threadIdx.x < 4u) qc4[threadIdx.x] = 0u;
         return;
     }
+#ifdef GSR_EXP_SORT_NOGATHER
+    const int where = sort_tile<GSR_SORT_BLOCK_SHORT>(sh, r, pairs, point_list, nullptr, tile % grid_x, tile / grid_x);
+#else
     const int where = sort_tile<GSR_SORT_BLOCK_SHORT>(sh, r, pairs, point_list, g.reach, tile % grid_x, tile / grid_x);
+#endif
+#ifdef GSR_EXP_SORT_NOEMIT
+    if (threadIdx.x < 4u) qc4[threadIdx.x] = 0u;
+    return;
+#endif
     if (where == GSR_IDS_H) { // ids in h, mask words in the first 4 KB of the key array, the to-do list behind them
         __syncthreads();
         uint32_t* const msk = sort_payload(sh);

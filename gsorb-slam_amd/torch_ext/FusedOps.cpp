@@ -1,0 +1,148 @@
+// FusedOps.cpp — see FusedOps.h.
+#include "FusedOps.h"
+
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+
+#include <stdexcept>
+#include <string>
+
+#include "../../include/gsr.h"
+
+namespace ORB_SLAM2 {
+namespace fused {
+
+namespace {
+
+void* stream_of(const torch::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+void check(int rc, const char* what)
+{
+    if (rc < 0) throw std::runtime_error(std::string(what) + ": " + gsr_error_string(rc));
+}
+const float* fp(const torch::Tensor& t) { return t.data_ptr<float>(); }
+
+struct ToCameraFn : public torch::autograd::Function<ToCameraFn> {
+    static torch::Tensor forward(torch::autograd::AutogradContext* ctx, torch::Tensor Tcw, torch::Tensor X)
+    {
+        const auto T = Tcw.contiguous(), Xc = X.contiguous();
+        c10::DeviceGuard guard(Xc.device());
+        auto out = torch::empty_like(Xc);
+        check(gsr_to_camera(fp(Xc), (size_t)Xc.size(0), fp(T), out.data_ptr<float>(), stream_of(Xc)), "gsr_to_camera");
+        ctx->save_for_backward({T, Xc});
+        return out;
+    }
+    static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::tensor_list g)
+    {
+        const auto saved = ctx->get_saved_variables();
+        const auto &T = saved[0], &X = saved[1];
+        const bool want_T = ctx->needs_input_grad(0), want_X = ctx->needs_input_grad(1);
+        if (!want_T && !want_X) return {torch::Tensor(), torch::Tensor()};
+        c10::DeviceGuard guard(X.device());
+        const auto dmc = g[0].contiguous();
+        torch::Tensor part, dX, dT;
+        if (want_T) part = torch::empty({GSR_POSE_PARTIALS, 12}, X.options());
+        if (want_X) dX = torch::empty_like(X);
+        check(gsr_pose_grad(fp(X), fp(dmc), (size_t)X.size(0), fp(T), want_T ? part.data_ptr<float>() : nullptr,
+                            want_X ? dX.data_ptr<float>() : nullptr, stream_of(X)), "gsr_pose_grad");
+        if (want_T) {
+            const auto s = part.sum(0);
+            dT = torch::zeros({4, 4}, X.options());
+            dT.slice(0, 0, 3).slice(1, 0, 3).copy_(s.slice(0, 0, 9).reshape({3, 3}));
+            dT.slice(0, 0, 3).slice(1, 3, 4).copy_(s.slice(0, 9, 12).reshape({3, 1}));
+        }
+        return {dT, dX};
+    }
+};
+
+struct Rt2TFn : public torch::autograd::Function<Rt2TFn> {
+    static torch::Tensor forward(torch::autograd::AutogradContext* ctx, torch::Tensor quat, torch::Tensor trans)
+    {
+        const auto q = quat.contiguous(), t = trans.contiguous();
+        c10::DeviceGuard guard(q.device());
+        auto T = torch::empty({4, 4}, q.options());
+        check(gsr_pose_from_quat(fp(q), fp(t), T.data_ptr<float>(), stream_of(q)), "gsr_pose_from_quat");
+        ctx->save_for_backward({q});
+        ctx->saved_data["qs"] = quat.sizes().vec();
+        ctx->saved_data["ts"] = trans.sizes().vec();
+        return T;
+    }
+    static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::tensor_list g)
+    {
+        const auto q = ctx->get_saved_variables()[0];
+        c10::DeviceGuard guard(q.device());
+        auto dq = torch::empty({4}, q.options()), dt = torch::empty({3}, q.options());
+        const auto dT = g[0].contiguous();
+        check(gsr_pose_from_quat_backward(fp(q), fp(dT), dq.data_ptr<float>(), dt.data_ptr<float>(), stream_of(q)), "gsr_pose_from_quat_backward");
+        return {dq.reshape(ctx->saved_data["qs"].toIntVector()), dt.reshape(ctx->saved_data["ts"].toIntVector())};
+    }
+};
+
+struct SsimFn : public torch::autograd::Function<SsimFn> {
+    static torch::Tensor forward(torch::autograd::AutogradContext* ctx, torch::Tensor img1, torch::Tensor img2, std::vector<double> taps)
+    {
+        const bool need = ctx->needs_input_grad(0);
+        const auto a = img1.contiguous(), b = img2.contiguous();
+        c10::DeviceGuard guard(a.device());
+        const int C = (int)a.size(0), H = (int)a.size(1), W = (int)a.size(2);
+        float tp[11];
+        for (int i = 0; i < 11; i++) tp[i] = (float)taps[i];
+        auto partial = torch::empty({(int64_t)gsr_ssim_partials(C, H, W)}, a.options());
+        torch::Tensor dmaps = need ? torch::empty({3, C, H, W}, a.options()) : torch::Tensor();
+        check(gsr_ssim_forward(fp(a), fp(b), C, H, W, tp, partial.data_ptr<float>(), need ? dmaps.data_ptr<float>() : nullptr, stream_of(a)),
+              "gsr_ssim_forward");
+        ctx->save_for_backward({a, b, need ? dmaps : a});
+        ctx->saved_data["taps"] = taps;
+        ctx->saved_data["need"] = need;
+        return partial.sum() / (double)((int64_t)C * H * W);
+    }
+    static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::tensor_list g)
+    {
+        if (!ctx->saved_data["need"].toBool()) return {torch::Tensor(), torch::Tensor(), torch::Tensor()};
+        const auto saved = ctx->get_saved_variables();
+        const auto &a = saved[0], &b = saved[1], &dmaps = saved[2];
+        c10::DeviceGuard guard(a.device());
+        const auto taps = ctx->saved_data["taps"].toDoubleVector();
+        float tp[11];
+        for (int i = 0; i < 11; i++) tp[i] = (float)taps[i];
+        const auto gm = g[0].to(torch::kFloat32).contiguous();
+        auto out = torch::empty_like(a);
+        check(gsr_ssim_backward(fp(a), fp(b), fp(dmaps), (int)a.size(0), (int)a.size(1), (int)a.size(2), tp, fp(gm), out.data_ptr<float>(), stream_of(a)),
+              "gsr_ssim_backward");
+        return {out, torch::Tensor(), torch::Tensor()};
+    }
+};
+
+} // namespace
+
+torch::Tensor to_camera(const torch::Tensor& Tcw, const torch::Tensor& X) { return ToCameraFn::apply(Tcw, X); }
+torch::Tensor rt2T(const torch::Tensor& quat, const torch::Tensor& trans) { return Rt2TFn::apply(quat, trans); }
+torch::Tensor ssim_mean(const torch::Tensor& img1, const torch::Tensor& img2, const std::vector<float>& taps11)
+{
+    return SsimFn::apply(img1, img2.detach(), std::vector<double>(taps11.begin(), taps11.end()));
+}
+
+void Adam::step()
+{
+    torch::NoGradGuard ng;
+    if (state_.size() != groups_.size()) state_.resize(groups_.size());
+    for (size_t i = 0; i < groups_.size(); i++) {
+        auto& p = groups_[i].param;
+        if (!p.grad().defined()) continue;
+        auto& st = state_[i];
+        if (!st.exp_avg.defined()) { st.exp_avg = torch::zeros_like(p); st.exp_avg_sq = torch::zeros_like(p); }
+        st.step += 1;
+        const auto g = p.grad().contiguous();
+        c10::DeviceGuard guard(p.device());
+        check(gsr_adam_step(p.data_ptr<float>(), fp(g), st.exp_avg.data_ptr<float>(), st.exp_avg_sq.data_ptr<float>(), (size_t)p.numel(), groups_[i].lr,
+                            0.9, 0.999, eps_, st.step, stream_of(p)), "gsr_adam_step");
+    }
+}
+
+void Adam::zero_grad()
+{
+    for (auto& g : groups_)
+        if (g.param.grad().defined()) g.param.mutable_grad() = torch::Tensor();
+}
+
+} // namespace fused
+} // namespace ORB_SLAM2

@@ -1,0 +1,75 @@
+// SlamLoop.h — the tracking and mapping loops of GSORB-SLAM's Render / Gaussian classes as a libtorch (C++) driver on top of
+// the drop-in operator (Rasterizer.h): host code in C++, like the reference's (src/Render.cc:402-493 RenderForFrame /
+// mapping iterations, :985-1141 RenderStartTraking; src/Gaussian.cc:144-175 optimisers; include/Utils.h:56-77 rt2T;
+// src/Utils.cc:39-100 losses). What a maintainer would keep of Render.cc once the rasterizer underneath is this library: the
+// loop bodies, with the two renders of an iteration fused into GaussianRasterizer::forward_pair.
+// The Python twin (same arithmetic, used by the parity tests) is gsorb-slam_amd/harness.py.
+#pragma once
+
+#include <torch/torch.h>
+
+#include <memory>
+#include <vector>
+
+#include "FusedOps.h"
+#include "Rasterizer.h"
+
+namespace ORB_SLAM2 {
+
+// Examples/RGB-D/replica.yaml:87-117 (Mapping / Tracking blocks)
+struct LoopConfig {
+    double im_weight_mapping = 1.0, depth_weight_mapping = 0.7, sur_depth_weight_mapping = 0.35, reg_long_weight = 5.0,
+           reg_scalar_weight = 10.0, lam = 0.8;
+    double lr_mean3d = 0.0001, lr_rgb = 0.0025, lr_rotation = 0.001, lr_opacities = 0.05, lr_scales = 0.001;
+    double lr_cam_quat = 0.0004; // used for BOTH pose groups, like the reference (Gaussian.cc:149-150)
+    double im_weight_tracking = 0.7, depth_weight_tracking = 1.0;
+    double scale_modifier = 1.0, scene_radius = 1.0;
+    bool use_sur_depth = true;
+    bool fused_pair = true; // one rasterizer pass per iteration (forward_pair); false: two passes like Render.cc:927-981
+    bool fused_ops = true;  // camera transform, pose matrix, SSIM and Adam through the loop kernels of the C ABI (FusedOps.h);
+                            // false: the reference's plain libtorch arithmetic (matmul, scalar-tensor rt2T, conv2d, torch::optim::Adam)
+};
+
+struct LoopFrame {
+    torch::Tensor rgb;   // [3,H,W]
+    torch::Tensor depth; // [H,W], 0 = invalid
+    torch::Tensor Tcw;   // [4,4]
+};
+
+class SlamLoop {
+public:
+    SlamLoop(const LoopConfig& cfg, int width, int height, float fx, float fy, torch::Device device);
+
+    // Gaussian::GaussianOptimizer (Gaussian.cc:152-175): five Adam groups, eps 1e-15
+    void SetMap(torch::Tensor xyz, torch::Tensor rgb, torch::Tensor unnorm_quat, torch::Tensor logit_opacities, torch::Tensor log_scales);
+
+    // Render.cc:1054-1126: pose-only optimisation against one frame; returns the loss of every iteration that ran and the
+    // best pose (lowest loss) in *Tcw_best
+    std::vector<double> Track(const LoopFrame& frame, const torch::Tensor& Tcw_init, int iters, torch::Tensor* Tcw_best);
+
+    // Render.cc:420-483: one mapping iteration on one keyframe (loss, backward, Adam step); returns the loss
+    double MappingIteration(const LoopFrame& frame);
+
+    // both renders of an iteration: {colour [3,H,W], surface (median) depth [1,H,W], depth/silhouette [2,H,W]}
+    std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> RenderPair(const torch::Tensor& Tcw, bool tracking);
+
+    torch::Tensor xyz, rgb, unnorm_quat, logit_opacities, log_scales;
+
+private:
+    LoopConfig cfg_;
+    int W_, H_;
+    float fx_, fy_;
+    torch::Device dev_;
+    GaussianRasterizer rasterizer_;
+    std::unique_ptr<torch::optim::Adam> opt_, opt_pose_;
+    std::unique_ptr<fused::Adam> fopt_, fopt_pose_;
+    torch::Tensor cam_quat_, cam_trans_, taps_;
+    std::vector<float> taps_host_;
+};
+
+// include/Utils.h:56-77: Tcw [4,4] from an un-normalised quaternion (r,x,y,z) [4,1] and a translation [3,1]
+torch::Tensor rt2T(const torch::Tensor& quat, const torch::Tensor& trans);
+// cv::Quatd::createFromRotMat as Gaussian::InitCameraPose uses it (Gaussian.cc:97-128)
+torch::Tensor rot_to_quat(const torch::Tensor& R);
+
+} // namespace ORB_SLAM2

@@ -1,5 +1,5 @@
 """Turns gpurun_out/prof_<tag>/ (scripts/profile_round.sh) into the committed summaries under profiles/:
-   <tag>_kernel_stats.md, <tag>_pmc.md, <tag>_bench.json and r02_traffic.json (read by bench.py)."""
+   <tag>_kernel_stats.md, <tag>_pmc.md, <tag>_bench.json and rNN_traffic.json (read by bench.py)."""
 import collections
 import csv
 import glob
@@ -19,7 +19,9 @@ def short(name):
     if "gsr::" not in name:
         return name.split("<")[0]
     name = name.replace("gsr::", "")
-    return name if name.startswith("K_tile_sort") or name.startswith("K_scan") else name.split("<")[0]
+    if name.startswith("K_blend"):
+        return name.split("<")[0] + ("_dual" if name.rstrip().endswith("true>") else "")
+    return name.split("<")[0]
 
 
 bench = None
@@ -59,9 +61,10 @@ for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), r
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         cnt[k][row["Counter_Name"]] += 1
 avg = {k: {c: v / cnt[k][c] for c, v in d.items()} for k, d in agg.items()}
-order = ["K_preprocess", "K_scan_tiles<true>", "K_fill", "K_tile_sort<true>", "K_tile_sort<false>", "K_blend_fwd", "K_blend_bwd", "K_splat_bwd"]
+order = ["K_preprocess", "K_bin_count", "K_bin_colscan", "K_scan_tiles", "K_bin_fill", "K_tile_sort_short", "K_tile_sort_long", "K_blend_fwd", "K_blend_bwd", "K_splat_bwd"]
 sq = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY",
-      "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE"]
+      "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
+      "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"]
 stats_avg = {short(x["Name"]): float(x["AverageNs"]) / 1e3 for x in rows}
 with open(os.path.join(dst, tag + "_pmc.md"), "w") as o:
     o.write("# Round %s, profile %s — PMC counters (rocprofv3 --pmc, separate passes, --kernel-trace only)\n\n" % (tag[1:3].lstrip("0"), tag))
@@ -71,7 +74,7 @@ with open(os.path.join(dst, tag + "_pmc.md"), "w") as o:
         if k in avg:
             o.write("| %s | " % k + " | ".join("%.3g" % avg[k].get(c, float("nan")) for c in sq) + " |\n")
     o.write("\nDerived (per launch; kernel time = the rocprofv3 --stats average of the same build):\n\n")
-    o.write("| kernel | us | clock GHz (GUI_ACTIVE/8/us) | waves resident per SIMD (WAVE_CYCLES*4/cycles/1024) | VALU insts x 4 cyc / (1024 SIMD x 2.4 GHz x time) | cycles per VALU inst per wave | wave time: active / issue-stalled / waiting | LDS conflict cycles / LDS active |\n|---|---|---|---|---|---|---|---|\n")
+    o.write("| kernel | us | clock GHz (GUI_ACTIVE/8/us) | waves resident per SIMD (WAVE_CYCLES*4/cycles/1024) | VALU insts / us (chip, thousands) | cycles per VALU inst per wave | wave time: active / issue-stalled / waiting | LDS pipe busy (LDS_IDX_ACTIVE / BUSY_CU_CYCLES) |\n|---|---|---|---|---|---|---|---|\n")
     for k in order:
         if k in avg and k in stats_avg and "SQ_WAVE_CYCLES" in avg[k]:
             a_ = avg[k]
@@ -80,10 +83,10 @@ with open(os.path.join(dst, tag + "_pmc.md"), "w") as o:
             wc = a_["SQ_WAVE_CYCLES"] * 4
             o.write("| %s | %.1f | %.2f | %.2f | %.2f | %.1f | %.0f %% / %.0f %% / %.0f %% | %.2f |\n" % (
                 k, us, cyc / us / 1e3, wc / cyc / 1024 if cyc == cyc else float("nan"),
-                a_["SQ_INSTS_VALU"] * 4 / 1024 / 2.4e3 / us, wc / max(a_["SQ_INSTS_VALU"], 1),
+                a_["SQ_INSTS_VALU"] / us / 1e3, wc / max(a_["SQ_INSTS_VALU"], 1),
                 100 * a_.get("SQ_ACTIVE_INST_ANY", float("nan")) / a_["SQ_WAVE_CYCLES"], 100 * a_["SQ_WAIT_INST_ANY"] / a_["SQ_WAVE_CYCLES"],
                 100 * a_["SQ_WAIT_ANY"] / a_["SQ_WAVE_CYCLES"],
-                a_["SQ_LDS_BANK_CONFLICT"] / a_["SQ_ACTIVE_INST_LDS"] if a_.get("SQ_ACTIVE_INST_LDS") else 0.0))
+                a_["SQ_LDS_IDX_ACTIVE"] / a_["SQ_BUSY_CU_CYCLES"] if a_.get("SQ_BUSY_CU_CYCLES") and a_.get("SQ_LDS_IDX_ACTIVE") else 0.0))
     o.write("\nVALU instruction classes on gfx950 (scripts/valu_bench.hip, valu_bench2.hip, wave-instructions/s per SIMD at 8 waves): "
             "v_add/mul/fma/and/mov 0.9-1.0 G (2 cycles); v_cmp, v_cndmask, v_min/max, shifts, v_mad_u32_u24, every DPP op, v_pk_* 0.5-0.58 G "
             "(4 cycles); v_exp/rcp/log/sqrt, v_permlane*_swap 0.29 G (8 cycles); f32 MFMA 16x16x4 0.07 G (32 cycles, no overlap with VALU).\n")
@@ -104,5 +107,11 @@ with open(os.path.join(dst, tag + "_pmc.md"), "w") as o:
             tj["kernels"][k]["profiled_launch_us"] = stats_avg[k]
             if avg[k].get("SQ_ACTIVE_INST_LDS"):
                 tj["kernels"][k]["lds_conflict_frac"] = avg[k]["SQ_LDS_BANK_CONFLICT"] / avg[k]["SQ_ACTIVE_INST_LDS"]
-    json.dump(tj, open(os.path.join(dst, "r02_traffic.json"), "w"), indent=1)
+            if avg[k].get("SQ_BUSY_CU_CYCLES") and avg[k].get("SQ_LDS_IDX_ACTIVE"):
+                tj["kernels"][k]["lds_pipe_busy"] = avg[k]["SQ_LDS_IDX_ACTIVE"] / avg[k]["SQ_BUSY_CU_CYCLES"]
+            if avg[k].get("GRBM_GUI_ACTIVE"):
+                tj["kernels"][k]["clock_ghz"] = avg[k]["GRBM_GUI_ACTIVE"] / 8 / stats_avg[k] / 1e3
+            if avg[k].get("SQ_WAVE_CYCLES") and avg[k].get("GRBM_GUI_ACTIVE"):
+                tj["kernels"][k]["waves_per_simd"] = avg[k]["SQ_WAVE_CYCLES"] * 4 / (avg[k]["GRBM_GUI_ACTIVE"] / 8) / 1024
+    json.dump(tj, open(os.path.join(dst, tag[:3] + "_traffic.json"), "w"), indent=1)
 print("written", tag)

@@ -1,0 +1,70 @@
+// slam_loop_main.cpp — runs ORB_SLAM2::SlamLoop (gsorb-slam_amd/torch_ext/SlamLoop.h) on a scene file written by
+// tests/test_gpu_cpp_loop.py and prints what the Python harness is compared with: the loss of every tracking iteration, the
+// best pose, the loss of every mapping iteration, and the time per iteration. Test infrastructure (the product is SlamLoop).
+//   file: int32 P, W, H, track_iters, map_iters, flags (bit 0 fused pair, bit 1 fused loop kernels); float32 fx, fy; then float32 arrays xyz[P,3] rgb[P,3] quat[P,4] logit[P,1]
+//         logs[P,3] frame_rgb[3,H,W] frame_depth[H,W] Tcw[4,4] T_init[4,4]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <vector>
+
+#include "../../gsorb-slam_amd/torch_ext/SlamLoop.h"
+
+static torch::Tensor rd(std::ifstream& f, std::vector<int64_t> shape)
+{
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    auto t = torch::empty({n}, torch::kFloat32);
+    f.read(reinterpret_cast<char*>(t.data_ptr<float>()), n * 4);
+    return t.reshape(shape);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) { std::fprintf(stderr, "usage: slam_loop_main scene.bin\n"); return 2; }
+    std::ifstream f(argv[1], std::ios::binary);
+    int32_t hdr[6];
+    float ff[2];
+    f.read(reinterpret_cast<char*>(hdr), sizeof(hdr));
+    f.read(reinterpret_cast<char*>(ff), sizeof(ff));
+    const int P = hdr[0], W = hdr[1], H = hdr[2], track_iters = hdr[3], map_iters = hdr[4];
+    const torch::Device dev(torch::kCUDA, 0);
+    ORB_SLAM2::LoopConfig cfg;
+    cfg.fused_pair = (hdr[5] & 1) != 0;
+    cfg.fused_ops = (hdr[5] & 2) != 0;
+    ORB_SLAM2::SlamLoop loop(cfg, W, H, ff[0], ff[1], dev);
+    auto xyz = rd(f, {P, 3}), rgb = rd(f, {P, 3}), quat = rd(f, {P, 4}), logit = rd(f, {P, 1}), logs = rd(f, {P, 3});
+    loop.SetMap(xyz, rgb, quat, logit, logs);
+    ORB_SLAM2::LoopFrame fr;
+    fr.rgb = rd(f, {3, H, W}).to(dev); fr.depth = rd(f, {H, W}).to(dev); fr.Tcw = rd(f, {4, 4}).to(dev);
+    const auto T_init = rd(f, {4, 4});
+    if (!f) { std::fprintf(stderr, "short scene file\n"); return 2; }
+    std::cout.precision(9);
+    torch::Tensor Tbest;
+    { // warm-up on a throw-away copy of the map (allocator, clocks, MIOpen's first-call search for the SSIM convolutions)
+        ORB_SLAM2::SlamLoop warm(cfg, W, H, ff[0], ff[1], dev);
+        warm.SetMap(xyz, rgb, quat, logit, logs);
+        warm.Track(fr, T_init, 2, &Tbest);
+        for (int i = 0; i < 3; i++) warm.MappingIteration(fr);
+    }
+    torch::cuda::synchronize();
+    auto t0 = std::chrono::steady_clock::now();
+    const auto th = loop.Track(fr, T_init, track_iters, &Tbest);
+    torch::cuda::synchronize();
+    const double track_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / std::max<size_t>(th.size(), 1);
+    std::cout << "track";
+    for (double v : th) std::cout << " " << v;
+    std::cout << "\npose";
+    const auto Tb = Tbest.to(torch::kCPU).contiguous();
+    for (int i = 0; i < 16; i++) std::cout << " " << Tb.data_ptr<float>()[i];
+    std::cout << "\nmap";
+    t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < map_iters; i++) std::cout << " " << loop.MappingIteration(fr);
+    torch::cuda::synchronize();
+    const double map_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / std::max(map_iters, 1);
+    std::cout << "\ntrack_ms_per_iter " << track_ms << "\nmap_ms_per_iter " << map_ms << std::endl;
+    std::cout.flush();
+    std::_Exit(0); // (skip static destruction: libtorch's HIP caches and the library's pinned staging words have no defined order)
+}
