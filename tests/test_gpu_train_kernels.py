@@ -33,6 +33,19 @@ def test_fused_ssim_matches_the_torch_convolutions(gsr, hz, shape):
         assert abs(float(hz.ssim(a, b)) - float(ref.detach())) <= 2e-6
 
 
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_fused_ssim_matches_the_reference_ssim_golden(gsr, hz, name):
+    """tests/golden/ref_loss.npz: loss_utils._ssim of the REFERENCE (imported in the build container) fed GSORB-SLAM's window."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_loss.npz"))
+    x = torch.tensor(G[f"{name}_img1"]).cuda().requires_grad_(True)
+    v = hz.ssim(x, torch.tensor(G[f"{name}_img2"]).cuda())
+    v.backward()
+    assert abs(float(v.detach()) - float(G[f"{name}_ssim_gsorb_window"])) <= 3e-6
+    gref = G[f"{name}_dssim_dimg1_gsorb_window"]
+    assert np.abs(x.grad.cpu().numpy() - gref).max() <= 3e-5 * np.abs(gref).max()
+
+
 def test_fused_ssim_gradient_reaches_a_non_contiguous_render(gsr, hz):
     """A cropped / permuted render is copied by .contiguous() inside forward(), where grad mode is off: the copy has
     requires_grad False, and the need for a gradient must come from the autograd context, not from that copy."""
