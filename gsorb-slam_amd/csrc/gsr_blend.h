@@ -544,7 +544,11 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
             }
             lds_turn();
             const uint16_t* __restrict__ mylist = LIST + r * (Q + 4);
-            auto step = [&](const float4 A, const float4 B, const float4 Cz) {
+            // The loop reads 36 of an entry's 48 bytes: the list position (for n_contrib) and the depth (for the median depth) of
+            // the LAST entry that updated a pixel are looked up once per round through the iteration index instead of being
+            // carried through every iteration (the forward is bound by the LDS pipe: 0.81 busy, profiles/r03a_pmc.md)
+            int li = -1, di = -1;
+            auto step = [&](const int it, const float4 A, const float4 B, const float Cb) {
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 const float power2 = pair_power2(dx, dy, A.z, A.w, B.x); // = power * log2(e): same sign as power
                 const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(power2));
@@ -556,32 +560,45 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                 const float wgt = u ? alpha * T : 0.f;
                 C0 = fmaf(B.z, wgt, C0);
                 C1 = fmaf(B.w, wgt, C1);
-                C2 = fmaf(Cz.x, wgt, C2);
-                if (DUAL) { C3 = fmaf(Cz.y, wgt, C3); C4 += wgt; } // alpha-blended view depth, accumulated opacity
-                Dp = lane_of(upd & wm(T > 0.5f)) ? Cz.y : Dp; // median depth (forward.cu:374-379)
+                C2 = fmaf(Cb, wgt, C2);
+                if (DUAL) C4 += wgt;                              // accumulated opacity (the depth channel: below, per round)
+                di = lane_of(upd & wm(T > 0.5f)) ? it : di;       // median depth (forward.cu:374-379)
                 T = u ? test_T : T;
-                last = u ? __float_as_uint(Cz.z) : last;
+                li = u ? it : li;
+                return wgt;
             };
             if (maxc > 0) {
                 uint32_t o0 = mylist[0], o1 = mylist[1];
                 float4 A0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o0);
                 float4 B0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o0);
-                float4 Z0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + o0);
-                float4 A1, B1, Z1;
+                float Z0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(E2) + o0), Zd0 = 0.f, Zd1 = 0.f;
+                if (DUAL) Zd0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(E2) + o0 + 4);
+                float4 A1, B1;
+                float Z1;
                 for (int it = 0; it < maxc; it += 2) {
                     A1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o1);
                     B1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o1);
-                    Z1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + o1);
+                    Z1 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(E2) + o1);
+                    if (DUAL) Zd1 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(E2) + o1 + 4);
                     o0 = mylist[it + 2];
                     __builtin_amdgcn_sched_barrier(0); // keep the prefetch above the iteration it overlaps with
-                    step(A0, B0, Z0);
+                    const float w0 = step(it, A0, B0, Z0);
+                    if (DUAL) C3 = fmaf(Zd0, w0, C3);             // alpha-blended view depth
                     A0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o0);
                     B0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o0);
-                    Z0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + o0);
+                    Z0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(E2) + o0);
+                    if (DUAL) Zd0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(E2) + o0 + 4);
                     o1 = mylist[it + 3];
                     __builtin_amdgcn_sched_barrier(0);
-                    step(A1, B1, Z1);
+                    const float w1 = step(it + 1, A1, B1, Z1);
+                    if (DUAL) C3 = fmaf(Zd1, w1, C3);
                 }
+                // the round's last updates: list position + 1 and depth of the entries behind the two indices
+                const uint32_t ol = mylist[max(li, 0)], od = mylist[max(di, 0)];
+                const uint32_t lpos = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(E2) + ol + 8);
+                const float ddep = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(E2) + od + 4);
+                last = li >= 0 ? lpos : last;
+                Dp = di >= 0 ? ddep : Dp;
             }
             lds_turn();
         }
