@@ -558,3 +558,10 @@ int gsr_debug_export(int P, int width, int height, int R, const char* geom, cons
 }
 
 } // extern "C"
+
+#ifdef GSR_EXP_TIMELINE
+extern "C" int gsr_debug_timeline(unsigned long long* dst, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gsr::g_timeline), (size_t)n_words * 8);
+}
+#endif

@@ -19,6 +19,7 @@
 #pragma once
 
 #include "gsr_device.h"
+#include <type_traits>
 
 namespace gsr {
 
@@ -109,6 +110,7 @@ __device__ __forceinline__ bool quad_reach(const float4 a, const float4 b, float
 #endif
 #define GSR_ACCW 12 // floats per LDS accumulator record (nine used): 48 bytes, so that it moves as three b128
 typedef float v2f __attribute__((ext_vector_type(2)));
+#define GSR_INV_NONE 0x10u // "entry not in this row" byte of INV (slots are 0..15); 0x10101010 is a finite float
 
 // Exact cull of one parked entry (conic staged for pair_power2, i.e. in log2 units) against the 2x2
 // patches of 4x4 pixel centres of the quad at (X0, Y0); same construction and margin as quad_reach.
@@ -142,6 +144,20 @@ __device__ __forceinline__ void patch_reach4(const float4 A, const float4 B, flo
         }
 }
 
+#ifdef GSR_EXP_TIMELINE // instrumented build (scripts/timeline.py): start / end time and placement of every backward workgroup
+__device__ unsigned long long g_timeline[4 * 65536];
+struct TimelineMark {
+    unsigned long long t0; uint32_t b;
+    __device__ TimelineMark(uint32_t block) : t0(wall_clock64()), b(block) {}
+    __device__ ~TimelineMark() {
+        if (threadIdx.x == 0 && b < 65536u) {
+            g_timeline[4 * b] = t0; g_timeline[4 * b + 1] = wall_clock64();
+            g_timeline[4 * b + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+            g_timeline[4 * b + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+        }
+    }
+};
+#endif
 // DUAL: the fused colour + depth / silhouette render (gsr_forward_args.out_ds): two more channels ride on the same
 // alphas — the splat's view depth z and the constant 1 (what the reference renders in a second pass with colours
 // [z, 1, 0], src/Render.cc:949-981). dL_dds [2,H,W] is their upstream gradient; the z channel adds a tenth sum per
@@ -156,7 +172,13 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     // compare and no index select in the blend loop
     __shared__ float4 E0[Q + 1], E1[Q + 1], E2[Q + 1]; // (px, py, a2, b2) (c2, opacity, red, green) (blue, list position, view depth, splat id | patch mask << 28)
     // per-patch hit lists as BYTE OFFSETS (entry * 16 into E0/E1/E2): shifts and integer mads are half-rate VALU work
-    __shared__ uint16_t LIST[4 * (Q + 4)];
+    // LDS budget: gfx950 hands LDS out in blocks of 1280 bytes (scripts/lds_granule.hip: 12 800 bytes per workgroup -> 12 single-wave
+    // workgroups per CU, 12 816 -> 11), so the kernel is held at exactly ten blocks — the 12 waves per CU its registers allow.
+    // The fused pair pays for its fourth dL/dpixel channel with byte-sized list entries (one shift per entry read).
+    using blist_t = typename std::conditional<DUAL, uint8_t, uint16_t>::type;
+    constexpr uint32_t LUNIT = DUAL ? 1u : 16u;
+    auto loff = [](const blist_t x) -> uint32_t { return DUAL ? (uint32_t)x << 4 : (uint32_t)x; };
+    __shared__ blist_t LIST[4 * (Q + 4)];
     // One block of LDS used three ways, one after the other:
     //  UD  the ring: (u, dcol) of pixel p of pair q = row * 16 + (iteration % 16) at float2 UD[p * 65 + q]. A blend iteration
     //      writes 16 consecutive p for 4 values of q (stride 65 float2: the 16 lanes of a row fall on 16 different bank
@@ -164,14 +186,22 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     //  ST  float4 ST[3 * 64]: the nine sums of pair q at ST[k * 64 + q], k = 0..2 (reduce phase -> merge by entry);
     //  ACC float ACC[64 * 12]: the per-entry totals of the round, staged for the coalesced flush.
     __shared__ float4 POOL[(16 * (4 * GSR_RING + 1) * 8) / 16];
-    __shared__ float4 GP[4][17]; // dL/dpixel of pixel p of patch r (17: the four rows on different banks)
-    __shared__ uint32_t INV[Q + 4]; // per batch: byte r of word e = ring slot of entry e in row r, or 0xFF
+    // dL/dpixel of pixel p of patch r, one plane per channel (17: the four rows on different banks; planes instead of float4:
+    // the plain render has three channels, and the reduce phase holds 12 instead of 16 registers of them)
+    __shared__ float GP[DUAL ? 4 : 3][4 * 17];
 #ifdef GSR_EXP_LDSPAD // occupancy experiment: more LDS per wave, fewer waves per SIMD
     __shared__ uint32_t PADX[GSR_EXP_LDSPAD];
     if (W == -1) PADX[threadIdx.x] = 1u;
 #endif
     v2f* const UD = reinterpret_cast<v2f*>(POOL);
     float4* const ST = POOL;
+    // INV, per reduce phase: byte r of word e = ring slot of entry e in row r, or GSR_INV_NONE. It lives behind ST inside the
+    // block (it is only alive while the block is ST); its words are finite as floats, so the ring slots it leaves behind are
+    // harmless when they are read as stale slots
+    uint32_t* const INV = reinterpret_cast<uint32_t*>(POOL + 3 * 64);
+#ifdef GSR_EXP_TIMELINE
+    TimelineMark mark(blockIdx.x);
+#endif
     const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
     const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u;
     const int tx = tile % grid_x, ty = tile / grid_x;
@@ -203,7 +233,8 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f;
     constexpr int NC = DUAL ? 10 : 9;                     // sums per (quad, splat) record
     const int fe = lane / NC, fc = lane - NC * fe;        // flush lane -> (entry, component)
-    GP[r][l] = make_float4(g0, g1, g2, g3);
+    GP[0][r * 17 + l] = g0; GP[1][r * 17 + l] = g1; GP[2][r * 17 + l] = g2;
+    if (DUAL) GP[DUAL ? 3 : 0][r * 17 + l] = g3;
     if (lane == 0) {
         E0[Q] = make_float4(-1.0e5f, -1.0e5f, -1.f, 0.f); // power2 ~ -2e10: exp2 gives 0
         E1[Q] = make_float4(-1.f, 0.f, 0.f, 0.f);
@@ -225,10 +256,40 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     uint2 rec_c = qh[max(cq - 1 - lane, 0)];
     uint2 rec_n = qh[max(cq - 1 - (lane + GSR_BSTEP), 0)];
     float4 a_c = g.g0[rec_c.y & GSR_ID_MASK], b_c = g.g1[rec_c.y & GSR_ID_MASK], c_c = g.col[rec_c.y & GSR_ID_MASK];
+    // ---- flush: a round leaves the totals of its entries staged in the block (12 words per entry: NC sums, the splat id in
+    //      the last one); they are sent seven entries per instruction, NC consecutive lanes per 64-byte accumulator record:
+    //      one L2 atomic record per (quad, splat). The flush of round i runs inside round i + 1, right AFTER that round's
+    //      gathers were issued and before its blend loop: the wave's next wait on vector memory (for those gathers, a whole
+    //      blend loop later; atomics count in vmcnt on gfx9 and a wait behind a loop of them is a wait for all of them) then
+    //      finds the atomics long acknowledged. Issued at the end of their own round they were waited for at the top of the
+    //      next one — the round trip of a write-through atomic per round, per wave, with nothing else to do.
+    constexpr int FPER = 64 / NC;              // entries per flush instruction
+    constexpr int FITER = (64 + FPER - 1) / FPER;
+    const float* const accf = reinterpret_cast<const float*>(POOL);
+    auto flush = [&](const int cnt) {
+        float val[FITER];
+        uint32_t sid[FITER];
+#pragma unroll
+        for (int i = 0; i < FITER; i++) { // all LDS reads first: one round trip instead of two per instruction
+            const int e = min(i * FPER + fe, 63);
+            val[i] = accf[e * GSR_ACCW + fc];
+            sid[i] = __float_as_uint(accf[e * GSR_ACCW + GSR_ACCW - 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < FITER; i++) {
+            const bool ok = lane < FPER * NC && i * FPER + fe < cnt && val[i] != 0.f;
+#ifndef GSR_EXP_NOFLUSH
+            if (ok) unsafeAtomicAdd(&g.acc[(size_t)sid[i] * GSR_ACC_STRIDE + fc], val[i]);
+#else
+            if (ok && val[i] == 123.456f) g.acc[0] = val[i];
+#endif
+        }
+        lds_turn(); // the block becomes the ring again
+    };
+    int pend = 0; // entries of the previous round waiting to be flushed
     while (k0 < cq) {
         // ---- gather + compaction (records past the last contributor of every pixel are dropped): one step, <= 64 entries
         int count = 0;
-        uint32_t my_id = 0u; // lane e: the splat id of parked entry e
         {
             const uint32_t id = rec_c.y & GSR_ID_MASK, pos = rec_c.x, pmask = rec_c.y >> GSR_ID_BITS;
             const float4 a = a_c, b = b_c, c = c_c; // the whole 48-byte record of the next step is in flight during this round
@@ -237,6 +298,10 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             rec_c = rec_n;
             a_c = g.g0[rec_c.y & GSR_ID_MASK]; b_c = g.g1[rec_c.y & GSR_ID_MASK]; c_c = g.col[rec_c.y & GSR_ID_MASK];
             rec_n = qh[max(cq - 1 - (k + 2 * GSR_BSTEP), 0)];
+            // Wait for THIS round's gathers here, on every path (their use below is under `if (hit)`: on the path around it
+            // they would count as still in flight — on the first round they are — and the compiler would place the wait
+            // behind the flush's atomics, i.e. wait for those as well).
+            asm volatile("" ::"v"(a.x), "v"(b.x), "v"(c.x));
             const unsigned long long m = __ballot(hit);
             if (hit) {
                 const int e = mbcnt64(m);
@@ -247,6 +312,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             count = (int)__popcll(m);
             k0 += GSR_BSTEP;
         }
+        if (pend > 0) { flush(pend); pend = 0; }
         if (count == 0) continue;
         lds_turn();
         // ---- per-patch hit lists (lane e looks at parked entry e)
@@ -256,11 +322,10 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             if (lane < count) { // the forward already ran the patch cull: its verdict travels in the record
                 const float4 z = E2[lane];
                 const uint32_t pm = __float_as_uint(z.w) >> GSR_ID_BITS;
-                my_id = __float_as_uint(z.w) & GSR_ID_MASK;
                 h[0] = (pm & 1u) != 0u; h[1] = (pm & 2u) != 0u; h[2] = (pm & 4u) != 0u; h[3] = (pm & 8u) != 0u;
             }
             const unsigned long long m0 = __ballot(h[0]), m1 = __ballot(h[1]), m2 = __ballot(h[2]), m3 = __ballot(h[3]);
-            const uint16_t off = (uint16_t)(lane * 16);
+            const blist_t off = (blist_t)(lane * LUNIT);
             if (h[0]) LIST[0 * (Q + 4) + mbcnt64(m0)] = off;
             if (h[1]) LIST[1 * (Q + 4) + mbcnt64(m1)] = off;
             if (h[2]) LIST[2 * (Q + 4) + mbcnt64(m2)] = off;
@@ -271,7 +336,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
         const int maxc = (max(max(c0, c1), max(c2, c3)) + 1) & ~1;
         {
             const int cr = r == 0 ? c0 : r == 1 ? c1 : r == 2 ? c2 : c3;
-            for (int p = cr + l; p < maxc + 4; p += 16) LIST[r * (Q + 4) + p] = (uint16_t)(Q * 16);
+            for (int p = cr + l; p < maxc + 4; p += 16) LIST[r * (Q + 4) + p] = (blist_t)(Q * LUNIT);
         }
 #ifdef GSR_EXP_ROWFILL // instrumented build (scripts/rowfill.py): how full the padded lists and the 16-slot reduce blocks are
         if (lane == 0) {
@@ -283,7 +348,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
         }
 #endif
         lds_turn();
-        const uint16_t* __restrict__ mylist = LIST + r * (Q + 4);
+        const blist_t* __restrict__ mylist = LIST + r * (Q + 4);
         // per-entry totals of this round, in the registers of lane e
         float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, t4 = 0.f, t5 = 0.f, t6 = 0.f, t7 = 0.f, t8 = 0.f, t9 = 0.f;
         // ---- blend. An iteration is split in two: what does not depend on the pixel's running state (alpha and the
@@ -321,12 +386,13 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
         //      list position b0 + l of row r into nine numbers; (2) the sums go to ST, and every row publishes where its
         //      entries sit (INV); (3) lane e collects the sums of entry e from the (at most four) rows that hold it.
         //      No read-modify-write on shared data anywhere: nothing to serialise, nothing to make atomic.
+        auto gp_load = [&](const int p) -> float4 {
+            return make_float4(GP[0][r * 17 + p], GP[1][r * 17 + p], GP[2][r * 17 + p], DUAL ? GP[DUAL ? 3 : 0][r * 17 + p] : 0.f);
+        };
         auto reduce = [&](const int b0, const int nb) {
             lds_turn();
-            const uint32_t o = mylist[min(b0 + l, maxc + 3)]; // padded lists: always a valid entry (slots >= nb: not published)
+            const uint32_t o = loff(mylist[min(b0 + l, maxc + 3)]); // padded lists: always a valid entry (slots >= nb: not published)
             const float2 c = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(E0) + o); // splat centre
-            INV[lane] = 0xFFFFFFFFu;
-            if (lane < 4) INV[64 + lane] = 0xFFFFFFFFu;
             // all sixteen ring reads and the first dL/dpixel reads go out before the first use: with ~3 waves per SIMD
             // an LDS round trip per pixel would be the longest thing in this phase
             v2f ud[16];
@@ -334,7 +400,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             for (int p = 0; p < 16; p++) ud[p] = UD[p * (4 * GSR_RING + 1) + lane];
             float4 gq[4];
 #pragma unroll
-            for (int p = 0; p < 4; p++) gq[p] = GP[r][p];
+            for (int p = 0; p < 4; p++) gq[p] = gp_load(p);
             __builtin_amdgcn_sched_barrier(0);
             float dxk[4], dyk[4];
 #pragma unroll
@@ -359,7 +425,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
 #pragma unroll
             for (int p = 0; p < 16; p++) {
                 const float4 gp = gq[p & 3];
-                if (p + 4 < 16) gq[p & 3] = GP[r][p + 4];
+                if (p + 4 < 16) gq[p & 3] = gp_load(p + 4);
                 q0 = fmaf(ud[p].y, gp.x, q0); q1 = fmaf(ud[p].y, gp.y, q1); q2 = fmaf(ud[p].y, gp.z, q2);
                 if (DUAL) q3 = fmaf(ud[p].y, gp.w, q3);
             }
@@ -367,6 +433,8 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             ST[0 * 64 + lane] = make_float4(m0, m1, m2, m3);
             ST[1 * 64 + lane] = make_float4(m4, m5, q0, q1);
             ST[2 * 64 + lane] = make_float4(q2, q3, 0.f, 0.f);
+            INV[lane] = GSR_INV_NONE * 0x01010101u;
+            if (lane < 4) INV[64 + lane] = GSR_INV_NONE * 0x01010101u;
             if (l < nb) reinterpret_cast<uint8_t*>(INV)[(o >> 2) + r] = (uint8_t)l; // o >> 2 = entry * 4; the dummy (index Q) lands in the slack
             lds_turn();
             const uint32_t inv = INV[lane]; // lane e: where entry e sits in the four rows
@@ -378,7 +446,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             }
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
-                const float f = ((inv >> (8 * rr)) & 0xFFu) != 0xFFu ? 1.f : 0.f;
+                const float f = ((inv >> (8 * rr)) & GSR_INV_NONE) == 0u ? 1.f : 0.f;
                 t0 = fmaf(f, s0[rr].x, t0); t1 = fmaf(f, s0[rr].y, t1); t2 = fmaf(f, s0[rr].z, t2); t3 = fmaf(f, s0[rr].w, t3);
                 t4 = fmaf(f, s1[rr].x, t4); t5 = fmaf(f, s1[rr].y, t5); t6 = fmaf(f, s1[rr].z, t6); t7 = fmaf(f, s1[rr].w, t7);
                 t8 = fmaf(f, s2[rr].x, t8);
@@ -392,7 +460,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
         A = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + (off)); \
         B = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + (off)); \
         C = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E2) + (off))
-        uint32_t o0 = mylist[0], o1 = mylist[1], o2 = mylist[2], o3 = mylist[3];
+        uint32_t o0 = loff(mylist[0]), o1 = loff(mylist[1]), o2 = loff(mylist[2]), o3 = loff(mylist[3]);
         float4 A0, B0, C0, A1, B1, C1, A2, B2, C2, A3, B3, C3;
         GSR_LOAD3(A0, B0, C0, o0); GSR_LOAD3(A1, B1, C1, o1);
         int ring = 0;
@@ -416,38 +484,24 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
 #endif
         for (int it = 0; it < maxc; it += 4) {
             GSR_LOAD3(A2, B2, C2, o2); GSR_LOAD3(A3, B3, C3, o3);
-            o0 = mylist[it + 4]; o1 = mylist[it + 5]; // the lists are padded up to maxc + 3
+            o0 = loff(mylist[it + 4]); o1 = loff(mylist[it + 5]); // the lists are padded up to maxc + 3
             __builtin_amdgcn_sched_barrier(0); // keep the prefetch above the pair it overlaps with
             pair(it, A0, B0, C0, A1, B1, C1);
             if (it + 2 >= maxc) break;
             GSR_LOAD3(A0, B0, C0, o0); GSR_LOAD3(A1, B1, C1, o1);
-            o2 = mylist[it + 6]; o3 = mylist[it + 7];
+            o2 = loff(mylist[it + 6]); o3 = loff(mylist[it + 7]);
             __builtin_amdgcn_sched_barrier(0);
             pair(it + 2, A2, B2, C2, A3, B3, C3);
         }
 #undef GSR_LOAD3
-        // ---- flush: lane e holds the nine totals of entry e; stage them (12 floats per entry) and send seven entries per
-        //      instruction, nine consecutive lanes per 64-byte record: one L2 atomic record per (quad, splat)
-        float* const accf = reinterpret_cast<float*>(POOL);
+        // ---- lane e holds the totals of entry e: stage them for the flush (which runs inside the next round, see above)
         ST[lane * 3 + 0] = make_float4(t0, t1, t2, t3);
         ST[lane * 3 + 1] = make_float4(t4, t5, t6, t7);
-        ST[lane * 3 + 2] = make_float4(t8, t9, 0.f, 0.f);
-        lds_turn();
-        constexpr int FPER = 64 / NC; // entries per flush instruction: NC consecutive lanes per 64-byte accumulator record
-        for (int fb = 0; fb < count; fb += FPER) {
-            const int e = fb + fe;
-            if (lane < FPER * NC && e < count) {
-                const float val = accf[e * GSR_ACCW + fc];
-#ifndef GSR_EXP_NOFLUSH
-                if (val != 0.f) unsafeAtomicAdd(&g.acc[(size_t)(__float_as_uint(E2[e].w) & GSR_ID_MASK) * GSR_ACC_STRIDE + fc], val);
-#else
-                if (val == 123.456f) g.acc[0] = val;
-#endif
-            }
-        }
-        (void)my_id;
+        ST[lane * 3 + 2] = make_float4(t8, t9, 0.f, __uint_as_float(__float_as_uint(E2[lane].w) & GSR_ID_MASK)); // (slots >= count: never flushed)
+        pend = count;
         lds_turn();
     }
+    if (pend > 0) flush(pend);
 }
 
 // =====================================================================================
