@@ -271,7 +271,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
         uint32_t sid[FITER];
 #pragma unroll
         for (int i = 0; i < FITER; i++) { // all LDS reads first: one round trip instead of two per instruction
-            const int e = min(i * FPER + fe, 63);
+            const int e = i * FPER + fe; // (e > 63 reads on into the block, never used: one base register + immediate offsets)
             val[i] = accf[e * GSR_ACCW + fc];
             sid[i] = __float_as_uint(accf[e * GSR_ACCW + GSR_ACCW - 1]);
         }
@@ -403,8 +403,12 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             for (int p = 0; p < 4; p++) gq[p] = gp_load(p);
             __builtin_amdgcn_sched_barrier(0);
             float dxk[4], dyk[4];
+            // (the fused pair is over its register budget: there the pixel coordinates X0p + k are formed here, six additions
+            // per phase, instead of living in six registers hoisted out of the round loop)
+            float x0 = X0pf, y0 = Y0pf;
+            if (DUAL) asm volatile("" : "+v"(x0), "+v"(y0));
 #pragma unroll
-            for (int k = 0; k < 4; k++) { dxk[k] = c.x - (X0pf + (float)k); dyk[k] = c.y - (Y0pf + (float)k); }
+            for (int k = 0; k < 4; k++) { dxk[k] = c.x - (x0 + (float)k); dyk[k] = c.y - (y0 + (float)k); }
             // moments of u about the splat centre over the 4x4 patch, through its column and row sums (dx depends on the
             // column i = p & 3 only, dy on the row j = p >> 2 only): 71 instead of 128 instructions
             float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
