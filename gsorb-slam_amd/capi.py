@@ -18,7 +18,8 @@ _LIB = None
 EXPORTS = ["gsr_forward", "gsr_forward_ws", "gsr_ws_status", "gsr_backward", "gsr_mark_visible",
            "gsr_visible_filter", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
            "gsr_debug_export", "gsr_acc_view", "gsr_knn_bytes", "gsr_dist2", "gsr_ssim_partials", "gsr_ssim_forward", "gsr_ssim_backward",
-           "gsr_adam_step", "gsr_pose_grad", "gsr_to_camera", "gsr_pose_from_quat", "gsr_pose_from_quat_backward", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
+           "gsr_adam_step", "gsr_pose_grad", "gsr_to_camera", "gsr_pose_from_quat", "gsr_pose_from_quat_backward",
+           "gsr_pixel_loss", "gsr_pixel_loss_backward", "gsr_scale_reg", "gsr_scale_reg_backward", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
 
 
 def library_path() -> str:
@@ -122,6 +123,14 @@ def lib():
     L.gsr_adam_step.restype = C.c_int
     L.gsr_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
                                 C.c_int, C.c_void_p]
+    L.gsr_pixel_loss.restype = C.c_int
+    L.gsr_pixel_loss.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gsr_pixel_loss_backward.restype = C.c_int
+    L.gsr_pixel_loss_backward.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float)] + [C.c_void_p] * 5
+    L.gsr_scale_reg.restype = C.c_int
+    L.gsr_scale_reg.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gsr_scale_reg_backward.restype = C.c_int
+    L.gsr_scale_reg_backward.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gsr_error_string.restype = C.c_char_p
     L.gsr_error_string.argtypes = [C.c_int]
     L.gsr_last_hip_error.restype = C.c_char_p
@@ -454,6 +463,89 @@ def ssim_mean(img1, img2, taps):
     if img2.requires_grad:
         raise GsrError("ssim_mean: only the first image may require a gradient")
     return _FusedSSIM.apply(_f32(img1, img1.device) if img1.dtype != torch.float32 else img1, img2.to(torch.float32), tuple(taps))
+
+
+LOSS_PARTIALS = 256  # GSR_LOSS_PARTIALS
+
+
+class _PixelLoss(torch.autograd.Function):
+    """The pixel terms of the tracking (mode 0) / mapping (mode 1) loss as one reduction pass + one gradient pass
+    (include/gsr.h: gsr_pixel_loss). Differentiable in `image` and `depth`; `sur` (median depth) has no gradient."""
+
+    @staticmethod
+    def forward(ctx, image, depth, sur, sil, frame_rgb, frame_depth, mode, sil_thr, w):
+        L = lib()
+        dev = image.device
+        c = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        image, depth, sur, sil, frame_rgb, frame_depth = c(image), c(depth), c(sur), c(sil), c(frame_rgb), c(frame_depth)
+        H, W = int(image.shape[-2]), int(image.shape[-1])
+        w3 = (C.c_float * 3)(*[float(x) for x in w])
+        partial = torch.empty((LOSS_PARTIALS * 5,), dtype=torch.float32, device=dev)
+        sums = torch.empty((8,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _check(L.gsr_pixel_loss(_p(image), _p(depth) if depth is not None else None, _p(sur) if sur is not None else None,
+                                    _p(sil) if sil is not None else None, _p(frame_rgb), _p(frame_depth), H, W, int(mode), float(sil_thr), w3,
+                                    _p(partial), _p(sums), _stream()))
+        ctx.saved = (image, depth, sil, frame_rgb, frame_depth, sums)
+        ctx.cfg = (H, W, int(mode), float(sil_thr), w3)
+        ctx.mark_non_differentiable(sums)
+        return sums[5], sums
+
+    @staticmethod
+    def backward(ctx, go, _):
+        image, depth, sil, frame_rgb, frame_depth, sums = ctx.saved
+        H, W, mode, thr, w3 = ctx.cfg
+        g = go.detach().to(torch.float32).contiguous()
+        dimage = torch.empty_like(image)
+        ddepth = torch.empty_like(depth) if depth is not None and ctx.needs_input_grad[1] else None
+        with torch.cuda.device(image.device):
+            _check(lib().gsr_pixel_loss_backward(_p(image), _p(depth) if depth is not None else None, _p(sil) if sil is not None else None,
+                                                 _p(frame_rgb), _p(frame_depth), H, W, mode, thr, w3, _p(sums), _p(g), _p(dimage),
+                                                 _p(ddepth) if ddepth is not None else None, _stream()))
+        return dimage, ddepth, None, None, None, None, None, None, None
+
+
+def tracking_pixel_loss(image, depth, sil, frame_rgb, frame_depth, w_image, w_depth, sil_thr=0.99, depth_is_surface=False):
+    """w_image * sum_M |image - rgb| + w_depth * sum_M |depth - frame depth|, M = sil > thr & ~isnan(frame depth)
+    (Render.cc:1088-1105). depth_is_surface: `depth` is the median-depth plane (no gradient flows into it)."""
+    d, s = (None, depth) if depth_is_surface else (depth, None)
+    return _PixelLoss.apply(image, d, s, sil, frame_rgb, frame_depth, 0, sil_thr, (w_image, w_depth, 0.0))[0]
+
+
+def mapping_pixel_loss(image, depth, sur, sil, frame_rgb, frame_depth, w_l1, w_depth, w_sur, sil_thr=0.99):
+    """w_l1 * mean |image - rgb| + w_depth * masked mean |depth - fd| (fd > 0) + w_sur * masked mean |sur - fd| (fd > 0 & sil > thr)
+    (Render.cc:436-471). Returns (loss, sums [8]: see include/gsr.h)."""
+    return _PixelLoss.apply(image, depth, sur, sil, frame_rgb, frame_depth, 1, sil_thr, (w_l1, w_depth, w_sur))
+
+
+class _ScaleReg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, log_scales, limit, w_long, w_scalar):
+        ls = log_scales.detach().to(torch.float32).contiguous()
+        partial = torch.empty((LOSS_PARTIALS * 3,), dtype=torch.float32, device=ls.device)
+        out = torch.empty((4,), dtype=torch.float32, device=ls.device)
+        with torch.cuda.device(ls.device):
+            _check(lib().gsr_scale_reg(_p(ls), ls.shape[0], float(limit), float(w_long), float(w_scalar), _p(partial), _p(out), _stream()))
+        ctx.saved = (ls, out)
+        ctx.cfg = (float(limit), float(w_long), float(w_scalar))
+        ctx.mark_non_differentiable(out)
+        return out[3], out
+
+    @staticmethod
+    def backward(ctx, go, _):
+        ls, out = ctx.saved
+        limit, wl, wsc = ctx.cfg
+        g = go.detach().to(torch.float32).contiguous()
+        d = torch.empty_like(ls)
+        with torch.cuda.device(ls.device):
+            _check(lib().gsr_scale_reg_backward(_p(ls), ls.shape[0], limit, wl, wsc, _p(out), _p(g), _p(d), _stream()))
+        return d, None, None, None
+
+
+def scale_regularisers(log_scales, limit, w_long, w_scalar):
+    """w_long * reg_long + w_scalar * reg_scalar of Render.cc:449-462 for log_scales [n,3]; returns (value, out [4] =
+    {number of oversized components, reg_scalar, sum of max - min over them, value})."""
+    return _ScaleReg.apply(log_scales, limit, w_long, w_scalar)
 
 
 POSE_PARTIALS = 512  # GSR_POSE_PARTIALS

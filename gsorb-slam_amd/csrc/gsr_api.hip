@@ -524,6 +524,60 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     return GSR_OK;
 }
 
+int gsr_pixel_loss(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb,
+                   const float* frame_depth, int H, int W, int mode, float sil_thr, const float* w3, float* partial, float* sums, void* stream)
+{
+    static_assert(GSR_LOSS_PARTIALS == GSR_LOSS_BLOCKS, "header and kernels agree on the number of partial rows");
+    if (!image || !frame_rgb || !frame_depth || !w3 || !partial || !sums || H <= 0 || W <= 0 || (mode != 0 && mode != 1)) return GSR_EINVAL;
+    if (mode == 0 && !depth && !sur) return GSR_EINVAL;
+    const size_t N = (size_t)H * W;
+    const gsr::LossPlanes p{image, depth, sur, sil, frame_rgb, frame_depth};
+    gsr::LossWeights w{{w3[0], w3[1], w3[2]}};
+    const int nb = (int)std::min<size_t>(GSR_LOSS_BLOCKS, (N + 255) / 256);
+    hipLaunchKernelGGL(gsr::K_loss_sums, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, N, mode, sil_thr, partial);
+    GSR_LAUNCHED();
+    hipLaunchKernelGGL(gsr::K_loss_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nb, mode, N, w, depth ? 0 : 1, sums);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_pixel_loss_backward(const float* image, const float* depth, const float* sil, const float* frame_rgb, const float* frame_depth,
+                            int H, int W, int mode, float sil_thr, const float* w3, const float* sums, const float* dL_dloss,
+                            float* dL_dimage, float* dL_ddepth, void* stream)
+{
+    if (!image || !frame_rgb || !frame_depth || !w3 || !sums || !dL_dloss || !dL_dimage || H <= 0 || W <= 0 || (mode != 0 && mode != 1)) return GSR_EINVAL;
+    const size_t N = (size_t)H * W;
+    if ((N + 255) / 256 > 0x7FFFFFFFu) return GSR_EINVAL;
+    const gsr::LossPlanes p{image, depth, nullptr, sil, frame_rgb, frame_depth};
+    gsr::LossWeights w{{w3[0], w3[1], w3[2]}};
+    hipLaunchKernelGGL(gsr::K_loss_grad, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, N, mode, sil_thr, w, sums, dL_dloss,
+                       dL_dimage, dL_ddepth);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_scale_reg(const float* log_scales, size_t n, float limit, float w_long, float w_scalar, float* partial, float* out, void* stream)
+{
+    if (!partial || !out || (n > 0 && !log_scales)) return GSR_EINVAL;
+    const int nb = (int)std::max<size_t>(1, std::min<size_t>(GSR_LOSS_BLOCKS, (n + 255) / 256));
+    hipLaunchKernelGGL(gsr::K_scale_reg, dim3(nb), dim3(256), 0, (hipStream_t)stream, log_scales, n, limit, partial);
+    GSR_LAUNCHED();
+    hipLaunchKernelGGL(gsr::K_scale_reg_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nb, w_long, w_scalar, out);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_scale_reg_backward(const float* log_scales, size_t n, float limit, float w_long, float w_scalar, const float* out,
+                           const float* dL_dvalue, float* dL_dlog_scales, void* stream)
+{
+    if (n == 0) return GSR_OK;
+    if (!log_scales || !out || !dL_dvalue || !dL_dlog_scales || (n + 255) / 256 > 0x7FFFFFFFu) return GSR_EINVAL;
+    hipLaunchKernelGGL(gsr::K_scale_reg_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, log_scales, n, limit, w_long, w_scalar,
+                       out, dL_dvalue, dL_dlog_scales);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
 int gsr_debug_export(int P, int width, int height, int R, const char* geom, const char* binning,
                      const char* image, const gsr_debug_arrays* out, void* stream)
 {

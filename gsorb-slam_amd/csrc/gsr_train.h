@@ -262,4 +262,172 @@ __global__ void K_rt2T_bwd(const float* __restrict__ quat, const float* __restri
     dtrans[0] = dT[3]; dtrans[1] = dT[7]; dtrans[2] = dT[11];
 }
 
+// =====================================================================================
+// Loss terms of the two loops, fused (round 3). The reference forms them from libtorch tensor expressions — tracking
+// (src/Render.cc:1088-1105, L1LossForTracking src/Utils.cc:58-65): silhouette / NaN mask, two masked L1 sums; mapping
+// (src/Render.cc:436-471, L1LossForMapping src/Utils.cc:39-56): colour L1 mean, masked depth L1 mean, masked surface-depth
+// L1 mean, the two scale regularisers — about 35 (tracking) and 80 (mapping) elementwise / reduction launches per iteration
+// forwards and backwards, each a few microseconds of a dependent launch chain. Here: one pass over the pixels that leaves a
+// row of partial sums per workgroup, one single-workgroup kernel that adds the rows (deterministic) and forms the loss, and
+// one pass that writes the gradient planes (scaled by the upstream gradient, read from the device).
+//   mode 0 (tracking): M = sil > thr && !isnan(frame depth);  loss = w[0] * sum_M |img - rgb| + w[1] * sum_M |d - fd|
+//   mode 1 (mapping) : V = fd > 0, S = V && sil > thr;
+//                      loss = w[0] * sum |img - rgb| / (3 H W) + w[1] * sum_V |d - fd| / |V| + w[2] * sum_S |sur - fd| / max(|S|, 1)
+// sums[8] = {sum |img - rgb|, sum |d - fd|, count, sum |sur - fd|, count_S, loss, 0, 0}. `d` is the differentiable depth plane
+// (NULL: no such term), `sur` the median-depth plane (no gradient: the rasterizer does not differentiate it).
+// =====================================================================================
+#define GSR_LOSS_BLOCKS 256
+struct LossPlanes {
+    const float* image;  // [3,H,W]
+    const float* depth;  // [H,W] or nullptr
+    const float* sur;    // [H,W] or nullptr
+    const float* sil;    // [H,W] or nullptr (mask = all pixels that pass the frame test)
+    const float* frgb;   // [3,H,W]
+    const float* fdepth; // [H,W]
+};
+__device__ __forceinline__ float sgn(float x) { return (float)(x > 0.f) - (float)(x < 0.f); } // torch.abs' gradient: sign(x), 0 at 0
+__global__ void __launch_bounds__(256)
+K_loss_sums(LossPlanes p, size_t N, int mode, float thr, float* __restrict__ partial)
+{
+    __shared__ float ws[4][5];
+    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (size_t)gridDim.x * 256) {
+        const float fd = p.fdepth[i];
+        const bool solid = !p.sil || p.sil[i] > thr;
+        const bool colour_in = mode == 0 ? (solid && fd == fd) : true;
+        const bool depth_in = mode == 0 ? colour_in : fd > 0.f;
+        if (colour_in) a[0] += (fabsf(p.image[i] - p.frgb[i]) + fabsf(p.image[N + i] - p.frgb[N + i])) + fabsf(p.image[2 * N + i] - p.frgb[2 * N + i]);
+        if (depth_in) {
+            if (p.depth) a[1] += fabsf(p.depth[i] - fd);
+            a[2] += 1.f;
+        }
+        if (mode == 1 && p.sur && depth_in && solid) { a[3] += fabsf(p.sur[i] - fd); a[4] += 1.f; }
+        if (mode == 0 && p.sur && depth_in) a[3] += fabsf(p.sur[i] - fd); // tracking on the surface depth (use_sur_depth)
+    }
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 5; q++) ws[threadIdx.x >> 6][q] = a[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) partial[blockIdx.x * 5 + threadIdx.x] = (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]);
+}
+struct LossWeights {
+    float w[3];
+};
+__global__ void __launch_bounds__(64)
+K_loss_finish(const float* __restrict__ partial, int nblocks, int mode, size_t N, LossWeights w, int depth_from_sur, float* __restrict__ sums)
+{
+    const int lane = threadIdx.x;
+    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = lane; b < nblocks; b += 64) {
+#pragma unroll
+        for (int q = 0; q < 5; q++) a[q] += partial[b * 5 + q];
+    }
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off, 64);
+    }
+    if (lane == 0) {
+        float loss;
+        if (mode == 0) loss = w.w[0] * a[0] + w.w[1] * (depth_from_sur ? a[3] : a[1]);
+        else loss = w.w[0] * (a[0] / (3.f * (float)N)) + w.w[1] * (a[1] / a[2]) + w.w[2] * (a[3] / fmaxf(a[4], 1.f));
+        sums[0] = a[0]; sums[1] = a[1]; sums[2] = a[2]; sums[3] = a[3]; sums[4] = a[4]; sums[5] = loss; sums[6] = 0.f; sums[7] = 0.f;
+    }
+}
+// gradient planes: dL/dimage [3,H,W] and dL/ddepth [H,W] (nullptr: not wanted), times the upstream gradient *go
+__global__ void __launch_bounds__(256)
+K_loss_grad(LossPlanes p, size_t N, int mode, float thr, LossWeights w, const float* __restrict__ sums, const float* __restrict__ go,
+            float* __restrict__ dimage, float* __restrict__ ddepth)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float g = go[0];
+    const float fd = p.fdepth[i];
+    const bool solid = !p.sil || p.sil[i] > thr;
+    const bool colour_in = mode == 0 ? (solid && fd == fd) : true;
+    const bool depth_in = mode == 0 ? colour_in : fd > 0.f;
+    const float ci = mode == 0 ? g * w.w[0] : g * w.w[0] / (3.f * (float)N);
+    const float cd = mode == 0 ? g * w.w[1] : g * w.w[1] / sums[2];
+#pragma unroll
+    for (int c = 0; c < 3; c++) dimage[c * N + i] = colour_in ? ci * sgn(p.image[c * N + i] - p.frgb[c * N + i]) : 0.f;
+    if (ddepth) ddepth[i] = (depth_in && p.depth) ? cd * sgn(p.depth[i] - fd) : 0.f;
+}
+
+// The two scale regularisers of the mapping loss (src/Render.cc:449-462): with sc = exp(log_scales), limit = 0.1 * scene radius,
+// w_i = number of components of sc_i above the limit (the reference gathers the rows of every such COMPONENT: a row with two
+// oversized axes counts twice), mx / mn = the row's largest / smallest component:
+//   reg_scalar = sum_i w_i (mx_i - limit);  reg_long = sum_i w_i (mx_i - mn_i) / sum_i w_i  (0 if nothing is oversized)
+//   value = w_long * reg_long + w_scalar * reg_scalar.   out[4] = {sum w, reg_scalar, sum w (mx - mn), value}
+__global__ void __launch_bounds__(256)
+K_scale_reg(const float* __restrict__ ls, size_t n, float limit, float* __restrict__ partial)
+{
+    __shared__ float ws[4][3];
+    float a[3] = {0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float s0 = expf(ls[3 * i]), s1 = expf(ls[3 * i + 1]), s2 = expf(ls[3 * i + 2]);
+        const float wgt = (float)(s0 > limit) + (float)(s1 > limit) + (float)(s2 > limit);
+        const float mx = fmaxf(s0, fmaxf(s1, s2)), mn = fminf(s0, fminf(s1, s2));
+        a[0] += wgt; a[1] += wgt * (mx - limit); a[2] += wgt * (mx - mn);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) ws[threadIdx.x >> 6][q] = a[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) partial[blockIdx.x * 3 + threadIdx.x] = (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]);
+}
+__global__ void __launch_bounds__(64)
+K_scale_reg_finish(const float* __restrict__ partial, int nblocks, float w_long, float w_scalar, float* __restrict__ out)
+{
+    const int lane = threadIdx.x;
+    float a[3] = {0.f, 0.f, 0.f};
+    for (int b = lane; b < nblocks; b += 64) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) a[q] += partial[b * 3 + q];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off, 64);
+    }
+    if (lane == 0) {
+        out[0] = a[0]; out[1] = a[1]; out[2] = a[2];
+        out[3] = w_long * (a[0] > 0.f ? a[2] / a[0] : 0.f) + w_scalar * a[1];
+    }
+}
+// d(value)/d(log_scales): through mx (its first largest component), mn (its first smallest) and sc = exp(ls); w is a count (no gradient)
+__global__ void __launch_bounds__(256)
+K_scale_reg_bwd(const float* __restrict__ ls, size_t n, float limit, float w_long, float w_scalar, const float* __restrict__ out,
+                const float* __restrict__ go, float* __restrict__ dls)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float s[3] = {expf(ls[3 * i]), expf(ls[3 * i + 1]), expf(ls[3 * i + 2])};
+    const float wgt = (float)(s[0] > limit) + (float)(s[1] > limit) + (float)(s[2] > limit);
+    float d[3] = {0.f, 0.f, 0.f};
+    if (wgt > 0.f) {
+        int imax = 0, imin = 0;
+        if (s[1] > s[imax]) imax = 1;
+        if (s[2] > s[imax]) imax = 2;
+        if (s[1] < s[imin]) imin = 1;
+        if (s[2] < s[imin]) imin = 2;
+        const float cnt = out[0], g = go[0];
+        const float a = g * w_scalar * wgt, b = cnt > 0.f ? g * w_long * wgt / cnt : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) d[k] = ((k == imax ? a + b : 0.f) - (k == imin ? b : 0.f)) * s[k];
+    }
+    dls[3 * i] = d[0]; dls[3 * i + 1] = d[1]; dls[3 * i + 2] = d[2];
+}
+
 } // namespace gsr

@@ -112,7 +112,93 @@ struct SsimFn : public torch::autograd::Function<SsimFn> {
     }
 };
 
+// the pixel terms of a loop's loss: one reduction pass + one gradient pass (include/gsr.h: gsr_pixel_loss)
+struct PixelLossFn : public torch::autograd::Function<PixelLossFn> {
+    static torch::Tensor forward(torch::autograd::AutogradContext* ctx, torch::Tensor image, torch::Tensor depth, torch::Tensor sur, torch::Tensor sil,
+                                 torch::Tensor frgb, torch::Tensor fdepth, int64_t mode, double thr, std::vector<double> w)
+    {
+        // (an absent plane travels as an empty tensor: autograd::Function::apply does not take undefined tensors)
+        auto c = [](const torch::Tensor& t) { return t.numel() ? t.detach().contiguous() : torch::Tensor(); };
+        const auto im = c(image), d = c(depth), su = c(sur), si = c(sil), fr = c(frgb), fd = c(fdepth);
+        c10::DeviceGuard guard(im.device());
+        const int H = (int)im.size(-2), W = (int)im.size(-1);
+        const float w3[3] = {(float)w[0], (float)w[1], (float)w[2]};
+        auto partial = torch::empty({GSR_LOSS_PARTIALS * 5}, im.options()), sums = torch::empty({8}, im.options());
+        auto opt = [](const torch::Tensor& t) -> const float* { return t.defined() ? t.data_ptr<float>() : nullptr; };
+        check(gsr_pixel_loss(fp(im), opt(d), opt(su), opt(si), fp(fr), fp(fd), H, W, (int)mode, (float)thr, w3, partial.data_ptr<float>(),
+                             sums.data_ptr<float>(), stream_of(im)), "gsr_pixel_loss");
+        ctx->save_for_backward({im, d.defined() ? d : im, si.defined() ? si : im, fr, fd, sums});
+        ctx->saved_data["has_d"] = d.defined();
+        ctx->saved_data["has_s"] = si.defined();
+        ctx->saved_data["mode"] = mode;
+        ctx->saved_data["thr"] = thr;
+        ctx->saved_data["w"] = w;
+        return sums[5];
+    }
+    static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::tensor_list g)
+    {
+        const auto saved = ctx->get_saved_variables();
+        const auto &im = saved[0], &fr = saved[3], &fd = saved[4], &sums = saved[5];
+        const bool has_d = ctx->saved_data["has_d"].toBool(), has_s = ctx->saved_data["has_s"].toBool();
+        c10::DeviceGuard guard(im.device());
+        const auto w = ctx->saved_data["w"].toDoubleVector();
+        const float w3[3] = {(float)w[0], (float)w[1], (float)w[2]};
+        const auto go = g[0].to(torch::kFloat32).contiguous();
+        auto dimage = torch::empty_like(im);
+        torch::Tensor ddepth = has_d && ctx->needs_input_grad(1) ? torch::empty_like(saved[1]) : torch::Tensor();
+        check(gsr_pixel_loss_backward(fp(im), has_d ? fp(saved[1]) : nullptr, has_s ? fp(saved[2]) : nullptr, fp(fr), fp(fd), (int)im.size(-2), (int)im.size(-1),
+                                      (int)ctx->saved_data["mode"].toInt(), (float)ctx->saved_data["thr"].toDouble(), w3, fp(sums), fp(go),
+                                      dimage.data_ptr<float>(), ddepth.defined() ? ddepth.data_ptr<float>() : nullptr, stream_of(im)),
+              "gsr_pixel_loss_backward");
+        return {dimage, ddepth, torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor()};
+    }
+};
+
+struct ScaleRegFn : public torch::autograd::Function<ScaleRegFn> {
+    static torch::Tensor forward(torch::autograd::AutogradContext* ctx, torch::Tensor log_scales, double limit, double w_long, double w_scalar)
+    {
+        const auto ls = log_scales.detach().contiguous();
+        c10::DeviceGuard guard(ls.device());
+        auto partial = torch::empty({GSR_LOSS_PARTIALS * 3}, ls.options()), out = torch::empty({4}, ls.options());
+        check(gsr_scale_reg(fp(ls), (size_t)ls.size(0), (float)limit, (float)w_long, (float)w_scalar, partial.data_ptr<float>(), out.data_ptr<float>(),
+                            stream_of(ls)), "gsr_scale_reg");
+        ctx->save_for_backward({ls, out});
+        ctx->saved_data["limit"] = limit;
+        ctx->saved_data["wl"] = w_long;
+        ctx->saved_data["ws"] = w_scalar;
+        return out[3];
+    }
+    static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::tensor_list g)
+    {
+        const auto saved = ctx->get_saved_variables();
+        const auto &ls = saved[0], &out = saved[1];
+        c10::DeviceGuard guard(ls.device());
+        const auto go = g[0].to(torch::kFloat32).contiguous();
+        auto d = torch::empty_like(ls);
+        check(gsr_scale_reg_backward(fp(ls), (size_t)ls.size(0), (float)ctx->saved_data["limit"].toDouble(), (float)ctx->saved_data["wl"].toDouble(),
+                                     (float)ctx->saved_data["ws"].toDouble(), fp(out), fp(go), d.data_ptr<float>(), stream_of(ls)), "gsr_scale_reg_backward");
+        return {d, torch::Tensor(), torch::Tensor(), torch::Tensor()};
+    }
+};
+
 } // namespace
+
+torch::Tensor tracking_pixel_loss(const torch::Tensor& image, const torch::Tensor& depth, const torch::Tensor& sil, const torch::Tensor& frame_rgb,
+                                  const torch::Tensor& frame_depth, double w_image, double w_depth, bool depth_is_surface)
+{
+    const auto none = torch::empty({0}, image.options());
+    return PixelLossFn::apply(image, depth_is_surface ? none : depth, depth_is_surface ? depth : none, sil, frame_rgb, frame_depth, 0, 0.99,
+                              std::vector<double>{w_image, w_depth, 0.0});
+}
+torch::Tensor mapping_pixel_loss(const torch::Tensor& image, const torch::Tensor& depth, const torch::Tensor& sur, const torch::Tensor& sil,
+                                 const torch::Tensor& frame_rgb, const torch::Tensor& frame_depth, double w_l1, double w_depth, double w_sur)
+{
+    return PixelLossFn::apply(image, depth, sur, sil, frame_rgb, frame_depth, 1, 0.99, std::vector<double>{w_l1, w_depth, w_sur});
+}
+torch::Tensor scale_regularisers(const torch::Tensor& log_scales, double limit, double w_long, double w_scalar)
+{
+    return ScaleRegFn::apply(log_scales, limit, w_long, w_scalar);
+}
 
 torch::Tensor to_camera(const torch::Tensor& Tcw, const torch::Tensor& X) { return ToCameraFn::apply(Tcw, X); }
 torch::Tensor rt2T(const torch::Tensor& quat, const torch::Tensor& trans) { return Rt2TFn::apply(quat, trans); }

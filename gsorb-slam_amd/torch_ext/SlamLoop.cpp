@@ -138,7 +138,8 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> SlamLoop::RenderPair(con
     // Render.cc:750-758: camera-frame means and activations, formed once for both renders
     const auto mc = cfg_.fused_ops ? fused::to_camera(Tcw, X)
                                    : X.matmul(Tcw.slice(0, 0, 3).slice(1, 0, 3).t()) + Tcw.slice(0, 0, 3).slice(1, 3, 4).reshape({1, 3});
-    const auto opac = torch::sigmoid(O), scales = torch::exp(S), rots = torch::nn::functional::normalize(Q);
+    const bool cached = tracking && act_.size() == 3;
+    const auto opac = cached ? act_[0] : torch::sigmoid(O), scales = cached ? act_[1] : torch::exp(S), rots = cached ? act_[2] : torch::nn::functional::normalize(Q);
     const auto mean2D = torch::zeros_like(mc).requires_grad_(true);
     const int dn = dev_.index() < 0 ? 0 : dev_.index();
     if (cfg_.fused_pair) {
@@ -167,13 +168,21 @@ std::vector<double> SlamLoop::Track(const LoopFrame& frame, const torch::Tensor&
     double min_loss = std::numeric_limits<double>::infinity(), last_loss = 0.0;
     std::vector<double> history;
     const auto nan_mask = ~torch::isnan(frame.depth);
+    // the map does not move while the pose is tracked: its activations are formed once per call, not once per iteration
+    if (cfg_.fused_ops) { torch::NoGradGuard ng; act_ = {torch::sigmoid(logit_opacities), torch::exp(log_scales), torch::nn::functional::normalize(unnorm_quat)}; }
     for (int it = 0; it < iters; it++) {
         const auto Tcw = cfg_.fused_ops ? fused::rt2T(cam_quat_, cam_trans_) : rt2T(cam_quat_.clone(), cam_trans_.clone());
         auto [rimage, rsur, rdepth] = RenderPair(Tcw, true);
-        const auto certain = ((rdepth[1] > 0.99) & nan_mask).detach();                                   // Render.cc:1088-1090
-        const auto image_l1 = l1_sum(rimage, frame.rgb, certain.unsqueeze(0).repeat({3, 1, 1}));
-        const auto depth_l1 = l1_sum(cfg_.use_sur_depth ? rsur[0] : rdepth[0], frame.depth, certain);
-        const auto loss = cfg_.im_weight_tracking * image_l1 + cfg_.depth_weight_tracking * depth_l1;
+        torch::Tensor loss;
+        if (cfg_.fused_ops) {                                                                            // Render.cc:1088-1105 as two launches
+            loss = fused::tracking_pixel_loss(rimage, cfg_.use_sur_depth ? rsur[0] : rdepth[0], rdepth[1], frame.rgb, frame.depth,
+                                              cfg_.im_weight_tracking, cfg_.depth_weight_tracking, cfg_.use_sur_depth);
+        } else {
+            const auto certain = ((rdepth[1] > 0.99) & nan_mask).detach();                               // Render.cc:1088-1090
+            const auto image_l1 = l1_sum(rimage, frame.rgb, certain.unsqueeze(0).repeat({3, 1, 1}));
+            const auto depth_l1 = l1_sum(cfg_.use_sur_depth ? rsur[0] : rdepth[0], frame.depth, certain);
+            loss = cfg_.im_weight_tracking * image_l1 + cfg_.depth_weight_tracking * depth_l1;
+        }
         loss.backward();
         torch::NoGradGuard ng;
         const double lv = loss.item<double>();
@@ -184,6 +193,7 @@ std::vector<double> SlamLoop::Track(const LoopFrame& frame, const torch::Tensor&
         if (cfg_.fused_ops) { fopt_pose_->step(); fopt_pose_->zero_grad(); }
         else { opt_pose_->step(); opt_pose_->zero_grad(); }
     }
+    act_.clear();
     if (Tcw_best) *Tcw_best = rt2T(best_q, best_t).detach();
     return history;
 }
@@ -192,6 +202,17 @@ double SlamLoop::MappingIteration(const LoopFrame& fr)
 {
     const auto Tcw = fr.Tcw.to(dev_, torch::kFloat32);
     auto [rimage, rsur, rdepth] = RenderPair(Tcw, false);
+    if (cfg_.fused_ops) { // Render.cc:436-471 as: pixel terms (2 launches), SSIM (1 + a sum), regularisers (2), a handful of scalar operations
+        const auto pix = fused::mapping_pixel_loss(rimage, rdepth[0], rsur[0], rdepth[1], fr.rgb, fr.depth, cfg_.im_weight_mapping * cfg_.lam,
+                                                   cfg_.depth_weight_mapping, cfg_.sur_depth_weight_mapping);
+        const auto ssim_v = fused::ssim_mean(rimage, fr.rgb, taps_host_);
+        const auto reg = fused::scale_regularisers(log_scales, 0.1 * cfg_.scene_radius, cfg_.reg_long_weight, cfg_.reg_scalar_weight);
+        const auto loss = pix + (cfg_.im_weight_mapping * (1 - cfg_.lam)) * (1.0 - ssim_v) + reg;
+        loss.backward();
+        torch::NoGradGuard ng;
+        fopt_->step(); fopt_->zero_grad();
+        return loss.item<double>();
+    }
     const auto valid = (fr.depth > 0).detach();
     const auto valid_sur = ((fr.depth > 0) & (rdepth[1] > 0.99)).detach();
     const auto ssim_v = cfg_.fused_ops ? fused::ssim_mean(rimage, fr.rgb, taps_host_) : ssim(rimage, fr.rgb, taps_);

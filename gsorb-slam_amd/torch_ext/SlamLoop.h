@@ -65,6 +65,7 @@ private:
     std::unique_ptr<fused::Adam> fopt_, fopt_pose_;
     torch::Tensor cam_quat_, cam_trans_, taps_;
     std::vector<float> taps_host_;
+    std::vector<torch::Tensor> act_; // Track(): the map's activations (opacity, scales, unit quaternions), formed once per call
 };
 
 // include/Utils.h:56-77: Tcw [4,4] from an un-normalised quaternion (r,x,y,z) [4,1] and a translation [3,1]

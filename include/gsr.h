@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 3 /* 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs */
+#define GSR_ABI_VERSION 4 /* 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added */
 
 #define GSR_OK 0
 #define GSR_EINVAL (-1)    /* bad argument combination (NULL where data is required, sizes < 0 …) */
@@ -237,6 +237,32 @@ int gsr_pose_from_quat(const float* quat, const float* trans, float* Tcw, void* 
 int gsr_pose_from_quat_backward(const float* quat, const float* dL_dTcw, float* dL_dquat, float* dL_dtrans, void* stream);
 int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
                   double beta1, double beta2, double eps, int step, void* stream);
+
+/* ---- the loss terms of the two loops, fused (reference src/Render.cc:1088-1105 tracking, :436-471 mapping; src/Utils.cc:39-65:
+ * libtorch tensor expressions, ~35 / ~80 small launches per iteration forwards and backwards). All pointers are DEVICE pointers.
+ *   gsr_pixel_loss  mode 0 (tracking): M = sil > sil_thr && !isnan(frame_depth);
+ *                       loss = w[0] * sum_M |image - frame_rgb| + w[1] * sum_M |D - frame_depth|, D = depth, or sur when depth == NULL
+ *                   mode 1 (mapping): V = frame_depth > 0, S = V && sil > sil_thr;
+ *                       loss = w[0] * mean |image - frame_rgb| + w[1] * sum_V |depth - frame_depth| / |V|
+ *                              + w[2] * sum_S |sur - frame_depth| / max(|S|, 1)
+ *                   image, frame_rgb [3,H,W]; depth, sur, sil, frame_depth [H,W] (depth / sur / sil may be NULL: term or test absent).
+ *                   partial: scratch of GSR_LOSS_PARTIALS * 5 floats; sums [8] = {sum |image - rgb|, sum |depth - fd|, its count,
+ *                   sum |sur - fd|, its count (mapping), loss, 0, 0}
+ *   gsr_pixel_loss_backward  dL_dimage [3,H,W] and dL_ddepth [H,W] (NULL: not wanted; zeros when depth == NULL), times *dL_dloss;
+ *                   `sums` is the forward's (the mapping depth term divides by its count). sur has no gradient.
+ *   gsr_scale_reg   the two scale regularisers (src/Render.cc:449-462) of log_scales [n,3]:
+ *                   out [4] = {sum w, reg_scalar, sum w (max - min), w_long * reg_long + w_scalar * reg_scalar}; partial: GSR_LOSS_PARTIALS * 3 floats
+ *   gsr_scale_reg_backward  dL_dlog_scales [n,3] (written, not accumulated) = *dL_dvalue * d(out[3]) / d(log_scales) */
+#define GSR_LOSS_PARTIALS 256
+int gsr_pixel_loss(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb,
+                   const float* frame_depth, int H, int W, int mode, float sil_thr, const float* w3 /* host, 3 floats */,
+                   float* partial, float* sums, void* stream);
+int gsr_pixel_loss_backward(const float* image, const float* depth, const float* sil, const float* frame_rgb, const float* frame_depth,
+                            int H, int W, int mode, float sil_thr, const float* w3 /* host */, const float* sums,
+                            const float* dL_dloss, float* dL_dimage, float* dL_ddepth, void* stream);
+int gsr_scale_reg(const float* log_scales, size_t n, float limit, float w_long, float w_scalar, float* partial, float* out, void* stream);
+int gsr_scale_reg_backward(const float* log_scales, size_t n, float limit, float w_long, float w_scalar, const float* out,
+                           const float* dL_dvalue, float* dL_dlog_scales, void* stream);
 
 /* Workspace sizes: replace required<GeometryState/ImageState/BinningState>
  * (rasterizer_impl.h:67-73). */

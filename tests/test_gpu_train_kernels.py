@@ -159,3 +159,89 @@ def test_rt2T_kernel_matches_the_tensor_formulas_and_their_autograd(gsr, hz):
         assert float((Tb.cpu().double() - Ta).abs().max()) <= 1e-6
         assert float((qb.grad.cpu().double() - qa.grad).abs().max()) <= 1e-5 * max(1.0, float(qa.grad.abs().max()))
         assert float((tb.grad.cpu().double() - ta.grad).abs().max()) <= 1e-6
+
+
+# ---- the fused loss terms of the loops (include/gsr.h: gsr_pixel_loss*, gsr_scale_reg*) against the tensor expressions of
+# ---- SlamLoop.cpp / harness.py (= src/Render.cc:1088-1105, :436-471, :449-462) in float64
+def _loss_inputs(H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand((3, H, W), generator=g)
+    dep = 1.0 + 2.0 * torch.rand((H, W), generator=g)
+    sur = dep + 0.05 * torch.randn((H, W), generator=g)
+    sil = 0.9 + 0.1 * torch.rand((H, W), generator=g) + 0.02     # ~ a fifth of the pixels under the 0.99 threshold
+    frgb = torch.rand((3, H, W), generator=g)
+    fd = 1.0 + 2.0 * torch.rand((H, W), generator=g)
+    img[:, 3, 5] = frgb[:, 3, 5]                                 # |0|: gradient 0, like torch.abs
+    return img, dep, sur, sil, frgb, fd
+
+
+@pytest.mark.parametrize("shape,surface", [((37, 53), False), ((480, 640), False), ((120, 200), True)])
+def test_fused_tracking_loss_matches_the_masked_l1_sums(gsr, shape, surface):
+    H, W = shape
+    img, dep, sur, sil, frgb, fd = _loss_inputs(H, W, 3)
+    fd[::7, ::5] = float("nan")                                  # invalid sensor depth (Render.cc:1088: ~isnan)
+    wi, wd = 0.5, 1.0
+    a = img.double().requires_grad_(True); d = (sur if surface else dep).double().requires_grad_(True)
+    certain = (sil.double() > 0.99) & ~torch.isnan(fd)
+    ref = wi * torch.where(certain.unsqueeze(0).expand(3, H, W), (a - frgb.double()).abs(), torch.zeros_like(a)).sum() \
+        + wd * torch.where(certain, (d - fd.double()).abs(), torch.zeros_like(d)).sum()
+    ref.backward()
+    ai = img.cuda().requires_grad_(True); di = (sur if surface else dep).cuda().requires_grad_(True)
+    out = gsr.capi.tracking_pixel_loss(ai, di, sil.cuda(), frgb.cuda(), fd.cuda(), wi, wd, depth_is_surface=surface)
+    (out * 2.0).backward()                                       # an upstream gradient other than 1
+    assert abs(float(out) - float(ref)) <= 2e-5 * abs(float(ref))
+    assert torch.equal(ai.grad.cpu(), (2.0 * a.grad).float())
+    if surface:
+        assert di.grad is None                                   # the median-depth plane has no gradient
+    else:
+        assert torch.equal(di.grad.cpu(), (2.0 * d.grad).float())
+
+
+@pytest.mark.parametrize("shape", [(37, 53), (680, 1200)])
+def test_fused_mapping_pixel_loss_matches_the_masked_means(gsr, shape):
+    H, W = shape
+    img, dep, sur, sil, frgb, fd = _loss_inputs(H, W, 4)
+    fd[::3, ::4] = 0.0                                           # pixels without a depth measurement
+    w1, w2, w3 = 0.45, 1.0, 0.3
+    a = img.double().requires_grad_(True); d = dep.double().requires_grad_(True)
+    valid = fd.double() > 0
+    valid_sur = valid & (sil.double() > 0.99)
+    ref = w1 * (a - frgb.double()).abs().mean() + w2 * torch.where(valid, (d - fd.double()).abs(), torch.zeros_like(d)).sum() / valid.sum() \
+        + w3 * torch.where(valid_sur, (sur.double() - fd.double()).abs(), torch.zeros_like(d)).sum() / valid_sur.sum().clamp_min(1)
+    ref.backward()
+    ai = img.cuda().requires_grad_(True); di = dep.cuda().requires_grad_(True)
+    out, sums = gsr.capi.mapping_pixel_loss(ai, di, sur.cuda(), sil.cuda(), frgb.cuda(), fd.cuda(), w1, w2, w3)
+    out.backward()
+    assert abs(float(out) - float(ref)) <= 2e-5 * abs(float(ref))
+    assert int(sums[2]) == int(valid.sum()) and int(sums[4]) == int(valid_sur.sum())
+    assert (ai.grad.cpu().double() - a.grad).abs().max() <= 1e-6 * a.grad.abs().max()
+    assert (di.grad.cpu().double() - d.grad).abs().max() <= 1e-6 * d.grad.abs().max()
+    # no surface pixel at all: the term is an exact zero (the deviation from the reference's NaN that harness.py documents)
+    out0, sums0 = gsr.capi.mapping_pixel_loss(ai.detach(), di.detach(), sur.cuda(), torch.zeros_like(sil).cuda(), frgb.cuda(), fd.cuda(), 0.0, 0.0, 1.0)
+    assert float(out0) == 0.0 and float(sums0[4]) == 0.0
+
+
+@pytest.mark.parametrize("n,frac", [(1000, 0.1), (300_000, 0.01), (5000, 0.0)])
+def test_fused_scale_regularisers_match_the_tensor_expressions(gsr, n, frac):
+    g = torch.Generator().manual_seed(n)
+    ls = torch.log(0.01 + 0.02 * torch.rand((n, 3), generator=g))
+    big = torch.rand((n,), generator=g) < frac
+    ls[big, 0] = torch.log(torch.tensor(0.5)) + 0.3 * torch.rand((int(big.sum()),), generator=g)   # one oversized axis ...
+    ls[big & (torch.arange(n) % 2 == 0), 2] = torch.log(torch.tensor(0.4))                        # ... or two
+    limit, wl, ws = 0.3, 0.7, 0.2
+    x = ls.double().requires_grad_(True)
+    sc = torch.exp(x)
+    w = (sc > limit).sum(1).to(sc.dtype)
+    mx, mn = sc.max(1)[0], sc.min(1)[0]
+    cnt = w.sum()
+    reg_scalar = (w * (mx - limit)).sum()
+    spread = (w * (mx - mn)).sum()
+    reg_long = torch.where(cnt > 0, spread / cnt.clamp_min(1), torch.zeros_like(spread))
+    ref = wl * reg_long + ws * reg_scalar
+    ref.backward()
+    xi = ls.cuda().requires_grad_(True)
+    val, out = gsr.capi.scale_regularisers(xi, limit, wl, ws)
+    (val * 3.0).backward()
+    assert float(out[0]) == float(cnt)
+    assert abs(float(val) - float(ref)) <= 2e-5 * max(abs(float(ref)), 1e-12)
+    assert (xi.grad.cpu().double() - 3.0 * x.grad).abs().max() <= 2e-6 * max(float(x.grad.abs().max()) * 3.0, 1e-12)
