@@ -293,6 +293,10 @@ class SlamRenderer:
         self.rng = torch.Generator().manual_seed(seed)
         self.tracking_counts = self.mapping_counts = 0
         self.fused_pair = True   # render_pair: one fused pass when the rasterizer has forward_pair (False: two passes, like the reference)
+        # the pixel terms and scale regularisers of the losses as fused kernels (capi.tracking_pixel_loss / mapping_pixel_loss /
+        # scale_regularisers) when the renders are on the GPU; False: the tensor expressions below (what CPU-side oracle loops run)
+        self.fused_losses = True
+        self._track_act = None   # track(): the (fixed) map's activations, formed once per call
 
     @staticmethod
     def to_camera(Tcw, mean3D):
@@ -342,7 +346,8 @@ class SlamRenderer:
         # the reference forms the camera-frame means and the activations once per render; both renders of an iteration see
         # the same parameters and pose, so they are formed once here (autograd adds the two gradients: same numbers)
         xyz, rgb, q, o, s = self._params(tracking)
-        mc, act = self.to_camera(Tcw, xyz), self.activations(q, o, s)
+        mc = self.to_camera(Tcw, xyz)
+        act = self._track_act if tracking and self._track_act is not None else self.activations(q, o, s)
         if self.fused_pair and hasattr(self.rasterizer, "forward_pair"):
             # ONE pass of the rasterizer for both renders (the view matrix is the identity and the means are camera-frame:
             # the depth channel's colour IS mc[:, 2]; tracking detaches it, like render_depth)
@@ -372,6 +377,18 @@ class SlamRenderer:
         g, c = self.map, self.map.cfg
         Tcw = fr.Tcw.to(g.device)
         rimage, rsur, rdepth = self.render_pair(Tcw)
+        strict = getattr(self, "strict_empty_terms", False)
+        fused = self.fused_losses and rimage.is_cuda and not strict
+        max_scalar = 0.1 * g.scene_radius
+        if fused:
+            # the same terms as below: the pixel terms in two launches, the regularisers in two (own hook: a sharded mapper
+            # sums the regulariser sums over its ranks first and keeps the tensor expressions)
+            pix, _ = _capi().mapping_pixel_loss(rimage, rdepth[0], rsur[0], rdepth[1], fr.rgb, fr.depth, c.im_weight_mapping * c.lam,
+                                                c.depth_weight_mapping, c.sur_depth_weight_mapping)
+            loss = pix + (c.im_weight_mapping * (1 - c.lam)) * (1.0 - ssim(rimage, fr.rgb))
+            if type(self)._reduce_regularisers is SlamRenderer._reduce_regularisers:
+                return loss + _capi().scale_regularisers(g.log_scales, max_scalar, c.reg_long_weight, c.reg_scalar_weight)[0]
+            return loss + self._regularisers(max_scalar, strict)
         valid = fr.depth > 0
         valid_sur = (fr.depth > 0) & (rdepth[1] > 0.99)
         image_loss = c.lam * l1_mapping(rimage, fr.rgb) + (1 - c.lam) * (1.0 - ssim(rimage, fr.rgb))
@@ -382,9 +399,14 @@ class SlamRenderer:
         # NaN in the reference is an ordinary step here. (strict_empty_terms=True reproduces the reference's NaN.)
         n_sur = valid_sur.sum()
         sur_loss = torch.where(valid_sur.detach(), torch.abs(rsur[0] - fr.depth), torch.zeros_like(fr.depth)).sum() / n_sur.clamp_min(1)
-        if getattr(self, "strict_empty_terms", False):
+        if strict:
             sur_loss = torch.where(n_sur > 0, sur_loss, torch.full_like(sur_loss, float("nan")))
-        max_scalar = 0.1 * g.scene_radius
+        return (c.im_weight_mapping * image_loss + c.depth_weight_mapping * depth_loss + c.sur_depth_weight_mapping * sur_loss
+                + self._regularisers(max_scalar, strict))
+
+    def _regularisers(self, max_scalar, strict=False):
+        """reg_long_weight * reg_long + reg_scalar_weight * reg_scalar (Render.cc:449-462) as tensor expressions."""
+        g, c = self.map, self.map.cfg
         sc = torch.exp(g.log_scales)
         # Render.cc:449-462 gathers the rows of every scale COMPONENT above the limit (torch::where(...)[0]: a row with two
         # oversized axes counts twice) and takes max / min of those rows. The same sums with the multiplicity as a weight,
@@ -395,10 +417,9 @@ class SlamRenderer:
         cnt = torch.as_tensor(cnt, dtype=sc.dtype, device=sc.device)
         reg_scalar = over
         reg_long = torch.where(cnt > 0, spread / cnt.clamp_min(1), torch.zeros_like(spread))   # mean over the oversized splats
-        if getattr(self, "strict_empty_terms", False):
+        if strict:
             reg_long = torch.where(cnt > 0, reg_long, torch.full_like(reg_long, float("nan")))
-        return (c.im_weight_mapping * image_loss + c.depth_weight_mapping * depth_loss + c.sur_depth_weight_mapping * sur_loss
-                + c.reg_long_weight * reg_long + c.reg_scalar_weight * reg_scalar)
+        return c.reg_long_weight * reg_long + c.reg_scalar_weight * reg_scalar
 
     def mapping_iteration(self, frames):
         g = self.map
@@ -424,9 +445,19 @@ class SlamRenderer:
         iters = iters or c.tracking_iters
         inline = None
         history = []
+        if self.fused_losses and g.xyz.is_cuda:   # the map does not move while the pose is tracked
+            with torch.no_grad():
+                self._track_act = self.activations(g.unnorm_quat, g.logit_opacities, g.log_scales)
+        try:
+            return self._track_loop(frame, iters, matches, K, best_q, best_t, min_loss, last_loss, inline, history)
+        finally:
+            self._track_act = None
+
+    def _track_loop(self, frame, iters, matches, K, best_q, best_t, min_loss, last_loss, inline, history):
+        g, c = self.map, self.map.cfg
         for it in range(iters):
             Tcw = rt2T(g.cam_quat.clone(), g.cam_trans.clone())
-            lrpj = Tcw.sum() * 0
+            lrpj = None
             if matches is not None:
                 obs, Xw4, inv_s2 = matches
                 M = obs.shape[0]
@@ -446,10 +477,16 @@ class SlamRenderer:
                 if gs != 1.0:
                     lrpj = lrpj * gs + lrpj.detach() * (1.0 - gs)
             rimage, rsur, rdepth = self.render_pair(Tcw, tracking=True)
-            certain = (rdepth[1] > 0.99) & ~torch.isnan(frame.depth)
-            image_l1 = l1_tracking(rimage, frame.rgb, certain.unsqueeze(0).repeat(3, 1, 1).detach())
-            depth_l1 = l1_tracking(rsur[0] if c.use_sur_depth else rdepth[0], frame.depth, certain.detach())
-            loss = c.im_weight_tracking * image_l1 + c.depth_weight_tracking * depth_l1 + c.feature_weight_tracking * lrpj
+            if self.fused_losses and rimage.is_cuda:   # Render.cc:1088-1105 in two launches
+                loss = _capi().tracking_pixel_loss(rimage, rsur[0] if c.use_sur_depth else rdepth[0], rdepth[1], frame.rgb, frame.depth,
+                                                   c.im_weight_tracking, c.depth_weight_tracking, depth_is_surface=c.use_sur_depth)
+                if matches is not None:
+                    loss = loss + c.feature_weight_tracking * lrpj
+            else:
+                certain = (rdepth[1] > 0.99) & ~torch.isnan(frame.depth)
+                image_l1 = l1_tracking(rimage, frame.rgb, certain.unsqueeze(0).repeat(3, 1, 1).detach())
+                depth_l1 = l1_tracking(rsur[0] if c.use_sur_depth else rdepth[0], frame.depth, certain.detach())
+                loss = c.im_weight_tracking * image_l1 + c.depth_weight_tracking * depth_l1 + c.feature_weight_tracking * (lrpj if lrpj is not None else Tcw.sum() * 0)
             loss.backward()
             with torch.no_grad():
                 lv = float(loss.detach())
