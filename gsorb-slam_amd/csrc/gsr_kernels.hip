@@ -332,7 +332,7 @@ K_scan_tiles(int T, const uint32_t* __restrict__ cnt, int cnt_stride, uint32_t* 
         if (c > GSR_SORT_SMALL && c <= GSR_SORT_CAP) sortq[GSR_SORTQ_HEAD + omid++] = (uint32_t)i;
         if (c > GSR_SORT_CAP) sortq[GSR_SORTQ_HEAD + T + olong++] = (uint32_t)i;
     });
-    if (tid == 0) { sortq[0] = tmid; sortq[1] = tlong; }
+    if (tid == 0) { sortq[0] = tmid; sortq[1] = tlong; sortq[2] = 0u; } // [2]: K_tile_sort_long's pop counter
 }
 
 // the forward's capacity guess was too small: switch the header to the exact capacity before the tail re-runs
@@ -753,10 +753,11 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
 // in flight; bins in LDS. Passes: min/max, count, [equalise + count again], scatter by bin, rank among bin-mates.
 // Crowded lists (exact depth ties) fall back to the bitonic network in global memory (sort_tile).
 #define GSR_SORT_LONG_BINS 8192
-__device__ __forceinline__ void sort_long_list(SortShared<GSR_SORT_BLOCK>& sh, const uint2 r, uint64_t* __restrict__ pairs,
+template <int KIND>
+__device__ __forceinline__ void sort_long_list(SortShared<KIND>& sh, const uint2 r, uint64_t* __restrict__ pairs,
                                                uint32_t* __restrict__ point_list, uint2* __restrict__ qhits)
 {
-    constexpr int NT = GSR_SORT_BIG_THREADS, NB = GSR_SORT_LONG_BINS, BPT = NB / NT, LOGNB = 13, U = 8;
+    constexpr int NT = SortShared<KIND>::NT, NB = GSR_SORT_LONG_BINS, BPT = NB / NT, LOGNB = 13, U = 8;
     static_assert((1 << LOGNB) == NB && BPT % 4 == 0, "whole uint4 of bins per thread");
     static_assert(sizeof(sh.s) >= NB * sizeof(uint32_t), "the bins live in the network's key array");
     uint32_t* const hb = reinterpret_cast<uint32_t*>(sh.s);
@@ -853,7 +854,7 @@ __device__ __forceinline__ void sort_long_list(SortShared<GSR_SORT_BLOCK>& sh, c
         }
         if (crowded) { // exact ties: the network, in place in the list segment
             __syncthreads();
-            (void)sort_tile<GSR_SORT_BLOCK>(sh, r, pairs, point_list);
+            (void)sort_tile<KIND>(sh, r, pairs, point_list);
             __syncthreads();
             return;
         }
@@ -938,9 +939,11 @@ __device__ __forceinline__ void cut_quad_lists(Get get, const int n, const int q
     uint32_t cnt[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) cnt[q] = 0u;
+    uint2 nxt = get(min(lane, n - 1));
     for (int base = 0; base < n; base += 64) {
         const int k = base + lane;
-        const uint2 e = get(min(k, n - 1));
+        const uint2 e = nxt;
+        nxt = get(min(k + 64, n - 1)); // the next 64 entries are in flight while these are cut (a global round trip per step otherwise)
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             const uint32_t pm = k < n ? quad_mask_of_tile_mask(e.y, q0 + q) : 0u;
@@ -956,7 +959,7 @@ __device__ __forceinline__ void cut_quad_lists(Get get, const int n, const int q
 // Lists whose sorted ids and mask words sit in LDS (ids[i], msk[i]; nthreads threads of the workgroup share the list):
 // the untested entries are collected (their positions in `todo`, u16), tested in one batch — one gather of the two
 // 16-byte words per such entry — and then the lists are cut: four quads by the one wave, or one quad per wave.
-template <bool ONEWAVE>
+template <bool ONEWAVE, int UB>
 __device__ __forceinline__ void emit_from_lds(const uint32_t* ids, uint32_t* msk, uint16_t* todo, uint32_t* counter, const int n, const int tile,
                                               const int grid_x, const GeomView& g, uint2* __restrict__ qh, uint32_t* __restrict__ qcount4)
 {
@@ -964,14 +967,41 @@ __device__ __forceinline__ void emit_from_lds(const uint32_t* ids, uint32_t* msk
     const int tx = tile % grid_x, ty = tile / grid_x;
     if (tid == 0) *counter = 0u;
     sort_sync<ONEWAVE>();
-    for (int i = tid; i < n; i += nt)
-        if (msk[i] & GSR_MASK_UNTESTED) todo[lds_take(counter)] = (uint16_t)i;
+    for (int i0 = 0; i0 < n; i0 += nt) { // one LDS atomic per wave and step, not per entry: a map of fat splats has every entry here
+        const int i = i0 + tid;
+        const bool u = i < n && (msk[min(i, n - 1)] & GSR_MASK_UNTESTED) != 0u;
+        const unsigned long long m = __ballot(u);
+        if (m) {
+            uint32_t base = 0u;
+            if ((tid & 63) == 0) base = __hip_atomic_fetch_add(counter, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (u) todo[base + (uint32_t)mbcnt64(m)] = (uint16_t)i;
+        }
+    }
     sort_sync<ONEWAVE>();
     const int nu = (int)*counter;
-    for (int u = tid; u < nu; u += nt) {
-        const int i = todo[u];
-        const uint32_t id = ids[i];
-        msk[i] = exact_tile_mask(g.g0[id], g.g1[id], tx, ty);
+    // UB entries per thread have their records gathered together (a map of fat splats has every entry here)
+    if constexpr (UB == 1) {
+        for (int u = tid; u < nu; u += nt) {
+            const int i = todo[u];
+            const uint32_t id = ids[i];
+            msk[i] = exact_tile_mask(g.g0[id], g.g1[id], tx, ty);
+        }
+    } else
+    for (int u0 = 0; u0 < nu; u0 += nt * UB) {
+        int i[UB];
+        float4 a[UB], b[UB];
+#pragma unroll
+        for (int v = 0; v < UB; v++) {
+            i[v] = todo[min(u0 + v * nt + tid, nu - 1)];
+            const uint32_t id = ids[i[v]];
+            a[v] = g.g0[id]; b[v] = g.g1[id];
+        }
+#pragma unroll
+        for (int v = 0; v < UB; v++) {
+            const uint32_t m = exact_tile_mask(a[v], b[v], tx, ty);
+            if (u0 + v * nt + tid < nu) msk[i[v]] = m;
+        }
     }
     sort_sync<ONEWAVE>();
     auto get = [&](int i) { return make_uint2(ids[i], msk[i]); };
@@ -981,21 +1011,43 @@ __device__ __forceinline__ void emit_from_lds(const uint32_t* ids, uint32_t* msk
 // Lists without their mask words at hand (the bitonic network ran: exact depth ties; or the list went through global
 // scratch): ids read back from point_list (just written by this workgroup: made visible by the fence + barrier, read past
 // the L1), the mask recomputed from the gathered centre and reach word; wave w of the workgroup cuts quad w.
+template <int U>
 __device__ __forceinline__ void emit_from_global(const uint2 r, const int tile, const int grid_x, const GeomView& g,
-                                                 const uint32_t* point_list, uint2* __restrict__ qhits, uint32_t* __restrict__ qcount)
+                                                 const uint32_t* point_list, uint64_t* __restrict__ pairs, uint2* __restrict__ qhits,
+                                                 uint32_t* __restrict__ qcount)
 {
+    // Two phases. (1) every thread of the workgroup: sorted id -> reach entry -> tile mask (exact test for the larger splats),
+    // U independent chains per thread, (id, mask) parked in the list's key segment (`pairs`: dead once the list is sorted).
+    // (2) one wave per quad cuts its list out of the parked pairs: coalesced, independent loads, one step ahead.
+    // (One pass used to do both, every 64-entry step waiting for two dependent global round trips — id, then its reach
+    // entry: 3.9 ms of a 5.7 ms step at 10 M splats.)
     __threadfence();
     __syncthreads();
     const uint32_t* pl = point_list + r.x;
+    uint64_t* const pm = pairs + r.x;
+    const int n = (int)(r.y - r.x), tid = (int)threadIdx.x, nt = (int)blockDim.x;
     const int tx = tile % grid_x, ty = tile / grid_x;
-    cut_quad_lists<1>(
-        [&](int i) {
-            const uint32_t id = __hip_atomic_load(pl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t m = tile_mask_from_reach(g.reach[id], tx, ty);
-            if (m & GSR_MASK_UNTESTED) m = exact_tile_mask(g.g0[id], g.g1[id], tx, ty);
-            return make_uint2(id, m);
-        },
-        (int)(r.y - r.x), (int)(threadIdx.x >> 6), qhits + 4 * (size_t)r.x, qcount + 4 * (size_t)tile);
+    for (int i0 = 0; i0 < n; i0 += nt * U) {
+        uint32_t id[U];
+        uint2 re[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) id[u] = __hip_atomic_load(pl + min(i0 + u * nt + tid, n - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < U; u++) re[u] = g.reach[id[u]];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            uint32_t m = tile_mask_from_reach(re[u], tx, ty);
+            if (m & GSR_MASK_UNTESTED) m = exact_tile_mask(g.g0[id[u]], g.g1[id[u]], tx, ty);
+            if (i0 + u * nt + tid < n) pm[i0 + u * nt + tid] = (uint64_t)id[u] | ((uint64_t)m << 32);
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    auto get = [&](int i) {
+        const uint64_t v = __hip_atomic_load(pm + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+    };
+    cut_quad_lists<1>(get, n, (int)(threadIdx.x >> 6), qhits + 4 * (size_t)r.x, qcount + 4 * (size_t)tile);
 }
 
 // The rasterizer's sort, two launches. K_tile_sort_short: one 256-thread workgroup per tile, for the lists of up to 1024
@@ -1033,46 +1085,58 @@ K_tile_sort_short(int T, int grid_x, const uint2* __restrict__ ranges, GeomView 
     if (where == GSR_IDS_H) { // ids in h, mask words in the first 4 KB of the key array, the to-do list behind them
         __syncthreads();
         uint32_t* const msk = sort_payload(sh);
-        emit_from_lds<false>(sh.h, msk, reinterpret_cast<uint16_t*>(msk + GSR_SORT_SMALL), &counter, n, tile, grid_x, g, qhits + 4 * (size_t)r.x, qc4);
+        emit_from_lds<false, 1>(sh.h, msk, reinterpret_cast<uint16_t*>(msk + GSR_SORT_SMALL), &counter, n, tile, grid_x, g, qhits + 4 * (size_t)r.x, qc4);
     } else { // the network ran (exact depth ties)
-        emit_from_global(r, tile, grid_x, g, point_list, qhits, qcount);
+        emit_from_global<1>(r, tile, grid_x, g, point_list, pairs, qhits, qcount); // (rare here: keep the short kernel's registers)
     }
 }
 
-#define GSR_SORT_ALL_LONG 256
-#define GSR_SORT_ALL_MID 512
+#define GSR_SORT_LONG_GRID 512 // two workgroups per CU are resident (216 VGPRs, 48 KB of LDS)
 __global__ void __launch_bounds__(GSR_SORT_BIG_THREADS)
 K_tile_sort_long(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g, uint64_t* __restrict__ pairs,
-                 uint32_t* __restrict__ point_list, uint2* __restrict__ qhits, const uint32_t* __restrict__ sortq, uint32_t* __restrict__ qcount)
+                 uint32_t* __restrict__ point_list, uint2* __restrict__ qhits, uint32_t* __restrict__ sortq, uint32_t* __restrict__ qcount)
 {
     __shared__ SortShared<GSR_SORT_BLOCK> sh;
     __shared__ uint32_t counter;
     if (g.hdr->overflow) return;
-    int b = blockIdx.x;
-    if (b < GSR_SORT_ALL_LONG) {
-        const uint32_t cnt = sortq[1];
-        for (uint32_t t = b; t < cnt; t += GSR_SORT_ALL_LONG) {
+    if (sortq[0] + sortq[1] == 0u) return; // (the 1 M-splat headline frame: every list is short)
+    // The launch's workgroups pop tiles from the two queues (the longest lists first) through one counter, zeroed by
+    // K_scan_tiles: a frame whose lists are all of one class (10 M splats: every list over 4096 entries) has the whole grid
+    // at work, and a frame with both classes no workgroup that is handed a long list AND its share of the others.
+    __shared__ uint32_t next;
+    const uint32_t nlong = sortq[1], total = nlong + sortq[0];
+    for (;;) {
+        if (threadIdx.x == 0) next = __hip_atomic_fetch_add(&sortq[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const uint32_t t = next;
+        __syncthreads(); // everybody has read it
+        if (t >= total) break;
+        if (t < nlong) {
             const int tile = (int)sortq[GSR_SORTQ_HEAD + T + t];
             const uint2 r = ranges[tile];
-            sort_long_list(sh, r, pairs, point_list, qhits);
-            emit_from_global(r, tile, grid_x, g, point_list, qhits, qcount); // (the sort's scratch in qhits is dead by now)
-            __syncthreads();
-        }
-        return;
-    }
-    b -= GSR_SORT_ALL_LONG;
-    const uint32_t cnt = sortq[0];
-    for (uint32_t t = b; t < cnt; t += GSR_SORT_ALL_MID) {
-        const int tile = (int)sortq[GSR_SORTQ_HEAD + t];
-        const uint2 r = ranges[tile];
-        const int where = sort_tile<GSR_SORT_BLOCK>(sh, r, pairs, point_list, g.reach, tile % grid_x, tile / grid_x);
-        if (where == GSR_IDS_H) { // ids in h, mask words in the first 16 KB of the key array, the to-do list behind them
-            __syncthreads();
-            uint32_t* const msk = sort_payload(sh);
-            emit_from_lds<false>(sh.h, msk, reinterpret_cast<uint16_t*>(msk + GSR_SORT_CAP), &counter, (int)(r.y - r.x), tile, grid_x, g,
-                                 qhits + 4 * (size_t)r.x, qcount + 4 * (size_t)tile);
+            sort_long_list<GSR_SORT_BLOCK>(sh, r, pairs, point_list, qhits);
+            emit_from_global<4>(r, tile, grid_x, g, point_list, pairs, qhits, qcount); // (the sort's scratch in qhits is dead by now)
         } else {
-            emit_from_global(r, tile, grid_x, g, point_list, qhits, qcount);
+            const int tile = (int)sortq[GSR_SORTQ_HEAD + (t - nlong)];
+            const uint2 r = ranges[tile];
+#ifdef GSR_EXP_LONG_NOGATHER
+            const int where = sort_tile<GSR_SORT_BLOCK>(sh, r, pairs, point_list, nullptr, tile % grid_x, tile / grid_x);
+#else
+            const int where = sort_tile<GSR_SORT_BLOCK>(sh, r, pairs, point_list, g.reach, tile % grid_x, tile / grid_x);
+#endif
+#ifdef GSR_EXP_LONG_NOEMIT
+            if (threadIdx.x < 4u) qcount[4 * (size_t)tile + threadIdx.x] = 0u;
+            __syncthreads();
+            continue;
+#endif
+            if (where == GSR_IDS_H) { // ids in h, mask words in the first 16 KB of the key array, the to-do list behind them
+                __syncthreads();
+                uint32_t* const msk = sort_payload(sh);
+                emit_from_lds<false, 4>(sh.h, msk, reinterpret_cast<uint16_t*>(msk + GSR_SORT_CAP), &counter, (int)(r.y - r.x), tile, grid_x, g,
+                                        qhits + 4 * (size_t)r.x, qcount + 4 * (size_t)tile);
+            } else {
+                emit_from_global<4>(r, tile, grid_x, g, point_list, pairs, qhits, qcount);
+            }
         }
         __syncthreads();
     }
