@@ -209,7 +209,7 @@ __device__ __forceinline__ float pair_power2(float dx, float dy, float ca2, floa
 // hoisted out of the NW x NW loop.
 struct ReachSetup {
     float ax, ay, hca, hcc, cb, kx, ky, tau;
-    bool pd, never, small;
+    bool pd, never, small, medium;
 };
 __device__ __forceinline__ ReachSetup reach_setup(float px, float py, float conic_a, float conic_b, float conic_c, float op)
 {
@@ -228,21 +228,26 @@ __device__ __forceinline__ ReachSetup reach_setup(float px, float py, float coni
     // splats reach 2.2 .. 6.3 pixels)
     const float lim = 64.0f * 0.9f * det;
     s.small = s.pd && 2.f * s.tau * cc <= lim && 2.f * s.tau * ca <= lim;
+    // "medium": both half extents below ~15.2 pixels — the ellipse cannot leave the 5x5 QUADS (8x8 pixels) around the quad that
+    // holds its centre. Its reach is decided per quad (a quad that is reached counts as reached in all four of its patches:
+    // the blend loop tests every pixel anyway); splats that have grown beyond their single-pixel initialisation live here.
+    s.medium = s.pd && !s.small && 2.f * s.tau * cc <= 4.f * lim && 2.f * s.tau * ca <= 4.f * lim;
     return s;
 }
+// `cell`: pixels per cell side (4: patches, 8: quads) — a per-lane value, so that small and medium splats of a wave share the code
 template <int NW>
-__device__ __forceinline__ uint32_t window_reach(const ReachSetup& s, float wx, float wy)
+__device__ __forceinline__ uint32_t window_reach(const ReachSetup& s, float wx, float wy, float cell = 4.f)
 {
     float dl[NW], dh[NW], el[NW], eh[NW], Ax[NW], Bx[NW], Kx[NW], Ay[NW], By[NW], Ky[NW];
     uint32_t zc = 0u, zr = 0u; // columns / rows whose range contains the centre coordinate
 #pragma unroll
     for (int i = 0; i < NW; i++) {
-        dl[i] = s.ax - (wx + 4.f * i + 3.f); dh[i] = s.ax - (wx + 4.f * i);
+        dl[i] = s.ax - (wx + cell * i + (cell - 1.f)); dh[i] = s.ax - (wx + cell * i);
         const float dc = __builtin_amdgcn_fmed3f(0.f, dl[i], dh[i]); // point of the range closest to 0 (one v_med3 instead of max + min; a NaN gives the lower end, like the pair did)
         Ax[i] = dc != 0.f ? s.hca * dc * dc : 3.0e38f;    // a side faces the centre only if the centre is outside the range
         Bx[i] = s.cb * dc; Kx[i] = s.kx * dc;
         zc |= dc == 0.f ? 1u << i : 0u;
-        el[i] = s.ay - (wy + 4.f * i + 3.f); eh[i] = s.ay - (wy + 4.f * i);
+        el[i] = s.ay - (wy + cell * i + (cell - 1.f)); eh[i] = s.ay - (wy + cell * i);
         const float ec = __builtin_amdgcn_fmed3f(0.f, el[i], eh[i]);
         Ay[i] = ec != 0.f ? s.hcc * ec * ec : 3.0e38f;
         By[i] = s.cb * ec; Ky[i] = s.ky * ec;
@@ -263,45 +268,50 @@ __device__ __forceinline__ uint32_t window_reach(const ReachSetup& s, float wx, 
     }
     return mask;
 }
-// What K_preprocess keeps in col.w next to the three SH clamp flags (bits 0..2):
+// The reach word K_preprocess writes into the splat's entry of the dense reach array (neither bit 2 nor bit 3: decided per
+// tile instance by the tile sort, exact_tile_mask):
 //   bit 3 "small"  : the 25 bits below are the splat's complete patch reach
 //   bits 4..28     : reach over the 5x5 patches whose first patch is column floor(px/4) - 2, row floor(py/4) - 2
 //                    of the GLOBAL patch grid (patch column c = pixels 4c .. 4c+3)
+//   bit 2 "medium" : the 25 bits below are the splat's complete QUAD reach: 5x5 quads (8x8 pixels) whose first quad is column
+//                    floor(px/8) - 2, row floor(py/8) - 2 of the global quad grid
 #define GSR_REACH_SMALL 8u
+#define GSR_REACH_MEDIUM 4u
 __device__ __forceinline__ uint32_t splat_reach25(float px, float py, float conic_a, float conic_b, float conic_c, float op)
 {
     const ReachSetup s = reach_setup(px, py, conic_a, conic_b, conic_c, op);
     if (s.never) return GSR_REACH_SMALL; // reaches nothing
-    if (!s.small) return 0u;
-    const float wx = 4.f * (floorf(px * 0.25f) - 2.f), wy = 4.f * (floorf(py * 0.25f) - 2.f);
-    return GSR_REACH_SMALL | (window_reach<5>(s, wx, wy) << 4);
+    if (!s.small && !s.medium) return 0u;
+    const float cell = s.small ? 4.f : 8.f, inv = s.small ? 0.25f : 0.125f;
+    const float wx = cell * (floorf(px * inv) - 2.f), wy = cell * (floorf(py * inv) - 2.f);
+    return (s.small ? GSR_REACH_SMALL : GSR_REACH_MEDIUM) | (window_reach<5>(s, wx, wy, cell) << 4);
 }
-// The 2x2 patches of the 8x8 quad whose first patch is (qcx, qcy) of the global patch grid, from a small splat's word:
-// bit (j * 2 + i) = patch (qcx + i, qcy + j).
-__device__ __forceinline__ uint32_t quad_mask_from_word(uint32_t colw, float px, float py, int qcx, int qcy)
-{
-    const uint32_t m = colw >> 4;
-    const int sh = qcx - (int)floorf(px * 0.25f) + 3; // = first window column of the quad + 1: the 5-bit row is shifted up by one
-    const int j0 = qcy - (int)floorf(py * 0.25f) + 2; // first window row of the quad
-    const uint32_t r0 = (uint32_t)j0 < 5u ? (m >> (5 * j0)) & 31u : 0u;
-    const uint32_t r1 = (uint32_t)(j0 + 1) < 5u ? (m >> (5 * (j0 + 1))) & 31u : 0u;
-    const uint32_t c0 = (uint32_t)sh <= 5u ? ((r0 << 1) >> sh) & 3u : 0u;
-    const uint32_t c1 = (uint32_t)sh <= 5u ? ((r1 << 1) >> sh) & 3u : 0u;
-    return c0 | (c1 << 2);
-}
-
-// The same for the 4x4 patches of a whole 16x16 tile (tx, ty): bit (j * 4 + i) = patch (4 tx + i, 4 ty + j), from the
-// splat's entry of the dense reach array (K_preprocess). Splats that are not "small" get GSR_MASK_UNTESTED.
+// The 4x4 patches of a whole 16x16 tile (tx, ty): bit (j * 4 + i) = patch (4 tx + i, 4 ty + j), from the
+// splat's entry of the dense reach array (K_preprocess). Splats that are neither "small" nor "medium" get GSR_MASK_UNTESTED.
 #define GSR_MASK_UNTESTED 0x10000u
 __device__ __forceinline__ uint2 reach_entry(uint32_t word, float px, float py)
 {
     const int pcx = max(-32768, min(32767, (int)floorf(px * 0.25f))), pcy = max(-32768, min(32767, (int)floorf(py * 0.25f)));
-    return make_uint2(word & ~7u, ((uint32_t)pcx & 0xFFFFu) | ((uint32_t)pcy << 16));
+    return make_uint2(word & ~3u, ((uint32_t)pcx & 0xFFFFu) | ((uint32_t)pcy << 16));
 }
 __device__ __forceinline__ uint32_t tile_mask_from_reach(uint2 re, int tx, int ty)
 {
-    if (!(re.x & GSR_REACH_SMALL)) return GSR_MASK_UNTESTED;
+    if (!(re.x & (GSR_REACH_SMALL | GSR_REACH_MEDIUM))) return GSR_MASK_UNTESTED;
     const uint32_t m = re.x >> 4;
+    if (!(re.x & GSR_REACH_SMALL)) { // medium: quad (2 tx + i, 2 ty + j) of the tile, reached = all four of its patches
+        const int sx = 2 * tx - ((int)(short)(re.y & 0xFFFFu) >> 1) + 2; // window column / row of the tile's first quad
+        const int sy = 2 * ty - (((int)re.y >> 16) >> 1) + 2;
+        uint32_t out = 0u;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int wc = sx + i, wr = sy + j;
+                const bool hit = (uint32_t)wc < 5u && (uint32_t)wr < 5u && ((m >> (5 * wr + wc)) & 1u) != 0u;
+                out |= hit ? 0x33u << (8 * j + 2 * i) : 0u;
+            }
+        return out;
+    }
     const int sx = 4 * tx - (int)(short)(re.y & 0xFFFFu) + 2; // window column / row of the tile's first patch
     const int sy = 4 * ty - ((int)re.y >> 16) + 2;
     uint32_t out = 0u;

@@ -915,19 +915,25 @@ __device__ __forceinline__ void sort_long_list(SortShared<KIND>& sh, const uint2
 // them in one batch per list.
 __device__ __forceinline__ uint32_t exact_tile_mask(const float4 a, const float4 b, const int tx, const int ty)
 {
-    const float4 A = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
-    const float4 B = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, 0.f, 0.f);
+    // (only splats whose alpha >= 1/255 region extends beyond ~15 pixels come here: a quad such a splat reaches counts as reached in
+    // all four of its patches — the exact patch test cost more here than the few border patches it removed from the blend lists)
     uint32_t m16 = 0u;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const float X0 = (float)(tx * 16 + (q & 1) * 8), Y0 = (float)(ty * 16 + (q >> 1) * 8);
+#ifdef GSR_EXP_EXACT_PATCH
         if (quad_reach(a, b, X0, Y0)) {
+            const float4 A = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
+            const float4 B = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, 0.f, 0.f);
             bool h[4];
             patch_reach4(A, B, X0, Y0, h);
             const uint32_t sh = 8 * (q >> 1) + 2 * (q & 1);
             m16 |= ((h[0] ? 1u : 0u) | (h[1] ? 2u : 0u)) << sh;
             m16 |= ((h[2] ? 1u : 0u) | (h[3] ? 2u : 0u)) << (sh + 4);
         }
+#else
+        if (quad_reach(a, b, X0, Y0)) m16 |= 0x33u << (8 * (q >> 1) + 2 * (q & 1));
+#endif
     }
     return m16;
 }
