@@ -538,8 +538,9 @@ def rasterize(a, gsr, td, rank, world, dev):
                        "parallelism": f"scene-shard x{world}" if world > 1 else "single GPU",
                        "omitted_stores": "dL_dconic and dL_dcov3D are not materialised (the operator wrappers pass no buffer for them on the "
                                          "scales + rotations path: INTEGRATION.md section 3); the reference kernel stores both"},
-            "roofline": {"bound": "hbm", "limiter": "VALU issue (and the LDS pipe beside it), not HBM: see roofline_valu — the contract's "
-                                                    "HBM figure is reported as asked",
+            "roofline": {"bound": "hbm", "limiter": "instruction issue and the latency of a wave's own instruction chain at 12 waves per CU (VALU pipe 0.55 busy, "
+                                                    "LDS pipe 0.66), not HBM: see roofline_valu and DESIGN.md section 4 — the contract's HBM figure is "
+                                                    "reported as asked",
                          "kernel": "K_blend_bwd", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes": alg_bytes, "avg_launch_ms": bwd_blend_ms,
