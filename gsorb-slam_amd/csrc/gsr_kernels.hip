@@ -474,11 +474,15 @@ __device__ __forceinline__ void lds_sort(uint64_t* s, int cap)
 #define GSR_SORT_WAVE 0
 #define GSR_SORT_BLOCK 1
 #define GSR_SORT_BLOCK_SHORT 2
+// KIND 4: 256 threads per list of <= 2048 keys, 8 keys per thread: the lower half of K_tile_sort_long's middle class (a list of
+// 1 300 keys in KIND 1's 4096 slots is mostly padding work)
+#define GSR_SORT_BLOCK_HALF 4
 template <int KIND>
 struct SortShared {
-    static constexpr int NT = KIND == 0 ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS, CAP = KIND == 1 ? GSR_SORT_CAP : GSR_SORT_SMALL;
+    static constexpr int NT = KIND == 0 ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS;
+    static constexpr int CAP = KIND == 1 ? GSR_SORT_CAP : KIND == 4 ? GSR_SORT_CAP / 2 : GSR_SORT_SMALL;
     uint64_t s[CAP];
-    __attribute__((aligned(16))) uint32_t h[CAP + 4];
+    __attribute__((aligned(16))) uint32_t h[CAP + 64]; // 64 spare words: one per lane for the padding keys' (zero) atomics
     uint32_t red[9][NT / 64];
 };
 // reach (rasterizer only): the dense per-splat reach array; every key's entry is gathered through its id as soon as the
@@ -497,7 +501,7 @@ __device__ __forceinline__ int sort_tile(SortShared<KIND>& sh, const uint2 r, ui
                                          const uint2* __restrict__ reach = nullptr, int tx = 0, int ty = 0)
 {
     constexpr int NT = SortShared<KIND>::NT, CAP = SortShared<KIND>::CAP;
-    constexpr int EPT = CAP / NT, LOGCAP = CAP == 1024 ? 10 : 12, MATES = EPT < GSR_SORT_MATES ? EPT : GSR_SORT_MATES;
+    constexpr int EPT = CAP / NT, LOGCAP = CAP == 1024 ? 10 : CAP == 2048 ? 11 : 12, MATES = EPT < GSR_SORT_MATES ? EPT : GSR_SORT_MATES;
     static_assert(EPT % 4 == 0 && (1 << LOGCAP) == CAP, "whole uint4 of bins per thread");
     uint64_t* const s = sh.s;
     uint32_t* const h = sh.h;
@@ -539,7 +543,9 @@ __device__ __forceinline__ int sort_tile(SortShared<KIND>& sh, const uint2 r, ui
 #pragma unroll
         for (int j = 0; j < EPT; j++) {
             const bool valid = j * NT + tid < n;
-            bin[j] = valid ? ((uint32_t)(k[j] >> 32) - dmin) >> shift : (uint32_t)(CAP + (lane & 3)); // padding: four spare words
+            // padding keys: a spare word per lane (four spare words for all of them were 700 returning atomics per address on a
+            // 1 300-key list in 4096 slots)
+            bin[j] = valid ? ((uint32_t)(k[j] >> 32) - dmin) >> shift : (uint32_t)(CAP + lane);
             rnk[j] = __hip_atomic_fetch_add(&h[bin[j]], valid ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         sort_sync<KIND == 0>();
@@ -599,7 +605,7 @@ __device__ __forceinline__ int sort_tile(SortShared<KIND>& sh, const uint2 r, ui
                 const bool valid = j * NT + tid < n;
                 const uint32_t m = h[min(bin[j], (uint32_t)CAP - 1u)];
                 const uint32_t inside = (((uint32_t)(k[j] >> 32) - dmin) - (bin[j] << shift)) >> down;
-                bin[j] = valid ? (m & 0xFFFFu) + ((inside * (m >> 16)) >> frac) : (uint32_t)(CAP + (lane & 3));
+                bin[j] = valid ? (m & 0xFFFFu) + ((inside * (m >> 16)) >> frac) : (uint32_t)(CAP + lane);
                 rnk[j] = __hip_atomic_fetch_add(&h2[bin[j]], valid ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             sort_sync<KIND == 0>();
@@ -1125,11 +1131,16 @@ K_tile_sort_long(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g
         } else {
             const int tile = (int)sortq[GSR_SORTQ_HEAD + (t - nlong)];
             const uint2 r = ranges[tile];
+            const int n = (int)(r.y - r.x);
+            const bool half = n <= GSR_SORT_CAP / 2; // the shorter lists of the class in half the slots (8 keys per thread)
+            auto& shh = reinterpret_cast<SortShared<GSR_SORT_BLOCK_HALF>&>(sh);
 #ifdef GSR_EXP_LONG_NOGATHER
-            const int where = sort_tile<GSR_SORT_BLOCK>(sh, r, pairs, point_list, nullptr, tile % grid_x, tile / grid_x);
+            const uint2* const reach = nullptr;
 #else
-            const int where = sort_tile<GSR_SORT_BLOCK>(sh, r, pairs, point_list, g.reach, tile % grid_x, tile / grid_x);
+            const uint2* const reach = g.reach;
 #endif
+            const int where = half ? sort_tile<GSR_SORT_BLOCK_HALF>(shh, r, pairs, point_list, reach, tile % grid_x, tile / grid_x)
+                                   : sort_tile<GSR_SORT_BLOCK>(sh, r, pairs, point_list, reach, tile % grid_x, tile / grid_x);
 #ifdef GSR_EXP_LONG_NOEMIT
             if (threadIdx.x < 4u) qcount[4 * (size_t)tile + threadIdx.x] = 0u;
             __syncthreads();
@@ -1138,8 +1149,8 @@ K_tile_sort_long(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g
             if (where == GSR_IDS_H) { // ids in h, mask words in the first 16 KB of the key array, the to-do list behind them
                 __syncthreads();
                 uint32_t* const msk = sort_payload(sh);
-                emit_from_lds<false, 4>(sh.h, msk, reinterpret_cast<uint16_t*>(msk + GSR_SORT_CAP), &counter, (int)(r.y - r.x), tile, grid_x, g,
-                                        qhits + 4 * (size_t)r.x, qcount + 4 * (size_t)tile);
+                emit_from_lds<false, 4>(half ? shh.h : sh.h, msk, reinterpret_cast<uint16_t*>(msk + (half ? GSR_SORT_CAP / 2 : GSR_SORT_CAP)), &counter, n, tile,
+                                        grid_x, g, qhits + 4 * (size_t)r.x, qcount + 4 * (size_t)tile);
             } else {
                 emit_from_global<4>(r, tile, grid_x, g, point_list, pairs, qhits, qcount);
             }
