@@ -109,7 +109,7 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     tm.begin(GSR_FWD_SORT);
     hipLaunchKernelGGL(gsr::K_tile_sort_short, dim3(T), dim3(GSR_SORT_BIG_THREADS), 0, st, T, f.grid_x, iv.ranges, gv, bv.pairs, bv.point_list,
                        bv.qhits, iv.qcount);
-    hipLaunchKernelGGL(gsr::K_tile_sort_long, dim3(GSR_SORT_LONG_GRID), dim3(GSR_SORT_BIG_THREADS), 0, st, T, f.grid_x, iv.ranges, gv,
+    hipLaunchKernelGGL(gsr::K_tile_sort_long, dim3(GSR_SORT_LONG_GRID), dim3(GSR_SORT_LONG_THREADS), 0, st, T, f.grid_x, iv.ranges, gv,
                        bv.pairs, bv.point_list, bv.qhits, iv.sortq, iv.qcount);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SORT);

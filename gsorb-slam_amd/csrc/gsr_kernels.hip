@@ -477,10 +477,16 @@ __device__ __forceinline__ void lds_sort(uint64_t* s, int cap)
 // KIND 4: 256 threads per list of <= 2048 keys, 8 keys per thread: the lower half of K_tile_sort_long's middle class (a list of
 // 1 300 keys in KIND 1's 4096 slots is mostly padding work)
 #define GSR_SORT_BLOCK_HALF 4
+#ifndef GSR_SORT_LONG_THREADS
+#define GSR_SORT_LONG_THREADS 256
+#endif
+// KIND 5 / 6: KIND 1 / 4 with GSR_SORT_LONG_THREADS threads (K_tile_sort_long)
+#define GSR_SORT_LONG_FULL 5
+#define GSR_SORT_LONG_HALF 6
 template <int KIND>
 struct SortShared {
-    static constexpr int NT = KIND == 0 ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS;
-    static constexpr int CAP = KIND == 1 ? GSR_SORT_CAP : KIND == 4 ? GSR_SORT_CAP / 2 : GSR_SORT_SMALL;
+    static constexpr int NT = KIND == 0 ? GSR_SORT_SMALL_THREADS : KIND >= 5 ? GSR_SORT_LONG_THREADS : GSR_SORT_BIG_THREADS;
+    static constexpr int CAP = (KIND == 1 || KIND == 5) ? GSR_SORT_CAP : (KIND == 4 || KIND == 6) ? GSR_SORT_CAP / 2 : GSR_SORT_SMALL;
     uint64_t s[CAP];
     __attribute__((aligned(16))) uint32_t h[CAP + 64]; // 64 spare words: one per lane for the padding keys' (zero) atomics
     uint32_t red[9][NT / 64];
@@ -684,7 +690,7 @@ __device__ __forceinline__ int sort_tile(SortShared<KIND>& sh, const uint2 r, ui
         return GSR_IDS_S;
     }
     // oversize tile: chunk-local stages in LDS, long-stride stages in global memory
-    if constexpr (KIND != GSR_SORT_BLOCK) return GSR_IDS_GLOBAL; // (only the 4096-key workgroups are handed such lists)
+    if constexpr (KIND != GSR_SORT_BLOCK && KIND != GSR_SORT_LONG_FULL) return GSR_IDS_GLOBAL; // (only the 4096-key workgroups are handed such lists)
     else {
     long n2 = GSR_SORT_CAP;
     while (n2 < n) n2 <<= 1;
@@ -1018,7 +1024,7 @@ __device__ __forceinline__ void emit_from_lds(const uint32_t* ids, uint32_t* msk
     sort_sync<ONEWAVE>();
     auto get = [&](int i) { return make_uint2(ids[i], msk[i]); };
     if (ONEWAVE) cut_quad_lists<4>(get, n, 0, qh, qcount4);
-    else cut_quad_lists<1>(get, n, (int)(threadIdx.x >> 6), qh, qcount4);
+    else if (threadIdx.x < 256u) cut_quad_lists<1>(get, n, (int)(threadIdx.x >> 6), qh, qcount4); // (waves 0..3: one quad each)
 }
 // Lists without their mask words at hand (the bitonic network ran: exact depth ties; or the list went through global
 // scratch): ids read back from point_list (just written by this workgroup: made visible by the fence + barrier, read past
@@ -1059,7 +1065,7 @@ __device__ __forceinline__ void emit_from_global(const uint2 r, const int tile, 
         const uint64_t v = __hip_atomic_load(pm + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
     };
-    cut_quad_lists<1>(get, n, (int)(threadIdx.x >> 6), qhits + 4 * (size_t)r.x, qcount + 4 * (size_t)tile);
+    if (threadIdx.x < 256u) cut_quad_lists<1>(get, n, (int)(threadIdx.x >> 6), qhits + 4 * (size_t)r.x, qcount + 4 * (size_t)tile);
 }
 
 // The rasterizer's sort, two launches. K_tile_sort_short: one 256-thread workgroup per tile, for the lists of up to 1024
@@ -1104,11 +1110,14 @@ K_tile_sort_short(int T, int grid_x, const uint2* __restrict__ ranges, GeomView 
 }
 
 #define GSR_SORT_LONG_GRID 512 // two workgroups per CU are resident (216 VGPRs, 48 KB of LDS)
-__global__ void __launch_bounds__(GSR_SORT_BIG_THREADS)
+#if GSR_SORT_LONG_THREADS == 512
+__attribute__((amdgpu_waves_per_eu(4, 4))) // two 8-wave workgroups per CU
+#endif
+__global__ void __launch_bounds__(GSR_SORT_LONG_THREADS)
 K_tile_sort_long(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g, uint64_t* __restrict__ pairs,
                  uint32_t* __restrict__ point_list, uint2* __restrict__ qhits, uint32_t* __restrict__ sortq, uint32_t* __restrict__ qcount)
 {
-    __shared__ SortShared<GSR_SORT_BLOCK> sh;
+    __shared__ SortShared<GSR_SORT_LONG_FULL> sh;
     __shared__ uint32_t counter;
     if (g.hdr->overflow) return;
     if (sortq[0] + sortq[1] == 0u) return; // (the 1 M-splat headline frame: every list is short)
@@ -1126,21 +1135,21 @@ K_tile_sort_long(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g
         if (t < nlong) {
             const int tile = (int)sortq[GSR_SORTQ_HEAD + T + t];
             const uint2 r = ranges[tile];
-            sort_long_list<GSR_SORT_BLOCK>(sh, r, pairs, point_list, qhits);
+            sort_long_list<GSR_SORT_LONG_FULL>(sh, r, pairs, point_list, qhits);
             emit_from_global<4>(r, tile, grid_x, g, point_list, pairs, qhits, qcount); // (the sort's scratch in qhits is dead by now)
         } else {
             const int tile = (int)sortq[GSR_SORTQ_HEAD + (t - nlong)];
             const uint2 r = ranges[tile];
             const int n = (int)(r.y - r.x);
             const bool half = n <= GSR_SORT_CAP / 2; // the shorter lists of the class in half the slots (8 keys per thread)
-            auto& shh = reinterpret_cast<SortShared<GSR_SORT_BLOCK_HALF>&>(sh);
+            auto& shh = reinterpret_cast<SortShared<GSR_SORT_LONG_HALF>&>(sh);
 #ifdef GSR_EXP_LONG_NOGATHER
             const uint2* const reach = nullptr;
 #else
             const uint2* const reach = g.reach;
 #endif
-            const int where = half ? sort_tile<GSR_SORT_BLOCK_HALF>(shh, r, pairs, point_list, reach, tile % grid_x, tile / grid_x)
-                                   : sort_tile<GSR_SORT_BLOCK>(sh, r, pairs, point_list, reach, tile % grid_x, tile / grid_x);
+            const int where = half ? sort_tile<GSR_SORT_LONG_HALF>(shh, r, pairs, point_list, reach, tile % grid_x, tile / grid_x)
+                                   : sort_tile<GSR_SORT_LONG_FULL>(sh, r, pairs, point_list, reach, tile % grid_x, tile / grid_x);
 #ifdef GSR_EXP_LONG_NOEMIT
             if (threadIdx.x < 4u) qcount[4 * (size_t)tile + threadIdx.x] = 0u;
             __syncthreads();
