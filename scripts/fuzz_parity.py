@@ -10,6 +10,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed0)
 worst = 0.0
+fails = []
 for it in range(n):
     W = int(rng.integers(17, 700)); H = int(rng.integers(17, 500))
     fx = float(rng.uniform(0.4, 1.5) * W); fy = float(fx * rng.uniform(0.9, 1.1))
@@ -44,5 +45,6 @@ for it in range(n):
     worst = max(worst, e)
     flag = "" if e <= 1e-4 else "  <-- FAIL"
     print(f"[{it}] {W}x{H} P={P} x{mult} {mode} R={f.num_rendered} knife={(~ok).mean():.4f} img={e_img:.1e} grad={max(errs.values()):.1e}{flag}", flush=True)
-    assert e <= 1e-4, errs
-print("worst", worst)
+    if e > 1e-4: fails.append((it, {k: float("%.2e" % v) for k, v in errs.items() if v > 1e-4}))
+print("worst", worst, "failures", fails)
+assert not fails
