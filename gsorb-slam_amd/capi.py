@@ -479,6 +479,13 @@ class _PixelLoss(torch.autograd.Function):
         c = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
         image, depth, sur, sil, frame_rgb, frame_depth = c(image), c(depth), c(sur), c(sil), c(frame_rgb), c(frame_depth)
         H, W = int(image.shape[-2]), int(image.shape[-1])
+        # the kernels take raw pointers: every plane must live on the image's device and hold H*W (3*H*W) floats
+        if not image.is_cuda or image.numel() != 3 * H * W:
+            raise GsrError("fused pixel loss: image must be a [3,H,W] tensor on the GPU")
+        for name, t, n in (("depth", depth, H * W), ("sur", sur, H * W), ("sil", sil, H * W), ("frame_rgb", frame_rgb, 3 * H * W),
+                           ("frame_depth", frame_depth, H * W)):
+            if t is not None and (t.device != dev or t.numel() != n):
+                raise GsrError(f"fused pixel loss: {name} must hold {n} elements on {dev} (got {tuple(t.shape)} on {t.device})")
         w3 = (C.c_float * 3)(*[float(x) for x in w])
         partial = torch.empty((LOSS_PARTIALS * 5,), dtype=torch.float32, device=dev)
         sums = torch.empty((8,), dtype=torch.float32, device=dev)
@@ -489,7 +496,7 @@ class _PixelLoss(torch.autograd.Function):
         ctx.saved = (image, depth, sil, frame_rgb, frame_depth, sums)
         ctx.cfg = (H, W, int(mode), float(sil_thr), w3)
         ctx.mark_non_differentiable(sums)
-        return sums[5], sums
+        return sums[5].clone(), sums   # (the loss is not a view of the buffer saved for backward)
 
     @staticmethod
     def backward(ctx, go, _):
@@ -522,6 +529,8 @@ class _ScaleReg(torch.autograd.Function):
     @staticmethod
     def forward(ctx, log_scales, limit, w_long, w_scalar):
         ls = log_scales.detach().to(torch.float32).contiguous()
+        if not ls.is_cuda or ls.dim() != 2 or ls.shape[1] != 3:
+            raise GsrError("fused scale regularisers: log_scales must be an [n,3] tensor on the GPU")
         partial = torch.empty((LOSS_PARTIALS * 3,), dtype=torch.float32, device=ls.device)
         out = torch.empty((4,), dtype=torch.float32, device=ls.device)
         with torch.cuda.device(ls.device):
@@ -529,7 +538,7 @@ class _ScaleReg(torch.autograd.Function):
         ctx.saved = (ls, out)
         ctx.cfg = (float(limit), float(w_long), float(w_scalar))
         ctx.mark_non_differentiable(out)
-        return out[3], out
+        return out[3].clone(), out
 
     @staticmethod
     def backward(ctx, go, _):

@@ -78,9 +78,11 @@ struct Rt2TFn : public torch::autograd::Function<Rt2TFn> {
 };
 
 struct SsimFn : public torch::autograd::Function<SsimFn> {
-    static torch::Tensor forward(torch::autograd::AutogradContext* ctx, torch::Tensor img1, torch::Tensor img2, std::vector<double> taps)
+    // `need`: img1 wants a gradient — decided by the caller BEFORE apply(): inside forward() ctx->needs_input_grad() throws
+    // ("Index out of range") when nothing requires grad or grad mode is off (libtorch leaves next_edges empty then), i.e.
+    // exactly when SSIM is evaluated as a metric
+    static torch::Tensor forward(torch::autograd::AutogradContext* ctx, torch::Tensor img1, torch::Tensor img2, std::vector<double> taps, bool need)
     {
-        const bool need = ctx->needs_input_grad(0);
         const auto a = img1.contiguous(), b = img2.contiguous();
         c10::DeviceGuard guard(a.device());
         const int C = (int)a.size(0), H = (int)a.size(1), W = (int)a.size(2);
@@ -97,7 +99,7 @@ struct SsimFn : public torch::autograd::Function<SsimFn> {
     }
     static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::tensor_list g)
     {
-        if (!ctx->saved_data["need"].toBool()) return {torch::Tensor(), torch::Tensor(), torch::Tensor()};
+        if (!ctx->saved_data["need"].toBool()) return {torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor()};
         const auto saved = ctx->get_saved_variables();
         const auto &a = saved[0], &b = saved[1], &dmaps = saved[2];
         c10::DeviceGuard guard(a.device());
@@ -108,7 +110,7 @@ struct SsimFn : public torch::autograd::Function<SsimFn> {
         auto out = torch::empty_like(a);
         check(gsr_ssim_backward(fp(a), fp(b), fp(dmaps), (int)a.size(0), (int)a.size(1), (int)a.size(2), tp, fp(gm), out.data_ptr<float>(), stream_of(a)),
               "gsr_ssim_backward");
-        return {out, torch::Tensor(), torch::Tensor()};
+        return {out, torch::Tensor(), torch::Tensor(), torch::Tensor()};
     }
 };
 
@@ -122,6 +124,14 @@ struct PixelLossFn : public torch::autograd::Function<PixelLossFn> {
         const auto im = c(image), d = c(depth), su = c(sur), si = c(sil), fr = c(frgb), fd = c(fdepth);
         c10::DeviceGuard guard(im.device());
         const int H = (int)im.size(-2), W = (int)im.size(-1);
+        // the kernels take raw pointers: every plane must live on the image's device and hold H*W (3*H*W) floats
+        const int64_t N = (int64_t)H * W;
+        auto plane_ok = [&](const torch::Tensor& t, int64_t n, const char* name) {
+            TORCH_CHECK(!t.defined() || (t.device() == im.device() && t.scalar_type() == torch::kFloat32 && t.numel() == n),
+                        "fused pixel loss: ", name, " must be a float32 tensor of ", n, " elements on ", im.device());
+        };
+        TORCH_CHECK(im.is_cuda() && im.scalar_type() == torch::kFloat32 && im.numel() == 3 * N, "fused pixel loss: image must be a float32 [3,H,W] tensor on the GPU");
+        plane_ok(d, N, "depth"); plane_ok(su, N, "sur"); plane_ok(si, N, "sil"); plane_ok(fr, 3 * N, "frame_rgb"); plane_ok(fd, N, "frame_depth");
         const float w3[3] = {(float)w[0], (float)w[1], (float)w[2]};
         auto partial = torch::empty({GSR_LOSS_PARTIALS * 5}, im.options()), sums = torch::empty({8}, im.options());
         auto opt = [](const torch::Tensor& t) -> const float* { return t.defined() ? t.data_ptr<float>() : nullptr; };
@@ -133,7 +143,7 @@ struct PixelLossFn : public torch::autograd::Function<PixelLossFn> {
         ctx->saved_data["mode"] = mode;
         ctx->saved_data["thr"] = thr;
         ctx->saved_data["w"] = w;
-        return sums[5];
+        return sums[5].clone(); // (not a view of the buffer saved for backward: an in-place op on the loss would trip its version counter)
     }
     static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::tensor_list g)
     {
@@ -158,6 +168,7 @@ struct ScaleRegFn : public torch::autograd::Function<ScaleRegFn> {
     static torch::Tensor forward(torch::autograd::AutogradContext* ctx, torch::Tensor log_scales, double limit, double w_long, double w_scalar)
     {
         const auto ls = log_scales.detach().contiguous();
+        TORCH_CHECK(ls.is_cuda() && ls.scalar_type() == torch::kFloat32 && ls.dim() == 2 && ls.size(1) == 3, "fused scale regularisers: log_scales must be a float32 [n,3] tensor on the GPU");
         c10::DeviceGuard guard(ls.device());
         auto partial = torch::empty({GSR_LOSS_PARTIALS * 3}, ls.options()), out = torch::empty({4}, ls.options());
         check(gsr_scale_reg(fp(ls), (size_t)ls.size(0), (float)limit, (float)w_long, (float)w_scalar, partial.data_ptr<float>(), out.data_ptr<float>(),
@@ -166,7 +177,7 @@ struct ScaleRegFn : public torch::autograd::Function<ScaleRegFn> {
         ctx->saved_data["limit"] = limit;
         ctx->saved_data["wl"] = w_long;
         ctx->saved_data["ws"] = w_scalar;
-        return out[3];
+        return out[3].clone();
     }
     static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::tensor_list g)
     {
@@ -204,7 +215,8 @@ torch::Tensor to_camera(const torch::Tensor& Tcw, const torch::Tensor& X) { retu
 torch::Tensor rt2T(const torch::Tensor& quat, const torch::Tensor& trans) { return Rt2TFn::apply(quat, trans); }
 torch::Tensor ssim_mean(const torch::Tensor& img1, const torch::Tensor& img2, const std::vector<float>& taps11)
 {
-    return SsimFn::apply(img1, img2.detach(), std::vector<double>(taps11.begin(), taps11.end()));
+    const bool need = img1.requires_grad() && torch::GradMode::is_enabled();
+    return SsimFn::apply(img1, img2.detach(), std::vector<double>(taps11.begin(), taps11.end()), need);
 }
 
 void Adam::step()
