@@ -129,6 +129,185 @@ def parity_block(gsr, sc, s, ws, ins, dev):
             "indices_compared": "radii, ranges, sorted point_list, num_rendered"}
 
 
+def quick_raster(gsr, dev, cam, arrays, grad_in, steps=50, prewarm=30, dual=False, grad_ds=None):
+    """fwd+bwd of one scene through the sync-free C-ABI entry points, like the headline step (same buffers, same stages):
+    ms per step and the two blend kernels' live HIP-event averages. `arrays`: dict of numpy / torch inputs (means3D,
+    opacities, colors, scales, rotations, all activated and camera-frame). dual: the fused colour + depth / silhouette pass."""
+    s = gsr.capi.Settings.from_camera(cam, device=dev)
+    t = lambda x: torch.as_tensor(x, dtype=torch.float32, device=dev).contiguous()
+    ins = dict(means3D=t(arrays["means3D"]), opacities=t(arrays["opacities"]), colors=t(arrays["colors"]), shs=None,
+               scales=t(arrays["scales"]), rotations=t(arrays["rotations"]), cov3D=None)
+    P, W, H = int(ins["means3D"].shape[0]), cam.width, cam.height
+    g_in = t(grad_in)
+    g_ds = t(grad_ds) if dual else None
+    st0 = gsr.forward(s, ins["means3D"], ins["opacities"], colors=ins["colors"], scales=ins["scales"], rotations=ins["rotations"])
+    R, V = st0.num_rendered, int((st0.radii > 0).sum())
+    del st0
+    ws = gsr.capi.Workspace(P, W, H, max_rendered=int(R * 1.25) + 1024, device=dev)
+    grads = gsr.capi.alloc_grads(P, 0, dev, intermediates=False)
+    hip = _hip()
+    stream = torch.cuda.current_stream().cuda_stream
+    ev = []
+    for _ in range(steps):
+        e = [C.c_void_p() for _ in range(4)]
+        for x in e:
+            hip.hipEventCreate(C.byref(x))
+        f = (C.c_void_p * 10)()
+        b = (C.c_void_p * 6)()
+        f[8], f[9] = e[2], e[3]     # GSR_FWD_BLEND
+        b[2], b[3] = e[0], e[1]     # GSR_BWD_BLEND
+        ev.append((e, f, b))
+
+    def step(fe=None, be=None):
+        st = gsr.forward_ws(s, ws, ins, None, events=fe, dual=dual)
+        gsr.backward(st, g_in, grads=grads, events=be, once=True, dL_dds=g_ds)
+    for _ in range(prewarm):
+        step()
+    n, ovf = ws.status()
+    assert not ovf and n == R, (n, R, ovf)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e, f, b in ev:
+        step(f, b)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / max(steps, 1) * 1e3
+
+    def avg(i0, i1):
+        tot = 0.0
+        for e, _, _ in ev:
+            v = C.c_float(0)
+            hip.hipEventElapsedTime(C.byref(v), e[i0], e[i1])
+            tot += v.value
+        return tot / max(steps, 1)
+    return {"splats": P, "width": W, "height": H, "visible": V, "tile_instances": R, "ms_per_step": ms,
+            "bwd_blend_ms": avg(0, 1), "fwd_blend_ms": avg(2, 3), "steps": steps, "prewarm_steps": prewarm,
+            "splats_pixels_per_s": P * W * H / (ms * 1e-3)}
+
+
+def post_mapping_map(gsr, dev, P=300_000, iters=100):
+    """BASELINE config 2's stand-in for a TRAINED map (no dataset offline): a Replica-camera map of P SinglePixel-initialised
+    Gaussians (src/Gaussian.cc:70-74) put through the harness's own mapping loop — one densification (Render.cc:557-594),
+    `iters` mapping iterations with the scale regularisers (Render.cc:420-483), one opacity pruning (Render.cc:598-616) —
+    against the render of a fatter 'true' scene (splats 3x the single-pixel size), so that the optimiser grows and reshapes
+    the splats like a mapping session does. Returns the camera, the optimised map's activated parameters and what happened."""
+    syn = gsr.synthetic
+    hz = __import__("gsorb_slam_amd.harness", fromlist=["x"])
+    camd = syn.CAMERAS["replica"]
+    cam = syn.make_camera(**camd)
+    W, H = cam.width, cam.height
+    truth = syn.make_scene(P, cam, seed=77, scale_mult=3.0)
+    def as_map(sc, noise):
+        g = hz.GaussianMap(hz.Config(), camd["fx"], camd["fy"], device=dev)
+        rng = np.random.default_rng(5)
+        xyz = sc.means3D + noise * 0.003 * rng.standard_normal(sc.means3D.shape).astype(np.float32)
+        col = np.clip(sc.colors + noise * 0.1 * rng.standard_normal(sc.colors.shape), 0, 1).astype(np.float32)
+        g.add_points(torch.tensor(xyz), torch.tensor(col))
+        return g
+    gt = as_map(truth, 0.0)
+    op = torch.tensor(truth.opacities)
+    with torch.no_grad():
+        gt.log_scales.copy_(torch.log(torch.tensor(truth.scales))); gt.unnorm_quat.copy_(torch.tensor(truth.rotations))
+        gt.logit_opacities.copy_(torch.log(op / (1 - op)))
+        T = torch.eye(4, device=dev)
+        rgb, sur, _ = hz.SlamRenderer(gt, W, H).render_rgb(T, tracking=True)
+    frame = hz.Frame(rgb.clone(), sur[0].clone(), T)
+    # the map under optimisation: every 2nd true point, single-pixel sized (holes: the densification has something to add)
+    sub = syn.Scene(cam, truth.means3D[::2], truth.scales[::2], truth.rotations[::2], truth.opacities[::2], truth.colors[::2])
+    g = as_map(sub, 1.0)
+    g.scene_radius = float(np.abs(truth.means3D).max())
+    r = hz.SlamRenderer(g, W, H)
+    n0 = len(g)
+    added = r.densify(frame)
+    losses = r.map_frames([frame], iters=iters)
+    pruned = r.remove_low_opacity()
+    with torch.no_grad():
+        opac, scales, rots = r.activations(g.unnorm_quat, g.logit_opacities, g.log_scales)
+        arrays = dict(means3D=g.xyz.detach().clone(), opacities=opac.clone(), colors=g.rgb.detach().clone(), scales=scales.clone(), rotations=rots.clone())
+    rng = np.random.default_rng(11)
+    info = {"initial_splats": n0, "densified": int(added), "pruned": int(pruned), "mapping_iterations": iters,
+            "loss_first": float(losses[0]), "loss_last": float(losses[-1]),
+            "mean_scale_over_single_pixel": float((scales.mean(1) / (g.xyz[:, 2].abs() / camd["fx"])).mean())}
+    return cam, arrays, rng.standard_normal((3, H, W)).astype(np.float32), info
+
+
+def other_workloads(a, gsr, dev):
+    """The same fwd+bwd step on the other shapes BASELINE.json's configs describe, timed AFTER the headline (<= 50 steps each):
+    the round-3 build bought the headline with these, so the driver's line carries them from now on."""
+    syn = gsr.synthetic
+    out = {}
+    def synth(name, splats, camera, what, scale_mult=1.0, two_walls=False):
+        cam = syn.make_camera(**syn.CAMERAS[camera])
+        sc = syn.make_scene(splats, cam, seed=0, scale_mult=scale_mult)
+        if two_walls:
+            rng = np.random.default_rng(3)
+            z = np.where(rng.random(splats) < 0.5, 1.5, 4.0) + 0.02 * rng.random(splats)
+            sc.means3D = (sc.means3D * (z / sc.means3D[:, 2])[:, None]).astype(np.float32)
+        arrays = dict(means3D=sc.means3D, opacities=sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+        d = quick_raster(gsr, dev, cam, arrays, sc.dL_dpix, steps=a.other_steps)
+        d["what"] = what
+        out[name] = d
+    synth("scannet-2M", 2_000_000, "scannet", "2 M Gaussians, 640x480 ScanNet camera (BASELINE config 5's shape): tile lists of ~3 900 entries")
+    synth("fat-x4", 1_000_000, "replica", "the headline scene with every splat 4x the single-pixel size (beyond the 5x5-patch reach word)", scale_mult=4.0)
+    synth("scale-x2", 1_000_000, "replica", "the headline scene with every splat 2x the single-pixel size (lists just over 1024 entries)", scale_mult=2.0)
+    synth("two-walls", 1_000_000, "replica", "the headline scene with every splat on one of two thin depth slabs (the tile sort's crowded-bin case)", two_walls=True)
+    cam, arrays, g_in, info = post_mapping_map(gsr, dev)
+    d = quick_raster(gsr, dev, cam, arrays, g_in, steps=a.other_steps)
+    d["what"] = "a map AFTER mapping (BASELINE config 2's trained-map stand-in): see bench.py:post_mapping_map"
+    d["map"] = info
+    out["post-mapping-300k"] = d
+    return out
+
+
+def cpp_loop_ms(a, gsr, dev, P=1_000_000, track_iters=20, map_iters=20):
+    """The C++ loop driver (torch_ext/SlamLoop.{h,cpp} in libgsr_torch.so) at the headline frame: ms per tracking iteration and
+    per mapping iteration, through tests/cpp/slam_loop_main.bin on a scene file (the same front end tests/test_gpu_cpp_loop.py
+    uses), and the fused rasterizer pair (colour + depth / silhouette in one pass, fwd+bwd) of the same scene through the C ABI."""
+    import struct
+    import subprocess
+    import tempfile
+    syn = gsr.synthetic
+    hz = __import__("gsorb_slam_amd.harness", fromlist=["x"])
+    exe = os.path.join(ROOT, "tests", "cpp", "slam_loop_main.bin")
+    if not os.path.exists(exe):
+        return {"error": "tests/cpp/slam_loop_main.bin is missing: run __graft_entry__.build()"}
+    camd = syn.CAMERAS[a.camera]
+    cam = syn.make_camera(**camd)
+    W, H = cam.width, cam.height
+    sc = syn.make_scene(P, cam, seed=0)
+    rng = np.random.default_rng(3)
+    op = sc.opacities.reshape(-1, 1)
+    logit = np.log(op / (1 - op)).astype(np.float32)
+    g = hz.GaussianMap(hz.Config(), camd["fx"], camd["fy"], device=dev)
+    g.add_points(torch.tensor(sc.means3D), torch.tensor(sc.colors))
+    with torch.no_grad():
+        g.log_scales.copy_(torch.log(torch.tensor(sc.scales))); g.unnorm_quat.copy_(torch.tensor(sc.rotations))
+        g.logit_opacities.copy_(torch.tensor(logit))
+        T_true = torch.eye(4, device=dev)
+        rgb, sur, _ = hz.SlamRenderer(g, W, H).render_rgb(T_true, tracking=True)
+    T_init = np.eye(4, dtype=np.float32)
+    T_init[:3, 3] = (0.004, -0.003, 0.005)
+    xyz = sc.means3D + 0.002 * rng.standard_normal(sc.means3D.shape).astype(np.float32)
+    col = np.clip(sc.colors + 0.05 * rng.standard_normal(sc.colors.shape), 0, 1).astype(np.float32)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "scene.bin")
+        with open(path, "wb") as f:
+            f.write(struct.pack("<6i2f", P, W, H, track_iters, map_iters, 3, camd["fx"], camd["fy"]))
+            for arr in (xyz, col, sc.rotations, logit, np.log(sc.scales), rgb.cpu().numpy(), sur[0].cpu().numpy(), T_true.cpu().numpy(), T_init):
+                f.write(np.ascontiguousarray(arr, np.float32).tobytes())
+        r = subprocess.run([exe, path], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        return {"error": r.stderr[-500:]}
+    o = {ln.split()[0]: [float(x) for x in ln.split()[1:]] for ln in r.stdout.splitlines() if ln.strip()}
+    arrays = dict(means3D=sc.means3D, opacities=sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    pair = quick_raster(gsr, dev, cam, arrays, sc.dL_dpix, steps=a.other_steps, dual=True,
+                        grad_ds=np.random.default_rng(5).standard_normal((2, H, W)).astype(np.float32))
+    return {"what": f"ORB_SLAM2::SlamLoop (C++, libgsr_torch.so) at {P} Gaussians, {W}x{H}: wall clock per iteration incl. the one loss read-back "
+                    "(fused pair, fused loss / SSIM / Adam / pose kernels); raster_pair = fwd+bwd of the fused colour + depth/silhouette pass alone",
+            "mapping": o["map_ms_per_iter"][0], "tracking": o["track_ms_per_iter"][0], "raster_pair": pair["ms_per_step"],
+            "raster_pair_bwd_blend_ms": pair["bwd_blend_ms"], "raster_pair_fwd_blend_ms": pair["fwd_blend_ms"],
+            "tracking_iterations_run": len(o.get("track", [])), "mapping_iterations_run": map_iters}
+
+
 def boundary_ms(gsr, sc, dev, steps=20):
     """fwd+bwd through the operator boundary GSORB-SLAM calls (the diff_gaussian_rasterization Python op over the libtorch
     host layer over the C ABI): what a maintainer's loop sees per call pair, host overhead and allocations included."""
@@ -314,6 +493,8 @@ def main():
                     help="rasterize: the headline fwd+bwd line only; shard-step: only the sharded mapping/tracking step; all: both")
     ap.add_argument("--shard-steps", type=int, default=20, help="timed iterations of each shard_step loop")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-other", action="store_true", help="skip the other_workloads / loop_ms blocks (N = 1 only, after the headline)")
+    ap.add_argument("--other-steps", type=int, default=50, help="timed steps of each entry of other_workloads")
     ap.add_argument("--depth-layout", choices=["uniform", "two-walls"], default="uniform",
                     help="experiment: 'two-walls' moves every splat along its pixel ray onto one of two thin depth slabs "
                          "(1.5 m and 4 m, 2 cm thick): every tile list has two depth clusters, the tile sort's hard case")
@@ -350,6 +531,9 @@ def main():
     out = {}
     if a.mode in ("all", "rasterize"):
         out = rasterize(a, gsr, td, rank, world, dev)
+        if world == 1 and not a.no_other and a.splats == 1_000_000 and a.camera == "replica" and a.scale_mult == 1.0 and a.depth_layout == "uniform":
+            out["other_workloads"] = other_workloads(a, gsr, dev)
+            out["loop_ms"] = cpp_loop_ms(a, gsr, dev)
         sr = shard_render(a, gsr, td, rank, world, dev)
         if rank == 0:
             if world > 1:
@@ -495,7 +679,8 @@ def rasterize(a, gsr, td, rank, world, dev):
         # algorithmic bytes of the backward blend kernel per launch: 40R + 20N + 36V
         alg_bytes = 40 * R + 20 * N + 36 * V
         achieved = alg_bytes / (bwd_blend_ms * 1e-3) / 1e9
-        total_alg = 152 * P + 340 * V + 128 * R + 44 * N   # whole fwd+bwd
+        total_alg_ref = 152 * P + 340 * V + 128 * R + 44 * N   # whole fwd+bwd as SURVEY.md §8d counts it (every store of the reference)
+        total_alg = total_alg_ref - 40 * V                     # ... minus the two intermediates the timed call does not store (dL_dconic 16 B, dL_dcov3D 24 B)
         traffic = None   # HBM/fabric bytes per launch of the dominant kernel: PMC counters cannot be read live,
         pmc = {}         # so the committed rocprofv3 --pmc summary of this same command is quoted
         mix = {}
@@ -545,7 +730,10 @@ def rasterize(a, gsr, td, rank, world, dev):
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes": alg_bytes, "avg_launch_ms": bwd_blend_ms,
                          "fwd_blend_avg_launch_ms": fwd_blend_ms,
-                         "whole_step": {"algorithmic_bytes": total_alg,
+                         "whole_step": {"algorithmic_bytes": total_alg, "algorithmic_bytes_with_reference_intermediates": total_alg_ref,
+                                        "note": "algorithmic_bytes counts the stores the timed call makes (no dL_dconic / dL_dcov3D: config.omitted_stores); "
+                                                "one backward per forward: the accumulators are cleared by the forward blend's tail, not by a re-zero in the backward "
+                                                "(the stages the operator wrappers pass: torch_ext/Rasterizer.cpp)",
                                         "achieved": total_alg / (ms_step * 1e-3) / 1e9,
                                         "frac": total_alg / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
