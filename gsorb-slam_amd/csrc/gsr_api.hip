@@ -107,10 +107,8 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     GSR_LAUNCHED();
     tm.end(GSR_FWD_FILL);
     tm.begin(GSR_FWD_SORT);
-    hipLaunchKernelGGL(gsr::K_tile_sort_short, dim3(T), dim3(GSR_SORT_BIG_THREADS), 0, st, T, f.grid_x, iv.ranges, gv, bv.pairs, bv.point_list,
+    hipLaunchKernelGGL(gsr::K_tile_sort_cut, dim3(T), dim3(GSR_SORT_BIG_THREADS), 0, st, T, f.grid_x, iv.ranges, gv, bv.pairs, bv.point_list,
                        bv.qhits, iv.qcount);
-    hipLaunchKernelGGL(gsr::K_tile_sort_long, dim3(GSR_SORT_LONG_GRID), dim3(GSR_SORT_LONG_THREADS), 0, st, T, f.grid_x, iv.ranges, gv,
-                       bv.pairs, bv.point_list, bv.qhits, iv.sortq, iv.qcount);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SORT);
     tm.begin(GSR_FWD_BLEND);
@@ -148,7 +146,7 @@ int forward_head(const gsr_forward_args* a, char* geom, char* image, hipStream_t
     const BinGrid bg = bin_grid(P, T, 1, GSR_BIN_WINDOW);
     hipLaunchKernelGGL(gsr::K_bin_count, bg.grid, dim3(GSR_BIN_THREADS), (size_t)bg.twmax * 4, st, P, bg.per, T, f.grid_x, bg.wx, bg.nwin, *gv, iv->binmat);
     hipLaunchKernelGGL(gsr::K_bin_colscan, dim3((T + 31) / 32), dim3(1024), 0, st, bg.rows, T, iv->binmat, iv->tile_cnt);
-    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, T, iv->tile_cnt, 1, iv->tile_start, 1, iv->ranges, gv->hdr, capacity, iv->sortq);
+    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, T, iv->tile_cnt, 1, iv->tile_start, 1, iv->ranges, gv->hdr, capacity);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SCAN);
     *fo = f;
@@ -426,13 +424,13 @@ int gsr_dist2(int P, const float* points, float* mean_dists, char* workspace, si
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_knn_code, dim3(blocks256(P)), dim3(256), 0, st, P, shift, points, k.bbox, k.buckets, k.code, k.slot);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, nb, &k.buckets->cnt, 16, &k.buckets->start, 16, k.ranges, k.hdr, 0xFFFFFFFFu, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, nb, &k.buckets->cnt, 16, &k.buckets->start, 16, k.ranges, k.hdr, 0xFFFFFFFFu);
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_knn_fill, dim3(blocks256(P)), dim3(256), 0, st, P, shift, k.code, k.slot, k.buckets, k.pairs);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_tile_sort<GSR_SORT_WAVE>, dim3(nb), dim3(GSR_SORT_SMALL_THREADS), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(gsr::K_tile_sort<GSR_SORT_WAVE>, dim3(nb), dim3(GSR_SORT_SMALL_THREADS), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_tile_sort<GSR_SORT_BLOCK>, dim3(nb), dim3(256), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(gsr::K_tile_sort<GSR_SORT_BLOCK>, dim3(nb), dim3(256), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order);
     GSR_LAUNCHED();
     hipLaunchKernelGGL(gsr::K_knn_boxes, dim3(nbox), dim3(256), 0, st, P, points, k.order, k.spts, k.boxes);
     GSR_LAUNCHED();

@@ -16,8 +16,7 @@
 //                        {sum u, u*dx, u*dy, u*dx^2, u*dx*dy, u*dy^2}, dcolor.rgb, 7 unused
 //   image blob     (gsr_image_bytes(W,H)):
 //     final_T f32[N], n_contrib u32[N], ranges uint2[T], tile_cnt u32[T], tile_start u32[T],
-//     binmat u32[GSR_BIN_ROWS][T] (the count matrix of the binning, below), sortq u32[64 + 2T] (queues of the tiles
-//     with long lists for the sort), qcount u32[4T], qdone u32[4T]
+//     binmat u32[GSR_BIN_ROWS][T] (the count matrix of the binning, below), qcount u32[4T], qdone u32[4T]
 //   binning blob   (gsr_binning_bytes(capacity)), 44 B per tile instance:
 //     pairs u64[R] (depth bits << 32 | splat id, grouped per tile), point_list u32[R],
 //     qhits uint2[4R] (per 8x8 quad: the tile-list entries that reach it, with their 4-bit patch masks; written by the
@@ -34,12 +33,10 @@
 #define GSR_ALIGN 256
 #define GSR_ACC_STRIDE 16 // floats; 9 used
 
-// Tile-sort size classes (gsr_kernels.hip): one wave sorts lists of <= GSR_SORT_SMALL keys in LDS, 256 threads those of
-// <= GSR_SORT_CAP, longer lists go through a bucket sort in global scratch. K_scan_tiles queues the tiles of the two
-// upper classes so that their kernels launch a handful of workgroups instead of one per tile.
+// Sort capacities (gsr_kernels.hip): lists (rasterizer: chunks of a list) of <= GSR_SORT_SMALL keys are bucket-sorted in LDS by 256
+// threads; the k-NN path also sorts buckets of <= GSR_SORT_CAP keys with 256 threads (16 keys per thread).
 #define GSR_SORT_SMALL 1024
 #define GSR_SORT_CAP 4096
-#define GSR_SORTQ_HEAD 64 // words before the two tile queues: [0] tiles in the middle class, [1] tiles in the long class
 
 
 struct GeomHeader {
@@ -101,7 +98,6 @@ struct ImageView {
     uint32_t* tile_cnt;   // [T] instances per tile
     uint32_t* tile_start; // [T] where the tile's list segment starts
     uint32_t* binmat;     // [GSR_BIN_ROWS][T] count matrix (after K_bin_colscan: exclusive column prefixes)
-    uint32_t* sortq;  // [GSR_SORTQ_HEAD + 2T] queues of the tiles with more than GSR_SORT_SMALL / GSR_SORT_CAP list entries
     uint32_t* qcount; // [4*T] quad-hit records per 8x8 quad (written by the tile sort)
     uint32_t* qdone;  // [4*T] how many of them the forward blend consumed before every pixel of the quad was done
 };
@@ -142,7 +138,6 @@ __host__ __device__ inline size_t image_layout(char* base, int W, int H, ImageVi
     g.tile_cnt = (uint32_t*)(base + off); off = gsr_align_up(off + T * 4);
     g.tile_start = (uint32_t*)(base + off); off = gsr_align_up(off + T * 4);
     g.binmat = (uint32_t*)(base + off); off = gsr_align_up(off + T * GSR_BIN_ROWS * 4);
-    g.sortq = (uint32_t*)(base + off); off = gsr_align_up(off + (GSR_SORTQ_HEAD + 2 * T) * 4);
     g.qcount = (uint32_t*)(base + off); off = gsr_align_up(off + T * 16);
     g.qdone = (uint32_t*)(base + off); off = gsr_align_up(off + T * 16);
     if (v) *v = g;

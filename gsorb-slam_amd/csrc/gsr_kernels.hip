@@ -250,7 +250,7 @@ K_bin_colscan(int rows, int T, uint32_t* __restrict__ binmat, uint32_t* __restri
 // fences of the hand-over cost 45 us, the separate launch 5.)
 __global__ void __launch_bounds__(1024)
 K_scan_tiles(int T, const uint32_t* __restrict__ cnt, int cnt_stride, uint32_t* __restrict__ start, int start_stride,
-             uint2* __restrict__ ranges, GeomHeader* __restrict__ hdr, uint32_t capacity, uint32_t* __restrict__ sortq)
+             uint2* __restrict__ ranges, GeomHeader* __restrict__ hdr, uint32_t capacity)
 {
     // each thread owns `per` consecutive tiles (its counts stay in registers when per <= 8), the block
     // scan is one shuffle scan per wave plus one over the 16 wave totals: two barriers in all
@@ -305,34 +305,6 @@ K_scan_tiles(int T, const uint32_t* __restrict__ cnt, int cnt_stride, uint32_t* 
         hdr->overflow = total > capacity ? 1u : 0u;
         hdr->capacity = capacity;
     }
-    if (!sortq) return;
-    // queues of the tiles whose lists do not fit the one-wave sort (gsr_device.h): the same scan over two more counts
-    __shared__ uint32_t qsum[2][16];
-    auto for_own = [&](auto fn) {
-        if (per <= 8) {
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                if (j < per && b + j < e) fn(b + j, ks[j]);
-        } else {
-            for (int i = b; i < e; i++) fn(i, cnt[(size_t)i * cnt_stride]);
-        }
-    };
-    uint32_t nmid = 0, nlong = 0;
-    for_own([&](int, uint32_t c) { nmid += (c > GSR_SORT_SMALL && c <= GSR_SORT_CAP) ? 1u : 0u; nlong += c > GSR_SORT_CAP ? 1u : 0u; });
-    const uint32_t imid = wave_scan_add(nmid), ilong = wave_scan_add(nlong);
-    if (lane == 63) { qsum[0][wv] = imid; qsum[1][wv] = ilong; }
-    __syncthreads();
-    uint32_t omid = imid - nmid, olong = ilong - nlong, tmid = 0, tlong = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        if (j < wv) { omid += qsum[0][j]; olong += qsum[1][j]; }
-        tmid += qsum[0][j]; tlong += qsum[1][j];
-    }
-    for_own([&](int i, uint32_t c) {
-        if (c > GSR_SORT_SMALL && c <= GSR_SORT_CAP) sortq[GSR_SORTQ_HEAD + omid++] = (uint32_t)i;
-        if (c > GSR_SORT_CAP) sortq[GSR_SORTQ_HEAD + T + olong++] = (uint32_t)i;
-    });
-    if (tid == 0) { sortq[0] = tmid; sortq[1] = tlong; sortq[2] = 0u; } // [2]: K_tile_sort_long's pop counter
 }
 
 // the forward's capacity guess was too small: switch the header to the exact capacity before the tail re-runs
@@ -474,19 +446,10 @@ __device__ __forceinline__ void lds_sort(uint64_t* s, int cap)
 #define GSR_SORT_WAVE 0
 #define GSR_SORT_BLOCK 1
 #define GSR_SORT_BLOCK_SHORT 2
-// KIND 4: 256 threads per list of <= 2048 keys, 8 keys per thread: the lower half of K_tile_sort_long's middle class (a list of
-// 1 300 keys in KIND 1's 4096 slots is mostly padding work)
-#define GSR_SORT_BLOCK_HALF 4
-#ifndef GSR_SORT_LONG_THREADS
-#define GSR_SORT_LONG_THREADS 256
-#endif
-// KIND 5 / 6: KIND 1 / 4 with GSR_SORT_LONG_THREADS threads (K_tile_sort_long)
-#define GSR_SORT_LONG_FULL 5
-#define GSR_SORT_LONG_HALF 6
 template <int KIND>
 struct SortShared {
-    static constexpr int NT = KIND == 0 ? GSR_SORT_SMALL_THREADS : KIND >= 5 ? GSR_SORT_LONG_THREADS : GSR_SORT_BIG_THREADS;
-    static constexpr int CAP = (KIND == 1 || KIND == 5) ? GSR_SORT_CAP : (KIND == 4 || KIND == 6) ? GSR_SORT_CAP / 2 : GSR_SORT_SMALL;
+    static constexpr int NT = KIND == 0 ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS;
+    static constexpr int CAP = KIND == 1 ? GSR_SORT_CAP : GSR_SORT_SMALL;
     uint64_t s[CAP];
     __attribute__((aligned(16))) uint32_t h[CAP + 64]; // 64 spare words: one per lane for the padding keys' (zero) atomics
     uint32_t red[9][NT / 64];
@@ -502,8 +465,61 @@ struct SortShared {
 #define GSR_IDS_GLOBAL 2
 template <int KIND>
 __device__ __forceinline__ uint32_t* sort_payload(SortShared<KIND>& sh) { return reinterpret_cast<uint32_t*>(sh.s); }
+// Oversize list: the bitonic network with chunk-local stages in LDS and long-stride stages in global memory, in place in seg
+// (the k-NN buckets over 4096 points; in the rasterizer only lists the depth bins cannot split: > 1024 exact depth ties).
+// Not inlined: a rare path must not set the register allocation of the kernels that can reach it.
+#define GSR_OVERSIZE_G 3 // 8 keys per thread and trip (16 on the LDS paths): this path only has to be correct, and its registers count for every kernel that can reach it
 template <int KIND>
-__device__ __forceinline__ int sort_tile(SortShared<KIND>& sh, const uint2 r, uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list,
+__device__ __forceinline__ void sort_oversize(SortShared<KIND>& sh, uint64_t* __restrict__ seg, const int n, uint32_t* __restrict__ out)
+{
+    constexpr int NT = SortShared<KIND>::NT, CAP = SortShared<KIND>::CAP, LOGCAP = CAP == 1024 ? 10 : CAP == 2048 ? 11 : 12;
+    uint64_t* const s = sh.s;
+    int tid_ = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid_)); // (see sort_tile)
+    const int tid = tid_;
+    long n2 = CAP;
+    while (n2 < n) n2 <<= 1;
+    const int nchunks = (int)(n2 / CAP);
+    for (int c = 0; c < nchunks; c++) {
+        const long base = (long)c * CAP;
+        if (base >= n) break;
+        for (int i = tid; i < CAP; i += NT) s[swz(i)] = base + i < n ? seg[base + i] : ~0ull;
+        __syncthreads();
+        lds_sort<GSR_OVERSIZE_G, false>(s, CAP);
+        for (int i = tid; i < CAP; i += NT) if (base + i < n) seg[base + i] = s[swz(i)];
+        __syncthreads();
+    }
+    for (long k = 2L * CAP; k <= n2; k <<= 1) {
+        for (long i = tid; i < n2 / 2; i += NT) { // flip in global memory
+            const long blk = i / (k >> 1), off = i % (k >> 1);
+            const long lo = blk * k + off, hi = blk * k + (k - 1 - off);
+            if (hi < n) { uint64_t a = seg[lo], b = seg[hi]; if (a > b) { seg[lo] = b; seg[hi] = a; } }
+        }
+        __syncthreads();
+        long j = k >> 2;
+        for (; j >= CAP; j >>= 1) { // disperse with stride >= chunk: global memory
+            for (long i = tid; i < n2 / 2; i += NT) {
+                const long lo = (i / j) * 2 * j + (i % j), hi = lo + j;
+                if (hi < n) { uint64_t a = seg[lo], b = seg[hi]; if (a > b) { seg[lo] = b; seg[hi] = a; } }
+            }
+            __syncthreads();
+        }
+        for (int c = 0; c < nchunks; c++) { // remaining strides are chunk-local
+            const long base = (long)c * CAP;
+            if (base >= n) break;
+            for (int i = tid; i < CAP; i += NT) s[swz(i)] = base + i < n ? seg[base + i] : ~0ull;
+            __syncthreads();
+            lds_disperse_from<GSR_OVERSIZE_G, false>(s, CAP, LOGCAP - 1); // strides CAP/2 ... 1
+            for (int i = tid; i < CAP; i += NT) if (base + i < n) seg[base + i] = s[swz(i)];
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += NT) out[i] = (uint32_t)seg[i];
+}
+
+// seg[0 .. n): the keys (sorted in place only on the oversize path); out[0 .. n): the sorted ids
+template <int KIND>
+__device__ __forceinline__ int sort_tile(SortShared<KIND>& sh, uint64_t* __restrict__ seg, const int n, uint32_t* __restrict__ out,
                                          const uint2* __restrict__ reach = nullptr, int tx = 0, int ty = 0)
 {
     constexpr int NT = SortShared<KIND>::NT, CAP = SortShared<KIND>::CAP;
@@ -512,9 +528,11 @@ __device__ __forceinline__ int sort_tile(SortShared<KIND>& sh, const uint2 r, ui
     uint64_t* const s = sh.s;
     uint32_t* const h = sh.h;
     auto& red = sh.red;
-    const int n = (int)(r.y - r.x);
-    uint64_t* seg = pairs + r.x;
-    const int tid = sort_tid<KIND == 0>(), lane = tid & 63, wv = tid >> 6;
+    // (opaque to the optimiser: the rasterizer calls this in a loop over the chunks of a list, and loop-invariant code motion
+    // would hoist every address derived from the thread id out of that loop and keep it live across the whole body: +20 VGPRs)
+    int tid_ = sort_tid<KIND == 0>();
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_, lane = tid & 63, wv = tid >> 6;
     if (n <= CAP) {
         // Straight-line code: a load inside a divergent branch is waited for inside that branch, sixteen branches would be
         // sixteen serial round trips. Loads use clamped addresses and selects, only stores are predicated.
@@ -674,7 +692,7 @@ __device__ __forceinline__ int sort_tile(SortShared<KIND>& sh, const uint2 r, ui
 #pragma unroll
             for (int j = 0; j < EPT; j++) {
                 const uint32_t id = h[j * NT + tid];
-                if (j * NT + tid < n) point_list[r.x + j * NT + tid] = id;
+                if (j * NT + tid < n) out[j * NT + tid] = id;
             }
             return GSR_IDS_H;
         }
@@ -686,96 +704,59 @@ __device__ __forceinline__ int sort_tile(SortShared<KIND>& sh, const uint2 r, ui
         for (int i = tid; i < n2; i += sort_nt<KIND == 0>()) s[swz(i)] = i < n ? seg[i] : ~0ull;
         sort_sync<KIND == 0>();
         lds_sort<GSR_SORT_G, KIND == 0>(s, n2);
-        for (int i = tid; i < n; i += sort_nt<KIND == 0>()) point_list[r.x + i] = (uint32_t)s[swz(i)];
+        for (int i = tid; i < n; i += sort_nt<KIND == 0>()) out[i] = (uint32_t)s[swz(i)];
         return GSR_IDS_S;
     }
-    // oversize tile: chunk-local stages in LDS, long-stride stages in global memory
-    if constexpr (KIND != GSR_SORT_BLOCK && KIND != GSR_SORT_LONG_FULL) return GSR_IDS_GLOBAL; // (only the 4096-key workgroups are handed such lists)
+    if constexpr (KIND == GSR_SORT_WAVE) return GSR_IDS_GLOBAL; // (the one-wave sort is never handed such lists)
     else {
-    long n2 = GSR_SORT_CAP;
-    while (n2 < n) n2 <<= 1;
-    const int nchunks = (int)(n2 / GSR_SORT_CAP);
-    for (int c = 0; c < nchunks; c++) {
-        const long base = (long)c * GSR_SORT_CAP;
-        if (base >= n) break;
-        for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<KIND == 0>()) s[swz(i)] = base + i < n ? seg[base + i] : ~0ull;
-        __syncthreads();
-        lds_sort<GSR_SORT_G, false>(s, GSR_SORT_CAP);
-        for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<KIND == 0>()) if (base + i < n) seg[base + i] = s[swz(i)];
-        __syncthreads();
-    }
-    for (long k = 2L * GSR_SORT_CAP; k <= n2; k <<= 1) {
-        for (long i = tid; i < n2 / 2; i += sort_nt<KIND == 0>()) { // flip in global memory
-            const long blk = i / (k >> 1), off = i % (k >> 1);
-            const long lo = blk * k + off, hi = blk * k + (k - 1 - off);
-            if (hi < n) { uint64_t a = seg[lo], b = seg[hi]; if (a > b) { seg[lo] = b; seg[hi] = a; } }
-        }
-        __syncthreads();
-        long j = k >> 2;
-        for (; j >= GSR_SORT_CAP; j >>= 1) { // disperse with stride >= chunk: global memory
-            for (long i = tid; i < n2 / 2; i += sort_nt<KIND == 0>()) {
-                const long lo = (i / j) * 2 * j + (i % j), hi = lo + j;
-                if (hi < n) { uint64_t a = seg[lo], b = seg[hi]; if (a > b) { seg[lo] = b; seg[hi] = a; } }
-            }
-            __syncthreads();
-        }
-        for (int c = 0; c < nchunks; c++) { // remaining strides are chunk-local
-            const long base = (long)c * GSR_SORT_CAP;
-            if (base >= n) break;
-            for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<KIND == 0>()) s[swz(i)] = base + i < n ? seg[base + i] : ~0ull;
-            __syncthreads();
-            lds_disperse_from<GSR_SORT_G, false>(s, GSR_SORT_CAP, 11); // strides 2048 ... 1 (GSR_SORT_CAP / 2 = 2^11)
-            for (int i = tid; i < GSR_SORT_CAP; i += sort_nt<KIND == 0>()) if (base + i < n) seg[base + i] = s[swz(i)];
-            __syncthreads();
-        }
-    }
-    for (int i = tid; i < n; i += sort_nt<KIND == 0>()) point_list[r.x + i] = (uint32_t)seg[i];
-    return GSR_IDS_GLOBAL;
+        sort_oversize<KIND>(sh, seg, n, out);
+        return GSR_IDS_GLOBAL;
     }
 }
 
-// Launch modes: one workgroup per tile (sortq == nullptr: the k-NN path, and always for SMALL), or a fixed grid that
-// walks K_scan_tiles's queue of the tiles in the middle class — a frame without such tiles (the 1 M-splat headline
-// frame has none) then costs a few hundred empty workgroups instead of one per tile.
+// One workgroup per list (the k-NN path's buckets; the rasterizer's tiles go through K_tile_sort_cut).
 template <int KIND>
 __global__ void __launch_bounds__(KIND == 0 ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS)
 K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __restrict__ hdr,
-            uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list, const uint32_t* __restrict__ sortq)
+            uint64_t* __restrict__ pairs, uint32_t* __restrict__ point_list)
 {
     __shared__ SortShared<KIND> sh;
     if (hdr->overflow) return;
-    if constexpr (KIND != 0) {
-        if (sortq) {
-            const uint32_t cnt = sortq[0];
-            for (uint32_t t = blockIdx.x; t < cnt; t += gridDim.x) {
-                (void)sort_tile<KIND>(sh, ranges[sortq[GSR_SORTQ_HEAD + t]], pairs, point_list);
-                __syncthreads();
-            }
-            return;
-        }
-    }
     const uint2 r = ranges[xcd_remap(blockIdx.x, ntiles)];
     const int n = (int)(r.y - r.x);
     if (n == 0 || (n <= GSR_SORT_SMALL) != (KIND == 0)) return;
-    (void)sort_tile<KIND>(sh, r, pairs, point_list);
+    (void)sort_tile<KIND>(sh, pairs + r.x, n, point_list + r.x);
 }
 
-// Lists longer than GSR_SORT_CAP: the same bucket sort with the keys in global scratch instead of LDS (the tile's own
-// share of the quad-hit log, which the forward blend fills only later). 256 threads per list, eight keys per thread
-// in flight; bins in LDS. Passes: min/max, count, [equalise + count again], scatter by bin, rank among bin-mates.
-// Crowded lists (exact depth ties) fall back to the bitonic network in global memory (sort_tile).
-#define GSR_SORT_LONG_BINS 8192
+// Lists of more than 1024 entries (rasterizer): the list is first cut into depth-ordered CHUNKS of at most 1024 keys, and
+// every chunk is then sorted, masked and cut into the quad lists by the same code as a short list, one chunk after the
+// other in the same 256-thread workgroup (~70 VGPRs, 13 KB of LDS: seven workgroups per CU whatever the frame holds; the
+// round-3 build ran such lists in a second kernel with 16 keys per thread — 220 VGPRs, 48 KB of LDS, two workgroups per CU,
+// 30-60 us of barrier-separated phases per list — and launched that kernel, empty, on frames without them).
+// Partition = one counting sort over GSR_PART_BINS equal-width bins of the depth word: min / max, count, [equalise: every
+// non-empty bin cut into sub-bins in proportion to its count, count again], scan, scatter into the tile's own share of the
+// quad-hit log (dead until the first chunk is cut: a chunk's quad-list records never reach beyond the keys already
+// consumed). A chunk = the bins whose first key falls into the same window of S list positions, S = 1025 - the largest
+// bin count: at most 1024 keys, found with one LDS atomic-min per bin. Lists that cannot be split that way (more than 960
+// keys of one depth, or more than GSR_PART_SLOTS windows) are sorted whole by the bitonic network in global memory.
+#define GSR_PART_BINS 2048
+#define GSR_PART_SLOTS 256
+#define GSR_PART_NONE 0xFFFFFFFFu
+// Returns the window size S (> 0: chunk_first[w] = list position of window w's first key, GSR_PART_NONE for an empty window,
+// keys by bin in temp[0 .. n)) or 0 (no partition: sort seg whole).
 template <int KIND>
-__device__ __forceinline__ void sort_long_list(SortShared<KIND>& sh, const uint2 r, uint64_t* __restrict__ pairs,
-                                               uint32_t* __restrict__ point_list, uint2* __restrict__ qhits)
+__device__ __forceinline__ int partition_list(SortShared<KIND>& sh, uint32_t* chunk_first, const uint64_t* __restrict__ seg, const int n,
+                                              uint64_t* __restrict__ temp, uint32_t* __restrict__ map)
 {
-    constexpr int NT = SortShared<KIND>::NT, NB = GSR_SORT_LONG_BINS, BPT = NB / NT, LOGNB = 13, U = 8;
+    constexpr int NT = SortShared<KIND>::NT, NB = GSR_PART_BINS, BPT = NB / NT, LOGNB = 11, U = 8;
     static_assert((1 << LOGNB) == NB && BPT % 4 == 0, "whole uint4 of bins per thread");
-    static_assert(sizeof(sh.s) >= NB * sizeof(uint32_t), "the bins live in the network's key array");
+    static_assert(sizeof(sh.s) >= NB * sizeof(uint32_t), "the bins live in the sort's key array");
     uint32_t* const hb = reinterpret_cast<uint32_t*>(sh.s);
-    auto& red = sh.red; // (the network fallback uses them only for lists that fit LDS)
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int slot = 0; // every block_sums call of a list its own words of `red`; lists are separated by barriers
+    auto& red = sh.red;
+    int tid_ = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid_)); // (see sort_tile: nothing derived from the thread id is shared with the chunk code)
+    const int tid = tid_, lane = tid & 63, wv = tid >> 6;
+    int slot = 0; // every block reduction of a list its own words of `red`
     auto block_sums = [&](const uint32_t v, uint32_t& before, uint32_t& total) {
         const uint32_t inc = wave_scan_add(v);
         if (lane == 63) red[slot][wv] = inc;
@@ -785,135 +766,100 @@ __device__ __forceinline__ void sort_long_list(SortShared<KIND>& sh, const uint2
         for (int q = 0; q < NT / 64; q++) { if (q < wv) before += red[slot][q]; total += red[slot][q]; }
         slot++;
     };
-    {
-        const int n = (int)(r.y - r.x);
-        const uint64_t* __restrict__ seg = pairs + r.x;
-        uint64_t* const temp = reinterpret_cast<uint64_t*>(qhits + 4 * (size_t)r.x); // [n] keys by bin
-        uint32_t* const map = reinterpret_cast<uint32_t*>(temp + n);                  // [NB] equalisation map (32 KB <= 24 n bytes)
-        slot = 0;
-        // ---- min / max of the depth words
-        uint32_t dmin = ~0u, dmax = 0u;
+    // ---- min / max of the depth words
+    uint32_t dmin = ~0u, dmax = 0u;
+    for (int i0 = 0; i0 < n; i0 += NT * U) {
+        uint64_t k[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) k[u] = seg[min(i0 + u * NT + tid, n - 1)];
+#pragma unroll
+        for (int u = 0; u < U; u++) { dmin = min(dmin, (uint32_t)(k[u] >> 32)); dmax = max(dmax, (uint32_t)(k[u] >> 32)); }
+    }
+    dmin = wave_min_u32(dmin); dmax = wave_max_dpp(dmax);
+    if (lane == 0) { red[7][wv] = dmin; red[8][wv] = dmax; }
+    for (int b = tid; b < NB; b += NT) hb[b] = 0u;
+    for (int w = tid; w < GSR_PART_SLOTS; w += NT) chunk_first[w] = GSR_PART_NONE;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NT / 64; q++) { dmin = min(dmin, red[7][q]); dmax = max(dmax, red[8][q]); }
+    const int shift = max(0, 32 - __clz((int)(dmax - dmin)) - LOGNB);
+    const int down = max(0, shift - 16), frac = min(shift, 16);
+    bool equalised = false;
+    auto bin_of = [&](const uint64_t key) -> uint32_t {
+        const uint32_t rel = (uint32_t)(key >> 32) - dmin, b = rel >> shift;
+        if (!equalised) return b;
+        const uint32_t m = map[b];
+        return (m & 0xFFFFu) + ((((rel - (b << shift)) >> down) * (m >> 16)) >> frac);
+    };
+    auto count_keys = [&]() {
         for (int i0 = 0; i0 < n; i0 += NT * U) {
             uint64_t k[U];
 #pragma unroll
             for (int u = 0; u < U; u++) k[u] = seg[min(i0 + u * NT + tid, n - 1)];
 #pragma unroll
-            for (int u = 0; u < U; u++) { dmin = min(dmin, (uint32_t)(k[u] >> 32)); dmax = max(dmax, (uint32_t)(k[u] >> 32)); }
+            for (int u = 0; u < U; u++)
+                if (i0 + u * NT + tid < n) (void)lds_take(&hb[bin_of(k[u])]);
         }
-        dmin = wave_min_u32(dmin); dmax = wave_max_dpp(dmax);
-        if (lane == 0) { red[6][wv] = dmin; red[7][wv] = dmax; }
+        __syncthreads();
+    };
+    uint32_t c[BPT], run, nz, mx;
+    auto scan_counts = [&]() {
+#pragma unroll
+        for (int q = 0; q < BPT / 4; q++) {
+            const uint4 v = reinterpret_cast<const uint4*>(hb)[tid * (BPT / 4) + q];
+            c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+        }
+        uint32_t sum = 0, nz_own = 0, mx_own = 0, x;
+#pragma unroll
+        for (int j = 0; j < BPT; j++) { sum += c[j]; nz_own += c[j] ? 1u : 0u; mx_own = max(mx_own, c[j]); }
+        block_sums(sum, run, x);
+        block_sums(nz_own, x, nz);
+        mx_own = wave_max_dpp(mx_own);
+        if (lane == 0) red[slot][wv] = mx_own;
+        __syncthreads();
+        mx = 0;
+#pragma unroll
+        for (int q = 0; q < NT / 64; q++) mx = max(mx, red[slot][q]);
+        slot++;
+    };
+    count_keys();
+    scan_counts();
+    if (mx > 256u && shift > 0) { // crowded bins (two surfaces in one tile, a far outlier): equalised bins, as in sort_tile
+        const float share = (float)((uint32_t)NB - nz) / (float)n * 0.999f;
+        uint32_t nsub[BPT], tot = 0, first, x;
+#pragma unroll
+        for (int j = 0; j < BPT; j++) { nsub[j] = c[j] ? 1u + (uint32_t)((float)c[j] * share) : 0u; tot += nsub[j]; }
+        block_sums(tot, first, x);
+#pragma unroll
+        for (int j = 0; j < BPT; j++) { map[tid * BPT + j] = first | (nsub[j] << 16); first += nsub[j]; }
+        __syncthreads(); // every thread has read its counts, and the map is visible to the workgroup
         for (int b = tid; b < NB; b += NT) hb[b] = 0u;
         __syncthreads();
-#pragma unroll
-        for (int q = 0; q < NT / 64; q++) { dmin = min(dmin, red[6][q]); dmax = max(dmax, red[7][q]); }
-        const int shift = max(0, 32 - __clz((int)(dmax - dmin)) - LOGNB);
-        const int down = max(0, shift - 16), frac = min(shift, 16);
-        bool equalised = false;
-        auto bin_of = [&](const uint64_t key) -> uint32_t {
-            const uint32_t rel = (uint32_t)(key >> 32) - dmin, b = rel >> shift;
-            if (!equalised) return b;
-            const uint32_t m = map[b];
-            return (m & 0xFFFFu) + ((((rel - (b << shift)) >> down) * (m >> 16)) >> frac);
-        };
-        auto count_keys = [&]() {
-            for (int i0 = 0; i0 < n; i0 += NT * U) {
-                uint64_t k[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) k[u] = seg[min(i0 + u * NT + tid, n - 1)];
-#pragma unroll
-                for (int u = 0; u < U; u++)
-                    if (i0 + u * NT + tid < n) (void)lds_take(&hb[bin_of(k[u])]);
-            }
-            __syncthreads();
-        };
-        uint32_t c[BPT], run, sq, nz;
-        auto scan_counts = [&]() {
-#pragma unroll
-            for (int q = 0; q < BPT / 4; q++) {
-                const uint4 v = reinterpret_cast<const uint4*>(hb)[tid * (BPT / 4) + q];
-                c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
-            }
-            uint32_t sum = 0, sq_own = 0, nz_own = 0, x;
-#pragma unroll
-            for (int j = 0; j < BPT; j++) { // (saturating: a list of 10^5 tied keys must not wrap the sum of squares)
-                const uint32_t cc = min(c[j], 65535u);
-                sum += c[j]; sq_own = min(sq_own + min(cc * cc, 0x7FFFFFu), 0x7FFFFFu); nz_own += c[j] ? 1u : 0u;
-            }
-            block_sums(sum, run, x);
-            block_sums(sq_own, x, sq);
-            block_sums(nz_own, x, nz);
-        };
+        equalised = true;
         count_keys();
         scan_counts();
-        bool crowded = sq > 8u * (uint32_t)n;
-        if (crowded && shift > 0) { // second binning with equalised bins (see sort_tile)
-            const float share = (float)((uint32_t)NB - nz) / (float)n * 0.999f;
-            uint32_t nsub[BPT], tot = 0, first, x;
-#pragma unroll
-            for (int j = 0; j < BPT; j++) { nsub[j] = c[j] ? 1u + (uint32_t)((float)c[j] * share) : 0u; tot += nsub[j]; }
-            slot = 3;
-            block_sums(tot, first, x);
-#pragma unroll
-            for (int j = 0; j < BPT; j++) { map[tid * BPT + j] = first | (nsub[j] << 16); first += nsub[j]; }
-            __syncthreads(); // every thread has read its counts
-            for (int b = tid; b < NB; b += NT) hb[b] = 0u;
-            __syncthreads(); // ... and the map is visible to the workgroup
-            equalised = true;
-            count_keys();
-            slot = 0;
-            scan_counts();
-            crowded = sq > 8u * (uint32_t)n;
-        }
-        if (crowded) { // exact ties: the network, in place in the list segment
-            __syncthreads();
-            (void)sort_tile<KIND>(sh, r, pairs, point_list);
-            __syncthreads();
-            return;
-        }
-        __syncthreads(); // every thread has read its counts: the words turn into cursors
-#pragma unroll
-        for (int j = 0; j < BPT; j++) { hb[tid * BPT + j] = run; run += c[j]; }
-        __syncthreads();
-        // ---- keys to their bins (afterwards hb[b] = end of bin b = start of bin b + 1)
-        for (int i0 = 0; i0 < n; i0 += NT * U) {
-            uint64_t k[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) k[u] = seg[min(i0 + u * NT + tid, n - 1)];
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (i0 + u * NT + tid < n) temp[lds_take(&hb[bin_of(k[u])])] = k[u];
-        }
-        __syncthreads();
-        // ---- rank among the bin-mates, ids out
-        for (int i0 = 0; i0 < n; i0 += NT * U) {
-            uint64_t k[U];
-            uint32_t s0[U], e0[U], below[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) k[u] = temp[min(i0 + u * NT + tid, n - 1)];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t b = bin_of(k[u]);
-                s0[u] = b ? hb[b - 1] : 0u; e0[u] = hb[b]; below[u] = 0u;
-            }
-            // all U keys of a thread step through their bins together: U independent loads per step instead of one
-            // dependent global round trip per step and key (that was most of this path's time)
-            for (uint32_t q = 0;; q++) {
-                bool more = false;
-#pragma unroll
-                for (int u = 0; u < U; u++) more |= s0[u] + q < e0[u];
-                if (!__builtin_amdgcn_ballot_w64(more)) break;
-                uint64_t mate[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) mate[u] = temp[s0[u] + q < e0[u] ? s0[u] + q : 0u];
-#pragma unroll
-                for (int u = 0; u < U; u++) below[u] += (s0[u] + q < e0[u] && mate[u] < k[u]) ? 1u : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (i0 + u * NT + tid < n) point_list[r.x + s0[u] + below[u]] = (uint32_t)k[u];
-        }
-        __syncthreads();
     }
+    const int S = 1025 - (int)mx;
+    if (S < 64 || (n + S - 1) / S > GSR_PART_SLOTS) return 0;
+    __syncthreads(); // every thread has read its counts: the words turn into cursors
+#pragma unroll
+    for (int j = 0; j < BPT; j++) {
+        hb[tid * BPT + j] = run;
+        if (c[j]) (void)__hip_atomic_fetch_min(&chunk_first[run / (uint32_t)S], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        run += c[j];
+    }
+    __syncthreads();
+    // ---- keys to their bins
+    for (int i0 = 0; i0 < n; i0 += NT * U) {
+        uint64_t k[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) k[u] = seg[min(i0 + u * NT + tid, n - 1)];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (i0 + u * NT + tid < n) temp[lds_take(&hb[bin_of(k[u])])] = k[u];
+    }
+    __syncthreads(); // (workgroup-scope release / acquire: the scattered keys are read back by this workgroup only)
+    return S;
 }
 
 // Quad-hit lists. The blend kernels work per 8x8 quad (one wave, four 4x4 patch rows): what they walk is not the tile
@@ -933,79 +879,63 @@ __device__ __forceinline__ uint32_t exact_tile_mask(const float4 a, const float4
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const float X0 = (float)(tx * 16 + (q & 1) * 8), Y0 = (float)(ty * 16 + (q >> 1) * 8);
-#ifdef GSR_EXP_EXACT_PATCH
-        if (quad_reach(a, b, X0, Y0)) {
-            const float4 A = make_float4(a.x, a.y, a.z * (-0.5f * GSR_LOG2E), a.w * -GSR_LOG2E);
-            const float4 B = make_float4(b.x * (-0.5f * GSR_LOG2E), b.y, 0.f, 0.f);
-            bool h[4];
-            patch_reach4(A, B, X0, Y0, h);
-            const uint32_t sh = 8 * (q >> 1) + 2 * (q & 1);
-            m16 |= ((h[0] ? 1u : 0u) | (h[1] ? 2u : 0u)) << sh;
-            m16 |= ((h[2] ? 1u : 0u) | (h[3] ? 2u : 0u)) << (sh + 4);
-        }
-#else
         if (quad_reach(a, b, X0, Y0)) m16 |= 0x33u << (8 * (q >> 1) + 2 * (q & 1));
-#endif
     }
     return m16;
 }
-// ONE wave cuts the lists of quads [q0, q0 + NQ) out of entries [0, n) given by get(i) -> (id, tile mask).
-template <int NQ, typename Get>
-__device__ __forceinline__ void cut_quad_lists(Get get, const int n, const int q0, uint2* __restrict__ qh, uint32_t* __restrict__ qcount4)
+// Where a chunk of a tile list goes: the list has n_list entries (the stride of the four quad lists in qh), the chunk starts at
+// list position pos0, and qcnt[q] = records quad q's list holds so far (LDS, carried from chunk to chunk).
+struct CutTarget {
+    uint2* qh;
+    uint32_t* qcnt;
+    int n_list, pos0;
+};
+// ONE wave appends to the list of quad q the entries [0, m) of a chunk given by get(i) -> (id, tile mask).
+template <typename Get>
+__device__ __forceinline__ void cut_quad_list(Get get, const int m, const int q, const CutTarget& t)
 {
-    const int lane = (int)(threadIdx.x & 63u);
-    uint32_t cnt[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) cnt[q] = 0u;
-    uint2 nxt = get(min(lane, n - 1));
-    for (int base = 0; base < n; base += 64) {
+    int lane_ = (int)(threadIdx.x & 63u);
+    asm volatile("" : "+v"(lane_)); // (see sort_tile)
+    const int lane = lane_;
+    uint32_t cnt = t.qcnt[q];
+    uint2* const dst = t.qh + (size_t)q * (size_t)t.n_list;
+    uint2 nxt = get(min(lane, m - 1));
+    for (int base = 0; base < m; base += 64) {
         const int k = base + lane;
         const uint2 e = nxt;
-        nxt = get(min(k + 64, n - 1)); // the next 64 entries are in flight while these are cut (a global round trip per step otherwise)
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            const uint32_t pm = k < n ? quad_mask_of_tile_mask(e.y, q0 + q) : 0u;
-            const unsigned long long m = __ballot(pm != 0u);
-            if (pm != 0u) qh[(size_t)(q0 + q) * (size_t)n + cnt[q] + (uint32_t)mbcnt64(m)] = make_uint2((uint32_t)k, e.x | (pm << GSR_ID_BITS));
-            cnt[q] += (uint32_t)__popcll(m);
-        }
+        nxt = get(min(k + 64, m - 1)); // the next 64 entries are in flight while these are cut (a global round trip per step otherwise)
+        const uint32_t pm = k < m ? quad_mask_of_tile_mask(e.y, q) : 0u;
+        const unsigned long long mk = __ballot(pm != 0u);
+        if (pm != 0u) dst[cnt + (uint32_t)mbcnt64(mk)] = make_uint2((uint32_t)(t.pos0 + k), e.x | (pm << GSR_ID_BITS));
+        cnt += (uint32_t)__popcll(mk);
     }
-#pragma unroll
-    for (int q = 0; q < NQ; q++)
-        if (lane == q) qcount4[q0 + q] = cnt[q];
+    if (lane == 0) t.qcnt[q] = cnt;
 }
-// Lists whose sorted ids and mask words sit in LDS (ids[i], msk[i]; nthreads threads of the workgroup share the list):
-// the untested entries are collected (their positions in `todo`, u16), tested in one batch — one gather of the two
-// 16-byte words per such entry — and then the lists are cut: four quads by the one wave, or one quad per wave.
-template <bool ONEWAVE, int UB>
-__device__ __forceinline__ void emit_from_lds(const uint32_t* ids, uint32_t* msk, uint16_t* todo, uint32_t* counter, const int n, const int tile,
-                                              const int grid_x, const GeomView& g, uint2* __restrict__ qh, uint32_t* __restrict__ qcount4)
+// A chunk whose sorted ids and mask words sit in LDS (ids[i], msk[i]): the untested entries are collected (their positions in
+// `todo`, u16), tested in one batch — one gather of the two 16-byte words per such entry, UB entries per thread in flight —
+// and then the four quad lists are appended to, one quad per wave.
+template <int UB>
+__device__ __forceinline__ void emit_from_lds(const uint32_t* ids, uint32_t* msk, uint16_t* todo, uint32_t* counter, const int m, const int tx, const int ty,
+                                              const GeomView& g, const CutTarget& t)
 {
-    const int tid = sort_tid<ONEWAVE>(), nt = sort_nt<ONEWAVE>();
-    const int tx = tile % grid_x, ty = tile / grid_x;
+    int tid_ = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid_)); // (see sort_tile)
+    const int tid = tid_, nt = (int)blockDim.x;
     if (tid == 0) *counter = 0u;
-    sort_sync<ONEWAVE>();
-    for (int i0 = 0; i0 < n; i0 += nt) { // one LDS atomic per wave and step, not per entry: a map of fat splats has every entry here
+    __syncthreads();
+    for (int i0 = 0; i0 < m; i0 += nt) { // one LDS atomic per wave and step, not per entry: a map of fat splats has every entry here
         const int i = i0 + tid;
-        const bool u = i < n && (msk[min(i, n - 1)] & GSR_MASK_UNTESTED) != 0u;
-        const unsigned long long m = __ballot(u);
-        if (m) {
+        const bool u = i < m && (msk[min(i, m - 1)] & GSR_MASK_UNTESTED) != 0u;
+        const unsigned long long mk = __ballot(u);
+        if (mk) {
             uint32_t base = 0u;
-            if ((tid & 63) == 0) base = __hip_atomic_fetch_add(counter, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((tid & 63) == 0) base = __hip_atomic_fetch_add(counter, (uint32_t)__popcll(mk), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (u) todo[base + (uint32_t)mbcnt64(m)] = (uint16_t)i;
+            if (u) todo[base + (uint32_t)mbcnt64(mk)] = (uint16_t)i;
         }
     }
-    sort_sync<ONEWAVE>();
+    __syncthreads();
     const int nu = (int)*counter;
-    // UB entries per thread have their records gathered together (a map of fat splats has every entry here)
-    if constexpr (UB == 1) {
-        for (int u = tid; u < nu; u += nt) {
-            const int i = todo[u];
-            const uint32_t id = ids[i];
-            msk[i] = exact_tile_mask(g.g0[id], g.g1[id], tx, ty);
-        }
-    } else
     for (int u0 = 0; u0 < nu; u0 += nt * UB) {
         int i[UB];
         float4 a[UB], b[UB];
@@ -1017,155 +947,123 @@ __device__ __forceinline__ void emit_from_lds(const uint32_t* ids, uint32_t* msk
         }
 #pragma unroll
         for (int v = 0; v < UB; v++) {
-            const uint32_t m = exact_tile_mask(a[v], b[v], tx, ty);
-            if (u0 + v * nt + tid < nu) msk[i[v]] = m;
+            const uint32_t mk = exact_tile_mask(a[v], b[v], tx, ty);
+            if (u0 + v * nt + tid < nu) msk[i[v]] = mk;
         }
     }
-    sort_sync<ONEWAVE>();
-    auto get = [&](int i) { return make_uint2(ids[i], msk[i]); };
-    if (ONEWAVE) cut_quad_lists<4>(get, n, 0, qh, qcount4);
-    else if (threadIdx.x < 256u) cut_quad_lists<1>(get, n, (int)(threadIdx.x >> 6), qh, qcount4); // (waves 0..3: one quad each)
-}
-// Lists without their mask words at hand (the bitonic network ran: exact depth ties; or the list went through global
-// scratch): ids read back from point_list (just written by this workgroup: made visible by the fence + barrier, read past
-// the L1), the mask recomputed from the gathered centre and reach word; wave w of the workgroup cuts quad w.
-template <int U>
-__device__ __forceinline__ void emit_from_global(const uint2 r, const int tile, const int grid_x, const GeomView& g,
-                                                 const uint32_t* point_list, uint64_t* __restrict__ pairs, uint2* __restrict__ qhits,
-                                                 uint32_t* __restrict__ qcount)
-{
-    // Two phases. (1) every thread of the workgroup: sorted id -> reach entry -> tile mask (exact test for the larger splats),
-    // U independent chains per thread, (id, mask) parked in the list's key segment (`pairs`: dead once the list is sorted).
-    // (2) one wave per quad cuts its list out of the parked pairs: coalesced, independent loads, one step ahead.
-    // (One pass used to do both, every 64-entry step waiting for two dependent global round trips — id, then its reach
-    // entry: 3.9 ms of a 5.7 ms step at 10 M splats.)
-    __threadfence();
     __syncthreads();
-    const uint32_t* pl = point_list + r.x;
-    uint64_t* const pm = pairs + r.x;
-    const int n = (int)(r.y - r.x), tid = (int)threadIdx.x, nt = (int)blockDim.x;
-    const int tx = tile % grid_x, ty = tile / grid_x;
-    for (int i0 = 0; i0 < n; i0 += nt * U) {
+    auto get = [&](int i) { return make_uint2(ids[i], msk[i]); };
+    if (tid < 256) cut_quad_list(get, m, tid >> 6, t); // (waves 0..3: one quad each)
+}
+// A chunk without its mask words at hand (the bitonic network ran: exact depth ties): the sorted ids are read back from `out`
+// (just written by this workgroup), the masks recomputed from the gathered reach entries, (id, mask) parked in the chunk's
+// original key segment `park` (dead once it is sorted) — every thread of the workgroup, U independent chains each — and then
+// one wave per quad cuts its list out of the parked pairs: coalesced, independent loads, one step ahead.
+template <int U>
+__device__ __forceinline__ void emit_from_global(const uint32_t* out, uint64_t* park, const int m, const int tx, const int ty, const GeomView& g, const CutTarget& t)
+{
+    __syncthreads(); // (workgroup-scope release / acquire: the ids were stored by this workgroup)
+    int tid_ = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid_)); // (see sort_tile)
+    const int tid = tid_, nt = (int)blockDim.x;
+    for (int i0 = 0; i0 < m; i0 += nt * U) {
         uint32_t id[U];
         uint2 re[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) id[u] = __hip_atomic_load(pl + min(i0 + u * nt + tid, n - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int u = 0; u < U; u++) id[u] = out[min(i0 + u * nt + tid, m - 1)];
 #pragma unroll
         for (int u = 0; u < U; u++) re[u] = g.reach[id[u]];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            uint32_t m = tile_mask_from_reach(re[u], tx, ty);
-            if (m & GSR_MASK_UNTESTED) m = exact_tile_mask(g.g0[id[u]], g.g1[id[u]], tx, ty);
-            if (i0 + u * nt + tid < n) pm[i0 + u * nt + tid] = (uint64_t)id[u] | ((uint64_t)m << 32);
+            uint32_t mk = tile_mask_from_reach(re[u], tx, ty);
+            if (mk & GSR_MASK_UNTESTED) mk = exact_tile_mask(g.g0[id[u]], g.g1[id[u]], tx, ty);
+            if (i0 + u * nt + tid < m) park[i0 + u * nt + tid] = (uint64_t)id[u] | ((uint64_t)mk << 32);
         }
     }
-    __threadfence();
     __syncthreads();
-    auto get = [&](int i) {
-        const uint64_t v = __hip_atomic_load(pm + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
-    };
-    if (threadIdx.x < 256u) cut_quad_lists<1>(get, n, (int)(threadIdx.x >> 6), qhits + 4 * (size_t)r.x, qcount + 4 * (size_t)tile);
+    auto get = [&](int i) { const uint64_t v = park[i]; return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); };
+    if (tid < 256) cut_quad_list(get, m, tid >> 6, t);
 }
 
-// The rasterizer's sort, two launches. K_tile_sort_short: one 256-thread workgroup per tile, for the lists of up to 1024
-// entries (every list of the 1 M-splat headline frame; 12 KB of LDS and ~64 VGPRs per thread: eight workgroups per CU).
-// K_tile_sort_long: a fixed grid that walks K_scan_tiles's queues of the longer lists — 256 threads bucket-sort <= 4096
-// keys in LDS, longer lists go through global scratch. Every list is cut into its four quad-hit lists right after it is
-// sorted, one quad per wave. (History: one launch for all classes saved the 4-5 us an empty kernel costs, but tied the
-// short lists to the 48 KB of LDS and the ~200 VGPRs of the 16-keys-per-lane sort: two waves per SIMD, 63 us with the
-// list cutting in; as two launches 3x us.)
-__global__ void __launch_bounds__(GSR_SORT_BIG_THREADS)
-K_tile_sort_short(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g, uint64_t* __restrict__ pairs,
-                  uint32_t* __restrict__ point_list, uint2* __restrict__ qhits, uint32_t* __restrict__ qcount)
+// The rasterizer's tile sort: one 256-thread workgroup per tile, whatever the length of its list. Lists of up to 1024
+// entries (every list of the 1 M-splat headline frame) are bucket-sorted in LDS in one go; longer lists are partitioned into
+// depth-ordered chunks of at most 1024 keys first (partition_list) and the chunks take the same path one after the other.
+// Every chunk is cut into the tile's four quad-hit lists right after it is sorted, one quad per wave.
+// (History: one wave per list with 16 keys per lane — 63 us with the list cutting in; round 3: this kernel for the short lists
+// plus K_tile_sort_long — 48 KB of LDS, 220 VGPRs — for the others: 37.5 + 4.8 us on the headline frame, 130 / 275 us on the
+// 2 M-splat and fat-splat frames.)
+#ifndef GSR_SORT_WAVES
+#define GSR_SORT_WAVES 6 // waves per SIMD the register allocation is held to (80 VGPRs, no spills; 7 = 72 VGPRs spills six)
+#endif
+__global__ void __launch_bounds__(GSR_SORT_BIG_THREADS) __attribute__((amdgpu_waves_per_eu(GSR_SORT_WAVES, GSR_SORT_WAVES)))
+K_tile_sort_cut(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g, uint64_t* __restrict__ pairs,
+                uint32_t* __restrict__ point_list, uint2* __restrict__ qhits, uint32_t* __restrict__ qcount)
 {
     __shared__ SortShared<GSR_SORT_BLOCK_SHORT> sh;
-    __shared__ uint32_t counter;
+    __shared__ uint32_t counter, qcnt[4];
+    __shared__ uint32_t chunk_first[GSR_PART_SLOTS];
     if (g.hdr->overflow) return;
     const int tile = (int)xcd_remap(blockIdx.x, (uint32_t)T);
     const uint2 r = ranges[tile];
     const int n = (int)(r.y - r.x);
-    if (n > GSR_SORT_SMALL) return; // queued for K_tile_sort_long
     uint32_t* const qc4 = qcount + 4 * (size_t)tile;
     if (n == 0) { // an empty tile has four empty lists
         if (threadIdx.x < 4u) qc4[threadIdx.x] = 0u;
         return;
     }
+    const int tx = tile % grid_x, ty = tile / grid_x;
+    if (threadIdx.x < 4u) qcnt[threadIdx.x] = 0u;
+    CutTarget ct;
+    ct.qh = qhits + 4 * (size_t)r.x; ct.qcnt = qcnt; ct.n_list = n; ct.pos0 = 0;
 #ifdef GSR_EXP_SORT_NOGATHER
-    const int where = sort_tile<GSR_SORT_BLOCK_SHORT>(sh, r, pairs, point_list, nullptr, tile % grid_x, tile / grid_x);
+    const uint2* const reach = nullptr;
 #else
-    const int where = sort_tile<GSR_SORT_BLOCK_SHORT>(sh, r, pairs, point_list, g.reach, tile % grid_x, tile / grid_x);
+    const uint2* const reach = g.reach;
 #endif
+    // one chunk: keys src[0 .. m) = list positions pos0 .. pos0 + m
+    auto chunk = [&](uint64_t* src, const int m, const int pos0) {
+        ct.pos0 = pos0;
+        const int where = sort_tile<GSR_SORT_BLOCK_SHORT>(sh, src, m, point_list + r.x + pos0, reach, tx, ty);
 #ifdef GSR_EXP_SORT_NOEMIT
-    if (threadIdx.x < 4u) qc4[threadIdx.x] = 0u;
-    return;
+        return;
 #endif
-    if (where == GSR_IDS_H) { // ids in h, mask words in the first 4 KB of the key array, the to-do list behind them
-        __syncthreads();
-        uint32_t* const msk = sort_payload(sh);
-        emit_from_lds<false, 1>(sh.h, msk, reinterpret_cast<uint16_t*>(msk + GSR_SORT_SMALL), &counter, n, tile, grid_x, g, qhits + 4 * (size_t)r.x, qc4);
-    } else { // the network ran (exact depth ties)
-        emit_from_global<1>(r, tile, grid_x, g, point_list, pairs, qhits, qcount); // (rare here: keep the short kernel's registers)
-    }
-}
-
-#define GSR_SORT_LONG_GRID 512 // two workgroups per CU are resident (216 VGPRs, 48 KB of LDS)
-#if GSR_SORT_LONG_THREADS == 512
-__attribute__((amdgpu_waves_per_eu(4, 4))) // two 8-wave workgroups per CU
-#endif
-__global__ void __launch_bounds__(GSR_SORT_LONG_THREADS)
-K_tile_sort_long(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g, uint64_t* __restrict__ pairs,
-                 uint32_t* __restrict__ point_list, uint2* __restrict__ qhits, uint32_t* __restrict__ sortq, uint32_t* __restrict__ qcount)
-{
-    __shared__ SortShared<GSR_SORT_LONG_FULL> sh;
-    __shared__ uint32_t counter;
-    if (g.hdr->overflow) return;
-    if (sortq[0] + sortq[1] == 0u) return; // (the 1 M-splat headline frame: every list is short)
-    // The launch's workgroups pop tiles from the two queues (the longest lists first) through one counter, zeroed by
-    // K_scan_tiles: a frame whose lists are all of one class (10 M splats: every list over 4096 entries) has the whole grid
-    // at work, and a frame with both classes no workgroup that is handed a long list AND its share of the others.
-    __shared__ uint32_t next;
-    const uint32_t nlong = sortq[1], total = nlong + sortq[0];
-    for (;;) {
-        if (threadIdx.x == 0) next = __hip_atomic_fetch_add(&sortq[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const uint32_t t = next;
-        __syncthreads(); // everybody has read it
-        if (t >= total) break;
-        if (t < nlong) {
-            const int tile = (int)sortq[GSR_SORTQ_HEAD + T + t];
-            const uint2 r = ranges[tile];
-            sort_long_list<GSR_SORT_LONG_FULL>(sh, r, pairs, point_list, qhits);
-            emit_from_global<4>(r, tile, grid_x, g, point_list, pairs, qhits, qcount); // (the sort's scratch in qhits is dead by now)
-        } else {
-            const int tile = (int)sortq[GSR_SORTQ_HEAD + (t - nlong)];
-            const uint2 r = ranges[tile];
-            const int n = (int)(r.y - r.x);
-            const bool half = n <= GSR_SORT_CAP / 2; // the shorter lists of the class in half the slots (8 keys per thread)
-            auto& shh = reinterpret_cast<SortShared<GSR_SORT_LONG_HALF>&>(sh);
-#ifdef GSR_EXP_LONG_NOGATHER
-            const uint2* const reach = nullptr;
-#else
-            const uint2* const reach = g.reach;
-#endif
-            const int where = half ? sort_tile<GSR_SORT_LONG_HALF>(shh, r, pairs, point_list, reach, tile % grid_x, tile / grid_x)
-                                   : sort_tile<GSR_SORT_LONG_FULL>(sh, r, pairs, point_list, reach, tile % grid_x, tile / grid_x);
-#ifdef GSR_EXP_LONG_NOEMIT
-            if (threadIdx.x < 4u) qcount[4 * (size_t)tile + threadIdx.x] = 0u;
+        if (where == GSR_IDS_H) { // ids in h, mask words in the first 4 KB of the key array, the to-do list behind them
             __syncthreads();
-            continue;
-#endif
-            if (where == GSR_IDS_H) { // ids in h, mask words in the first 16 KB of the key array, the to-do list behind them
-                __syncthreads();
-                uint32_t* const msk = sort_payload(sh);
-                emit_from_lds<false, 4>(half ? shh.h : sh.h, msk, reinterpret_cast<uint16_t*>(msk + (half ? GSR_SORT_CAP / 2 : GSR_SORT_CAP)), &counter, n, tile,
-                                        grid_x, g, qhits + 4 * (size_t)r.x, qcount + 4 * (size_t)tile);
-            } else {
-                emit_from_global<4>(r, tile, grid_x, g, point_list, pairs, qhits, qcount);
-            }
+            uint32_t* const msk = sort_payload(sh);
+            emit_from_lds<2>(sh.h, msk, reinterpret_cast<uint16_t*>(msk + GSR_SORT_SMALL), &counter, m, tx, ty, g, ct);
+        } else { // the network ran (exact depth ties), in LDS or in global memory
+            // (parked in the list's original key segment, dead by now: the chunk's own keys may sit in the quad-hit log, where
+            // quad 0's records are being appended while the other waves still read the parked pairs)
+            emit_from_global<2>(point_list + r.x + pos0, pairs + r.x + pos0, m, tx, ty, g, ct);
         }
-        __syncthreads();
+        __syncthreads(); // the chunk's LDS is free again
+    };
+    // (one call site of the chunk code: a short list, or a list that cannot be split — sorted whole by the network in global
+    // memory, in place —, is a single chunk in its original key segment)
+    uint64_t* const temp = reinterpret_cast<uint64_t*>(qhits + 4 * (size_t)r.x);     // [n] keys by bin
+    uint32_t* const map = reinterpret_cast<uint32_t*>(temp + n);                      // [GSR_PART_BINS] equalisation map (8 KB <= 24 n bytes)
+    int S = 0, nw = 1, w = 0;
+    if (n > GSR_SORT_SMALL) {
+        // (values read from LDS are vector registers to the compiler: the loop state is made scalar explicitly, or it and
+        // everything derived from it — chunk pointers, lengths — stays live in VGPRs across the whole chunk body)
+        S = __builtin_amdgcn_readfirstlane(partition_list<GSR_SORT_BLOCK_SHORT>(sh, chunk_first, pairs + r.x, n, temp, map));
+        if (S > 0) {
+            nw = (n + S - 1) / S;
+            while (w < nw && __builtin_amdgcn_readfirstlane((int)chunk_first[w]) == (int)GSR_PART_NONE) w++;
+        }
     }
+    while (w < nw) {
+        int start = 0, end = n, w2 = nw;
+        if (S > 0) {
+            start = __builtin_amdgcn_readfirstlane((int)chunk_first[w]);
+            w2 = w + 1;
+            while (w2 < nw && __builtin_amdgcn_readfirstlane((int)chunk_first[w2]) == (int)GSR_PART_NONE) w2++;
+            end = w2 < nw ? __builtin_amdgcn_readfirstlane((int)chunk_first[w2]) : n;
+        }
+        chunk(S > 0 ? temp + start : pairs + r.x, end - start, start);
+        w = w2;
+    }
+    if (threadIdx.x < 4u) qc4[threadIdx.x] = qcnt[threadIdx.x];
 }
 
 // ===================================================================================
