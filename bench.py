@@ -289,7 +289,7 @@ def cpp_loop_ms(a, gsr, dev, P=1_000_000, track_iters=20, map_iters=20):
     xyz = sc.means3D + 0.002 * rng.standard_normal(sc.means3D.shape).astype(np.float32)
     col = np.clip(sc.colors + 0.05 * rng.standard_normal(sc.colors.shape), 0, 1).astype(np.float32)
     with tempfile.TemporaryDirectory() as tmp:
-        path = os.path.join(tmp, "scene.bin")
+        path = os.environ.get("GSR_LOOP_SCENE_OUT") or os.path.join(tmp, "scene.bin")   # (scripts/loop_profile.sh keeps the file)
         with open(path, "wb") as f:
             f.write(struct.pack("<6i2f", P, W, H, track_iters, map_iters, 3, camd["fx"], camd["fy"]))
             for arr in (xyz, col, sc.rotations, logit, np.log(sc.scales), rgb.cpu().numpy(), sur[0].cpu().numpy(), T_true.cpu().numpy(), T_init):

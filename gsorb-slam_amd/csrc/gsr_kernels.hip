@@ -560,8 +560,9 @@ __device__ __forceinline__ int sort_tile(SortShared<KIND>& sh, uint64_t* __restr
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < NT / 64; q++) { dmin = min(dmin, red[0][q]); dmax = max(dmax, red[1][q]); }
-        }
-        sort_sync<KIND == 0>();
+        } else {
+            sort_sync<true>();
+        } // (the barrier of the reduction also orders the zeroing of h before the atomics below)
         const int shift = max(0, 32 - __clz((int)(dmax - dmin)) - LOGCAP); // (dmax - dmin) >> shift < CAP
         uint32_t bin[EPT], rnk[EPT]; // rank of the key inside its bin, in arrival order
 #pragma unroll
@@ -594,12 +595,21 @@ __device__ __forceinline__ int sort_tile(SortShared<KIND>& sh, uint64_t* __restr
                 const uint4 v = reinterpret_cast<const uint4*>(arr)[tid * (EPT / 4) + q];
                 c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
             }
-            uint32_t sum = 0, sq_own = 0, nz_own = 0, t;
+            uint32_t sum = 0, sq_own = 0, nz_own = 0;
 #pragma unroll
             for (int j = 0; j < EPT; j++) { sum += c[j]; sq_own += c[j] * c[j]; nz_own += c[j] ? 1u : 0u; }
-            block_sums(sum, slot, run, t);
-            block_sums(sq_own, slot + 1, t, sq);
-            block_sums(nz_own, slot + 2, t, nz);
+            // three block reductions behind one barrier (a barrier-separated phase costs this workgroup ~1 us: it is latency-bound)
+            const uint32_t i0 = wave_scan_add(sum), i1 = wave_scan_add(sq_own), i2 = wave_scan_add(nz_own);
+            run = i0 - sum;
+            sq = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
+            nz = (uint32_t)__builtin_amdgcn_readlane((int)i2, 63);
+            if (KIND != 0) {
+                if (lane == 63) { red[slot][wv] = i0; red[slot + 1][wv] = i1; red[slot + 2][wv] = i2; }
+                __syncthreads();
+                sq = 0; nz = 0;
+#pragma unroll
+                for (int q = 0; q < NT / 64; q++) { if (q < wv) run += red[slot][q]; sq += red[slot + 1][q]; nz += red[slot + 2][q]; }
+            }
         };
         scan_counts(h, 2);
         bool crowded = sq > 8u * (uint32_t)n;
@@ -748,7 +758,7 @@ template <int KIND>
 __device__ __forceinline__ int partition_list(SortShared<KIND>& sh, uint32_t* chunk_first, const uint64_t* __restrict__ seg, const int n,
                                               uint64_t* __restrict__ temp, uint32_t* __restrict__ map)
 {
-    constexpr int NT = SortShared<KIND>::NT, NB = GSR_PART_BINS, BPT = NB / NT, LOGNB = 11, U = 8;
+    constexpr int NT = SortShared<KIND>::NT, NB = GSR_PART_BINS, BPT = NB / NT, LOGNB = 11, U = 16;
     static_assert((1 << LOGNB) == NB && BPT % 4 == 0, "whole uint4 of bins per thread");
     static_assert(sizeof(sh.s) >= NB * sizeof(uint32_t), "the bins live in the sort's key array");
     uint32_t* const hb = reinterpret_cast<uint32_t*>(sh.s);
@@ -766,12 +776,17 @@ __device__ __forceinline__ int partition_list(SortShared<KIND>& sh, uint32_t* ch
         for (int q = 0; q < NT / 64; q++) { if (q < wv) before += red[slot][q]; total += red[slot][q]; }
         slot++;
     };
-    // ---- min / max of the depth words
-    uint32_t dmin = ~0u, dmax = 0u;
-    for (int i0 = 0; i0 < n; i0 += NT * U) {
-        uint64_t k[U];
+    // ---- min / max of the depth words. Lists of up to NT * U = 4096 keys (all but the 10 M-splat experiment's) are loaded ONCE
+    //      and stay in registers through the three passes; longer lists are re-read trip by trip
+    const bool resident = n <= NT * U;
+    uint64_t k[U];
+    auto load_trip = [&](const int i0) {
 #pragma unroll
         for (int u = 0; u < U; u++) k[u] = seg[min(i0 + u * NT + tid, n - 1)];
+    };
+    uint32_t dmin = ~0u, dmax = 0u;
+    for (int i0 = 0; i0 < n; i0 += NT * U) {
+        load_trip(i0);
 #pragma unroll
         for (int u = 0; u < U; u++) { dmin = min(dmin, (uint32_t)(k[u] >> 32)); dmax = max(dmax, (uint32_t)(k[u] >> 32)); }
     }
@@ -793,9 +808,7 @@ __device__ __forceinline__ int partition_list(SortShared<KIND>& sh, uint32_t* ch
     };
     auto count_keys = [&]() {
         for (int i0 = 0; i0 < n; i0 += NT * U) {
-            uint64_t k[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) k[u] = seg[min(i0 + u * NT + tid, n - 1)];
+            if (!resident) load_trip(i0);
 #pragma unroll
             for (int u = 0; u < U; u++)
                 if (i0 + u * NT + tid < n) (void)lds_take(&hb[bin_of(k[u])]);
@@ -809,18 +822,17 @@ __device__ __forceinline__ int partition_list(SortShared<KIND>& sh, uint32_t* ch
             const uint4 v = reinterpret_cast<const uint4*>(hb)[tid * (BPT / 4) + q];
             c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
         }
-        uint32_t sum = 0, nz_own = 0, mx_own = 0, x;
+        uint32_t sum = 0, nz_own = 0, mx_own = 0;
 #pragma unroll
         for (int j = 0; j < BPT; j++) { sum += c[j]; nz_own += c[j] ? 1u : 0u; mx_own = max(mx_own, c[j]); }
-        block_sums(sum, run, x);
-        block_sums(nz_own, x, nz);
+        const uint32_t i0 = wave_scan_add(sum), i1 = wave_scan_add(nz_own);
         mx_own = wave_max_dpp(mx_own);
-        if (lane == 0) red[slot][wv] = mx_own;
+        if (lane == 63) { red[slot][wv] = i0; red[slot + 1][wv] = i1; red[slot + 2][wv] = mx_own; }
         __syncthreads();
-        mx = 0;
+        run = i0 - sum; nz = 0; mx = 0;
 #pragma unroll
-        for (int q = 0; q < NT / 64; q++) mx = max(mx, red[slot][q]);
-        slot++;
+        for (int q = 0; q < NT / 64; q++) { if (q < wv) run += red[slot][q]; nz += red[slot + 1][q]; mx = max(mx, red[slot + 2][q]); }
+        slot += 3;
     };
     count_keys();
     scan_counts();
@@ -851,9 +863,7 @@ __device__ __forceinline__ int partition_list(SortShared<KIND>& sh, uint32_t* ch
     __syncthreads();
     // ---- keys to their bins
     for (int i0 = 0; i0 < n; i0 += NT * U) {
-        uint64_t k[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) k[u] = seg[min(i0 + u * NT + tid, n - 1)];
+        if (!resident) load_trip(i0);
 #pragma unroll
         for (int u = 0; u < U; u++)
             if (i0 + u * NT + tid < n) temp[lds_take(&hb[bin_of(k[u])])] = k[u];
@@ -921,8 +931,7 @@ __device__ __forceinline__ void emit_from_lds(const uint32_t* ids, uint32_t* msk
     int tid_ = (int)threadIdx.x;
     asm volatile("" : "+v"(tid_)); // (see sort_tile)
     const int tid = tid_, nt = (int)blockDim.x;
-    if (tid == 0) *counter = 0u;
-    __syncthreads();
+    // (*counter was zeroed by the caller before the chunk was sorted: barriers in between)
     for (int i0 = 0; i0 < m; i0 += nt) { // one LDS atomic per wave and step, not per entry: a map of fat splats has every entry here
         const int i = i0 + tid;
         const bool u = i < m && (msk[min(i, m - 1)] & GSR_MASK_UNTESTED) != 0u;
@@ -935,7 +944,7 @@ __device__ __forceinline__ void emit_from_lds(const uint32_t* ids, uint32_t* msk
         }
     }
     __syncthreads();
-    const int nu = (int)*counter;
+    const int nu = __builtin_amdgcn_readfirstlane((int)*counter);
     for (int u0 = 0; u0 < nu; u0 += nt * UB) {
         int i[UB];
         float4 a[UB], b[UB];
@@ -951,7 +960,7 @@ __device__ __forceinline__ void emit_from_lds(const uint32_t* ids, uint32_t* msk
             if (u0 + v * nt + tid < nu) msk[i[v]] = mk;
         }
     }
-    __syncthreads();
+    if (nu > 0) __syncthreads();
     auto get = [&](int i) { return make_uint2(ids[i], msk[i]); };
     if (tid < 256) cut_quad_list(get, m, tid >> 6, t); // (waves 0..3: one quad each)
 }
@@ -1023,12 +1032,14 @@ K_tile_sort_cut(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g,
     // one chunk: keys src[0 .. m) = list positions pos0 .. pos0 + m
     auto chunk = [&](uint64_t* src, const int m, const int pos0) {
         ct.pos0 = pos0;
+        if (threadIdx.x == 0) counter = 0u; // (emit_from_lds's to-do counter: the sort's barriers lie between this and its use)
         const int where = sort_tile<GSR_SORT_BLOCK_SHORT>(sh, src, m, point_list + r.x + pos0, reach, tx, ty);
 #ifdef GSR_EXP_SORT_NOEMIT
         return;
 #endif
         if (where == GSR_IDS_H) { // ids in h, mask words in the first 4 KB of the key array, the to-do list behind them
-            __syncthreads();
+            // (no barrier here: the threads still copying ids out of h only read, and the to-do list lies in words of the key
+            // array nobody has touched since the barrier before the ranking)
             uint32_t* const msk = sort_payload(sh);
             emit_from_lds<2>(sh.h, msk, reinterpret_cast<uint16_t*>(msk + GSR_SORT_SMALL), &counter, m, tx, ty, g, ct);
         } else { // the network ran (exact depth ties), in LDS or in global memory
@@ -1036,7 +1047,6 @@ K_tile_sort_cut(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g,
             // quad 0's records are being appended while the other waves still read the parked pairs)
             emit_from_global<2>(point_list + r.x + pos0, pairs + r.x + pos0, m, tx, ty, g, ct);
         }
-        __syncthreads(); // the chunk's LDS is free again
     };
     // (one call site of the chunk code: a short list, or a list that cannot be split — sorted whole by the network in global
     // memory, in place —, is a single chunk in its original key segment)
@@ -1062,8 +1072,9 @@ K_tile_sort_cut(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g,
         }
         chunk(S > 0 ? temp + start : pairs + r.x, end - start, start);
         w = w2;
+        if (w < nw) __syncthreads(); // the chunk's LDS is free again
     }
-    if (threadIdx.x < 4u) qc4[threadIdx.x] = qcnt[threadIdx.x];
+    if (threadIdx.x < 256u && (threadIdx.x & 63u) == 0u) qc4[threadIdx.x >> 6] = qcnt[threadIdx.x >> 6]; // (the thread that wrote the count: no barrier)
 }
 
 // ===================================================================================
