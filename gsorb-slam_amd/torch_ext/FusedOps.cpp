@@ -236,6 +236,31 @@ void Adam::step()
     }
 }
 
+void Adam::replace_extended(size_t i, const torch::Tensor& param, int64_t added)
+{
+    if (state_.size() != groups_.size()) state_.resize(groups_.size());
+    auto& st = state_.at(i);
+    if (st.exp_avg.defined()) { // (a group that has not stepped yet has no moments: they start as zeros of the new size)
+        auto shape = st.exp_avg.sizes().vec();
+        shape[0] = added;
+        const auto z = torch::zeros(shape, st.exp_avg.options());
+        st.exp_avg = torch::cat({st.exp_avg, z}, 0);
+        st.exp_avg_sq = torch::cat({st.exp_avg_sq, z}, 0);
+    }
+    groups_.at(i).param = param;
+}
+
+void Adam::replace_selected(size_t i, const torch::Tensor& param, const torch::Tensor& keep)
+{
+    if (state_.size() != groups_.size()) state_.resize(groups_.size());
+    auto& st = state_.at(i);
+    if (st.exp_avg.defined()) {
+        st.exp_avg = st.exp_avg.index_select(0, keep);
+        st.exp_avg_sq = st.exp_avg_sq.index_select(0, keep);
+    }
+    groups_.at(i).param = param;
+}
+
 void Adam::zero_grad()
 {
     for (auto& g : groups_)

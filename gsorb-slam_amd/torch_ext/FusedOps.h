@@ -37,6 +37,10 @@ public:
     Adam(std::vector<Group> groups, double eps) : groups_(std::move(groups)), eps_(eps) {}
     void step();
     void zero_grad();
+    // Map growth (Gaussian::CatTensorToOptimizer / PruneOptimizer, src/Gaussian.cc:218-258): group i's parameter becomes
+    // `param` (a new leaf); its moments are extended with zeros for `added` new rows / reduced to the rows `keep`
+    void replace_extended(size_t i, const torch::Tensor& param, int64_t added);
+    void replace_selected(size_t i, const torch::Tensor& param, const torch::Tensor& keep);
 private:
     struct State { torch::Tensor exp_avg, exp_avg_sq; int step = 0; };
     std::vector<Group> groups_;

@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <limits>
+#include <stdexcept>
 
 namespace ORB_SLAM2 {
 
@@ -237,6 +238,120 @@ double SlamLoop::MappingIteration(const LoopFrame& fr)
     if (cfg_.fused_ops) { fopt_->step(); fopt_->zero_grad(); }
     else { opt_->step(); opt_->zero_grad(); }
     return loss.item<double>();
+}
+
+// ---- map growth ------------------------------------------------------------------------------------------------
+std::vector<torch::Tensor*> SlamLoop::params_() { return {&xyz, &rgb, &unnorm_quat, &logit_opacities, &log_scales}; }
+
+// The five parameter tensors are replaced by `fresh` (new leaves) in the map and in the optimiser, whose moments follow:
+// extended with zeros for `added` rows (CatTensorToOptimizer, Gaussian.cc:236-258) or reduced to the rows *keep
+// (PruneOptimizer, Gaussian.cc:218-234).
+void SlamLoop::replace_params_(const std::vector<torch::Tensor>& fresh, int64_t added, const torch::Tensor* keep)
+{
+    const auto ps = params_();
+    for (size_t i = 0; i < ps.size(); i++) {
+        const auto leaf = fresh[i].detach().contiguous().requires_grad_(true);
+        if (fopt_) {
+            if (keep) fopt_->replace_selected(i, leaf, *keep);
+            else fopt_->replace_extended(i, leaf, added);
+        } else if (opt_) {
+            auto& group = opt_->param_groups()[i];
+            void* const old_key = group.params()[0].unsafeGetTensorImpl();
+            auto it = opt_->state().find(old_key);
+            std::unique_ptr<torch::optim::OptimizerParamState> st;
+            if (it != opt_->state().end()) {
+                auto as = std::make_unique<torch::optim::AdamParamState>(static_cast<torch::optim::AdamParamState&>(*it->second));
+                if (keep) {
+                    as->exp_avg(as->exp_avg().index_select(0, *keep));
+                    as->exp_avg_sq(as->exp_avg_sq().index_select(0, *keep));
+                } else {
+                    auto shape = as->exp_avg().sizes().vec();
+                    shape[0] = added;
+                    const auto z = torch::zeros(shape, as->exp_avg().options());
+                    as->exp_avg(torch::cat({as->exp_avg(), z}, 0));
+                    as->exp_avg_sq(torch::cat({as->exp_avg_sq(), z}, 0));
+                }
+                opt_->state().erase(it);
+                st = std::move(as);
+            }
+            group.params()[0] = leaf;
+            if (st) opt_->state()[leaf.unsafeGetTensorImpl()] = std::move(st);
+        }
+        *ps[i] = leaf;
+    }
+}
+
+void SlamLoop::AddPoints(const torch::Tensor& pts_, const torch::Tensor& cols_)
+{
+    torch::NoGradGuard ng;
+    const auto pts = pts_.to(dev_, torch::kFloat32).contiguous(), cols = cols_.to(dev_, torch::kFloat32).contiguous();
+    const int64_t n = pts.size(0);
+    if (n == 0) return;
+    const auto opts = torch::TensorOptions().device(dev_).dtype(torch::kFloat32);
+    auto quat = torch::zeros({n, 4}, opts);
+    quat.select(1, 0).fill_(1.0);                                                                       // Gaussian.cc:52-55
+    const auto logit = torch::ones({n, 1}, opts);
+    torch::Tensor logs;
+    if (cfg_.init_scalar_method == 0 || cfg_.init_scalar_method == 1) {                                  // Gaussian.cc:59-69 (distCUDA2 on the device)
+        auto sq = torch::sqrt(torch::clamp_min(distCUDA2(pts, dev_), 1e-7));
+        if (cfg_.init_scalar_method == 1) sq = torch::clamp_max(sq, 8 * sq.mean());
+        logs = torch::log(sq).unsqueeze(-1).repeat({1, 3});
+    } else if (cfg_.init_scalar_method == 2) {                                                           // Gaussian.cc:70-74: one pixel wide at its depth
+        logs = torch::log(torch::sqrt(torch::pow(pts.select(1, 2) / ((fx_ + fy_) * 0.5), 2))).unsqueeze(-1).repeat({1, 3});
+    } else {
+        throw std::runtime_error("Unknown Init Scalar Method");
+    }
+    const std::vector<torch::Tensor> fresh_rows{pts, cols, quat, logit, logs.contiguous()};
+    if (!xyz.defined()) { SetMap(pts, cols, quat, logit, logs); return; }
+    std::vector<torch::Tensor> fresh;
+    const auto ps = params_();
+    for (size_t i = 0; i < ps.size(); i++) fresh.push_back(torch::cat({ps[i]->detach(), fresh_rows[i]}, 0));
+    replace_params_(fresh, n, nullptr);
+}
+
+int64_t SlamLoop::AddGaussians(const LoopFrame& frame)
+{
+    torch::NoGradGuard ng;
+    const auto Tcw = frame.Tcw.to(dev_, torch::kFloat32);
+    auto [rim, rsur, rdep] = RenderPair(Tcw, true);
+    (void)rsur;
+    const auto gray = (rim[0] * 299 + rim[1] * 587 + rim[2] * 114) / 1000;                               // Render.cc:560-561
+    const auto black = gray < 50 / 255.0;
+    const auto diff = torch::abs(frame.depth - rdep[0]);
+    const auto dmask = (diff < 0.05) & (frame.depth > 0) & (rdep[0] > 0);                                // :566-567
+    double th = 0.0;
+    if (dmask.any().item<bool>()) {
+        const auto vals = diff.masked_select(dmask);
+        th = (vals.sum() / dmask.sum()).item<double>() + cfg_.median_mul * vals.median().item<double>(); // :569-573
+    }
+    if (th < 0.01) th = 0.01;
+    auto add = ((~(rdep[1] > 0.99)) & black & (diff > th)) | (rdep[1] < 0.8);                             // :579-581
+    add = add & (frame.depth > 0);                                                                        // ProjectPixel: z > 0 (:632)
+    const auto vu = torch::nonzero(add);
+    const int64_t n = vu.size(0);
+    if (n == 0) return 0;
+    const auto v = vu.select(1, 0), u = vu.select(1, 1);
+    const auto z = frame.depth.index({v, u});
+    const double cx = (W_ - 1) / 2.0, cy = (H_ - 1) / 2.0;
+    const auto pc = torch::stack({(u.to(torch::kFloat32) - cx) * z / fx_, (v.to(torch::kFloat32) - cy) * z / fy_, z}, 1);  // :634-637
+    const auto Twc = torch::inverse(Tcw);
+    const auto pw = pc.matmul(Twc.slice(0, 0, 3).slice(1, 0, 3).t()) + Twc.slice(0, 0, 3).slice(1, 3, 4).reshape({1, 3});
+    const auto cols = frame.rgb.index({torch::indexing::Slice(), v, u}).t().contiguous();
+    AddPoints(pw, cols);
+    return n;
+}
+
+int64_t SlamLoop::PruneLowOpacity()
+{
+    torch::NoGradGuard ng;
+    const auto remove = (torch::sigmoid(logit_opacities) < cfg_.prune_opacities).squeeze(-1);             // Gaussian.cc:180-185
+    const int64_t n = remove.sum().item<int64_t>();
+    if (n == 0) return 0;                                                                                  // Render.cc:606
+    const auto keep = torch::nonzero(~remove).squeeze(-1);                                                 // Gaussian.cc:206-208
+    std::vector<torch::Tensor> fresh;
+    for (auto* p : params_()) fresh.push_back(p->detach().index_select(0, keep));
+    replace_params_(fresh, 0, &keep);
+    return n;
 }
 
 } // namespace ORB_SLAM2

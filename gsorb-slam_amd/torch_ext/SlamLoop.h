@@ -24,6 +24,8 @@ struct LoopConfig {
     double lr_cam_quat = 0.0004; // used for BOTH pose groups, like the reference (Gaussian.cc:149-150)
     double im_weight_tracking = 0.7, depth_weight_tracking = 1.0;
     double scale_modifier = 1.0, scene_radius = 1.0;
+    double prune_opacities = 0.005, median_mul = 40.0; // Mapping.PruneOpcities / Mapping.MedianMul
+    int init_scalar_method = 2;                        // 0 Distance, 1 DistanceMean, 2 SinglePixel (Gaussian.cc:59-79)
     bool use_sur_depth = true;
     bool fused_pair = true; // one rasterizer pass per iteration (forward_pair); false: two passes like Render.cc:927-981
     bool fused_ops = true;  // camera transform, pose matrix, SSIM and Adam through the loop kernels of the C ABI (FusedOps.h);
@@ -50,6 +52,18 @@ public:
     // Render.cc:420-483: one mapping iteration on one keyframe (loss, backward, Adam step); returns the loss
     double MappingIteration(const LoopFrame& frame);
 
+    // ---- map growth (the other half of the per-frame loop: Render.cc:557-616, Gaussian.cc:40-95, :180-258) ----
+    // Render::AddGaussian + ProjectPixel + Gaussian::AddGaussianPoints: renders the frame's view, masks the pixels the map does
+    // not explain (silhouette < 0.8, or not certain AND dark AND depth error above avg + MedianMul * median), back-projects
+    // them through the frame's depth and appends them as new Gaussians (logit opacity 1, identity quaternion, the configured
+    // scale init), Adam moments extended with zeros. Returns the number of Gaussians added.
+    int64_t AddGaussians(const LoopFrame& frame);
+    // Gaussian::AddGaussianPoints on given world points / colours ([n,3] each)
+    void AddPoints(const torch::Tensor& pts, const torch::Tensor& cols);
+    // Render::RemoveGaussian: drops the Gaussians whose opacity fell below prune_opacities, with their Adam moments.
+    int64_t PruneLowOpacity();
+    int64_t size() const { return xyz.defined() ? xyz.size(0) : 0; }
+
     // both renders of an iteration: {colour [3,H,W], surface (median) depth [1,H,W], depth/silhouette [2,H,W]}
     std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> RenderPair(const torch::Tensor& Tcw, bool tracking);
 
@@ -66,6 +80,8 @@ private:
     torch::Tensor cam_quat_, cam_trans_, taps_;
     std::vector<float> taps_host_;
     std::vector<torch::Tensor> act_; // Track(): the map's activations (opacity, scales, unit quaternions), formed once per call
+    std::vector<torch::Tensor*> params_();
+    void replace_params_(const std::vector<torch::Tensor>& fresh, int64_t added, const torch::Tensor* keep);
 };
 
 // include/Utils.h:56-77: Tcw [4,4] from an un-normalised quaternion (r,x,y,z) [4,1] and a translation [3,1]

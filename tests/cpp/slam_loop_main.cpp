@@ -1,7 +1,8 @@
 // slam_loop_main.cpp — runs ORB_SLAM2::SlamLoop (gsorb-slam_amd/torch_ext/SlamLoop.h) on a scene file written by
 // tests/test_gpu_cpp_loop.py and prints what the Python harness is compared with: the loss of every tracking iteration, the
 // best pose, the loss of every mapping iteration, and the time per iteration. Test infrastructure (the product is SlamLoop).
-//   file: int32 P, W, H, track_iters, map_iters, flags (bit 0 fused pair, bit 1 fused loop kernels); float32 fx, fy; then float32 arrays xyz[P,3] rgb[P,3] quat[P,4] logit[P,1]
+//   file: int32 P, W, H, track_iters, map_iters, flags (bit 0 fused pair, bit 1 fused loop kernels, bit 2 growth run: AddGaussians /
+//         PruneLowOpacity on a map of the first P/2 rows, bit 3 prune threshold 0.6); float32 fx, fy; then float32 arrays xyz[P,3] rgb[P,3] quat[P,4] logit[P,1]
 //         logs[P,3] frame_rgb[3,H,W] frame_depth[H,W] Tcw[4,4] T_init[4,4]
 #include <chrono>
 #include <cstdio>
@@ -43,6 +44,32 @@ int main(int argc, char** argv)
     if (!f) { std::fprintf(stderr, "short scene file\n"); return 2; }
     std::cout.precision(9);
     torch::Tensor Tbest;
+    if (hdr[5] & 4) { // growth run (flags bit 2): the map starts as the first half of the rows, then densify -> map -> prune -> map
+        if (hdr[5] & 8) cfg.prune_opacities = 0.6; // (bit 3: a threshold the test's opacities straddle)
+        const int64_t h = P / 2;
+        auto half = [&](const torch::Tensor& t) { return t.slice(0, 0, h); };
+        ORB_SLAM2::SlamLoop grow(cfg, W, H, ff[0], ff[1], dev);
+        grow.SetMap(half(xyz), half(rgb), half(quat), half(logit), half(logs));
+        for (int i = 0; i < 2; i++) grow.MappingIteration(fr); // (the moments exist before they are extended)
+        torch::cuda::synchronize();
+        auto g0 = std::chrono::steady_clock::now();
+        const int64_t added = grow.AddGaussians(fr);
+        torch::cuda::synchronize();
+        const double add_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g0).count();
+        std::cout << "grow " << h << " " << added << " " << grow.size() << "\nmap";
+        for (int i = 0; i < map_iters; i++) std::cout << " " << grow.MappingIteration(fr);
+        torch::cuda::synchronize();
+        g0 = std::chrono::steady_clock::now();
+        const int64_t pruned = grow.PruneLowOpacity();
+        torch::cuda::synchronize();
+        const double prune_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g0).count();
+        std::cout << "\nprune " << pruned << " " << grow.size() << "\nmap2";
+        for (int i = 0; i < 5; i++) std::cout << " " << grow.MappingIteration(fr);
+        std::cout << "\nadd_ms " << add_ms << "\nprune_ms " << prune_ms << std::endl;
+        std::cout.flush();
+        if (std::getenv("GSR_LOOP_NORMAL_EXIT")) return 0;
+        std::_Exit(0);
+    }
     { // warm-up on a throw-away copy of the map (allocator, clocks, MIOpen's first-call search for the SSIM convolutions)
         ORB_SLAM2::SlamLoop warm(cfg, W, H, ff[0], ff[1], dev);
         warm.SetMap(xyz, rgb, quat, logit, logs);

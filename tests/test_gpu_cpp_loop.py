@@ -101,3 +101,63 @@ def test_cpp_loop_follows_the_python_harness(gsr, syn, tmp_path, P):
         k = min(len(t2), len(tc), 10)
         assert np.abs(np.asarray(t2[:k]) - np.asarray(tc[:k])).max() / abs(tc[0]) < 1e-3
         assert np.abs(np.asarray(m2[:10]) - np.asarray(mc[:10])).max() / abs(mc[0]) < 1e-3
+
+
+def _cpp_growth_run(path, params, frgb, fdepth, T_true, T_init, flags):
+    exe = os.path.join(ROOT, "tests", "cpp", "slam_loop_main.bin")
+    if not os.path.exists(exe):
+        pytest.fail("tests/cpp/slam_loop_main.bin is missing: run __graft_entry__.build()")
+    P = params["xyz"].shape[0]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<6i2f", P, W, H, TRACK_ITERS, MAP_ITERS, flags, FX, FY))
+        for a in (params["xyz"], params["rgb"], params["quat"], params["logit"], params["logs"], frgb.cpu().numpy(), fdepth.cpu().numpy(),
+                  T_true.cpu().numpy(), T_init.numpy()):
+            f.write(np.ascontiguousarray(a, np.float32).tobytes())
+    r = subprocess.run([exe, path], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return {ln.split()[0]: [float(x) for x in ln.split()[1:]] for ln in r.stdout.splitlines() if ln.strip()}
+
+
+@pytest.mark.parametrize("fused", [7, 4])
+def test_cpp_map_growth_follows_the_python_harness(gsr, syn, tmp_path, fused):
+    """The map-growth half of the per-frame loop in C++ — SlamLoop::AddGaussians (Render::AddGaussian + ProjectPixel +
+    Gaussian::AddGaussianPoints, src/Render.cc:557-594,618-653, src/Gaussian.cc:40-95) and PruneLowOpacity (Render::RemoveGaussian,
+    Gaussian::RemovePoints / PruneOptimizer, src/Render.cc:598-616, src/Gaussian.cc:180-234) with the Adam-moment surgery — against
+    the Python harness (densify / remove_low_opacity / GaussianMap.add_points / prune) on the same half-empty map: the same
+    number of Gaussians added and pruned (the masks come from renders that agree to rounding) and the same mapping losses after
+    each surgery (wrong moments would show at once: Adam's step is m / sqrt(v)). fused = 7: the fused Adam's own state;
+    4: torch::optim::Adam's state map, the reference's structure."""
+    hz = __import__("gsorb_slam_amd.harness", fromlist=["x"])
+    P = 20000
+    params, frgb, fdepth, T_true, T_init = _scene(syn, hz, P)
+    h = P // 2
+    cfg = hz.Config()
+    cfg.prune_opacities = 0.6
+    g = hz.GaussianMap(cfg, FX, FY, device="cuda")
+    g.add_points(torch.tensor(params["xyz"][:h]), torch.tensor(params["rgb"][:h]))
+    with torch.no_grad():
+        g.log_scales.copy_(torch.tensor(params["logs"][:h])); g.unnorm_quat.copy_(torch.tensor(params["quat"][:h]))
+        g.logit_opacities.copy_(torch.tensor(params["logit"][:h]))
+    r = hz.SlamRenderer(g, W, H)
+    fr = hz.Frame(frgb, fdepth, T_true)
+    for _ in range(2):
+        r.mapping_iteration([fr])
+    added = r.densify(fr)
+    size1 = len(g)
+    m1 = [r.mapping_iteration([fr]) for _ in range(MAP_ITERS)]
+    pruned = r.remove_low_opacity()
+    size2 = len(g)
+    m2 = [r.mapping_iteration([fr]) for _ in range(5)]
+    o = _cpp_growth_run(str(tmp_path / "grow.bin"), params, frgb, fdepth, T_true, T_init, flags=(fused & 3) | 4 | 8)
+    c_h, c_added, c_size1 = o["grow"]
+    c_pruned, c_size2 = o["prune"]
+    print("\nmap growth, C++ vs Python harness: added %d / %d (map %d -> %d / %d), pruned %d / %d (-> %d / %d); densify %.2f ms, prune %.2f ms in C++"
+          % (c_added, added, h, c_size1, size1, c_pruned, pruned, c_size2, size2, o["add_ms"][0], o["prune_ms"][0]))
+    assert c_h == h and added > 1000 and pruned > 100                       # the test exercises both surgeries
+    assert abs(c_added - added) <= max(2, 0.002 * added) and c_size1 == h + c_added
+    assert abs(c_pruned - pruned) <= max(2, 0.01 * pruned) and c_size2 == c_size1 - c_pruned
+    rel1 = np.abs(np.asarray(o["map"]) - np.asarray(m1)) / np.abs(np.asarray(m1))
+    rel2 = np.abs(np.asarray(o["map2"]) - np.asarray(m2)) / np.abs(np.asarray(m2))
+    print("      mapping loss after densify: max rel diff %.1e, after prune %.1e" % (rel1.max(), rel2.max()))
+    assert rel1[:20].max() < 5e-3 and rel2.max() < 5e-3
+    assert o["map"][-1] < o["map"][0]
