@@ -512,6 +512,117 @@ void gsro_blend_census(int W, int H, const uint32_t* ranges, const uint32_t* poi
     *evaluated = ne;
 }
 
+/* Measurement instrumentation (not in the reference): what the backward blend kernel's round structure would
+ * cost for other PATCH GEOMETRIES. The kernel (csrc/gsr_blend.h) gives one wave an 8x8 pixel quad and cuts it into patches of
+ * pw x ph pixels, one patch per group of pw*ph lanes ("row"); a round parks <= 64 quad-hit records, every row walks the list of
+ * the records that reach ITS patch (exact test of the alpha >= 1/255 ellipse against the rectangle of the patch's pixel
+ * centres: the kernel's patch_reach4, restated for any rectangle), the wave runs max-over-rows iterations (rounded up to an
+ * even number) and turns around for a reduce phase every 64 / rows iterations (one lane per (row, iteration) pair).
+ * Per geometry g (pw = geoms[2g], ph = geoms[2g+1]) out[8g..]: 0 quad hits walked, 1 patch hits, 2 wave iterations,
+ * 3 reduce phases, 4 rounds, 5 lane slots of the blend loop (64 x iterations), 6 blended (pixel, splat) pairs, 7 (pixel, splat)
+ * pairs inside reached patches. Records behind the quad's last contributor are dropped as the kernel drops them; the forward's
+ * round alignment (qdone = multiple of 64 records) is reproduced. */
+static int gsro_rect_reach(float mx, float my, float ca, float cb, float cc, float op, float X0, float Y0, float w, float h)
+{
+    if (op < 1.0f / 255.0f) return 0;
+    if (!(ca > 0.f) || !(cc > 0.f) || !(ca * cc > cb * cb)) return 1;
+    const float tau = logf(255.0f * op) + 0.01f;
+    const float dxl = mx - (X0 + w - 1.f), dxh = mx - X0, dyl = my - (Y0 + h - 1.f), dyh = my - Y0;
+    const float dxc = fminf(fmaxf(0.f, dxl), dxh), dyc = fminf(fmaxf(0.f, dyl), dyh);
+    if (dxc == 0.f && dyc == 0.f) return 1;
+    float q = 3.0e38f;
+    if (dxc != 0.f) {
+        const float dy = fminf(fmaxf(-cb * dxc / cc, dyl), dyh);
+        q = fminf(q, 0.5f * (ca * dxc * dxc + cc * dy * dy) + cb * dxc * dy);
+    }
+    if (dyc != 0.f) {
+        const float dx = fminf(fmaxf(-cb * dyc / ca, dxl), dxh);
+        q = fminf(q, 0.5f * (ca * dx * dx + cc * dyc * dyc) + cb * dx * dyc);
+    }
+    return !(q > tau);
+}
+
+void gsro_geometry_census(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
+                          const float* conic_opacity, const uint32_t* n_contrib, int ngeom, const int* geoms,
+                          unsigned long long* out)
+{
+    const int gx = (W + GSRO_BLOCK_X - 1) / GSRO_BLOCK_X, gy = (H + GSRO_BLOCK_Y - 1) / GSRO_BLOCK_Y;
+    for (int g = 0; g < ngeom; g++) {
+        const int pw = geoms[2 * g], ph = geoms[2 * g + 1], ncx = 8 / pw, ncy = 8 / ph, rows = ncx * ncy, ring = 64 / rows;
+        unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+#ifdef GSRO_OMP
+#pragma omp parallel for schedule(dynamic, 1) collapse(2) reduction(+ : a0, a1, a2, a3, a4, a5, a6, a7)
+#endif
+        for (int ty = 0; ty < gy; ty++)
+            for (int tx = 0; tx < gx; tx++) {
+                const uint32_t r0 = ranges[2 * (ty * gx + tx)], r1 = ranges[2 * (ty * gx + tx) + 1];
+                const int n = (int)(r1 - r0);
+                if (n <= 0) continue;
+                uint64_t* pm = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n); /* patch masks of the quad's records */
+                uint32_t* ppos = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
+                for (int quad = 0; quad < 4; quad++) {
+                    const int X0 = tx * 16 + (quad & 1) * 8, Y0 = ty * 16 + (quad >> 1) * 8;
+                    uint32_t ntodo = 0;
+                    for (int j = 0; j < 8; j++)
+                        for (int i = 0; i < 8; i++)
+                            if (X0 + i < W && Y0 + j < H && n_contrib[W * (Y0 + j) + X0 + i] > ntodo) ntodo = n_contrib[W * (Y0 + j) + X0 + i];
+                    if (ntodo == 0) continue;
+                    /* the quad's records, front to back (all of the tile list: the forward's round alignment needs them) */
+                    int nq = 0, nlive = 0;
+                    for (int k = 0; k < n; k++) {
+                        const uint32_t id = point_list[r0 + k];
+                        const float* co = conic_opacity + 4 * id;
+                        const float mx = means2D[2 * id], my = means2D[2 * id + 1];
+                        uint64_t m = 0;
+                        for (int cy = 0; cy < ncy; cy++)
+                            for (int cx = 0; cx < ncx; cx++)
+                                if (gsro_rect_reach(mx, my, co[0], co[1], co[2], co[3], (float)(X0 + cx * pw), (float)(Y0 + cy * ph), (float)pw, (float)ph))
+                                    m |= 1ull << (cy * ncx + cx);
+                        if (!m) continue;
+                        pm[nq] = m; ppos[nq] = (uint32_t)k; nq++;
+                        if ((uint32_t)k < ntodo) nlive = nq;
+                    }
+                    int cq = ((nlive + 63) / 64) * 64; /* the forward stops after the round that finished the quad */
+                    if (cq > nq) cq = nq;
+                    for (int top = cq; top > 0; top -= 64) { /* backward rounds: records [top-64, top), back to front */
+                        int c[64], count = 0;
+                        for (int r = 0; r < rows; r++) c[r] = 0;
+                        for (int e = top - 1; e >= 0 && e >= top - 64; e--) {
+                            if (ppos[e] >= ntodo) continue; /* behind every pixel's last contributor: dropped */
+                            count++;
+                            const uint32_t id = point_list[r0 + ppos[e]];
+                            const float* co = conic_opacity + 4 * id;
+                            for (int r = 0; r < rows; r++)
+                                if ((pm[e] >> r) & 1) {
+                                    c[r]++; a1++; a7 += (unsigned long long)(pw * ph);
+                                    const int px0 = X0 + (r % ncx) * pw, py0 = Y0 + (r / ncx) * ph;
+                                    for (int j = 0; j < ph; j++)
+                                        for (int i = 0; i < pw; i++) {
+                                            const int px = px0 + i, py = py0 + j;
+                                            if (!(px < W && py < H) || ppos[e] >= n_contrib[W * py + px]) continue;
+                                            const float dx = means2D[2 * id] - (float)px, dy = means2D[2 * id + 1] - (float)py;
+                                            const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                                            if (power > 0.0f) continue;
+                                            if (fminf(0.99f, co[3] * expf(power)) < 1.0f / 255.0f) continue;
+                                            a6++;
+                                        }
+                                }
+                        }
+                        if (count == 0) continue;
+                        int maxc = 0;
+                        for (int r = 0; r < rows; r++) if (c[r] > maxc) maxc = c[r];
+                        maxc = (maxc + 1) & ~1;
+                        a0 += (unsigned long long)count; a2 += (unsigned long long)maxc; a3 += (unsigned long long)((maxc + ring - 1) / ring);
+                        a4++; a5 += 64ull * (unsigned long long)maxc;
+                    }
+                }
+                free(pm); free(ppos);
+            }
+        unsigned long long* o = out + 8 * g;
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = a4; o[5] = a5; o[6] = a6; o[7] = a7;
+    }
+}
+
 /* Test instrumentation (not in the reference): smallest relative distance of any
  * data-dependent branch of forward.cu:346-379 from flipping, per pixel. exp() is not
  * bit-reproducible across libm/CUDA/HIP, so a pixel whose margin is below the

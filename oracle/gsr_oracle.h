@@ -44,7 +44,10 @@ extern "C" {
 uint32_t gsro_higher_msb(uint32_t n);
 void gsro_blend_census(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
                        const float* conic_opacity, const uint32_t* n_contrib, unsigned long long* blended,
-                       unsigned long long* evaluated); /* measurement only: (pixel, splat) pairs blended / walked */
+                       unsigned long long* evaluated);
+void gsro_geometry_census(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
+                          const float* conic_opacity, const uint32_t* n_contrib, int ngeom, const int* geoms,
+                          unsigned long long* out); /* measurement: patch geometries of the backward blend (see the .c) */ /* measurement only: (pixel, splat) pairs blended / walked */
 void gsro_set_threads(int n); /* OpenMP build only: size of the thread team; no-op otherwise */
 
 /* DGR/cuda_rasterizer/rasterizer_impl.cu:55-67 + auxiliary.h:139-164 */

@@ -70,6 +70,8 @@ def _load(omp: bool):
     lib.gsro_dist2.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
     lib.gsro_blend_census.restype = None
     lib.gsro_blend_census.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 7
+    lib.gsro_geometry_census.restype = None
+    lib.gsro_geometry_census.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p]
     lib.gsro_set_threads.restype = None
     lib.gsro_set_threads.argtypes = [C.c_int]
     lib.gsro_higher_msb.restype = C.c_uint32
@@ -201,6 +203,17 @@ class Oracle:
             self.lib.gsro_blend_census(s.W, s.H, ptr(_STAGES["ranges"][0]), ptr(_STAGES["point_list"][0]), ptr(_STAGES["means2D"][0]),
                                        ptr(_STAGES["conic_opacity"][0]), ptr(_STAGES["n_contrib"][0]), C.byref(nb), C.byref(ne))
         return int(nb.value), int(ne.value)
+
+    def geometry_census(self, geoms):
+        """Round structure of the backward blend for patch geometries [(pw, ph), ...] (gsro_geometry_census): dicts of counts."""
+        s = self._s
+        ptr = lambda idx: C.c_void_p(self.lib.gsro_stage(self.state, idx, C.byref(C.c_size_t(0))))
+        ga = np.ascontiguousarray(np.array(geoms, np.int32).reshape(-1, 2))
+        out = np.zeros((len(ga), 8), np.uint64)
+        self.lib.gsro_geometry_census(s.W, s.H, ptr(_STAGES["ranges"][0]), ptr(_STAGES["point_list"][0]), ptr(_STAGES["means2D"][0]),
+                                      ptr(_STAGES["conic_opacity"][0]), ptr(_STAGES["n_contrib"][0]), len(ga), _ptr(ga), _ptr(out))
+        names = ("quad_hits", "patch_hits", "wave_iterations", "reduce_phases", "rounds", "lane_slots", "blended_pairs", "pairs_in_reached_patches")
+        return [dict(zip(names, (int(x) for x in row))) for row in out]
 
     def backward(self, dL_dpix, accum_double: bool = True) -> Backward:
         P, M = self._P, self._M

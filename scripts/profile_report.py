@@ -61,7 +61,7 @@ for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), r
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         cnt[k][row["Counter_Name"]] += 1
 avg = {k: {c: v / cnt[k][c] for c, v in d.items()} for k, d in agg.items()}
-order = ["K_preprocess", "K_bin_count", "K_bin_colscan", "K_scan_tiles", "K_bin_fill", "K_tile_sort_short", "K_tile_sort_long", "K_blend_fwd", "K_blend_bwd", "K_splat_bwd"]
+order = ["K_preprocess", "K_bin_count", "K_bin_colscan", "K_scan_tiles", "K_bin_fill", "K_tile_sort_cut", "K_tile_sort_short", "K_tile_sort_long", "K_blend_fwd", "K_blend_bwd", "K_splat_bwd"]
 sq = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY",
       "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
       "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"]
