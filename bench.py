@@ -301,9 +301,14 @@ def cpp_loop_ms(a, gsr, dev, P=1_000_000, track_iters=20, map_iters=20):
     arrays = dict(means3D=sc.means3D, opacities=sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
     pair = quick_raster(gsr, dev, cam, arrays, sc.dL_dpix, steps=a.other_steps, dual=True,
                         grad_ds=np.random.default_rng(5).standard_normal((2, H, W)).astype(np.float32))
-    return {"what": f"ORB_SLAM2::SlamLoop (C++, libgsr_torch.so) at {P} Gaussians, {W}x{H}: wall clock per iteration incl. the one loss read-back "
-                    "(fused pair, fused loss / SSIM / Adam / pose kernels); raster_pair = fwd+bwd of the fused colour + depth/silhouette pass alone",
-            "mapping": o["map_ms_per_iter"][0], "tracking": o["track_ms_per_iter"][0], "raster_pair": pair["ms_per_step"],
+    return {"what": f"ORB_SLAM2::SlamLoop (C++, libgsr_torch.so) at {P} Gaussians, {W}x{H}, wall clock per iteration: the iterations as fixed "
+                    "sequences of C-ABI launches on a persistent workspace (torch_ext/DirectLoop.cpp: fused pair, fused loss / SSIM kernels, "
+                    "gsr_map_prepare / gsr_map_update / gsr_pose_update). mapping = SlamLoop::MapFrame (Render::RenderForFrame's loop: the losses "
+                    "are read back once, after the last iteration, like the reference's loop, which never looks at one); mapping_per_iteration_readback "
+                    "= MappingIteration in a loop (one loss read-back and synchronisation per iteration); tracking reads its loss every iteration "
+                    "(Render.cc:1107); raster_pair = fwd+bwd of the fused colour + depth/silhouette pass alone",
+            "mapping": o.get("mapframe_ms_per_iter", o["map_ms_per_iter"])[0], "mapping_per_iteration_readback": o["map_ms_per_iter"][0],
+            "tracking": o["track_ms_per_iter"][0], "raster_pair": pair["ms_per_step"],
             "raster_pair_bwd_blend_ms": pair["bwd_blend_ms"], "raster_pair_fwd_blend_ms": pair["fwd_blend_ms"],
             "tracking_iterations_run": len(o.get("track", [])), "mapping_iterations_run": map_iters}
 

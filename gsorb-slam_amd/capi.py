@@ -19,7 +19,8 @@ EXPORTS = ["gsr_forward", "gsr_forward_ws", "gsr_ws_status", "gsr_backward", "gs
            "gsr_visible_filter", "gsr_geom_bytes", "gsr_image_bytes", "gsr_binning_bytes",
            "gsr_debug_export", "gsr_acc_view", "gsr_knn_bytes", "gsr_dist2", "gsr_ssim_partials", "gsr_ssim_forward", "gsr_ssim_backward",
            "gsr_adam_step", "gsr_pose_grad", "gsr_to_camera", "gsr_pose_from_quat", "gsr_pose_from_quat_backward",
-           "gsr_pixel_loss", "gsr_pixel_loss_backward", "gsr_scale_reg", "gsr_scale_reg_backward", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
+           "gsr_pixel_loss", "gsr_pixel_loss_backward", "gsr_pixel_loss_backward_add", "gsr_scale_reg", "gsr_scale_reg_backward",
+           "gsr_map_prepare", "gsr_map_update", "gsr_map_loss_total", "gsr_pose_update", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
 
 
 def library_path() -> str:
@@ -65,6 +66,23 @@ class DebugArrays(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("means2D", "depths", "conic_opacity", "rgb", "tiles_touched",
                                           "point_list", "point_list_keys", "ranges", "final_T",
                                           "n_contrib")]
+
+
+class MapUpdateArgs(C.Structure):
+    """gsr_map_update_args (include/gsr.h)"""
+    _fields_ = [("n", C.c_size_t), ("xyz", C.c_void_p), ("rgb", C.c_void_p), ("unnorm_quat", C.c_void_p), ("logit", C.c_void_p),
+                ("log_scales", C.c_void_p), ("exp_avg", C.c_void_p * 5), ("exp_avg_sq", C.c_void_p * 5), ("dL_dmeans_cam", C.c_void_p),
+                ("dL_dcolors", C.c_void_p), ("dL_drotations", C.c_void_p), ("dL_dopacities", C.c_void_p), ("dL_dscales", C.c_void_p),
+                ("opacities", C.c_void_p), ("scales", C.c_void_p), ("Tcw", C.c_void_p), ("reg_out", C.c_void_p), ("reg_limit", C.c_float),
+                ("w_long", C.c_float), ("w_scalar", C.c_float), ("geom", C.c_void_p), ("lr", C.c_double * 5), ("beta1", C.c_double),
+                ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int * 5)]
+
+
+class PoseUpdateArgs(C.Structure):
+    """gsr_pose_update_args (include/gsr.h)"""
+    _fields_ = [("quat_trans", C.c_void_p), ("moments", C.c_void_p), ("best", C.c_void_p), ("history", C.c_void_p), ("Tcw", C.c_void_p),
+                ("partial", C.c_void_p), ("loss", C.c_void_p), ("geom", C.c_void_p), ("lr", C.c_double), ("beta1", C.c_double),
+                ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int)]
 
 
 def lib():
@@ -131,6 +149,16 @@ def lib():
     L.gsr_scale_reg.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gsr_scale_reg_backward.restype = C.c_int
     L.gsr_scale_reg_backward.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gsr_pixel_loss_backward_add.restype = C.c_int
+    L.gsr_pixel_loss_backward_add.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float)] + [C.c_void_p] * 6
+    L.gsr_map_prepare.restype = C.c_int
+    L.gsr_map_prepare.argtypes = [C.c_size_t] + [C.c_void_p] * 9 + [C.c_float] * 3 + [C.c_void_p] * 3
+    L.gsr_map_update.restype = C.c_int
+    L.gsr_map_update.argtypes = [C.POINTER(MapUpdateArgs), C.c_void_p]
+    L.gsr_map_loss_total.restype = C.c_int
+    L.gsr_map_loss_total.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gsr_pose_update.restype = C.c_int
+    L.gsr_pose_update.argtypes = [C.POINTER(PoseUpdateArgs), C.c_void_p]
     L.gsr_error_string.restype = C.c_char_p
     L.gsr_error_string.argtypes = [C.c_int]
     L.gsr_last_hip_error.restype = C.c_char_p
@@ -465,7 +493,7 @@ def ssim_mean(img1, img2, taps):
     return _FusedSSIM.apply(_f32(img1, img1.device) if img1.dtype != torch.float32 else img1, img2.to(torch.float32), tuple(taps))
 
 
-LOSS_PARTIALS = 256  # GSR_LOSS_PARTIALS
+LOSS_PARTIALS = 1024  # GSR_LOSS_PARTIALS
 
 
 class _PixelLoss(torch.autograd.Function):
@@ -558,6 +586,49 @@ def scale_regularisers(log_scales, limit, w_long, w_scalar):
 
 
 POSE_PARTIALS = 512  # GSR_POSE_PARTIALS
+
+
+def map_prepare(xyz, logit, log_scales, unnorm_quat, Tcw, reg=None):
+    """gsr_map_prepare: (means_cam, opacities [n], scales, rotations[, reg_out [4]]) of n raw Gaussians under the device pose Tcw;
+    reg = (limit, w_long, w_scalar) also evaluates the scale regularisers in the same pass."""
+    n = int(xyz.shape[0])
+    mc, sc, rot = torch.empty_like(xyz), torch.empty_like(log_scales), torch.empty_like(unnorm_quat)
+    op = torch.empty((n,), dtype=torch.float32, device=xyz.device)
+    part = torch.empty((3 * ((n + 255) // 256),), dtype=torch.float32, device=xyz.device) if reg else None
+    out = torch.empty((4,), dtype=torch.float32, device=xyz.device) if reg else None
+    lim, wl, ws = reg if reg else (0.0, 0.0, 0.0)
+    with torch.cuda.device(xyz.device):
+        _check(lib().gsr_map_prepare(n, _p(xyz), _p(logit), _p(log_scales), _p(unnorm_quat), _p(Tcw), _p(mc), _p(op), _p(sc), _p(rot), float(lim),
+                                     float(wl), float(ws), _p(part) if reg else None, _p(out) if reg else None, _stream()))
+    return (mc, op, sc, rot, out) if reg else (mc, op, sc, rot)
+
+
+def map_update(params, moments, grads, acts, Tcw, lrs, steps, reg=None, geom=None, betas=(0.9, 0.999), eps=1e-15):
+    """gsr_map_update, in place: params = (xyz, rgb, unnorm_quat, logit, log_scales), moments = ((exp_avg,) * 5, (exp_avg_sq,) * 5),
+    grads = (dL_dmeans_cam, dL_dcolors, dL_drotations, dL_dopacities, dL_dscales), acts = (opacities, scales) of gsr_map_prepare;
+    reg = (reg_out, limit, w_long, w_scalar)."""
+    a = MapUpdateArgs()
+    a.n = int(params[0].shape[0])
+    a.xyz, a.rgb, a.unnorm_quat, a.logit, a.log_scales = (_p(t) for t in params)
+    for g in range(5):
+        a.exp_avg[g] = _p(moments[0][g]); a.exp_avg_sq[g] = _p(moments[1][g]); a.lr[g] = float(lrs[g]); a.step[g] = int(steps[g])
+    a.dL_dmeans_cam, a.dL_dcolors, a.dL_drotations, a.dL_dopacities, a.dL_dscales = (_p(t) for t in grads)
+    a.opacities, a.scales = _p(acts[0]), _p(acts[1])
+    a.Tcw = _p(Tcw)
+    if reg:
+        a.reg_out = _p(reg[0]); a.reg_limit, a.w_long, a.w_scalar = float(reg[1]), float(reg[2]), float(reg[3])
+    a.geom = _p(geom) if geom is not None else None
+    a.beta1, a.beta2, a.eps = float(betas[0]), float(betas[1]), float(eps)
+    with torch.cuda.device(params[0].device):
+        _check(lib().gsr_map_update(C.byref(a), _stream()))
+
+
+def pose_update(quat_trans, moments, best, history_slot, Tcw, partial, loss, lr, step, geom=None, betas=(0.9, 0.999), eps=1e-15):
+    """gsr_pose_update, in place (see include/gsr.h)."""
+    a = PoseUpdateArgs(_p(quat_trans), _p(moments), _p(best), _p(history_slot), _p(Tcw), _p(partial), _p(loss),
+                       _p(geom) if geom is not None else None, float(lr), float(betas[0]), float(betas[1]), float(eps), int(step))
+    with torch.cuda.device(quat_trans.device):
+        _check(lib().gsr_pose_update(C.byref(a), _stream()))
 
 
 class _ToCamera(torch.autograd.Function):

@@ -534,7 +534,7 @@ int gsr_pixel_loss(const float* image, const float* depth, const float* sur, con
     const int nb = (int)std::min<size_t>(GSR_LOSS_BLOCKS, (N + 255) / 256);
     hipLaunchKernelGGL(gsr::K_loss_sums, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, N, mode, sil_thr, partial);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_loss_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nb, mode, N, w, depth ? 0 : 1, sums);
+    hipLaunchKernelGGL(gsr::K_loss_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, partial, nb, mode, N, w, depth ? 0 : 1, sums);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -549,7 +549,97 @@ int gsr_pixel_loss_backward(const float* image, const float* depth, const float*
     const gsr::LossPlanes p{image, depth, nullptr, sil, frame_rgb, frame_depth};
     gsr::LossWeights w{{w3[0], w3[1], w3[2]}};
     hipLaunchKernelGGL(gsr::K_loss_grad, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, N, mode, sil_thr, w, sums, dL_dloss,
-                       dL_dimage, dL_ddepth);
+                       dL_dimage, dL_ddepth, (const float*)nullptr);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_pixel_loss_backward_add(const float* image, const float* depth, const float* sil, const float* frame_rgb, const float* frame_depth,
+                                int H, int W, int mode, float sil_thr, const float* w3, const float* sums, const float* dL_dloss,
+                                const float* add_image, float* dL_dimage, float* dL_ddepth, void* stream)
+{
+    if (!image || !frame_rgb || !frame_depth || !w3 || !sums || !dL_dimage || H <= 0 || W <= 0 || (mode != 0 && mode != 1)) return GSR_EINVAL;
+    const size_t N = (size_t)H * W;
+    if ((N + 255) / 256 > 0x7FFFFFFFu) return GSR_EINVAL;
+    const gsr::LossPlanes p{image, depth, nullptr, sil, frame_rgb, frame_depth};
+    gsr::LossWeights w{{w3[0], w3[1], w3[2]}};
+    hipLaunchKernelGGL(gsr::K_loss_grad, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, N, mode, sil_thr, w, sums, dL_dloss,
+                       dL_dimage, dL_ddepth, add_image);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+namespace {
+const uint32_t* overflow_flag(const char* geom)
+{
+    return geom ? &reinterpret_cast<const GeomHeader*>(geom)->overflow : nullptr;
+}
+} // namespace
+
+int gsr_map_prepare(size_t n, const float* xyz, const float* logit, const float* log_scales, const float* unnorm_quat, const float* Tcw,
+                    float* means_cam, float* opacities, float* scales, float* rotations, float reg_limit, float w_long, float w_scalar,
+                    float* reg_partial, float* reg_out, void* stream)
+{
+    if ((means_cam && (!xyz || !Tcw)) || (opacities && !logit) || ((scales || reg_partial) && !log_scales) || (rotations && !unnorm_quat) ||
+        ((reg_partial != nullptr) != (reg_out != nullptr)) || (n + 255) / 256 > 0x7FFFFFFFu)
+        return GSR_EINVAL;
+    const unsigned rows = (unsigned)((n + 255) / 256);
+    if (n > 0)
+        hipLaunchKernelGGL(gsr::K_map_prepare, dim3(rows), dim3(256), 0, (hipStream_t)stream, n, xyz, logit, log_scales, unnorm_quat, Tcw, means_cam,
+                           opacities, scales, rotations, reg_limit, reg_partial);
+    GSR_LAUNCHED();
+    if (reg_partial) {
+        hipLaunchKernelGGL(gsr::K_scale_reg_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, reg_partial, (int)rows, w_long, w_scalar, reg_out);
+        GSR_LAUNCHED();
+    }
+    return GSR_OK;
+}
+
+int gsr_map_update(const gsr_map_update_args* a, void* stream)
+{
+    if (!a) return GSR_EINVAL;
+    if (a->n == 0) return GSR_OK;
+    if (!a->xyz || !a->rgb || !a->unnorm_quat || !a->logit || !a->log_scales || !a->dL_dmeans_cam || !a->dL_dcolors || !a->dL_drotations ||
+        !a->dL_dopacities || !a->dL_dscales || !a->opacities || !a->scales || !a->Tcw || (a->n + 255) / 256 > 0x7FFFFFFFu)
+        return GSR_EINVAL;
+    gsr::MapUpdate u;
+    u.xyz = a->xyz; u.rgb = a->rgb; u.quat = a->unnorm_quat; u.logit = a->logit; u.ls = a->log_scales;
+    for (int g = 0; g < 5; g++) {
+        if (!a->exp_avg[g] || !a->exp_avg_sq[g] || a->step[g] < 1) return GSR_EINVAL;
+        u.m[g] = a->exp_avg[g]; u.v[g] = a->exp_avg_sq[g];
+        // (bias corrections in double, like gsr_adam_step)
+        const double bc1 = 1.0 - std::pow(a->beta1, (double)a->step[g]), bc2 = 1.0 - std::pow(a->beta2, (double)a->step[g]);
+        u.step_size[g] = (float)(a->lr[g] / bc1); u.sqrt_bias2[g] = (float)std::sqrt(bc2);
+    }
+    u.dmc = a->dL_dmeans_cam; u.dcol = a->dL_dcolors; u.drot = a->dL_drotations; u.dopac = a->dL_dopacities; u.dscale = a->dL_dscales;
+    u.opac = a->opacities; u.scales = a->scales; u.Tcw = a->Tcw; u.reg_out = a->reg_out; u.overflow = overflow_flag(a->geom);
+    u.limit = a->reg_limit; u.w_long = a->w_long; u.w_scalar = a->w_scalar;
+    u.w1 = (float)(1.0 - a->beta1); u.b2 = (float)a->beta2; u.w2 = (float)(1.0 - a->beta2); u.eps = (float)a->eps;
+    hipLaunchKernelGGL(gsr::K_map_update, dim3((unsigned)((a->n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, a->n, u); // four splats per thread
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_map_loss_total(const float* sums, const float* ssim_partial, int n_partial, size_t count, float c_ssim, const float* reg_out,
+                       const char* geom, float* loss, void* stream)
+{
+    if (!sums || !loss || n_partial < 0 || (n_partial > 0 && (!ssim_partial || count == 0))) return GSR_EINVAL;
+    hipLaunchKernelGGL(gsr::K_map_loss_total, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, sums, ssim_partial, n_partial,
+                       count ? 1.f / (float)count : 0.f, n_partial ? c_ssim : 0.f, reg_out, overflow_flag(geom), loss);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_pose_update(const gsr_pose_update_args* a, void* stream)
+{
+    if (!a || !a->quat_trans || !a->moments || !a->best || !a->history || !a->Tcw || !a->partial || !a->loss || a->step < 1) return GSR_EINVAL;
+    gsr::PoseUpdate u;
+    u.quat_trans = a->quat_trans; u.moments = a->moments; u.best = a->best; u.history = a->history; u.Tcw = a->Tcw;
+    u.partial = a->partial; u.loss = a->loss; u.overflow = overflow_flag(a->geom);
+    const double bc1 = 1.0 - std::pow(a->beta1, (double)a->step), bc2 = 1.0 - std::pow(a->beta2, (double)a->step);
+    u.w1 = (float)(1.0 - a->beta1); u.b2 = (float)a->beta2; u.w2 = (float)(1.0 - a->beta2); u.eps = (float)a->eps;
+    u.step_size = (float)(a->lr / bc1); u.sqrt_bias2 = (float)std::sqrt(bc2);
+    hipLaunchKernelGGL(gsr::K_pose_update, dim3(1), dim3(64), 0, (hipStream_t)stream, u);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -560,7 +650,7 @@ int gsr_scale_reg(const float* log_scales, size_t n, float limit, float w_long, 
     const int nb = (int)std::max<size_t>(1, std::min<size_t>(GSR_LOSS_BLOCKS, (n + 255) / 256));
     hipLaunchKernelGGL(gsr::K_scale_reg, dim3(nb), dim3(256), 0, (hipStream_t)stream, log_scales, n, limit, partial);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_scale_reg_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nb, w_long, w_scalar, out);
+    hipLaunchKernelGGL(gsr::K_scale_reg_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, partial, nb, w_long, w_scalar, out);
     GSR_LAUNCHED();
     return GSR_OK;
 }

@@ -543,11 +543,7 @@ __device__ __forceinline__ int sort_tile(SortShared<KIND>& sh, uint64_t* __restr
         for (int j = 0; j < EPT; j++) {
             const int i = j * NT + tid;
             const uint64_t v = seg[min(i, n - 1)];
-#ifdef GSR_EXP_SORT_NOGATHER
-            pay[j] = reach ? reach[r.x + min(i, n - 1)] : make_uint2(0u, 0u);
-#else
             pay[j] = reach ? reach[(uint32_t)v] : make_uint2(0u, 0u);
-#endif
             k[j] = i < n ? v : ~0ull; // padding keys: above every real key
             dmin = min(dmin, (uint32_t)(k[j] >> 32));
             dmax = max(dmax, i < n ? (uint32_t)(v >> 32) : 0u);

@@ -276,7 +276,26 @@ __global__ void K_rt2T_bwd(const float* __restrict__ quat, const float* __restri
 // sums[8] = {sum |img - rgb|, sum |d - fd|, count, sum |sur - fd|, count_S, loss, 0, 0}. `d` is the differentiable depth plane
 // (NULL: no such term), `sur` the median-depth plane (no gradient: the rasterizer does not differentiate it).
 // =====================================================================================
-#define GSR_LOSS_BLOCKS 256
+// Sum of K per-thread values over a 256-thread workgroup (the single-workgroup "finish" kernels: with one wave a few thousand
+// partial rows are a chain of dependent loads — 17 / 38 us for 3 900 / 9 700 rows — with four waves and four rows in flight a few us).
+#define GSR_FINISH_THREADS 256
+template <int K>
+__device__ __forceinline__ void finish_sum(float (&a)[K], float (*ws)[K])
+{
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < K; q++) ws[threadIdx.x >> 6][q] = a[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < K; q++) a[q] = (ws[0][q] + ws[1][q]) + (ws[2][q] + ws[3][q]);
+}
+#define GSR_LOSS_BLOCKS 1024
 struct LossPlanes {
     const float* image;  // [3,H,W]
     const float* depth;  // [H,W] or nullptr
@@ -319,20 +338,17 @@ K_loss_sums(LossPlanes p, size_t N, int mode, float thr, float* __restrict__ par
 struct LossWeights {
     float w[3];
 };
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(GSR_FINISH_THREADS)
 K_loss_finish(const float* __restrict__ partial, int nblocks, int mode, size_t N, LossWeights w, int depth_from_sur, float* __restrict__ sums)
 {
+    __shared__ float ws[4][5];
     const int lane = threadIdx.x;
     float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int b = lane; b < nblocks; b += 64) {
+    for (int b = lane; b < nblocks; b += GSR_FINISH_THREADS) {
 #pragma unroll
         for (int q = 0; q < 5; q++) a[q] += partial[b * 5 + q];
     }
-#pragma unroll
-    for (int q = 0; q < 5; q++) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off, 64);
-    }
+    finish_sum<5>(a, ws);
     if (lane == 0) {
         float loss;
         if (mode == 0) loss = w.w[0] * a[0] + w.w[1] * (depth_from_sur ? a[3] : a[1]);
@@ -343,11 +359,11 @@ K_loss_finish(const float* __restrict__ partial, int nblocks, int mode, size_t N
 // gradient planes: dL/dimage [3,H,W] and dL/ddepth [H,W] (nullptr: not wanted), times the upstream gradient *go
 __global__ void __launch_bounds__(256)
 K_loss_grad(LossPlanes p, size_t N, int mode, float thr, LossWeights w, const float* __restrict__ sums, const float* __restrict__ go,
-            float* __restrict__ dimage, float* __restrict__ ddepth)
+            float* __restrict__ dimage, float* __restrict__ ddepth, const float* __restrict__ add)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    const float g = go[0];
+    const float g = go ? go[0] : 1.f;
     const float fd = p.fdepth[i];
     const bool solid = !p.sil || p.sil[i] > thr;
     const bool colour_in = mode == 0 ? (solid && fd == fd) : true;
@@ -355,7 +371,7 @@ K_loss_grad(LossPlanes p, size_t N, int mode, float thr, LossWeights w, const fl
     const float ci = mode == 0 ? g * w.w[0] : g * w.w[0] / (3.f * (float)N);
     const float cd = mode == 0 ? g * w.w[1] : g * w.w[1] / sums[2];
 #pragma unroll
-    for (int c = 0; c < 3; c++) dimage[c * N + i] = colour_in ? ci * sgn(p.image[c * N + i] - p.frgb[c * N + i]) : 0.f;
+    for (int c = 0; c < 3; c++) dimage[c * N + i] = (colour_in ? ci * sgn(p.image[c * N + i] - p.frgb[c * N + i]) : 0.f) + (add ? add[c * N + i] : 0.f);
     if (ddepth) ddepth[i] = (depth_in && p.depth) ? cd * sgn(p.depth[i] - fd) : 0.f;
 }
 
@@ -387,20 +403,17 @@ K_scale_reg(const float* __restrict__ ls, size_t n, float limit, float* __restri
     __syncthreads();
     if (threadIdx.x < 3) partial[blockIdx.x * 3 + threadIdx.x] = (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]);
 }
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(GSR_FINISH_THREADS)
 K_scale_reg_finish(const float* __restrict__ partial, int nblocks, float w_long, float w_scalar, float* __restrict__ out)
 {
+    __shared__ float ws[4][3];
     const int lane = threadIdx.x;
     float a[3] = {0.f, 0.f, 0.f};
-    for (int b = lane; b < nblocks; b += 64) {
+    for (int b = lane; b < nblocks; b += GSR_FINISH_THREADS) {
 #pragma unroll
         for (int q = 0; q < 3; q++) a[q] += partial[b * 3 + q];
     }
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off, 64);
-    }
+    finish_sum<3>(a, ws);
     if (lane == 0) {
         out[0] = a[0]; out[1] = a[1]; out[2] = a[2];
         out[3] = w_long * (a[0] > 0.f ? a[2] / a[0] : 0.f) + w_scalar * a[1];
@@ -428,6 +441,319 @@ K_scale_reg_bwd(const float* __restrict__ ls, size_t n, float limit, float w_lon
         for (int k = 0; k < 3; k++) d[k] = ((k == imax ? a + b : 0.f) - (k == imin ? b : 0.f)) * s[k];
     }
     dls[3 * i] = d[0]; dls[3 * i + 1] = d[1]; dls[3 * i + 2] = d[2];
+}
+
+// =====================================================================================
+// The loops without a tensor library inside the iteration (round 4). Through libtorch a mapping iteration is ~60 launches
+// (activations and their autograd, gradient accumulation, zero fills, five Adam launches) and as many host-side dispatches;
+// profiled at 1 M Gaussians, 1200x680: 1.08-1.30 ms per iteration of which the rasterizer pair is 0.55. Here an iteration is
+//   K_map_prepare  raw parameters -> what the rasterizer takes: camera-frame means, sigmoid / exp / unit quaternion; the
+//                  scale regularisers' partial sums ride on the same pass over log_scales
+//   (rasterizer forward, loss kernels, rasterizer backward)
+//   K_map_update   gradients w.r.t. the rasterizer's inputs -> gradients of the raw parameters (camera transform, sigmoid,
+//                  exp, normalisation, the regularisers' gradient) -> Adam step of all five tensors, in place: no gradient
+//                  tensor of a raw parameter ever exists
+// and a tracking iteration ends in K_pose_update (sum of the pose partials -> rt2T backward -> best-pose bookkeeping -> Adam on
+// the seven pose numbers -> the next iteration's Tcw). Every update is predicated on the rasterizer's overflow flag (a
+// workspace that was too small skips the iteration's step instead of applying garbage; the host sees it at its next read).
+// Reference: src/Render.cc:420-483 (mapping), :1054-1126 (tracking), src/Gaussian.cc:144-175 (optimisers), :97-150 (pose).
+// =====================================================================================
+#define GSR_MAP_REG_ROWS(n) (((n) + 255) / 256) // partial rows K_map_prepare writes (3 floats each)
+__global__ void __launch_bounds__(256)
+K_map_prepare(size_t n, const float* __restrict__ xyz, const float* __restrict__ logit, const float* __restrict__ ls,
+              const float* __restrict__ quat, const float* __restrict__ Tcw, float* __restrict__ mc, float* __restrict__ opac,
+              float* __restrict__ scales, float* __restrict__ rots, float limit, float* __restrict__ reg_partial)
+{
+    __shared__ float ws[4][3];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float a[3] = {0.f, 0.f, 0.f};
+    if (i < n) {
+        if (mc) {
+            const Pose34 T = load_pose(Tcw);
+            const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+            mc[3 * i] = fmaf(T.r[2], z, fmaf(T.r[1], y, T.r[0] * x)) + T.t[0];
+            mc[3 * i + 1] = fmaf(T.r[5], z, fmaf(T.r[4], y, T.r[3] * x)) + T.t[1];
+            mc[3 * i + 2] = fmaf(T.r[8], z, fmaf(T.r[7], y, T.r[6] * x)) + T.t[2];
+        }
+        if (opac) opac[i] = 1.f / (1.f + expf(-logit[i]));
+        if (scales || reg_partial) {
+            const float s0 = expf(ls[3 * i]), s1 = expf(ls[3 * i + 1]), s2 = expf(ls[3 * i + 2]);
+            if (scales) { scales[3 * i] = s0; scales[3 * i + 1] = s1; scales[3 * i + 2] = s2; }
+            const float wgt = (float)(s0 > limit) + (float)(s1 > limit) + (float)(s2 > limit);
+            const float mx = fmaxf(s0, fmaxf(s1, s2)), mn = fminf(s0, fminf(s1, s2));
+            a[0] = wgt; a[1] = wgt * (mx - limit); a[2] = wgt * (mx - mn);
+        }
+        if (rots) { // torch::nn::functional::normalize: q / max(|q|, 1e-12)
+            const float4 q = reinterpret_cast<const float4*>(quat)[i];
+            const float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+            reinterpret_cast<float4*>(rots)[i] = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+        }
+    }
+    if (!reg_partial) return;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) ws[threadIdx.x >> 6][q] = a[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) reg_partial[(size_t)blockIdx.x * 3 + threadIdx.x] = (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]);
+}
+
+struct MapUpdate {
+    float *xyz, *rgb, *quat, *logit, *ls;                                  // raw parameters, updated in place
+    float *m[5], *v[5];                                                    // Adam moments, same order
+    const float *dmc, *dcol, *drot, *dopac, *dscale;                       // dL/d(camera-frame mean, colour, unit quaternion, opacity, scale)
+    const float *opac, *scales;                                            // the activations K_map_prepare wrote
+    const float* Tcw;
+    const float* reg_out;                                                  // K_scale_reg_finish's out[4] (nullptr: no regularisers)
+    const uint32_t* overflow;                                              // the rasterizer's flag (nullptr: never skip)
+    float limit, w_long, w_scalar;
+    float w1, b2, w2, eps, step_size[5], sqrt_bias2[5];
+};
+__device__ __forceinline__ void adam_one(float& pp, const float gg, float& mm, float& vv, const MapUpdate& u, const int g)
+{
+    mm = fmaf(u.w1, gg - mm, mm);
+    vv = fmaf(u.w2 * gg, gg, vv * u.b2);
+    const float denom = sqrtf(vv) / u.sqrt_bias2[g] + u.eps;
+    pp = fmaf(-u.step_size[g], mm / denom, pp);
+}
+__device__ __forceinline__ void map_update_one(const size_t i, const MapUpdate& u, const Pose34& T)
+{
+    { // means: mc = X R^T + t  =>  dL/dX = dmc R
+        const float g0 = u.dmc[3 * i], g1 = u.dmc[3 * i + 1], g2 = u.dmc[3 * i + 2];
+        const float d[3] = {fmaf(g2, T.r[6], fmaf(g1, T.r[3], g0 * T.r[0])), fmaf(g2, T.r[7], fmaf(g1, T.r[4], g0 * T.r[1])),
+                            fmaf(g2, T.r[8], fmaf(g1, T.r[5], g0 * T.r[2]))};
+#pragma unroll
+        for (int k = 0; k < 3; k++) adam_one(u.xyz[3 * i + k], d[k], u.m[0][3 * i + k], u.v[0][3 * i + k], u, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) adam_one(u.rgb[3 * i + k], u.dcol[3 * i + k], u.m[1][3 * i + k], u.v[1][3 * i + k], u, 1);
+    { // unit quaternion r = q / |q|: dL/dq = (dr - r (r . dr)) / |q|
+        float4 q = reinterpret_cast<float4*>(u.quat)[i];
+        const float4 dr = reinterpret_cast<const float4*>(u.drot)[i];
+        const float nn = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f), inv = 1.f / nn;
+        const float r0 = q.x * inv, r1 = q.y * inv, r2 = q.z * inv, r3 = q.w * inv;
+        const float dot = r0 * dr.x + r1 * dr.y + r2 * dr.z + r3 * dr.w;
+        float4 M = reinterpret_cast<float4*>(u.m[2])[i], V = reinterpret_cast<float4*>(u.v[2])[i];
+        adam_one(q.x, (dr.x - r0 * dot) * inv, M.x, V.x, u, 2); adam_one(q.y, (dr.y - r1 * dot) * inv, M.y, V.y, u, 2);
+        adam_one(q.z, (dr.z - r2 * dot) * inv, M.z, V.z, u, 2); adam_one(q.w, (dr.w - r3 * dot) * inv, M.w, V.w, u, 2);
+        reinterpret_cast<float4*>(u.quat)[i] = q; reinterpret_cast<float4*>(u.m[2])[i] = M; reinterpret_cast<float4*>(u.v[2])[i] = V;
+    }
+    { // opacity = sigmoid(logit)
+        const float o = u.opac[i];
+        adam_one(u.logit[i], u.dopac[i] * ((1.f - o) * o), u.m[3][i], u.v[3][i], u, 3);
+    }
+    { // scale = exp(log scale), plus the regularisers' gradient (K_scale_reg_bwd with an upstream gradient of 1)
+        const float s[3] = {u.scales[3 * i], u.scales[3 * i + 1], u.scales[3 * i + 2]};
+        float d[3] = {u.dscale[3 * i] * s[0], u.dscale[3 * i + 1] * s[1], u.dscale[3 * i + 2] * s[2]};
+        if (u.reg_out) {
+            const float wgt = (float)(s[0] > u.limit) + (float)(s[1] > u.limit) + (float)(s[2] > u.limit);
+            if (wgt > 0.f) {
+                int imax = 0, imin = 0;
+                if (s[1] > s[imax]) imax = 1;
+                if (s[2] > s[imax]) imax = 2;
+                if (s[1] < s[imin]) imin = 1;
+                if (s[2] < s[imin]) imin = 2;
+                const float cnt = u.reg_out[0];
+                const float a = u.w_scalar * wgt, b = cnt > 0.f ? u.w_long * wgt / cnt : 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; k++) d[k] += ((k == imax ? a + b : 0.f) - (k == imin ? b : 0.f)) * s[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) adam_one(u.ls[3 * i + k], d[k], u.m[4][3 * i + k], u.v[4][3 * i + k], u, 4);
+    }
+}
+
+// Four consecutive splats per thread: every tensor is then read and written as whole float4s (a [n,3] tensor is 12 floats per
+// thread: three aligned 16-byte accesses instead of twelve 4-byte ones at a stride of 12 bytes) — the update is pure HBM traffic,
+// ~408 bytes per Gaussian (107 us -> see profiles/r04_loop.md at 1 M Gaussians).
+template <int K>
+__device__ __forceinline__ void ld4(const float* __restrict__ p, const size_t i4, float (&x)[4 * K])
+{
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+        const float4 v = reinterpret_cast<const float4*>(p + K * i4)[q];
+        x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+    }
+}
+template <int K>
+__device__ __forceinline__ void st4(float* __restrict__ p, const size_t i4, const float (&x)[4 * K])
+{
+#pragma unroll
+    for (int q = 0; q < K; q++) reinterpret_cast<float4*>(p + K * i4)[q] = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+}
+__global__ void __launch_bounds__(256)
+K_map_update(size_t n, MapUpdate u)
+{
+    if (u.overflow && *u.overflow) return;
+    const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    const Pose34 T = load_pose(u.Tcw);
+    if (i4 + 4 > n) { // the last, partial group of four
+        for (size_t i = i4; i < n; i++) map_update_one(i, u, T);
+        return;
+    }
+    { // means
+        float P[12], G[12], M[12], V[12];
+        ld4<3>(u.xyz, i4, P); ld4<3>(u.dmc, i4, G); ld4<3>(u.m[0], i4, M); ld4<3>(u.v[0], i4, V);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const float g0 = G[3 * s], g1 = G[3 * s + 1], g2 = G[3 * s + 2];
+            const float d[3] = {fmaf(g2, T.r[6], fmaf(g1, T.r[3], g0 * T.r[0])), fmaf(g2, T.r[7], fmaf(g1, T.r[4], g0 * T.r[1])),
+                                fmaf(g2, T.r[8], fmaf(g1, T.r[5], g0 * T.r[2]))};
+#pragma unroll
+            for (int k = 0; k < 3; k++) adam_one(P[3 * s + k], d[k], M[3 * s + k], V[3 * s + k], u, 0);
+        }
+        st4<3>(u.xyz, i4, P); st4<3>(u.m[0], i4, M); st4<3>(u.v[0], i4, V);
+    }
+    { // colours
+        float P[12], G[12], M[12], V[12];
+        ld4<3>(u.rgb, i4, P); ld4<3>(u.dcol, i4, G); ld4<3>(u.m[1], i4, M); ld4<3>(u.v[1], i4, V);
+#pragma unroll
+        for (int k = 0; k < 12; k++) adam_one(P[k], G[k], M[k], V[k], u, 1);
+        st4<3>(u.rgb, i4, P); st4<3>(u.m[1], i4, M); st4<3>(u.v[1], i4, V);
+    }
+    { // quaternions
+        float P[16], G[16], M[16], V[16];
+        ld4<4>(u.quat, i4, P); ld4<4>(u.drot, i4, G); ld4<4>(u.m[2], i4, M); ld4<4>(u.v[2], i4, V);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const float q0 = P[4 * s], q1 = P[4 * s + 1], q2 = P[4 * s + 2], q3 = P[4 * s + 3];
+            const float nn = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f), inv = 1.f / nn;
+            const float r[4] = {q0 * inv, q1 * inv, q2 * inv, q3 * inv};
+            const float dot = r[0] * G[4 * s] + r[1] * G[4 * s + 1] + r[2] * G[4 * s + 2] + r[3] * G[4 * s + 3];
+#pragma unroll
+            for (int k = 0; k < 4; k++) adam_one(P[4 * s + k], (G[4 * s + k] - r[k] * dot) * inv, M[4 * s + k], V[4 * s + k], u, 2);
+        }
+        st4<4>(u.quat, i4, P); st4<4>(u.m[2], i4, M); st4<4>(u.v[2], i4, V);
+    }
+    { // opacities
+        float P[4], G[4], M[4], V[4], O[4];
+        ld4<1>(u.logit, i4, P); ld4<1>(u.dopac, i4, G); ld4<1>(u.m[3], i4, M); ld4<1>(u.v[3], i4, V); ld4<1>(u.opac, i4, O);
+#pragma unroll
+        for (int k = 0; k < 4; k++) adam_one(P[k], G[k] * ((1.f - O[k]) * O[k]), M[k], V[k], u, 3);
+        st4<1>(u.logit, i4, P); st4<1>(u.m[3], i4, M); st4<1>(u.v[3], i4, V);
+    }
+    { // scales
+        float P[12], G[12], M[12], V[12], S[12];
+        ld4<3>(u.ls, i4, P); ld4<3>(u.dscale, i4, G); ld4<3>(u.m[4], i4, M); ld4<3>(u.v[4], i4, V); ld4<3>(u.scales, i4, S);
+        const float cnt = u.reg_out ? u.reg_out[0] : 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const float sc[3] = {S[3 * s], S[3 * s + 1], S[3 * s + 2]};
+            float d[3] = {G[3 * s] * sc[0], G[3 * s + 1] * sc[1], G[3 * s + 2] * sc[2]};
+            if (u.reg_out) {
+                const float wgt = (float)(sc[0] > u.limit) + (float)(sc[1] > u.limit) + (float)(sc[2] > u.limit);
+                if (wgt > 0.f) {
+                    int imax = 0, imin = 0;
+                    if (sc[1] > sc[imax]) imax = 1;
+                    if (sc[2] > sc[imax]) imax = 2;
+                    if (sc[1] < sc[imin]) imin = 1;
+                    if (sc[2] < sc[imin]) imin = 2;
+                    const float a = u.w_scalar * wgt, b = cnt > 0.f ? u.w_long * wgt / cnt : 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) d[k] += ((k == imax ? a + b : 0.f) - (k == imin ? b : 0.f)) * sc[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) adam_one(P[3 * s + k], d[k], M[3 * s + k], V[3 * s + k], u, 4);
+        }
+        st4<3>(u.ls, i4, P); st4<3>(u.m[4], i4, M); st4<3>(u.v[4], i4, V);
+    }
+}
+
+// loss of a mapping iteration from its parts: pixel terms (K_loss_finish: sums[5]) + c_ssim * (1 - mean SSIM) + regularisers
+__global__ void __launch_bounds__(GSR_FINISH_THREADS)
+K_map_loss_total(const float* __restrict__ sums, const float* __restrict__ ssim_partial, int n_partial, float inv_count, float c_ssim,
+                 const float* __restrict__ reg_out, const uint32_t* __restrict__ overflow, float* __restrict__ loss)
+{
+    __shared__ float ws[4][4];
+    float a[4] = {0.f, 0.f, 0.f, 0.f}; // four independent chains per thread
+    for (int b = threadIdx.x; b < n_partial; b += 4 * GSR_FINISH_THREADS) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) a[q] += b + q * GSR_FINISH_THREADS < n_partial ? ssim_partial[b + q * GSR_FINISH_THREADS] : 0.f;
+    }
+    finish_sum<4>(a, ws);
+    const float t = (a[0] + a[1]) + (a[2] + a[3]);
+    if (threadIdx.x == 0) // (an iteration whose forward overflowed its workspace rendered nothing: NaN, and K_map_update skipped its step)
+        loss[0] = (overflow && *overflow) ? __builtin_nanf("") : sums[5] + c_ssim * (1.f - t * inv_count) + (reg_out ? reg_out[3] : 0.f);
+}
+
+// End of a tracking iteration, one workgroup. state[16]: {quat[4], trans[3], 0, m_quat[4], m_trans[3], 0}; state2[8]: {v_quat[4], v_trans[3], 0};
+// best[8]: {best loss, quat[4], trans[3]}; history[it] = the iteration's loss. Gaussian.cc:144-150 (both groups with one learning rate),
+// Render.cc:1107-1118 (the pose of the lowest loss is kept; the step that follows an iteration is taken before the host looks at its loss).
+struct PoseUpdate {
+    float* quat_trans;  // [7] the pose parameters (un-normalised quaternion r,x,y,z; translation), updated in place
+    float* moments;     // [14] exp_avg[7], exp_avg_sq[7]
+    float* best;        // [8] lowest loss so far and the pose that produced it
+    float* history;     // this iteration's slot
+    float* Tcw;         // [16] rewritten for the next iteration
+    const float* partial; // [GSR_POSE_BLOCKS][12] K_pose_grad's rows
+    const float* loss;    // the iteration's loss (K_loss_finish: sums + 5)
+    const uint32_t* overflow;
+    float w1, b2, w2, eps, step_size, sqrt_bias2;
+};
+__global__ void __launch_bounds__(64)
+K_pose_update(PoseUpdate u)
+{
+    const int lane = threadIdx.x;
+    float a[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = lane; b < GSR_POSE_BLOCKS; b += 64) {
+#pragma unroll
+        for (int q = 0; q < 12; q++) a[q] += u.partial[b * 12 + q];
+    }
+#pragma unroll
+    for (int q = 0; q < 12; q++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off, 64);
+    }
+    if (lane != 0) return;
+    const bool skip = u.overflow && *u.overflow;
+    float q[4] = {u.quat_trans[0], u.quat_trans[1], u.quat_trans[2], u.quat_trans[3]}, t[3] = {u.quat_trans[4], u.quat_trans[5], u.quat_trans[6]};
+    const float lv = skip ? __builtin_nanf("") : u.loss[0];
+    u.history[0] = lv;
+    if (lv == lv && lv < u.best[0]) {
+        u.best[0] = lv;
+#pragma unroll
+        for (int k = 0; k < 4; k++) u.best[1 + k] = q[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) u.best[5 + k] = t[k];
+    }
+    if (!skip) {
+        // rt2T backward (K_rt2T_bwd) from dL/dR = a[0..8] (row-major), dL/dt = a[9..11]
+        const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        const float r = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+        const float G00 = a[0], G01 = a[1], G02 = a[2], G10 = a[3], G11 = a[4], G12 = a[5], G20 = a[6], G21 = a[7], G22 = a[8];
+        const float dr = 2.f * (-z * G01 + y * G02 + z * G10 - x * G12 - y * G20 + x * G21);
+        const float dx = 2.f * (y * G01 + z * G02 + y * G10 - 2.f * x * G11 - r * G12 + z * G20 + r * G21 - 2.f * x * G22);
+        const float dy = 2.f * (-2.f * y * G00 + x * G01 + r * G02 + x * G10 + z * G12 - r * G20 + z * G21 - 2.f * y * G22);
+        const float dz = 2.f * (-2.f * z * G00 - r * G01 + x * G02 + r * G10 - 2.f * z * G11 + y * G12 + x * G20 + y * G21);
+        const float dot = r * dr + x * dx + y * dy + z * dz;
+        const float g[7] = {(dr - r * dot) / n, (dx - x * dot) / n, (dy - y * dot) / n, (dz - z * dot) / n, a[9], a[10], a[11]};
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            float p = k < 4 ? q[k] : t[k - 4], mm = u.moments[k], vv = u.moments[7 + k];
+            mm = fmaf(u.w1, g[k] - mm, mm);
+            vv = fmaf(u.w2 * g[k], g[k], vv * u.b2);
+            p = fmaf(-u.step_size, mm / (sqrtf(vv) / u.sqrt_bias2 + u.eps), p);
+            u.moments[k] = mm; u.moments[7 + k] = vv; u.quat_trans[k] = p;
+            if (k < 4) q[k] = p; else t[k - 4] = p;
+        }
+    }
+    { // the next iteration's pose matrix (K_rt2T)
+        const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        const float r = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+        float* const T = u.Tcw;
+        T[0] = 1.f - 2.f * (y * y + z * z); T[1] = 2.f * (x * y - r * z); T[2] = 2.f * (x * z + r * y); T[3] = t[0];
+        T[4] = 2.f * (x * y + r * z); T[5] = 1.f - 2.f * (x * x + z * z); T[6] = 2.f * (y * z - r * x); T[7] = t[1];
+        T[8] = 2.f * (x * z - r * y); T[9] = 2.f * (y * z + r * x); T[10] = 1.f - 2.f * (x * x + y * y); T[11] = t[2];
+        T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
+    }
 }
 
 } // namespace gsr

@@ -236,6 +236,17 @@ void Adam::step()
     }
 }
 
+void Adam::ensure_state_(size_t i)
+{
+    if (state_.size() != groups_.size()) state_.resize(groups_.size());
+    auto& st = state_.at(i);
+    if (!st.exp_avg.defined()) {
+        torch::NoGradGuard ng;
+        st.exp_avg = torch::zeros_like(groups_[i].param);
+        st.exp_avg_sq = torch::zeros_like(groups_[i].param);
+    }
+}
+
 void Adam::replace_extended(size_t i, const torch::Tensor& param, int64_t added)
 {
     if (state_.size() != groups_.size()) state_.resize(groups_.size());

@@ -41,7 +41,17 @@ public:
     // `param` (a new leaf); its moments are extended with zeros for `added` new rows / reduced to the rows `keep`
     void replace_extended(size_t i, const torch::Tensor& param, int64_t added);
     void replace_selected(size_t i, const torch::Tensor& param, const torch::Tensor& keep);
+    // For the loops that step through gsr_map_update (DirectLoop.cpp): the moments of group i (created as zeros on first use),
+    // its 1-based step count after `advance` more steps, its learning rate.
+    torch::Tensor& exp_avg(size_t i) { ensure_state_(i); return state_[i].exp_avg; }
+    torch::Tensor& exp_avg_sq(size_t i) { ensure_state_(i); return state_[i].exp_avg_sq; }
+    int advance_step(size_t i) { ensure_state_(i); return ++state_[i].step; }
+    void retract_step(size_t i) { ensure_state_(i); --state_[i].step; }
+    double lr(size_t i) const { return groups_.at(i).lr; }
+    double eps() const { return eps_; }
+    const torch::Tensor& param(size_t i) const { return groups_.at(i).param; }
 private:
+    void ensure_state_(size_t i);
     struct State { torch::Tensor exp_avg, exp_avg_sq; int step = 0; };
     std::vector<Group> groups_;
     std::vector<State> state_;

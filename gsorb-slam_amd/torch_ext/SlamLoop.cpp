@@ -159,6 +159,7 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> SlamLoop::RenderPair(con
 
 std::vector<double> SlamLoop::Track(const LoopFrame& frame, const torch::Tensor& Tcw_init, int iters, torch::Tensor* Tcw_best)
 {
+    if (direct_()) return direct_track_(frame, Tcw_init, iters, Tcw_best);
     // Gaussian::InitCameraPose (Gaussian.cc:97-150)
     const auto T0 = Tcw_init.to(dev_, torch::kFloat32);
     cam_quat_ = rot_to_quat(T0.slice(0, 0, 3).slice(1, 0, 3)).reshape({4, 1}).to(dev_).requires_grad_(true);
@@ -201,6 +202,7 @@ std::vector<double> SlamLoop::Track(const LoopFrame& frame, const torch::Tensor&
 
 double SlamLoop::MappingIteration(const LoopFrame& fr)
 {
+    if (direct_()) return MapFrame(fr, 1).at(0);
     const auto Tcw = fr.Tcw.to(dev_, torch::kFloat32);
     auto [rimage, rsur, rdepth] = RenderPair(Tcw, false);
     if (cfg_.fused_ops) { // Render.cc:436-471 as: pixel terms (2 launches), SSIM (1 + a sum), regularisers (2), a handful of scalar operations

@@ -30,6 +30,9 @@ struct LoopConfig {
     bool fused_pair = true; // one rasterizer pass per iteration (forward_pair); false: two passes like Render.cc:927-981
     bool fused_ops = true;  // camera transform, pose matrix, SSIM and Adam through the loop kernels of the C ABI (FusedOps.h);
                             // false: the reference's plain libtorch arithmetic (matmul, scalar-tensor rt2T, conv2d, torch::optim::Adam)
+    bool direct = true;     // (with fused_pair and fused_ops) an iteration is a fixed sequence of C-ABI launches on a persistent workspace
+                            // — no autograd graph, no allocation, no gradient tensors of the raw parameters (DirectLoop.cpp);
+                            // false: the same kernels through libtorch autograd
 };
 
 struct LoopFrame {
@@ -41,6 +44,7 @@ struct LoopFrame {
 class SlamLoop {
 public:
     SlamLoop(const LoopConfig& cfg, int width, int height, float fx, float fy, torch::Device device);
+    ~SlamLoop();
 
     // Gaussian::GaussianOptimizer (Gaussian.cc:152-175): five Adam groups, eps 1e-15
     void SetMap(torch::Tensor xyz, torch::Tensor rgb, torch::Tensor unnorm_quat, torch::Tensor logit_opacities, torch::Tensor log_scales);
@@ -51,6 +55,9 @@ public:
 
     // Render.cc:420-483: one mapping iteration on one keyframe (loss, backward, Adam step); returns the loss
     double MappingIteration(const LoopFrame& frame);
+    // The loop of Render::RenderForFrame (Render.cc:418-483) on one keyframe: `iters` mapping iterations. Like the reference's loop
+    // it never looks at a loss in between: the losses of all iterations are read back once, at the end.
+    std::vector<double> MapFrame(const LoopFrame& frame, int iters);
 
     // ---- map growth (the other half of the per-frame loop: Render.cc:557-616, Gaussian.cc:40-95, :180-258) ----
     // Render::AddGaussian + ProjectPixel + Gaussian::AddGaussianPoints: renders the frame's view, masks the pixels the map does
@@ -81,6 +88,18 @@ private:
     std::vector<float> taps_host_;
     std::vector<torch::Tensor> act_; // Track(): the map's activations (opacity, scales, unit quaternions), formed once per call
     std::vector<torch::Tensor*> params_();
+    // LoopConfig::direct (DirectLoop.cpp)
+    struct Direct;
+    std::shared_ptr<Direct> d_; // (shared_ptr: its deleter is bound where the type is complete)
+    bool direct_() const { return cfg_.direct && cfg_.fused_pair && cfg_.fused_ops; }
+    void* stream_() const;
+    void ensure_direct_(int64_t history_len);
+    void grow_binning_(size_t capacity);
+    void direct_forward_();
+    void direct_backward_(bool detach_depth_colour);
+    bool direct_overflowed_();
+    void direct_map_iteration_(const LoopFrame& frame, float* loss_slot);
+    std::vector<double> direct_track_(const LoopFrame& frame, const torch::Tensor& Tcw_init, int iters, torch::Tensor* Tcw_best);
     void replace_params_(const std::vector<torch::Tensor>& fresh, int64_t added, const torch::Tensor* keep);
 };
 

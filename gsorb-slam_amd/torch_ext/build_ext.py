@@ -1,6 +1,6 @@
 """Builds the libtorch host layer, in-tree:
 
-  torch_ext/libgsr_torch.so            Rasterizer.cpp + FusedOps.cpp + SlamLoop.cpp — what a GSORB-SLAM checkout links instead of its
+  torch_ext/libgsr_torch.so            Rasterizer.cpp + FusedOps.cpp + SlamLoop.cpp + DirectLoop.cpp — what a GSORB-SLAM checkout links instead of its
                                        diff_gaussian_rasterization target: the drop-in operator, the fused loop
                                        operations and the tracking / mapping / map-growth loops; linked against csrc/libgsr_hip.so
   diff_gaussian_rasterization/_C.so    ext.cpp (pybind11) on top of libgsr_torch.so: the Python operator's host layer
@@ -17,7 +17,7 @@ PKG = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libgsr_torch.so")
 OUT_DIR = os.path.join(PKG, "diff_gaussian_rasterization")
 OUT = os.path.join(OUT_DIR, "_C.so")
-LIB_SRCS = [os.path.join(HERE, f) for f in ("Rasterizer.cpp", "FusedOps.cpp", "SlamLoop.cpp")]
+LIB_SRCS = [os.path.join(HERE, f) for f in ("Rasterizer.cpp", "FusedOps.cpp", "SlamLoop.cpp", "DirectLoop.cpp")]
 HEADERS = [os.path.join(HERE, f) for f in ("Rasterizer.h", "FusedOps.h", "SlamLoop.h")] + [os.path.join(PKG, "..", "include", "gsr.h")]
 EXT_SRC = os.path.join(HERE, "ext.cpp")
 

@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 4 /* 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added */
+#define GSR_ABI_VERSION 5 /* 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
+                           * 5: gsr_map_prepare / gsr_map_update / gsr_map_loss_total / gsr_pose_update / gsr_pixel_loss_backward_add added, GSR_LOSS_PARTIALS 256 -> 1024 */
 
 #define GSR_OK 0
 #define GSR_EINVAL (-1)    /* bad argument combination (NULL where data is required, sizes < 0 …) */
@@ -253,7 +254,7 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  *   gsr_scale_reg   the two scale regularisers (src/Render.cc:449-462) of log_scales [n,3]:
  *                   out [4] = {sum w, reg_scalar, sum w (max - min), w_long * reg_long + w_scalar * reg_scalar}; partial: GSR_LOSS_PARTIALS * 3 floats
  *   gsr_scale_reg_backward  dL_dlog_scales [n,3] (written, not accumulated) = *dL_dvalue * d(out[3]) / d(log_scales) */
-#define GSR_LOSS_PARTIALS 256
+#define GSR_LOSS_PARTIALS 1024
 int gsr_pixel_loss(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb,
                    const float* frame_depth, int H, int W, int mode, float sil_thr, const float* w3 /* host, 3 floats */,
                    float* partial, float* sums, void* stream);
@@ -263,6 +264,69 @@ int gsr_pixel_loss_backward(const float* image, const float* depth, const float*
 int gsr_scale_reg(const float* log_scales, size_t n, float limit, float w_long, float w_scalar, float* partial, float* out, void* stream);
 int gsr_scale_reg_backward(const float* log_scales, size_t n, float limit, float w_long, float w_scalar, const float* out,
                            const float* dL_dvalue, float* dL_dlog_scales, void* stream);
+
+/* gsr_pixel_loss_backward with a plane added to dL/dimage (`add_image` [3,H,W], e.g. the SSIM term's gradient; NULL: none) and an
+ * upstream gradient that may be NULL (= 1). */
+int gsr_pixel_loss_backward_add(const float* image, const float* depth, const float* sil, const float* frame_rgb, const float* frame_depth,
+                                int H, int W, int mode, float sil_thr, const float* w3 /* host */, const float* sums,
+                                const float* dL_dloss, const float* add_image, float* dL_dimage, float* dL_ddepth, void* stream);
+
+/* ---- the loops without a tensor library inside the iteration (round 4; reference src/Render.cc:420-483 mapping iterations,
+ * :1054-1126 tracking iterations, src/Gaussian.cc:144-175 optimisers, :97-150 pose parameters, include/Utils.h:56-77 rt2T).
+ * The reference forms the rasterizer's inputs from the raw parameters with libtorch expressions (sigmoid, exp, normalize, the
+ * camera transform), differentiates them with autograd and steps five Adam groups: ~60 launches per mapping iteration around
+ * the two renders. These entry points are the same arithmetic as three launches; all pointers are DEVICE pointers unless noted,
+ * nothing allocates or synchronises.
+ *   gsr_map_prepare  n raw Gaussians -> means_cam [n,3] = xyz R^T + t (Tcw: device 4x4 row-major), opacities [n] = sigmoid(logit),
+ *                    scales [n,3] = exp(log_scales), rotations [n,4] = q / max(|q|, 1e-12); any output may be NULL. With
+ *                    reg_partial (scratch of 3 * ((n + 255) / 256) floats) and reg_out [4] it also evaluates the two scale
+ *                    regularisers (gsr_scale_reg's out: {sum w, reg_scalar, sum w (max - min), w_long * reg_long + w_scalar * reg_scalar}).
+ *   gsr_map_update   from the rasterizer's gradients (gsr_backward on camera-frame means with an identity view matrix: dL_dmean3D is
+ *                    dL/dmeans_cam) to an Adam step of the five raw tensors, in place: dL/dxyz = dmc R; dL/dlogit = dopac * o (1 - o);
+ *                    dL/dlog_scales = dscale * scale + the regularisers' gradient (reg_out != NULL); dL/dq through the normalisation;
+ *                    dL/drgb = dL_dcolors. Adam exactly as gsr_adam_step (per tensor lr and 1-based step; order xyz, rgb, quat, logit,
+ *                    log_scales). `geom` (the rasterizer's geometry blob of the iteration's forward, NULL: none): when its overflow flag
+ *                    is set (gsr_forward_ws ran out of workspace) the whole update is skipped.
+ *   gsr_map_loss_total  loss[0] = sums[5] (gsr_pixel_loss) + c_ssim * (1 - sum(ssim_partial) / count) + reg_out[3] (NULL: 0); NaN when
+ *                    the forward on `geom` (NULL: not checked) overflowed its workspace
+ *   gsr_pose_update  end of a tracking iteration (one launch): adds gsr_pose_grad's partial rows, takes them through rt2T's backward,
+ *                    records history[0] = *loss and keeps the pose of the lowest loss so far in best [8] = {loss, quat[4], trans[3]}
+ *                    (NaN losses never win, Render.cc:1109-1112), steps Adam on quat_trans [7] (un-normalised quaternion r,x,y,z and
+ *                    translation; moments [14] = exp_avg[7], exp_avg_sq[7]; one learning rate for both groups like Gaussian.cc:149-150)
+ *                    and writes the next iteration's Tcw [16]. An overflowed forward (geom) records NaN and skips the step. */
+int gsr_map_prepare(size_t n, const float* xyz, const float* logit, const float* log_scales, const float* unnorm_quat, const float* Tcw,
+                    float* means_cam, float* opacities, float* scales, float* rotations, float reg_limit, float w_long, float w_scalar,
+                    float* reg_partial, float* reg_out, void* stream);
+typedef struct gsr_map_update_args {
+    size_t n;
+    float *xyz, *rgb, *unnorm_quat, *logit, *log_scales;
+    float* exp_avg[5];
+    float* exp_avg_sq[5];
+    const float *dL_dmeans_cam, *dL_dcolors, *dL_drotations, *dL_dopacities, *dL_dscales;
+    const float *opacities, *scales; /* gsr_map_prepare's outputs of this iteration */
+    const float* Tcw;
+    const float* reg_out; /* NULL: no regulariser gradient */
+    float reg_limit, w_long, w_scalar;
+    const char* geom;
+    double lr[5], beta1, beta2, eps;
+    int step[5];
+} gsr_map_update_args;
+int gsr_map_update(const gsr_map_update_args* args, void* stream);
+int gsr_map_loss_total(const float* sums, const float* ssim_partial, int n_partial, size_t count, float c_ssim, const float* reg_out,
+                       const char* geom, float* loss, void* stream);
+typedef struct gsr_pose_update_args {
+    float* quat_trans;    /* [7] */
+    float* moments;       /* [14] */
+    float* best;          /* [8] */
+    float* history;       /* [1]: this iteration's slot */
+    float* Tcw;           /* [16] */
+    const float* partial; /* [GSR_POSE_PARTIALS][12] */
+    const float* loss;    /* [1] */
+    const char* geom;     /* NULL: no overflow predicate */
+    double lr, beta1, beta2, eps;
+    int step;
+} gsr_pose_update_args;
+int gsr_pose_update(const gsr_pose_update_args* args, void* stream);
 
 /* Workspace sizes: replace required<GeometryState/ImageState/BinningState>
  * (rasterizer_impl.h:67-73). */

@@ -30,4 +30,12 @@ out["last_50_finishers_job_us_mean"] = float(d[np.argsort(t1)[-50:]].mean())
 key = xcc * 1000 + se * 100 + sh * 50 + cu; out["distinct_cus_seen"] = int(len(np.unique(key)))
 per_xcd = [float(t1[xcc == x].max()) for x in range(8) if (xcc == x).any()]; out["xcd_finish_us"] = per_xcd
 first = d[order[:3000]]; out["first_round_job_us_mean"] = float(first.mean())
+# raw per-job data for offline scheduling simulations (scripts/lpt_sim.py): block id -> (start, end, xcd), and the quad's record counts
+def al(x): return (x + 255) & ~255
+N = c.width * c.height; T = ((c.width + 15) // 16) * ((c.height + 15) // 16)
+off = al(N * 4); off = al(off + N * 4); off = al(off + T * 8); off = al(off + T * 4); off = al(off + T * 4); off = al(off + T * 512 * 4)
+qcount = st.image[off:off + T * 16].view(torch.int32).cpu().numpy(); off = al(off + T * 16)
+qdone = st.image[off:off + T * 16].view(torch.int32).cpu().numpy()
+os.makedirs(R + "/gpurun_out", exist_ok=True)
+np.savez_compressed(R + "/gpurun_out/timeline_%s.npz" % (sys.argv[2] if len(sys.argv) > 2 else "bwd"), t0=t0[:4 * T], t1=t1[:4 * T], xcc=xcc[:4 * T], simd=simd[:4 * T], cu=key[:4 * T], qcount=qcount, qdone=qdone)
 print(json.dumps(out, indent=1))

@@ -2,7 +2,8 @@
 // tests/test_gpu_cpp_loop.py and prints what the Python harness is compared with: the loss of every tracking iteration, the
 // best pose, the loss of every mapping iteration, and the time per iteration. Test infrastructure (the product is SlamLoop).
 //   file: int32 P, W, H, track_iters, map_iters, flags (bit 0 fused pair, bit 1 fused loop kernels, bit 2 growth run: AddGaussians /
-//         PruneLowOpacity on a map of the first P/2 rows, bit 3 prune threshold 0.6); float32 fx, fy; then float32 arrays xyz[P,3] rgb[P,3] quat[P,4] logit[P,1]
+//         PruneLowOpacity on a map of the first P/2 rows, bit 3 prune threshold 0.6, bit 4 the iterations through libtorch autograd instead of
+//         the direct launch sequences of DirectLoop.cpp); float32 fx, fy; then float32 arrays xyz[P,3] rgb[P,3] quat[P,4] logit[P,1]
 //         logs[P,3] frame_rgb[3,H,W] frame_depth[H,W] Tcw[4,4] T_init[4,4]
 #include <chrono>
 #include <cstdio>
@@ -35,6 +36,7 @@ int main(int argc, char** argv)
     ORB_SLAM2::LoopConfig cfg;
     cfg.fused_pair = (hdr[5] & 1) != 0;
     cfg.fused_ops = (hdr[5] & 2) != 0;
+    cfg.direct = (hdr[5] & 16) == 0;
     ORB_SLAM2::SlamLoop loop(cfg, W, H, ff[0], ff[1], dev);
     auto xyz = rd(f, {P, 3}), rgb = rd(f, {P, 3}), quat = rd(f, {P, 4}), logit = rd(f, {P, 1}), logs = rd(f, {P, 3});
     loop.SetMap(xyz, rgb, quat, logit, logs);
@@ -91,7 +93,15 @@ int main(int argc, char** argv)
     for (int i = 0; i < map_iters; i++) std::cout << " " << loop.MappingIteration(fr);
     torch::cuda::synchronize();
     const double map_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / std::max(map_iters, 1);
-    std::cout << "\ntrack_ms_per_iter " << track_ms << "\nmap_ms_per_iter " << map_ms << std::endl;
+    // the same number of iterations again as ONE MapFrame call (Render::RenderForFrame's loop: no loss is looked at in between)
+    torch::cuda::synchronize();
+    t0 = std::chrono::steady_clock::now();
+    const auto mf = loop.MapFrame(fr, map_iters);
+    torch::cuda::synchronize();
+    const double mapframe_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / std::max(map_iters, 1);
+    std::cout << "\nmapframe";
+    for (double v : mf) std::cout << " " << v;
+    std::cout << "\ntrack_ms_per_iter " << track_ms << "\nmap_ms_per_iter " << map_ms << "\nmapframe_ms_per_iter " << mapframe_ms << std::endl;
     std::cout.flush();
     if (std::getenv("GSR_LOOP_NORMAL_EXIT")) return 0; // (under rocprofv3: its summaries are written by an exit handler)
     std::_Exit(0); // (skip static destruction: libtorch's HIP caches and the library's pinned staging words have no defined order)

@@ -74,6 +74,7 @@ def _cpp_run(path, params, frgb, fdepth, T_true, T_init, fused=3):
     r = subprocess.run([exe, path], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = {ln.split()[0]: [float(x) for x in ln.split()[1:]] for ln in r.stdout.splitlines() if ln.strip()}
+    _cpp_run.last = out
     return out["track"], np.asarray(out["pose"]).reshape(4, 4), out["map"], out["track_ms_per_iter"][0], out["map_ms_per_iter"][0]
 
 
@@ -95,6 +96,16 @@ def test_cpp_loop_follows_the_python_harness(gsr, syn, tmp_path, P):
     assert rel_t[:10].max() < 2e-2 and rel_m[:20].max() < 5e-3
     assert np.abs(Tc - Th).max() < 2e-3
     assert tc[-1] < 0.8 * tc[0] and mc[-1] < mc[0]                      # both loops actually optimise
+    # the direct path (DirectLoop.cpp: fixed launch sequences on a persistent workspace, what flags = 3 runs) against the same kernels
+    # through libtorch autograd (flags bit 4): same arithmetic up to the order of the activations' backward
+    mf = _cpp_run.last["mapframe"]
+    print("      MapFrame (one read-back for %d iterations): %.2f ms per iteration" % (len(mf), _cpp_run.last["mapframe_ms_per_iter"][0]))
+    assert len(mf) == MAP_ITERS and mf[-1] < mc[0] and np.isfinite(mf).all()
+    ta, Ta, ma, tta, tma = _cpp_run(str(tmp_path / "scene_autograd.bin"), params, frgb, fdepth, T_true, T_init, fused=3 | 16)
+    k = min(len(ta), len(tc), 10)
+    da_t = np.abs(np.asarray(ta[:k]) - np.asarray(tc[:k])).max() / abs(tc[0]); da_m = np.abs(np.asarray(ma[:20]) - np.asarray(mc[:20])).max() / abs(mc[0])
+    print("      through autograd: tracking %.2f ms, mapping %.2f ms per iteration; direct vs autograd curves: tracking %.1e, mapping %.1e" % (tta, tma, da_t, da_m))
+    assert da_t < 1e-3 and da_m < 1e-3 and np.abs(Ta - Tc).max() < 1e-3
     if P == 10000:   # the reference's structure — two passes, plain libtorch arithmetic (matmul, conv2d SSIM, torch::optim::Adam) — gives the same curve
         t2, T2, m2, tt2, tm2 = _cpp_run(str(tmp_path / "scene2.bin"), params, frgb, fdepth, T_true, T_init, fused=0)
         print("      two passes + plain libtorch ops: tracking %.2f ms, mapping %.2f ms per iteration" % (tt2, tm2))

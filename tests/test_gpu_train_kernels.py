@@ -245,3 +245,122 @@ def test_fused_scale_regularisers_match_the_tensor_expressions(gsr, n, frac):
     assert float(out[0]) == float(cnt)
     assert abs(float(val) - float(ref)) <= 2e-5 * max(abs(float(ref)), 1e-12)
     assert (xi.grad.cpu().double() - 3.0 * x.grad).abs().max() <= 2e-6 * max(float(x.grad.abs().max()) * 3.0, 1e-12)
+
+
+# ---- the direct loops' kernels (round 4: gsr_map_prepare / gsr_map_update / gsr_pose_update / gsr_map_loss_total) ----------------
+def _pose_T(seed=0):
+    from util import pose
+    return torch.tensor(pose(0.05 + 0.01 * seed, (0.03, -0.02, 0.04)), dtype=torch.float32)
+
+
+@pytest.mark.parametrize("n", [1, 257, 5000])
+def test_map_prepare_matches_the_tensor_expressions(gsr, n):
+    """gsr_map_prepare against what the reference forms with libtorch (Render.cc:750-758: camera transform, sigmoid, exp, normalize)
+    and against gsr_scale_reg's regulariser sums of the same log-scales."""
+    g = torch.Generator().manual_seed(n)
+    xyz = torch.randn((n, 3), generator=g); logit = torch.randn((n, 1), generator=g) * 2
+    ls = torch.log(0.01 + 0.3 * torch.rand((n, 3), generator=g)); q = torch.randn((n, 4), generator=g)
+    T = _pose_T()
+    limit, wl, ws = 0.2, 0.7, 0.3
+    mc, op, sc, rot, out = gsr.capi.map_prepare(xyz.cuda(), logit.cuda(), ls.cuda(), q.cuda(), T.cuda(), reg=(limit, wl, ws))
+    ref_mc = xyz.double() @ T[:3, :3].double().T + T[:3, 3].double()
+    assert (mc.cpu().double() - ref_mc).abs().max() < 2e-6 * max(float(ref_mc.abs().max()), 1.0)
+    assert (op.cpu() - torch.sigmoid(logit[:, 0])).abs().max() < 2e-7
+    assert ((sc.cpu() - torch.exp(ls)).abs() / torch.exp(ls)).max() < 1e-6
+    assert (rot.cpu() - torch.nn.functional.normalize(q)).abs().max() < 2e-7
+    val, out2 = gsr.capi.scale_regularisers(ls.cuda(), limit, wl, ws)
+    assert float(out[0]) == float(out2[0])
+    assert (out.cpu() - out2.cpu()).abs().max() <= 2e-5 * max(float(out2.abs().max()), 1e-12)
+
+
+@pytest.mark.parametrize("with_reg", [False, True])
+def test_map_update_is_autograd_through_the_activations_plus_adam(gsr, with_reg):
+    """gsr_map_update against float64 autograd through the camera transform / sigmoid / exp / normalize (and the regularisers) followed
+    by torch.optim.Adam (eps 1e-15) on the five raw tensors, over three steps with changing upstream gradients."""
+    n = 3003   # (not a multiple of four: the vector path and the tail)
+    g = torch.Generator().manual_seed(7)
+    raw = [torch.randn((n, 3), generator=g), torch.rand((n, 3), generator=g), torch.randn((n, 4), generator=g),
+           torch.randn((n, 1), generator=g), torch.log(0.01 + 0.3 * torch.rand((n, 3), generator=g))]
+    lrs = [1e-4, 2.5e-3, 1e-3, 5e-2, 1e-3]
+    limit, wl, ws = 0.2, 5.0, 10.0
+    T = _pose_T(1)
+    ref = [t.double().clone().requires_grad_(True) for t in raw]
+    opt = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(ref, lrs)], eps=1e-15)
+    dev = [t.cuda().contiguous() for t in raw]
+    m = [torch.zeros_like(t) for t in dev]; v = [torch.zeros_like(t) for t in dev]
+    for step in range(1, 4):
+        ups = [torch.randn((n, 3), generator=g), torch.randn((n, 3), generator=g), torch.randn((n, 4), generator=g),
+               torch.randn((n,), generator=g), torch.randn((n, 3), generator=g)]   # dL/d(mc, colour, rot, opac, scale)
+        xyz, rgb, q, logit, ls = ref
+        mc = xyz @ T[:3, :3].double().T + T[:3, 3].double()
+        loss = (mc * ups[0].double()).sum() + (rgb * ups[1].double()).sum() + (torch.nn.functional.normalize(q) * ups[2].double()).sum() \
+            + (torch.sigmoid(logit[:, 0]) * ups[3].double()).sum() + (torch.exp(ls) * ups[4].double()).sum()
+        if with_reg:
+            sc = torch.exp(ls)
+            w = (sc > limit).sum(1).to(sc.dtype); mx, mn = sc.max(1)[0], sc.min(1)[0]; cnt = w.sum()
+            loss = loss + wl * torch.where(cnt > 0, (w * (mx - mn)).sum() / cnt.clamp_min(1), torch.zeros_like(cnt)) + ws * (w * (mx - limit)).sum()
+        opt.zero_grad(); loss.backward(); opt.step()
+        outs = gsr.capi.map_prepare(dev[0], dev[3], dev[4], dev[2], T.cuda(), reg=(limit, wl, ws) if with_reg else None)
+        gsr.capi.map_update(dev, (m, v), [u.cuda().contiguous() for u in ups], (outs[1], outs[2]), T.cuda(), lrs, [step] * 5,
+                            reg=(outs[4], limit, wl, ws) if with_reg else None)
+    for name, a, b, lr in zip(("xyz", "rgb", "quat", "logit", "log_scales"), dev, ref, lrs):
+        moved = (b.detach() - raw[("xyz", "rgb", "quat", "logit", "log_scales").index(name)].double()).abs().max()
+        assert moved > lr                                                               # three Adam steps of ~lr each
+        assert (a.cpu().double() - b.detach()).abs().max() < 2e-3 * float(moved), name  # (sign flips of tiny gradients aside: Adam's m / sqrt(v) is +-1 at step 1)
+
+
+def test_map_update_skips_the_step_of_an_overflowed_forward(gsr, syn):
+    """The predicate of the direct loops: a forward that ran out of workspace leaves its overflow flag in the geometry blob and
+    gsr_map_update must then leave the parameters and the moments alone; gsr_map_loss_total reports NaN."""
+    cam = syn.make_camera(160, 120, 130.0, 130.0)
+    sc = syn.make_scene(3000, cam, seed=1)
+    s = gsr.capi.Settings.from_camera(cam)
+    ws = gsr.capi.Workspace(3000, 160, 120, 64)        # far too small
+    gsr.forward_ws(s, ws, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    torch.cuda.synchronize()
+    assert ws.status()[1]
+    n = 3000
+    dev = [torch.randn((n, k), device="cuda") for k in (3, 3, 4, 1, 3)]
+    before = [x.clone() for x in dev]
+    m = [torch.zeros_like(x) for x in dev]; v = [torch.zeros_like(x) for x in dev]
+    T = torch.eye(4, device="cuda")
+    outs = gsr.capi.map_prepare(dev[0], dev[3], dev[4], dev[2], T)
+    ups = [torch.randn((n, 3), device="cuda"), torch.randn((n, 3), device="cuda"), torch.randn((n, 4), device="cuda"), torch.randn((n,), device="cuda"),
+           torch.randn((n, 3), device="cuda")]
+    gsr.capi.map_update(dev, (m, v), ups, (outs[1], outs[2]), T, [1e-2] * 5, [1] * 5, geom=ws.geom)
+    assert all(torch.equal(a, b) for a, b in zip(dev, before)) and all(float(x.abs().max()) == 0.0 for x in m + v)
+    gsr.capi.map_update(dev, (m, v), ups, (outs[1], outs[2]), T, [1e-2] * 5, [1] * 5, geom=None)
+    assert not torch.equal(dev[0], before[0])
+    loss = torch.zeros((1,), device="cuda"); sums = torch.ones((8,), device="cuda")
+    gsr.capi._check(gsr.lib().gsr_map_loss_total(sums.data_ptr(), None, 0, 0, 0.0, None, ws.geom.data_ptr(), loss.data_ptr(), None))
+    assert bool(torch.isnan(loss).all())
+    gsr.capi._check(gsr.lib().gsr_map_loss_total(sums.data_ptr(), None, 0, 0, 0.0, None, None, loss.data_ptr(), None))
+    assert float(loss) == 1.0
+
+
+def test_pose_update_is_rt2T_backward_plus_adam_and_keeps_the_best_pose(gsr, hz):
+    """gsr_pose_update against float64 autograd through harness.rt2T + torch.optim.Adam on (quat, trans), the best-pose bookkeeping of
+    Render.cc:1107-1112 (NaN never wins) and the pose matrix it leaves for the next iteration."""
+    g = torch.Generator().manual_seed(3)
+    q0 = torch.tensor([0.9, 0.1, -0.2, 0.05]); t0 = torch.tensor([0.1, -0.2, 0.3])
+    qr = q0.double().reshape(4, 1).clone().requires_grad_(True); tr = t0.double().reshape(3, 1).clone().requires_grad_(True)
+    opt = torch.optim.Adam([{"params": [qr], "lr": 4e-4}, {"params": [tr], "lr": 4e-4}], eps=1e-15)
+    pose = torch.cat([q0, t0]).cuda(); mom = torch.zeros(14, device="cuda"); best = torch.zeros(8, device="cuda"); best[0] = float("inf")
+    hist = torch.zeros(4, device="cuda"); Tcw = torch.zeros(16, device="cuda")
+    losses = [3.0, 2.0, float("nan"), 2.5]
+    poses_before = []
+    for it, lv in enumerate(losses):
+        G = torch.randn((512, 12), generator=g) * 0.01                       # gsr_pose_grad's rows: dL/dR row-major, dL/dt
+        s = G.double().sum(0)
+        T = hz.rt2T(qr, tr)
+        opt.zero_grad()
+        ((T[:3, :3] * s[:9].reshape(3, 3)).sum() + (T[:3, 3] * s[9:]).sum()).backward()
+        poses_before.append(torch.cat([qr.detach().reshape(4), tr.detach().reshape(3)]).clone())
+        opt.step()
+        gsr.capi.pose_update(pose, mom, best, hist[it:], Tcw, G.cuda().contiguous(), torch.tensor([lv], device="cuda"), 4e-4, it + 1)
+        ref = torch.cat([qr.detach().reshape(4), tr.detach().reshape(3)])
+        assert (pose.cpu().double() - ref).abs().max() < 2e-6, it
+        assert (Tcw.cpu().double().reshape(4, 4) - hz.rt2T(qr.detach(), tr.detach())).abs().max() < 2e-6
+    h = hist.cpu()
+    assert float(h[0]) == 3.0 and float(h[1]) == 2.0 and bool(torch.isnan(h[2])) and float(h[3]) == 2.5
+    assert float(best[0]) == 2.0 and (best[1:].cpu().double() - poses_before[1]).abs().max() < 2e-6
