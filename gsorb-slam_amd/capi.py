@@ -20,7 +20,8 @@ EXPORTS = ["gsr_forward", "gsr_forward_ws", "gsr_ws_status", "gsr_backward", "gs
            "gsr_debug_export", "gsr_acc_view", "gsr_knn_bytes", "gsr_dist2", "gsr_ssim_partials", "gsr_ssim_forward", "gsr_ssim_backward",
            "gsr_adam_step", "gsr_pose_grad", "gsr_to_camera", "gsr_pose_from_quat", "gsr_pose_from_quat_backward",
            "gsr_pixel_loss", "gsr_pixel_loss_backward", "gsr_pixel_loss_backward_add", "gsr_scale_reg", "gsr_scale_reg_backward",
-           "gsr_map_prepare", "gsr_map_update", "gsr_map_loss_total", "gsr_pose_update", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
+           "gsr_map_prepare", "gsr_map_update", "gsr_map_loss_total", "gsr_pose_update", "gsr_composite_forward", "gsr_composite_backward_local",
+           "gsr_composite_backward_occlusion", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
 
 
 def library_path() -> str:
@@ -157,6 +158,12 @@ def lib():
     L.gsr_map_update.argtypes = [C.POINTER(MapUpdateArgs), C.c_void_p]
     L.gsr_map_loss_total.restype = C.c_int
     L.gsr_map_loss_total.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gsr_composite_forward.restype = C.c_int
+    L.gsr_composite_forward.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gsr_composite_backward_local.restype = C.c_int
+    L.gsr_composite_backward_local.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gsr_composite_backward_occlusion.restype = C.c_int
+    L.gsr_composite_backward_occlusion.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.gsr_pose_update.restype = C.c_int
     L.gsr_pose_update.argtypes = [C.POINTER(PoseUpdateArgs), C.c_void_p]
     L.gsr_error_string.restype = C.c_char_p
@@ -586,6 +593,37 @@ def scale_regularisers(log_scales, limit, w_long, w_scalar):
 
 
 POSE_PARTIALS = 512  # GSR_POSE_PARTIALS
+
+
+def composite_forward(world, rank, order, gathered, layer4, has_sur):
+    """gsr_composite_forward on device tensors: (contrib [4,H,W], sil_total [1,H,W], surf [1,H,W])."""
+    H, W = int(layer4.shape[-2]), int(layer4.shape[-1])
+    contrib = torch.empty_like(layer4)
+    sil = torch.empty((1, H, W), dtype=torch.float32, device=layer4.device)
+    surf = torch.empty_like(sil)
+    with torch.cuda.device(layer4.device):
+        _check(lib().gsr_composite_forward(int(world), int(rank), _p(order), _p(gathered), _p(layer4), H, W, int(bool(has_sur)), _p(contrib), _p(sil),
+                                           _p(surf), _stream()))
+    return contrib, sil, surf
+
+
+def composite_backward_local(world, rank, order, gathered, layer4, g4):
+    H, W = int(layer4.shape[-2]), int(layer4.shape[-1])
+    d_layer = torch.empty_like(layer4)
+    c_own = torch.empty((1, H, W), dtype=torch.float32, device=layer4.device)
+    with torch.cuda.device(layer4.device):
+        _check(lib().gsr_composite_backward_local(int(world), int(rank), _p(order), _p(gathered), _p(layer4), _p(g4) if g4 is not None else None, H, W,
+                                                  _p(d_layer), _p(c_own), _stream()))
+    return d_layer, c_own
+
+
+def composite_backward_occlusion(world, rank, order, gathered, c_all, g_sil):
+    H, W = int(gathered.shape[-2]), int(gathered.shape[-1])
+    dS = torch.empty((1, H, W), dtype=torch.float32, device=gathered.device)
+    with torch.cuda.device(gathered.device):
+        _check(lib().gsr_composite_backward_occlusion(int(world), int(rank), _p(order), _p(gathered), _p(c_all), _p(g_sil) if g_sil is not None else None,
+                                                      H, W, _p(dS), _stream()))
+    return dS
 
 
 def map_prepare(xyz, logit, log_scales, unnorm_quat, Tcw, reg=None):

@@ -40,6 +40,17 @@ def _all_gather(tensor: torch.Tensor, world: int, group=None):
     return parts
 
 
+def _all_reduce_sum(t: torch.Tensor, group=None):
+    """In-place sum over the ranks (gloo has no device collectives: device tensors are staged through host memory there)."""
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 class _CompositeFn(torch.autograd.Function):
     """Front-to-back "over" compositing of the ranks' layers with two small collectives instead of an all-gather of the
     whole layers. Per pixel, with the layers ordered front to back, out = sum_k P_k L_k, P_k = prod_{h before k} (1 - S_h):
@@ -49,7 +60,12 @@ class _CompositeFn(torch.autograd.Function):
                 dL/dS_own = - sum_{k behind own} (prod_{h before k, h != own} (1 - S_h)) (g . L_k) + g_sil * prod_{h != own} (1 - S_h),
                 needs the others' g . L_k: one all-gather of 1 float / pixel / rank.
     At 1200x680 (3.26 MB per plane): 6.5 MB x world gathered + 13 MB reduced forward, 3.3 MB x world gathered backward;
-    the all-gather of full 7-row layers it replaces moved 22.8 MB x world. No per-layer Python loop over full layers."""
+    the all-gather of full 7-row layers it replaces moved 22.8 MB x world.
+    GPU layers: what sits between the collectives is three elementwise HIP kernels behind the C ABI (csrc/gsr_shard.h:
+    gsr_composite_forward / _backward_local / _backward_occlusion; round 4 — ~15 tensor launches per direction and a Python loop
+    over the ranks before). CPU layers (the world-2 gloo tests, which drive the oracle): the tensor expressions below.
+    SPMD: forward AND backward contain collectives — every rank must call composite() and must backpropagate through its
+    result in the same iteration (LayerCompositor.composite makes the node part of the graph whenever grad mode is on)."""
 
     @staticmethod
     def forward(ctx, layer4, sil, sur, key, comp):
@@ -59,45 +75,55 @@ class _CompositeFn(torch.autograd.Function):
             pad = torch.zeros((1,) + tuple(sil.shape[1:]), dtype=sil.dtype, device=dev)
             pad[0, 0, 0] = key                                   # the order key travels in a padding row (may be a device scalar: no host sync)
             mine = torch.cat([sil, sur if sur is not None else torch.zeros_like(sil), pad], 0).contiguous()
-            g = torch.stack(_all_gather(mine, world, group))       # [world, 3, H, W]
-            order = torch.argsort(g[:, 2, 0, 0].double(), stable=True)   # front to back: by key, ties by rank
-            S = g[:, 0].index_select(0, order)                   # [world, H, W] silhouettes, front to back
-            SU = g[:, 1].index_select(0, order)
-            pos = (order == rank).nonzero()[0, 0]                # this rank's slot in the order (device scalar)
-            one_m = 1.0 - S
-            P = torch.cumprod(torch.cat([torch.ones_like(S[:1]), one_m[:-1]], 0), 0)    # exclusive prefix transmittance per slot
-            P_own = P.index_select(0, pos.reshape(1))[0:1]       # [1,H,W]
-            contrib = (P_own * layer4).contiguous()
-            if dist.get_backend(group) == "gloo" and contrib.is_cuda:
-                h = contrib.cpu()
-                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
-                out4 = h.to(dev)
+            g = torch.stack(_all_gather(mine, world, group)).contiguous()     # [world, 3, H, W], rank order
+            order = torch.argsort(g[:, 2, 0, 0].double(), stable=True)   # front to back: by key, ties by rank (stays on the device)
+            if layer4.is_cuda:
+                from . import capi
+                l4 = layer4.detach().to(torch.float32).contiguous()
+                contrib, sil_tot, surf = capi.composite_forward(world, rank, order, g, l4, sur is not None)
+                out4 = _all_reduce_sum(contrib, group)
+                ctx.fused = True
+                ctx.save_for_backward(l4, g, order)
             else:
-                out4 = contrib.clone()
-                dist.all_reduce(out4, op=dist.ReduceOp.SUM, group=group)
-            T_all = P[-1:] * one_m[-1:]                          # transmittance behind the last layer
-            sil_tot = 1.0 - T_all
-            # surface depth: of the first layer, front to back, behind which the accumulated transmittance is <= 0.5
-            # (else of the last layer that has one)
-            T_after = P * one_m
-            surf = torch.zeros_like(sil)
-            found = torch.zeros_like(sil, dtype=torch.bool)
-            if sur is not None:
-                for k in range(world):
-                    has = SU[k:k + 1] > 0
-                    surf = torch.where(~found & has, SU[k:k + 1], surf)
-                    found = found | (has & (T_after[k:k + 1] <= 0.5))
+                S = g[:, 0].index_select(0, order)                   # [world, H, W] silhouettes, front to back
+                SU = g[:, 1].index_select(0, order)
+                pos = torch.argmax((order == rank).to(torch.int8))   # this rank's slot in the order (no host sync)
+                one_m = 1.0 - S
+                P = torch.cumprod(torch.cat([torch.ones_like(S[:1]), one_m[:-1]], 0), 0)    # exclusive prefix transmittance per slot
+                P_own = P.index_select(0, pos.reshape(1))[0:1]       # [1,H,W]
+                out4 = _all_reduce_sum((P_own * layer4).contiguous().clone(), group)
+                T_all = P[-1:] * one_m[-1:]                          # transmittance behind the last layer
+                sil_tot = 1.0 - T_all
+                # surface depth: of the first layer, front to back, behind which the accumulated transmittance is <= 0.5
+                # (else of the last layer that has one)
+                T_after = P * one_m
+                surf = torch.zeros_like(sil)
+                found = torch.zeros_like(sil, dtype=torch.bool)
+                if sur is not None:
+                    for k in range(world):
+                        has = SU[k:k + 1] > 0
+                        surf = torch.where(~found & has, SU[k:k + 1], surf)
+                        found = found | (has & (T_after[k:k + 1] <= 0.5))
+                ctx.fused = False
+                ctx.order = order
+                ctx.save_for_backward(layer4, S, P, pos)
         ctx.comp = comp
-        ctx.order = order
-        ctx.save_for_backward(layer4, S, P, pos)
         ctx.mark_non_differentiable(surf)
         return out4, sil_tot, surf
 
     @staticmethod
     def backward(ctx, g4, gsil, _gsurf):
-        layer4, S, P, pos = ctx.saved_tensors
         comp = ctx.comp
-        world, group = comp.world, comp.group
+        world, rank, group = comp.world, comp.rank, comp.group
+        if ctx.fused:
+            from . import capi
+            l4, g, order = ctx.saved_tensors
+            c = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+            d_layer, c_own = capi.composite_backward_local(world, rank, order, g, l4, c(g4))
+            c_all = torch.stack(_all_gather(c_own, world, group)).contiguous()       # [world, 1, H, W] in RANK order
+            dS = capi.composite_backward_occlusion(world, rank, order, g, c_all, c(gsil))
+            return d_layer, dS, None, None, None
+        layer4, S, P, pos = ctx.saved_tensors
         if g4 is None:
             g4 = torch.zeros_like(layer4)
         P_own = P.index_select(0, pos.reshape(1))[0:1]
@@ -139,7 +165,11 @@ class LayerCompositor:
         all-gather of 1 float/pixel/rank backward)."""
         if self.world == 1:
             return (rgb, ds[0:1], ds[1:2]) if sur is None else (rgb, ds[0:1], ds[1:2], sur)
-        out4, sil, surf = _CompositeFn.apply(torch.cat([rgb, ds[0:1]], 0), ds[1:2], None if sur is None else sur.detach(), order_key, self)
+        layer4, own_sil = torch.cat([rgb, ds[0:1]], 0), ds[1:2]
+        if torch.is_grad_enabled() and not (layer4.requires_grad or own_sil.requires_grad):
+            # the backward of the node contains collectives: a rank whose layer happens to be detached must still take part
+            layer4 = layer4.detach().requires_grad_(True)
+        out4, sil, surf = _CompositeFn.apply(layer4, own_sil, None if sur is None else sur.detach(), order_key, self)
         res = (out4[0:3], out4[3:4], sil)
         return res if sur is None else res + (surf,)
 
@@ -148,16 +178,6 @@ class LayerCompositor:
         if self.world > 1:
             dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.group)
         return grad
-
-    def all_reduce_scalars(self, values) -> list:
-        """Sum of a few python floats over the ranks (loss terms, counts)."""
-        if self.world == 1:
-            return [float(v) for v in values]
-        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
-        if dist.get_backend(self.group) != "gloo":
-            t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return t.tolist()
 
     def all_reduce_vector(self, t: torch.Tensor) -> torch.Tensor:
         """Sum of a small tensor over the ranks, staying where it is (RCCL reduces device tensors in place; gloo, which

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define GSR_ABI_VERSION 5 /* 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
-                           * 5: gsr_map_prepare / gsr_map_update / gsr_map_loss_total / gsr_pose_update / gsr_pixel_loss_backward_add added, GSR_LOSS_PARTIALS 256 -> 1024 */
+                           * 5: gsr_map_prepare / gsr_map_update / gsr_map_loss_total / gsr_pose_update / gsr_pixel_loss_backward_add / gsr_composite_* added, GSR_LOSS_PARTIALS 256 -> 1024 */
 
 #define GSR_OK 0
 #define GSR_EINVAL (-1)    /* bad argument combination (NULL where data is required, sizes < 0 …) */
@@ -327,6 +327,25 @@ typedef struct gsr_pose_update_args {
     int step;
 } gsr_pose_update_args;
 int gsr_pose_update(const gsr_pose_update_args* args, void* stream);
+
+/* ---- multi-GPU scheme B (scene shards; gsorb-slam_amd/sharded.py): compositing of the ranks' layers around the
+ * two collectives of the forward and the one of the backward. The reference is single-GPU; north_star: "shard Gaussians across the GPUs,
+ * RCCL all-reduce on pose / loss gradients only". All pointers are DEVICE pointers; N = H * W.
+ *   gathered [world,3,H,W]  the all-gather of every rank's (silhouette S, surface depth, key row), in RANK order
+ *   order    [world] int64  the ranks front to back (argsort of the keys)
+ *   layer4   [4,H,W]        this rank's (rgb, depth) render
+ * gsr_composite_forward: contrib [4,H,W] = P_own * layer4 with P_own = prod_{layers in front} (1 - S) (the caller all-reduces it),
+ *   sil_total [H,W] = 1 - prod_all (1 - S), surf [H,W] (NULL: not wanted) = surface depth of the first layer, front to back, behind
+ *   which the accumulated transmittance is <= 0.5 (else of the last layer that has one; has_sur = 0: zeros).
+ * gsr_composite_backward_local: d_layer4 = P_own * g4 (g4 NULL: zeros) and c_own [H,W] = g4 . layer4, which the caller all-gathers.
+ * gsr_composite_backward_occlusion: dS [H,W] = - sum_{k behind own} (prod_{h before k, h != own} (1 - S_h)) c_k
+ *   + g_sil * prod_{h != own} (1 - S_h)   (c_all [world,H,W] in rank order; g_sil NULL: no silhouette gradient). */
+int gsr_composite_forward(int world, int rank, const long long* order, const float* gathered, const float* layer4, int H, int W, int has_sur,
+                          float* contrib, float* sil_total, float* surf, void* stream);
+int gsr_composite_backward_local(int world, int rank, const long long* order, const float* gathered, const float* layer4, const float* g4, int H, int W,
+                                 float* d_layer4, float* c_own, void* stream);
+int gsr_composite_backward_occlusion(int world, int rank, const long long* order, const float* gathered, const float* c_all, const float* g_sil, int H,
+                                     int W, float* dS, void* stream);
 
 /* Workspace sizes: replace required<GeometryState/ImageState/BinningState>
  * (rasterizer_impl.h:67-73). */

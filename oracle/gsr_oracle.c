@@ -656,8 +656,9 @@ void gsro_render_margins(int W, int H, const uint32_t* ranges, const uint32_t* p
                         mc = fminf(mc, fabsf(power) / pscale);
                         if (power > 0.0f) continue;
                         const float araw = co[3] * expf(power);
-                        /* d(alpha)/alpha = d(power): absolute power error matters, so weigh by max(1,|power|) */
-                        mc = fminf(mc, fabsf(araw * 255.0f - 1.0f) / fmaxf(1.0f, fabsf(power)));
+                        /* d(alpha)/alpha = d(power): the ABSOLUTE error of power matters, and that scales with the size of its terms,
+                         * not with power itself (an elongated splat far from the pixel: terms of hundreds cancelling to a power of -5) */
+                        mc = fminf(mc, fabsf(araw * 255.0f - 1.0f) / fmaxf(1.0f, pscale));
                         const float alpha = fminf(0.99f, araw);
                         if (alpha < 1.0f / 255.0f) continue;
                         const float test_T = T * (1 - alpha);
@@ -683,6 +684,10 @@ void gsro_render_backward(int W, int H, int P, const uint32_t* ranges, const uin
     const float ddelx_dx = (float)(0.5 * W);
     const float ddely_dy = (float)(0.5 * H);
     double* acc = NULL; /* [P][9]: mean2D.xy, conic.xyw, opacity, colour.rgb */
+    /* accum_double bit 0: per-splat sums in double; bit 1 (test instrumentation, not in the reference): ALSO the per-pixel state of
+     * backward.cu:470-530 in double — the exact value of the reference's formulas for the float alphas it blended with, against
+     * which the fp32 rounding of an implementation (the reference's own included) can be measured */
+    const int exact_state = (accum_double & 2) != 0;
     if (accum_double) acc = (double*)calloc((size_t)P * 9, sizeof(double));
 
 #ifdef GSRO_OMP
@@ -693,7 +698,7 @@ void gsro_render_backward(int W, int H, int P, const uint32_t* ranges, const uin
 #define ADD(slot, fptr, val)                                          \
     do {                                                              \
         if (acc) { GSRO_ATOMIC acc[(size_t)id * 9 + (slot)] += (double)(val); } \
-        else { GSRO_ATOMIC *(fptr) += (val); }                        \
+        else { GSRO_ATOMIC *(fptr) += (float)(val); }                 \
     } while (0)
 
 #ifdef GSRO_OMP
@@ -708,10 +713,12 @@ void gsro_render_backward(int W, int H, int P, const uint32_t* ranges, const uin
                     if (!(px < W && py < H)) continue;
                     const int pix_id = W * py + px;
                     const float pixf[2] = {(float)px, (float)py};
-                    const float T_final = final_T[pix_id];
-                    float T = T_final;
+                    if (!exact_state) {
+#define REAL float
+                    const REAL T_final = final_T[pix_id];
+                    REAL T = T_final;
                     const uint32_t last_contributor = n_contrib[pix_id];
-                    float accum_rec[3] = {0, 0, 0}, dL_dpixel[3], last_alpha = 0, last_color[3] = {0, 0, 0};
+                    REAL accum_rec[3] = {0, 0, 0}, dL_dpixel[3], last_alpha = 0, last_color[3] = {0, 0, 0};
                     for (int i = 0; i < 3; i++) dL_dpixel[i] = dL_dpix[i * H * W + pix_id];
                     /* positions >= last_contributor are skipped (backward.cu:484-486) */
                     uint32_t n = r1 - r0;
@@ -725,32 +732,81 @@ void gsro_render_backward(int W, int H, int P, const uint32_t* ranges, const uin
                         const float G = expf(power);
                         const float alpha = fminf(0.99f, co[3] * G);
                         if (alpha < 1.0f / 255.0f) continue;
-                        T = T / (1.f - alpha);
-                        const float dchannel_dcolor = alpha * T;
-                        float dL_dalpha = 0.0f;
+                        T = T / ((REAL)1 - alpha);
+                        const REAL dchannel_dcolor = alpha * T;
+                        REAL dL_dalpha = 0;
                         for (int ch = 0; ch < 3; ch++) {
-                            const float c = colors[id * 3 + ch];
-                            accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                            const REAL c = colors[id * 3 + ch];
+                            accum_rec[ch] = last_alpha * last_color[ch] + ((REAL)1 - last_alpha) * accum_rec[ch];
                             last_color[ch] = c;
-                            const float dL_dchannel = dL_dpixel[ch];
+                            const REAL dL_dchannel = dL_dpixel[ch];
                             dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
                             ADD(6 + ch, &dL_dcolor[id * 3 + ch], dchannel_dcolor * dL_dchannel);
                         }
                         dL_dalpha *= T;
                         last_alpha = alpha;
-                        float bg_dot_dpixel = 0;
+                        REAL bg_dot_dpixel = 0;
                         for (int i = 0; i < 3; i++) bg_dot_dpixel += bg[i] * dL_dpixel[i];
-                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-                        const float dL_dG = co[3] * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * co[0] - gdy * co[1];
-                        const float dG_ddely = -gdy * co[2] - gdx * co[1];
+                        dL_dalpha += (-T_final / ((REAL)1 - alpha)) * bg_dot_dpixel;
+                        const REAL dL_dG = co[3] * dL_dalpha;
+                        const REAL gdx = (REAL)G * dx, gdy = (REAL)G * dy;
+                        const REAL dG_ddelx = -gdx * co[0] - gdy * co[1];
+                        const REAL dG_ddely = -gdy * co[2] - gdx * co[1];
                         ADD(0, &dL_dmean2D[3 * id + 0], dL_dG * dG_ddelx * ddelx_dx);
                         ADD(1, &dL_dmean2D[3 * id + 1], dL_dG * dG_ddely * ddely_dy);
-                        ADD(2, &dL_dconic[4 * id + 0], -0.5f * gdx * dx * dL_dG);
-                        ADD(3, &dL_dconic[4 * id + 1], -0.5f * gdx * dy * dL_dG);
-                        ADD(4, &dL_dconic[4 * id + 3], -0.5f * gdy * dy * dL_dG);
+                        ADD(2, &dL_dconic[4 * id + 0], (REAL)-0.5 * gdx * dx * dL_dG);
+                        ADD(3, &dL_dconic[4 * id + 1], (REAL)-0.5 * gdx * dy * dL_dG);
+                        ADD(4, &dL_dconic[4 * id + 3], (REAL)-0.5 * gdy * dy * dL_dG);
                         ADD(5, &dL_dopacity[id], G * dL_dalpha);
+                    }
+#undef REAL
+                    } else { /* the same formulas with the per-pixel state (T, accum_rec, dL/dalpha and what is formed from it) in double */
+#define REAL double
+                    const REAL T_final = final_T[pix_id];
+                    REAL T = T_final;
+                    const uint32_t last_contributor = n_contrib[pix_id];
+                    REAL accum_rec[3] = {0, 0, 0}, dL_dpixel[3], last_alpha = 0, last_color[3] = {0, 0, 0};
+                    for (int i = 0; i < 3; i++) dL_dpixel[i] = dL_dpix[i * H * W + pix_id];
+                    /* positions >= last_contributor are skipped (backward.cu:484-486) */
+                    uint32_t n = r1 - r0;
+                    uint32_t start = last_contributor < n ? last_contributor : n;
+                    for (uint32_t pos = start; pos-- > 0;) {
+                        const uint32_t id = point_list[r0 + pos];
+                        const float dx = means2D[2 * id] - pixf[0], dy = means2D[2 * id + 1] - pixf[1];
+                        const float* co = conic_opacity + 4 * id;
+                        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        if (power > 0.0f) continue;
+                        const float G = expf(power);
+                        const float alpha = fminf(0.99f, co[3] * G);
+                        if (alpha < 1.0f / 255.0f) continue;
+                        T = T / ((REAL)1 - alpha);
+                        const REAL dchannel_dcolor = alpha * T;
+                        REAL dL_dalpha = 0;
+                        for (int ch = 0; ch < 3; ch++) {
+                            const REAL c = colors[id * 3 + ch];
+                            accum_rec[ch] = last_alpha * last_color[ch] + ((REAL)1 - last_alpha) * accum_rec[ch];
+                            last_color[ch] = c;
+                            const REAL dL_dchannel = dL_dpixel[ch];
+                            dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
+                            ADD(6 + ch, &dL_dcolor[id * 3 + ch], dchannel_dcolor * dL_dchannel);
+                        }
+                        dL_dalpha *= T;
+                        last_alpha = alpha;
+                        REAL bg_dot_dpixel = 0;
+                        for (int i = 0; i < 3; i++) bg_dot_dpixel += bg[i] * dL_dpixel[i];
+                        dL_dalpha += (-T_final / ((REAL)1 - alpha)) * bg_dot_dpixel;
+                        const REAL dL_dG = co[3] * dL_dalpha;
+                        const REAL gdx = (REAL)G * dx, gdy = (REAL)G * dy;
+                        const REAL dG_ddelx = -gdx * co[0] - gdy * co[1];
+                        const REAL dG_ddely = -gdy * co[2] - gdx * co[1];
+                        ADD(0, &dL_dmean2D[3 * id + 0], dL_dG * dG_ddelx * ddelx_dx);
+                        ADD(1, &dL_dmean2D[3 * id + 1], dL_dG * dG_ddely * ddely_dy);
+                        ADD(2, &dL_dconic[4 * id + 0], (REAL)-0.5 * gdx * dx * dL_dG);
+                        ADD(3, &dL_dconic[4 * id + 1], (REAL)-0.5 * gdx * dy * dL_dG);
+                        ADD(4, &dL_dconic[4 * id + 3], (REAL)-0.5 * gdy * dy * dL_dG);
+                        ADD(5, &dL_dopacity[id], G * dL_dalpha);
+                    }
+#undef REAL
                     }
                 }
         }

@@ -245,3 +245,61 @@ def test_bench_runs_its_multi_rank_branch_with_two_ranks():
     assert d["replica_rasterize"]["scaling"] == "weak" and d["replica_rasterize"]["value"] > 0
     ss = d["shard_step"]
     assert ss["rccl_ranks"] == 2 and ss["splats_per_rank"] == 20000 and ss["mapping_ms_per_iter"] > 0 and ss["tracking_ms_per_iter"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,has_sur", [(2, True), (3, True), (5, False), (8, True)])
+def test_fused_compositing_kernels_match_the_dense_composite(world, has_sur):
+    """csrc/gsr_shard.h (gsr_composite_forward / _backward_local / _backward_occlusion) for every rank of a simulated world, against
+    float64 autograd through the dense "over" composite of all layers in one process: the sum of the ranks' contributions is the
+    composite, every rank's (dL/dlayer, dL/dS) is its slice of the dense gradient, the surface-depth pick follows the rule."""
+    gsr, hz, sharded = _setup()
+    g = torch.Generator().manual_seed(world * 7 + has_sur)
+    Hh, Ww = 37, 53
+    L = torch.rand((world, 4, Hh, Ww), generator=g)
+    S = torch.rand((world, 1, Hh, Ww), generator=g) * 0.95
+    S[:, :, :5] = 0.0                                            # rows nothing covers
+    S[0, :, 5:9] = 1.0                                           # an opaque layer
+    SU = torch.where(torch.rand((world, 1, Hh, Ww), generator=g) < 0.7, 0.5 + 3 * torch.rand((world, 1, Hh, Ww), generator=g), torch.zeros(1))
+    keys = torch.rand((world,), generator=g) * 5
+    keys[-1] = keys[0]                                           # a tie: broken by rank (stable sort)
+    order = torch.argsort(keys.double(), stable=True)
+    G4 = torch.randn((4, Hh, Ww), generator=g); Gs = torch.randn((1, Hh, Ww), generator=g)
+    # dense reference in float64
+    Ld, Sd = L.double().requires_grad_(True), S.double().requires_grad_(True)
+    T = torch.ones((1, Hh, Ww), dtype=torch.float64)
+    out = torch.zeros((4, Hh, Ww), dtype=torch.float64)
+    surf_ref = torch.zeros((1, Hh, Ww)); found = torch.zeros((1, Hh, Ww), dtype=torch.bool)
+    for k in order.tolist():
+        out = out + T * Ld[k]
+        T = T * (1 - Sd[k])
+        has = SU[k] > 0
+        surf_ref = torch.where(~found & has, SU[k], surf_ref)
+        found = found | (has & (T.detach() <= 0.5))
+    sil = 1 - T
+    ((out * G4.double()).sum() + (sil * Gs.double()).sum()).backward()
+    # the kernels, rank by rank
+    pad = torch.zeros((world, 1, Hh, Ww)); pad[:, 0, 0, 0] = keys
+    gathered = torch.cat([S, SU if has_sur else torch.zeros_like(S), pad], 1).cuda().contiguous()
+    order_d = order.cuda()
+    contribs, locals_ = [], []
+    for r in range(world):
+        contrib, sil_tot, surf = gsr.capi.composite_forward(world, r, order_d, gathered, L[r].cuda().contiguous(), has_sur)
+        contribs.append(contrib)
+        assert (sil_tot.cpu().double() - sil.detach()).abs().max() < 2e-6
+        if has_sur:
+            assert torch.equal(surf.cpu(), surf_ref)
+        else:
+            assert float(surf.abs().max()) == 0.0
+        locals_.append(gsr.capi.composite_backward_local(world, r, order_d, gathered, L[r].cuda().contiguous(), G4.cuda()))
+    assert (torch.stack(contribs).sum(0).cpu().double() - out.detach()).abs().max() < 5e-6
+    c_all = torch.stack([c for _, c in locals_]).contiguous()
+    for r in range(world):
+        assert (locals_[r][0].cpu().double() - Ld.grad[r]).abs().max() < 5e-6
+        dS = gsr.capi.composite_backward_occlusion(world, r, order_d, gathered, c_all, Gs.cuda())
+        assert (dS.cpu().double() - Sd.grad[r]).abs().max() < 2e-5 * max(1.0, float(Sd.grad[r].abs().max()))
+    # no upstream gradient on the colours / on the silhouette
+    d0, c0 = gsr.capi.composite_backward_local(world, 0, order_d, gathered, L[0].cuda().contiguous(), None)
+    assert float(d0.abs().max()) == 0.0 and float(c0.abs().max()) == 0.0
+    dS0 = gsr.capi.composite_backward_occlusion(world, 0, order_d, gathered, c_all, None)
+    Ld.grad = None; Sd.grad = None
