@@ -419,9 +419,11 @@ def shard_step(a, gsr, td, rank, world, dev):
             "timed_iters": n}
 
 
-def shard_render(a, gsr, td, rank, world, dev):
-    """The rasterize path WITH its exchange, strong scaling: --splats Gaussians in total, split into depth slabs over the
-    ranks (sharded.shard_by_depth_slabs); per step every rank renders its slab (fused colour + depth / silhouette pass),
+def shard_render(a, gsr, td, rank, world, dev, weak=False):
+    """The rasterize path WITH its exchange. Strong scaling (default): --splats Gaussians in total, split into depth slabs over the
+    ranks (sharded.shard_by_depth_slabs). Weak scaling (weak=True; the use case BASELINE configs 4-5 describe: a map that grows with the
+    node): --splats Gaussians PER RANK — rank r owns the r-th of `world` equal depth slabs of the view's depth range, the map is
+    world x --splats Gaussians. Per step every rank renders its slab (fused colour + depth / silhouette pass),
     the layers are composited (all-gather of 2 floats/pixel/rank + one all-reduce of 4 channels), a fixed upstream
     gradient is taken back through the composite (all-gather of 1 float/pixel/rank) and the rasterizer's backward to the
     Gaussians and the pose, and the pose gradient is all-reduced (16 floats) — north_star: 'shards Gaussians across the
@@ -433,8 +435,14 @@ def shard_render(a, gsr, td, rank, world, dev):
     camd = syn.CAMERAS[a.camera]
     cam = syn.make_camera(**camd)
     W, H = cam.width, cam.height
-    sc = syn.make_scene(a.splats, cam, seed=1234, scale_mult=a.scale_mult)      # the SAME scene on every rank
-    idx = sharded.shard_by_depth_slabs(torch.tensor(sc.means3D[:, 2]), world)[rank].numpy()
+    if weak:   # every rank generates only ITS slab: depth range [0.5, 6.0] cut into `world` equal parts, --splats Gaussians each
+        z0, z1 = 0.5 + 5.5 * rank / world, 0.5 + 5.5 * (rank + 1) / world
+        sc = syn.make_scene(a.splats, cam, seed=1234 + rank, scale_mult=a.scale_mult, z_range=(z0, z1))
+        idx = np.arange(a.splats)
+    else:
+        sc = syn.make_scene(a.splats, cam, seed=1234, scale_mult=a.scale_mult)      # the SAME scene on every rank
+        idx = sharded.shard_by_depth_slabs(torch.tensor(sc.means3D[:, 2]), world)[rank].numpy()
+    total = a.splats * world if weak else a.splats
     s = gsr.capi.Settings.from_camera(cam, device=dev)
     rs = dgr.GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=s.tanfovx, tanfovy=s.tanfovy, bg=torch.zeros(3, device=dev),
                                            scale_modifier=1.0, viewmatrix=s.viewmatrix, projmatrix=s.projmatrix, sh_degree=0,
@@ -478,9 +486,9 @@ def shard_render(a, gsr, td, rank, world, dev):
     plane = W * H * 4
     return {"what": "sharded fwd+bwd rasterize with its exchange (see bench.py:shard_render): fused colour + depth/silhouette pass of the rank's depth slab, "
                     "layer compositing, backward through both, pose-gradient all-reduce; collectives INSIDE the timed region",
-            "scaling": "strong", "total_splats": a.splats, "splats_per_rank": int(len(idx)), "width": W, "height": H, "ms_per_step": ms,
-            "value": a.splats * W * H / (ms * 1e-3), "unit": "splats*pixels/s",
-            "backend": (td.get_backend() if world > 1 else "none (single process)"),
+            "scaling": "weak" if weak else "strong", "total_splats": total, "splats_per_rank": int(len(idx)), "width": W, "height": H, "ms_per_step": ms,
+            "value": total * W * H / (ms * 1e-3), "unit": "splats*pixels/s",
+            "backend": (td.get_backend() if world > 1 else "none (single process)"), "ranks": (td.get_world_size() if world > 1 else 1),
             "collective_bytes_per_rank_per_step": {"all_gather_fwd": 3 * plane * (world - 1) if world > 1 else 0, "all_reduce_fwd": 4 * plane if world > 1 else 0,
                                                    "all_gather_bwd": plane * (world - 1) if world > 1 else 0, "all_reduce_pose": 64 if world > 1 else 0}}
 
@@ -497,6 +505,9 @@ def main():
     ap.add_argument("--mode", choices=["all", "rasterize", "shard-step"], default="all",
                     help="rasterize: the headline fwd+bwd line only; shard-step: only the sharded mapping/tracking step; all: both")
     ap.add_argument("--shard-steps", type=int, default=20, help="timed iterations of each shard_step loop")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: which scene-shard mode gives the headline value (strong: --splats in total; weak: --splats per rank, the map grows "
+                         "N-fold); the other mode is reported beside it (shard_render_weak / shard_render_strong)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-other", action="store_true", help="skip the other_workloads / loop_ms blocks (N = 1 only, after the headline)")
     ap.add_argument("--other-steps", type=int, default=50, help="timed steps of each entry of other_workloads")
@@ -539,18 +550,25 @@ def main():
         if world == 1 and not a.no_other and a.splats == 1_000_000 and a.camera == "replica" and a.scale_mult == 1.0 and a.depth_layout == "uniform":
             out["other_workloads"] = other_workloads(a, gsr, dev)
             out["loop_ms"] = cpp_loop_ms(a, gsr, dev)
-        sr = shard_render(a, gsr, td, rank, world, dev)
+        sr = shard_render(a, gsr, td, rank, world, dev, weak=(a.scaling == "weak"))
+        sr_other = shard_render(a, gsr, td, rank, world, dev, weak=(a.scaling != "weak")) if world > 1 else None
+        if world > 1:
+            assert td.get_world_size() == a.gpus == world, (td.get_world_size(), a.gpus, world)   # one rank per GPU, all of them in the collectives
         if rank == 0:
             if world > 1:
                 # N > 1: the headline value is the step that EXCHANGES data (strong scaling: the same --splats scene split over the
                 # ranks); the collective-free replica figure (every rank its own scene: linear by construction) is kept beside it
                 out["replica_rasterize"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "scaling": "weak",
                                             "what": "every rank renders its OWN --splats scene, no collective in the timed region"}
-                out.update(value=sr["value"], ms_per_step=sr["ms_per_step"], scaling="strong")
-                out["config"]["workload"] = (f"{a.splats} Gaussians in TOTAL split into depth slabs over {world} ranks, {sr['width']}x{sr['height']}, "
-                                             "sharded fwd+bwd rasterize with layer compositing and pose-gradient all-reduce (RCCL) inside the timed region")
-                out["config"]["parallelism"] = f"scene shards (depth slabs) x{world}, strong scaling"
+                out.update(value=sr["value"], ms_per_step=sr["ms_per_step"], scaling=sr["scaling"])
+                what = (f"{a.splats} Gaussians PER RANK ({sr['total_splats']} in the map: rank r owns the r-th depth slab)" if a.scaling == "weak"
+                        else f"{a.splats} Gaussians in TOTAL split into depth slabs over {world} ranks")
+                out["config"]["workload"] = (what + f", {sr['width']}x{sr['height']}, sharded fwd+bwd rasterize with layer compositing (three HIP kernels, "
+                                             f"gsr_composite_*) and pose-gradient all-reduce inside the timed region; backend {sr['backend']} ({sr['ranks']} ranks)")
+                out["config"]["parallelism"] = f"scene shards (depth slabs) x{world}, {sr['scaling']} scaling, torch.distributed backend {sr['backend']}"
+                out["config"]["splats_total"] = sr["total_splats"]
                 out.pop("step_ms_percentiles", None)
+                out["shard_render_" + sr_other["scaling"]] = sr_other
             out["shard_render"] = sr
     if a.mode in ("all", "shard-step"):
         ss = shard_step(a, gsr, td, rank, world, dev)

@@ -243,6 +243,9 @@ def test_bench_runs_its_multi_rank_branch_with_two_ranks():
     assert sr["splats_per_rank"] == 20000 and sr["total_splats"] == 40000 and d["value"] == sr["value"] and d["ms_per_step"] == sr["ms_per_step"]
     assert sr["collective_bytes_per_rank_per_step"]["all_reduce_fwd"] == 4 * 640 * 480 * 4
     assert d["replica_rasterize"]["scaling"] == "weak" and d["replica_rasterize"]["value"] > 0
+    wk = d["shard_render_weak"]   # the weak-scaling scheme-B figure beside the strong headline: --splats per rank, the map grows with the ranks
+    assert wk["scaling"] == "weak" and wk["splats_per_rank"] == 40000 and wk["total_splats"] == 80000 and wk["ranks"] == 2 and wk["value"] > 0
+    assert sr["ranks"] == 2 and "gloo" in d["config"]["parallelism"]
     ss = d["shard_step"]
     assert ss["rccl_ranks"] == 2 and ss["splats_per_rank"] == 20000 and ss["mapping_ms_per_iter"] > 0 and ss["tracking_ms_per_iter"] > 0
 
