@@ -108,6 +108,9 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     GSR_LAUNCHED();
     tm.end(GSR_FWD_FILL);
     tm.begin(GSR_FWD_SORT);
+#ifdef GSR_EXP_MIDSORT // timing experiment: the keys-only 16-keys-per-thread sort of the lists over 1024 entries, run beside the real one
+    hipLaunchKernelGGL(gsr::K_tile_sort<GSR_SORT_BLOCK>, dim3(T), dim3(256), 0, st, T, iv.ranges, gv.hdr, bv.pairs, bv.point_list);
+#endif
     hipLaunchKernelGGL(gsr::K_tile_sort_cut, dim3(T), dim3(GSR_SORT_BIG_THREADS), 0, st, T, f.grid_x, iv.ranges, gv, bv.pairs, bv.point_list,
                        bv.qhits, iv.qcount);
     GSR_LAUNCHED();
@@ -140,7 +143,7 @@ int forward_head(const gsr_forward_args* a, char* geom, char* image, hipStream_t
                                              a->projmatrix, a->cam_pos);
     const StageTimer tm{a->profile_events, st};
     tm.begin(GSR_FWD_PREPROCESS);
-    hipLaunchKernelGGL(gsr::K_preprocess, dim3(blocks256(P)), dim3(256), 0, st, f, in, a->radii, *gv);
+    hipLaunchKernelGGL(gsr::K_preprocess, dim3((P + GSR_PRE_THREADS - 1) / GSR_PRE_THREADS), dim3(GSR_PRE_THREADS), 0, st, f, in, a->radii, *gv);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_PREPROCESS);
     tm.begin(GSR_FWD_SCAN);

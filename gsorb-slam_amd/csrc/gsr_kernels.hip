@@ -59,10 +59,13 @@ __device__ __forceinline__ void load_cov3d(const SplatInputs& in, const FramePar
     }
 }
 
-__global__ void __launch_bounds__(256)
+#ifndef GSR_PRE_THREADS
+#define GSR_PRE_THREADS 256
+#endif
+__global__ void __launch_bounds__(GSR_PRE_THREADS)
 K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomView g)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = blockIdx.x * GSR_PRE_THREADS + threadIdx.x;
     if (idx >= f.P) return;
     const float3 p = make_float3(in.means3D[3 * (size_t)idx], in.means3D[3 * (size_t)idx + 1], in.means3D[3 * (size_t)idx + 2]);
     float cov[6];
