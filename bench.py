@@ -708,7 +708,7 @@ def rasterize(a, gsr, td, rank, world, dev):
         pmc = {}         # so the committed rocprofv3 --pmc summary of this same command is quoted
         mix = {}
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
             mix = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_mix.json")))["kernels"]
             if P == 1_000_000 and a.camera == "replica" and a.scale_mult == 1.0:
                 pmc = tj["kernels"]

@@ -111,7 +111,7 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
 #ifdef GSR_EXP_MIDSORT // timing experiment: the keys-only 16-keys-per-thread sort of the lists over 1024 entries, run beside the real one
     hipLaunchKernelGGL(gsr::K_tile_sort<GSR_SORT_BLOCK>, dim3(T), dim3(256), 0, st, T, iv.ranges, gv.hdr, bv.pairs, bv.point_list);
 #endif
-    hipLaunchKernelGGL(gsr::K_tile_sort_cut, dim3(T), dim3(GSR_SORT_BIG_THREADS), 0, st, T, f.grid_x, iv.ranges, gv, bv.pairs, bv.point_list,
+    hipLaunchKernelGGL(gsr::K_tile_sort_cut, dim3(T), dim3(GSR_SORT_CUT_THREADS), 0, st, T, f.grid_x, iv.ranges, gv, bv.pairs, bv.point_list,
                        bv.qhits, iv.qcount);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SORT);
@@ -738,6 +738,12 @@ int gsr_debug_export(int P, int width, int height, int R, const char* geom, cons
 
 } // extern "C"
 
+#ifdef GSR_EXP_SORT_PHASES
+extern "C" int gsr_debug_sort_phases(unsigned long long* dst, int n_words)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gsr::g_sort_phases), (size_t)n_words * 8);
+}
+#endif
 #ifdef GSR_EXP_TIMELINE
 extern "C" int gsr_debug_timeline(unsigned long long* dst, int n_words)
 {

@@ -449,9 +449,12 @@ __device__ __forceinline__ void lds_sort(uint64_t* s, int cap)
 #define GSR_SORT_WAVE 0
 #define GSR_SORT_BLOCK 1
 #define GSR_SORT_BLOCK_SHORT 2
+#ifndef GSR_SORT_CUT_THREADS
+#define GSR_SORT_CUT_THREADS 256 // threads of K_tile_sort_cut's workgroup (KIND 2): 128 = 8 keys per thread
+#endif
 template <int KIND>
 struct SortShared {
-    static constexpr int NT = KIND == 0 ? GSR_SORT_SMALL_THREADS : GSR_SORT_BIG_THREADS;
+    static constexpr int NT = KIND == 0 ? GSR_SORT_SMALL_THREADS : KIND == 2 ? GSR_SORT_CUT_THREADS : GSR_SORT_BIG_THREADS;
     static constexpr int CAP = KIND == 1 ? GSR_SORT_CAP : GSR_SORT_SMALL;
     uint64_t s[CAP];
     __attribute__((aligned(16))) uint32_t h[CAP + 64]; // 64 spare words: one per lane for the padding keys' (zero) atomics
@@ -961,7 +964,7 @@ __device__ __forceinline__ void emit_from_lds(const uint32_t* ids, uint32_t* msk
     }
     if (nu > 0) __syncthreads();
     auto get = [&](int i) { return make_uint2(ids[i], msk[i]); };
-    if (tid < 256) cut_quad_list(get, m, tid >> 6, t); // (waves 0..3: one quad each)
+    for (int q = tid >> 6; q < 4; q += nt >> 6) cut_quad_list(get, m, q, t); // (four waves: one quad each)
 }
 // A chunk without its mask words at hand (the bitonic network ran: exact depth ties): the sorted ids are read back from `out`
 // (just written by this workgroup), the masks recomputed from the gathered reach entries, (id, mask) parked in the chunk's
@@ -990,7 +993,7 @@ __device__ __forceinline__ void emit_from_global(const uint32_t* out, uint64_t* 
     }
     __syncthreads();
     auto get = [&](int i) { const uint64_t v = park[i]; return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); };
-    if (tid < 256) cut_quad_list(get, m, tid >> 6, t);
+    for (int q = tid >> 6; q < 4; q += nt >> 6) cut_quad_list(get, m, q, t);
 }
 
 // The rasterizer's tile sort: one 256-thread workgroup per tile, whatever the length of its list. Lists of up to 1024
@@ -1000,10 +1003,16 @@ __device__ __forceinline__ void emit_from_global(const uint32_t* out, uint64_t* 
 // (History: one wave per list with 16 keys per lane — 63 us with the list cutting in; round 3: this kernel for the short lists
 // plus K_tile_sort_long — 48 KB of LDS, 220 VGPRs — for the others: 37.5 + 4.8 us on the headline frame, 130 / 275 us on the
 // 2 M-splat and fat-splat frames.)
+#ifdef GSR_EXP_SORT_PHASES // instrumented build (scripts/sort_phases.py): wall-clock stamps of the phases of every tile's workgroup
+__device__ unsigned long long g_sort_phases[16 * 16384];
+#define GSR_PHASE(k) do { if (threadIdx.x == 0 && tile < 16384) g_sort_phases[16 * tile + (k)] = wall_clock64(); } while (0)
+#else
+#define GSR_PHASE(k) do { } while (0)
+#endif
 #ifndef GSR_SORT_WAVES
 #define GSR_SORT_WAVES 6 // waves per SIMD the register allocation is held to (80 VGPRs, no spills; 7 = 72 VGPRs spills six)
 #endif
-__global__ void __launch_bounds__(GSR_SORT_BIG_THREADS) __attribute__((amdgpu_waves_per_eu(GSR_SORT_WAVES, GSR_SORT_WAVES)))
+__global__ void __launch_bounds__(GSR_SORT_CUT_THREADS) __attribute__((amdgpu_waves_per_eu(GSR_SORT_WAVES, GSR_SORT_WAVES)))
 K_tile_sort_cut(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g, uint64_t* __restrict__ pairs,
                 uint32_t* __restrict__ point_list, uint2* __restrict__ qhits, uint32_t* __restrict__ qcount)
 {
@@ -1021,6 +1030,7 @@ K_tile_sort_cut(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g,
     }
     const int tx = tile % grid_x, ty = tile / grid_x;
     if (threadIdx.x < 4u) qcnt[threadIdx.x] = 0u;
+    GSR_PHASE(0);
     CutTarget ct;
     ct.qh = qhits + 4 * (size_t)r.x; ct.qcnt = qcnt; ct.n_list = n; ct.pos0 = 0;
 #ifdef GSR_EXP_SORT_NOGATHER
@@ -1033,6 +1043,7 @@ K_tile_sort_cut(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g,
         ct.pos0 = pos0;
         if (threadIdx.x == 0) counter = 0u; // (emit_from_lds's to-do counter: the sort's barriers lie between this and its use)
         const int where = sort_tile<GSR_SORT_BLOCK_SHORT>(sh, src, m, point_list + r.x + pos0, reach, tx, ty);
+        GSR_PHASE(4); // (last chunk's)
 #ifdef GSR_EXP_SORT_NOEMIT
         return;
 #endif
@@ -1056,6 +1067,7 @@ K_tile_sort_cut(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g,
         // (values read from LDS are vector registers to the compiler: the loop state is made scalar explicitly, or it and
         // everything derived from it — chunk pointers, lengths — stays live in VGPRs across the whole chunk body)
         S = __builtin_amdgcn_readfirstlane(partition_list<GSR_SORT_BLOCK_SHORT>(sh, chunk_first, pairs + r.x, n, temp, map));
+        GSR_PHASE(1);
         if (S > 0) {
             nw = (n + S - 1) / S;
             while (w < nw && __builtin_amdgcn_readfirstlane((int)chunk_first[w]) == (int)GSR_PART_NONE) w++;
@@ -1069,11 +1081,17 @@ K_tile_sort_cut(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g,
             while (w2 < nw && __builtin_amdgcn_readfirstlane((int)chunk_first[w2]) == (int)GSR_PART_NONE) w2++;
             end = w2 < nw ? __builtin_amdgcn_readfirstlane((int)chunk_first[w2]) : n;
         }
+        if (w2 >= nw) GSR_PHASE(3); // start of the last chunk
         chunk(S > 0 ? temp + start : pairs + r.x, end - start, start);
         w = w2;
         if (w < nw) __syncthreads(); // the chunk's LDS is free again
     }
-    if (threadIdx.x < 256u && (threadIdx.x & 63u) == 0u) qc4[threadIdx.x >> 6] = qcnt[threadIdx.x >> 6]; // (the thread that wrote the count: no barrier)
+    if ((threadIdx.x & 63u) == 0u) // (the thread that wrote the count: no barrier)
+        for (uint32_t q = threadIdx.x >> 6; q < 4u; q += GSR_SORT_CUT_THREADS / 64) qc4[q] = qcnt[q];
+    GSR_PHASE(5);
+#ifdef GSR_EXP_SORT_PHASES
+    if (threadIdx.x == 0 && tile < 16384) g_sort_phases[16 * tile + 6] = (unsigned long long)n;
+#endif
 }
 
 // ===================================================================================

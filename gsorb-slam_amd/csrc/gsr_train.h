@@ -352,7 +352,7 @@ K_loss_finish(const float* __restrict__ partial, int nblocks, int mode, size_t N
     if (lane == 0) {
         float loss;
         if (mode == 0) loss = w.w[0] * a[0] + w.w[1] * (depth_from_sur ? a[3] : a[1]);
-        else loss = w.w[0] * (a[0] / (3.f * (float)N)) + w.w[1] * (a[1] / a[2]) + w.w[2] * (a[3] / fmaxf(a[4], 1.f));
+        else loss = w.w[0] * (a[0] / (3.f * (float)N)) + w.w[1] * (a[1] / fmaxf(a[2], 1.f)) + w.w[2] * (a[3] / fmaxf(a[4], 1.f)); // (an empty mask: 0, in the loss and in its gradient)
         sums[0] = a[0]; sums[1] = a[1]; sums[2] = a[2]; sums[3] = a[3]; sums[4] = a[4]; sums[5] = loss; sums[6] = 0.f; sums[7] = 0.f;
     }
 }
@@ -369,7 +369,7 @@ K_loss_grad(LossPlanes p, size_t N, int mode, float thr, LossWeights w, const fl
     const bool colour_in = mode == 0 ? (solid && fd == fd) : true;
     const bool depth_in = mode == 0 ? colour_in : fd > 0.f;
     const float ci = mode == 0 ? g * w.w[0] : g * w.w[0] / (3.f * (float)N);
-    const float cd = mode == 0 ? g * w.w[1] : g * w.w[1] / sums[2];
+    const float cd = mode == 0 ? g * w.w[1] : g * w.w[1] / fmaxf(sums[2], 1.f);
 #pragma unroll
     for (int c = 0; c < 3; c++) dimage[c * N + i] = (colour_in ? ci * sgn(p.image[c * N + i] - p.frgb[c * N + i]) : 0.f) + (add ? add[c * N + i] : 0.f);
     if (ddepth) ddepth[i] = (depth_in && p.depth) ? cd * sgn(p.depth[i] - fd) : 0.f;

@@ -246,6 +246,9 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
  *                   mode 1 (mapping): V = frame_depth > 0, S = V && sil > sil_thr;
  *                       loss = w[0] * mean |image - frame_rgb| + w[1] * sum_V |depth - frame_depth| / |V|
  *                              + w[2] * sum_S |sur - frame_depth| / max(|S|, 1)
+ *                       EMPTY MASKS: a term whose mask selects no pixel is 0, in the loss and in its gradient (counts are divided as max(count, 1)).
+ *                       The reference's masked_select().mean() gives NaN there (src/Render.cc:455-462, src/Utils.cc:39-56) and poisons the step; this is a
+ *                       deliberate deviation (the Python harness reproduces the reference's NaN with strict_empty_terms, on the unfused path).
  *                   image, frame_rgb [3,H,W]; depth, sur, sil, frame_depth [H,W] (depth / sur / sil may be NULL: term or test absent).
  *                   partial: scratch of GSR_LOSS_PARTIALS * 5 floats; sums [8] = {sum |image - rgb|, sum |depth - fd|, its count,
  *                   sum |sur - fd|, its count (mapping), loss, 0, 0}
