@@ -619,7 +619,8 @@ int gsr_map_update(const gsr_map_update_args* a, void* stream)
     u.opac = a->opacities; u.scales = a->scales; u.Tcw = a->Tcw; u.reg_out = a->reg_out; u.overflow = overflow_flag(a->geom);
     u.limit = a->reg_limit; u.w_long = a->w_long; u.w_scalar = a->w_scalar;
     u.w1 = (float)(1.0 - a->beta1); u.b2 = (float)a->beta2; u.w2 = (float)(1.0 - a->beta2); u.eps = (float)a->eps;
-    hipLaunchKernelGGL(gsr::K_map_update, dim3((unsigned)((a->n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, a->n, u); // four splats per thread
+    if (a->n < (size_t)1 << 18) hipLaunchKernelGGL(gsr::K_map_update_small, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a->n, u);
+    else hipLaunchKernelGGL(gsr::K_map_update, dim3((unsigned)((a->n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, a->n, u); // four splats per thread
     GSR_LAUNCHED();
     return GSR_OK;
 }

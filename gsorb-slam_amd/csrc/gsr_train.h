@@ -521,52 +521,74 @@ __device__ __forceinline__ void adam_one(float& pp, const float gg, float& mm, f
     const float denom = sqrtf(vv) / u.sqrt_bias2[g] + u.eps;
     pp = fmaf(-u.step_size[g], mm / denom, pp);
 }
+// One Gaussian. Every load is issued before the first store (the tensors may alias as far as the compiler knows: section by section
+// it would wait for each section's round trip — at 10 k Gaussians, where nothing else hides it, the launch took 19 us for 0.4 MB).
 __device__ __forceinline__ void map_update_one(const size_t i, const MapUpdate& u, const Pose34& T)
 {
-    { // means: mc = X R^T + t  =>  dL/dX = dmc R
-        const float g0 = u.dmc[3 * i], g1 = u.dmc[3 * i + 1], g2 = u.dmc[3 * i + 2];
-        const float d[3] = {fmaf(g2, T.r[6], fmaf(g1, T.r[3], g0 * T.r[0])), fmaf(g2, T.r[7], fmaf(g1, T.r[4], g0 * T.r[1])),
-                            fmaf(g2, T.r[8], fmaf(g1, T.r[5], g0 * T.r[2]))};
+    float X[3], GX[3], M0[3], V0[3], C[3], GC[3], M1[3], V1[3], LS[3], GS[3], M4[3], V4[3], S[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) adam_one(u.xyz[3 * i + k], d[k], u.m[0][3 * i + k], u.v[0][3 * i + k], u, 0);
+    for (int k = 0; k < 3; k++) {
+        X[k] = u.xyz[3 * i + k]; GX[k] = u.dmc[3 * i + k]; M0[k] = u.m[0][3 * i + k]; V0[k] = u.v[0][3 * i + k];
+        C[k] = u.rgb[3 * i + k]; GC[k] = u.dcol[3 * i + k]; M1[k] = u.m[1][3 * i + k]; V1[k] = u.v[1][3 * i + k];
+        LS[k] = u.ls[3 * i + k]; GS[k] = u.dscale[3 * i + k]; M4[k] = u.m[4][3 * i + k]; V4[k] = u.v[4][3 * i + k]; S[k] = u.scales[3 * i + k];
+    }
+    float4 q = reinterpret_cast<const float4*>(u.quat)[i];
+    const float4 dr = reinterpret_cast<const float4*>(u.drot)[i];
+    float4 M2 = reinterpret_cast<const float4*>(u.m[2])[i], V2 = reinterpret_cast<const float4*>(u.v[2])[i];
+    float L = u.logit[i], M3 = u.m[3][i], V3 = u.v[3][i];
+    const float gop = u.dopac[i], o = u.opac[i];
+    const float cnt = u.reg_out ? u.reg_out[0] : 0.f;
+    { // means: mc = X R^T + t  =>  dL/dX = dmc R
+        const float d[3] = {fmaf(GX[2], T.r[6], fmaf(GX[1], T.r[3], GX[0] * T.r[0])), fmaf(GX[2], T.r[7], fmaf(GX[1], T.r[4], GX[0] * T.r[1])),
+                            fmaf(GX[2], T.r[8], fmaf(GX[1], T.r[5], GX[0] * T.r[2]))};
+#pragma unroll
+        for (int k = 0; k < 3; k++) adam_one(X[k], d[k], M0[k], V0[k], u, 0);
     }
 #pragma unroll
-    for (int k = 0; k < 3; k++) adam_one(u.rgb[3 * i + k], u.dcol[3 * i + k], u.m[1][3 * i + k], u.v[1][3 * i + k], u, 1);
+    for (int k = 0; k < 3; k++) adam_one(C[k], GC[k], M1[k], V1[k], u, 1);
     { // unit quaternion r = q / |q|: dL/dq = (dr - r (r . dr)) / |q|
-        float4 q = reinterpret_cast<float4*>(u.quat)[i];
-        const float4 dr = reinterpret_cast<const float4*>(u.drot)[i];
         const float nn = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f), inv = 1.f / nn;
         const float r0 = q.x * inv, r1 = q.y * inv, r2 = q.z * inv, r3 = q.w * inv;
         const float dot = r0 * dr.x + r1 * dr.y + r2 * dr.z + r3 * dr.w;
-        float4 M = reinterpret_cast<float4*>(u.m[2])[i], V = reinterpret_cast<float4*>(u.v[2])[i];
-        adam_one(q.x, (dr.x - r0 * dot) * inv, M.x, V.x, u, 2); adam_one(q.y, (dr.y - r1 * dot) * inv, M.y, V.y, u, 2);
-        adam_one(q.z, (dr.z - r2 * dot) * inv, M.z, V.z, u, 2); adam_one(q.w, (dr.w - r3 * dot) * inv, M.w, V.w, u, 2);
-        reinterpret_cast<float4*>(u.quat)[i] = q; reinterpret_cast<float4*>(u.m[2])[i] = M; reinterpret_cast<float4*>(u.v[2])[i] = V;
+        adam_one(q.x, (dr.x - r0 * dot) * inv, M2.x, V2.x, u, 2); adam_one(q.y, (dr.y - r1 * dot) * inv, M2.y, V2.y, u, 2);
+        adam_one(q.z, (dr.z - r2 * dot) * inv, M2.z, V2.z, u, 2); adam_one(q.w, (dr.w - r3 * dot) * inv, M2.w, V2.w, u, 2);
     }
-    { // opacity = sigmoid(logit)
-        const float o = u.opac[i];
-        adam_one(u.logit[i], u.dopac[i] * ((1.f - o) * o), u.m[3][i], u.v[3][i], u, 3);
-    }
+    adam_one(L, gop * ((1.f - o) * o), M3, V3, u, 3); // opacity = sigmoid(logit)
     { // scale = exp(log scale), plus the regularisers' gradient (K_scale_reg_bwd with an upstream gradient of 1)
-        const float s[3] = {u.scales[3 * i], u.scales[3 * i + 1], u.scales[3 * i + 2]};
-        float d[3] = {u.dscale[3 * i] * s[0], u.dscale[3 * i + 1] * s[1], u.dscale[3 * i + 2] * s[2]};
+        float d[3] = {GS[0] * S[0], GS[1] * S[1], GS[2] * S[2]};
         if (u.reg_out) {
-            const float wgt = (float)(s[0] > u.limit) + (float)(s[1] > u.limit) + (float)(s[2] > u.limit);
+            const float wgt = (float)(S[0] > u.limit) + (float)(S[1] > u.limit) + (float)(S[2] > u.limit);
             if (wgt > 0.f) {
                 int imax = 0, imin = 0;
-                if (s[1] > s[imax]) imax = 1;
-                if (s[2] > s[imax]) imax = 2;
-                if (s[1] < s[imin]) imin = 1;
-                if (s[2] < s[imin]) imin = 2;
-                const float cnt = u.reg_out[0];
+                if (S[1] > S[imax]) imax = 1;
+                if (S[2] > S[imax]) imax = 2;
+                if (S[1] < S[imin]) imin = 1;
+                if (S[2] < S[imin]) imin = 2;
                 const float a = u.w_scalar * wgt, b = cnt > 0.f ? u.w_long * wgt / cnt : 0.f;
 #pragma unroll
-                for (int k = 0; k < 3; k++) d[k] += ((k == imax ? a + b : 0.f) - (k == imin ? b : 0.f)) * s[k];
+                for (int k = 0; k < 3; k++) d[k] += ((k == imax ? a + b : 0.f) - (k == imin ? b : 0.f)) * S[k];
             }
         }
 #pragma unroll
-        for (int k = 0; k < 3; k++) adam_one(u.ls[3 * i + k], d[k], u.m[4][3 * i + k], u.v[4][3 * i + k], u, 4);
+        for (int k = 0; k < 3; k++) adam_one(LS[k], d[k], M4[k], V4[k], u, 4);
     }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        u.xyz[3 * i + k] = X[k]; u.m[0][3 * i + k] = M0[k]; u.v[0][3 * i + k] = V0[k];
+        u.rgb[3 * i + k] = C[k]; u.m[1][3 * i + k] = M1[k]; u.v[1][3 * i + k] = V1[k];
+        u.ls[3 * i + k] = LS[k]; u.m[4][3 * i + k] = M4[k]; u.v[4][3 * i + k] = V4[k];
+    }
+    reinterpret_cast<float4*>(u.quat)[i] = q; reinterpret_cast<float4*>(u.m[2])[i] = M2; reinterpret_cast<float4*>(u.v[2])[i] = V2;
+    u.logit[i] = L; u.m[3][i] = M3; u.v[3][i] = V3;
+}
+// small maps: one Gaussian per thread (four per thread leaves a 10 k map with ten workgroups)
+__global__ void __launch_bounds__(256)
+K_map_update_small(size_t n, MapUpdate u)
+{
+    if (u.overflow && *u.overflow) return;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    map_update_one(i, u, load_pose(u.Tcw));
 }
 
 // Four consecutive splats per thread: every tensor is then read and written as whole float4s (a [n,3] tensor is 12 floats per

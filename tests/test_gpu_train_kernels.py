@@ -273,11 +273,11 @@ def test_map_prepare_matches_the_tensor_expressions(gsr, n):
     assert (out.cpu() - out2.cpu()).abs().max() <= 2e-5 * max(float(out2.abs().max()), 1e-12)
 
 
-@pytest.mark.parametrize("with_reg", [False, True])
-def test_map_update_is_autograd_through_the_activations_plus_adam(gsr, with_reg):
+@pytest.mark.parametrize("with_reg,n", [(False, 3003), (True, 3003), (True, (1 << 18) + 3)])
+def test_map_update_is_autograd_through_the_activations_plus_adam(gsr, with_reg, n):
     """gsr_map_update against float64 autograd through the camera transform / sigmoid / exp / normalize (and the regularisers) followed
     by torch.optim.Adam (eps 1e-15) on the five raw tensors, over three steps with changing upstream gradients."""
-    n = 3003   # (not a multiple of four: the vector path and the tail)
+    # (n < 2^18: one Gaussian per thread; above: four per thread as whole float4s, and the tail of a count that is not a multiple of four)
     g = torch.Generator().manual_seed(7)
     raw = [torch.randn((n, 3), generator=g), torch.rand((n, 3), generator=g), torch.randn((n, 4), generator=g),
            torch.randn((n, 1), generator=g), torch.log(0.01 + 0.3 * torch.rand((n, 3), generator=g))]
