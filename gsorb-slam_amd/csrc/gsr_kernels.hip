@@ -751,6 +751,16 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
 // consumed). A chunk = the bins whose first key falls into the same window of S list positions, S = 1025 - the largest
 // bin count: at most 1024 keys, found with one LDS atomic-min per bin. Lists that cannot be split that way (more than 960
 // keys of one depth, or more than GSR_PART_SLOTS windows) are sorted whole by the bitonic network in global memory.
+#ifdef GSR_EXP_SORT_PHASES // instrumented build (scripts/sort_phases.py): wall-clock stamps of the phases of every tile's workgroup
+__device__ unsigned long long g_sort_phases[16 * 16384];
+#define GSR_PHASE(k) do { if (threadIdx.x == 0 && tile < 16384) g_sort_phases[16 * tile + (k)] = wall_clock64(); } while (0)
+#define GSR_PHASE_ARG , const int tile
+#define GSR_PHASE_PASS , tile
+#else
+#define GSR_PHASE(k) do { } while (0)
+#define GSR_PHASE_ARG
+#define GSR_PHASE_PASS
+#endif
 #define GSR_PART_BINS 2048
 #define GSR_PART_SLOTS 256
 #define GSR_PART_NONE 0xFFFFFFFFu
@@ -758,7 +768,7 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
 // keys by bin in temp[0 .. n)) or 0 (no partition: sort seg whole).
 template <int KIND>
 __device__ __forceinline__ int partition_list(SortShared<KIND>& sh, uint32_t* chunk_first, const uint64_t* __restrict__ seg, const int n,
-                                              uint64_t* __restrict__ temp, uint32_t* __restrict__ map)
+                                              uint64_t* __restrict__ temp, uint32_t* __restrict__ map GSR_PHASE_ARG)
 {
     constexpr int NT = SortShared<KIND>::NT, NB = GSR_PART_BINS, BPT = NB / NT, LOGNB = 11, U = 16;
     static_assert((1 << LOGNB) == NB && BPT % 4 == 0, "whole uint4 of bins per thread");
@@ -802,6 +812,7 @@ __device__ __forceinline__ int partition_list(SortShared<KIND>& sh, uint32_t* ch
     const int shift = max(0, 32 - __clz((int)(dmax - dmin)) - LOGNB);
     const int down = max(0, shift - 16), frac = min(shift, 16);
     bool equalised = false;
+    GSR_PHASE(7);
     auto bin_of = [&](const uint64_t key) -> uint32_t {
         const uint32_t rel = (uint32_t)(key >> 32) - dmin, b = rel >> shift;
         if (!equalised) return b;
@@ -837,7 +848,9 @@ __device__ __forceinline__ int partition_list(SortShared<KIND>& sh, uint32_t* ch
         slot += 3;
     };
     count_keys();
+    GSR_PHASE(8);
     scan_counts();
+    GSR_PHASE(9);
     if (mx > 256u && shift > 0) { // crowded bins (two surfaces in one tile, a far outlier): equalised bins, as in sort_tile
         const float share = (float)((uint32_t)NB - nz) / (float)n * 0.999f;
         uint32_t nsub[BPT], tot = 0, first, x;
@@ -863,6 +876,7 @@ __device__ __forceinline__ int partition_list(SortShared<KIND>& sh, uint32_t* ch
         run += c[j];
     }
     __syncthreads();
+    GSR_PHASE(10);
     // ---- keys to their bins
     for (int i0 = 0; i0 < n; i0 += NT * U) {
         if (!resident) load_trip(i0);
@@ -1003,12 +1017,6 @@ __device__ __forceinline__ void emit_from_global(const uint32_t* out, uint64_t* 
 // (History: one wave per list with 16 keys per lane — 63 us with the list cutting in; round 3: this kernel for the short lists
 // plus K_tile_sort_long — 48 KB of LDS, 220 VGPRs — for the others: 37.5 + 4.8 us on the headline frame, 130 / 275 us on the
 // 2 M-splat and fat-splat frames.)
-#ifdef GSR_EXP_SORT_PHASES // instrumented build (scripts/sort_phases.py): wall-clock stamps of the phases of every tile's workgroup
-__device__ unsigned long long g_sort_phases[16 * 16384];
-#define GSR_PHASE(k) do { if (threadIdx.x == 0 && tile < 16384) g_sort_phases[16 * tile + (k)] = wall_clock64(); } while (0)
-#else
-#define GSR_PHASE(k) do { } while (0)
-#endif
 #ifndef GSR_SORT_WAVES
 #define GSR_SORT_WAVES 6 // waves per SIMD the register allocation is held to (80 VGPRs, no spills; 7 = 72 VGPRs spills six)
 #endif
@@ -1066,7 +1074,7 @@ K_tile_sort_cut(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g,
     if (n > GSR_SORT_SMALL) {
         // (values read from LDS are vector registers to the compiler: the loop state is made scalar explicitly, or it and
         // everything derived from it — chunk pointers, lengths — stays live in VGPRs across the whole chunk body)
-        S = __builtin_amdgcn_readfirstlane(partition_list<GSR_SORT_BLOCK_SHORT>(sh, chunk_first, pairs + r.x, n, temp, map));
+        S = __builtin_amdgcn_readfirstlane(partition_list<GSR_SORT_BLOCK_SHORT>(sh, chunk_first, pairs + r.x, n, temp, map GSR_PHASE_PASS));
         GSR_PHASE(1);
         if (S > 0) {
             nw = (n + S - 1) / S;

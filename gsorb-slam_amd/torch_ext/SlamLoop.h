@@ -96,7 +96,7 @@ private:
     void ensure_direct_(int64_t history_len);
     void grow_binning_(size_t capacity);
     void direct_forward_();
-    void direct_backward_(bool detach_depth_colour);
+    void direct_backward_(bool detach_depth_colour, bool means_only);
     bool direct_overflowed_();
     void direct_map_iteration_(const LoopFrame& frame, float* loss_slot);
     std::vector<double> direct_track_(const LoopFrame& frame, const torch::Tensor& Tcw_init, int iters, torch::Tensor* Tcw_best);

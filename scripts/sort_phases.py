@@ -18,6 +18,7 @@ T = ((c.width + 15) // 16) * ((c.height + 15) // 16)
 L = gsr.capi.lib(); buf = (C.c_ulonglong * (16 * T))(); L.gsr_debug_sort_phases.argtypes = [C.c_void_p, C.c_int]; assert L.gsr_debug_sort_phases(buf, 16 * T) == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(T, 16).astype(np.int64)
 t = (a[:, :6] - a[:, 0].min()) / 100.0
+tp = (a[:, 7:11] - a[:, 0].min()) / 100.0   # inside the partition: after min/max, after the count, after the scan, before the scatter
 n = a[:, 6]
 long_ = n > 1024
 out = {"tiles": T, "long_lists": int(long_.sum()), "mean_list": float(n.mean()), "kernel_us": float(t[:, 5].max()),
@@ -25,6 +26,9 @@ out = {"tiles": T, "long_lists": int(long_.sum()), "mean_list": float(n.mean()),
 if long_.any():
     l = t[long_]
     out["long"] = {"workgroup_us": float((l[:, 5] - l[:, 0]).mean()), "partition_us": float((l[:, 1] - l[:, 0]).mean()),
+                   "partition_parts_us": {"load_minmax": float((tp[long_][:, 0] - l[:, 0]).mean()), "count": float((tp[long_][:, 1] - tp[long_][:, 0]).mean()),
+                                          "scan": float((tp[long_][:, 2] - tp[long_][:, 1]).mean()), "cursors_or_equalise": float((tp[long_][:, 3] - tp[long_][:, 2]).mean()),
+                                          "scatter": float((l[:, 1] - tp[long_][:, 3]).mean())},
                    "chunks_before_last_us": float((l[:, 3] - l[:, 1]).mean()), "last_chunk_sort_us": float((l[:, 4] - l[:, 3]).mean()),
                    "last_chunk_emit_us": float((l[:, 5] - l[:, 4]).mean())}
 if (~long_ & (n > 0)).any():
