@@ -162,7 +162,9 @@ struct TimelineMark {
 // alphas — the splat's view depth z and the constant 1 (what the reference renders in a second pass with colours
 // [z, 1, 0], src/Render.cc:949-981). dL_dds [2,H,W] is their upstream gradient; the z channel adds a tenth sum per
 // (quad, splat): dL/dz-colour, which K_splat_bwd folds into the mean.
-template <int Q, bool DUAL>
+// COLORS = false: nobody consumes the colour sums (a tracking iteration: the pose is the only parameter, the colours and the depth channel's
+// colour are constants) — the reduce phase then skips its dL/dpixel reads and three or four of its nine or ten sums, the records are six floats.
+template <int Q, bool DUAL, bool COLORS = true>
 __attribute__((amdgpu_waves_per_eu(3, 3))) __global__ void __launch_bounds__(64)
 K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* __restrict__ bg, int W, int H,
                  int grid_x, int ntiles, int tile0, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dds)
@@ -231,10 +233,12 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     // similar colours (depth renders!), and contracting first turns an exact small difference into the
     // difference of two rounded large numbers (measured: 9e-5 instead of 1e-6 on long lists).
     float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f;
-    constexpr int NC = DUAL ? 10 : 9;                     // sums per (quad, splat) record
+    constexpr int NC = !COLORS ? 6 : DUAL ? 10 : 9;       // sums per (quad, splat) record
     const int fe = lane / NC, fc = lane - NC * fe;        // flush lane -> (entry, component)
-    GP[0][r * 17 + l] = g0; GP[1][r * 17 + l] = g1; GP[2][r * 17 + l] = g2;
-    if (DUAL) GP[DUAL ? 3 : 0][r * 17 + l] = g3;
+    if (COLORS) {
+        GP[0][r * 17 + l] = g0; GP[1][r * 17 + l] = g1; GP[2][r * 17 + l] = g2;
+        if (DUAL) GP[DUAL ? 3 : 0][r * 17 + l] = g3;
+    }
     if (lane == 0) {
         E0[Q] = make_float4(-1.0e5f, -1.0e5f, -1.f, 0.f); // power2 ~ -2e10: exp2 gives 0
         E1[Q] = make_float4(-1.f, 0.f, 0.f, 0.f);
@@ -399,8 +403,10 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
 #pragma unroll
             for (int p = 0; p < 16; p++) ud[p] = UD[p * (4 * GSR_RING + 1) + lane];
             float4 gq[4];
+            if (COLORS) {
 #pragma unroll
-            for (int p = 0; p < 4; p++) gq[p] = gp_load(p);
+                for (int p = 0; p < 4; p++) gq[p] = gp_load(p);
+            }
             __builtin_amdgcn_sched_barrier(0);
             float dxk[4], dyk[4];
             // (the fused pair is over its register budget: there the pixel coordinates X0p + k are formed here, six additions
@@ -426,17 +432,19 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             const float m3 = fmaf(dxk[3] * dxk[3], col[3], fmaf(dxk[2] * dxk[2], col[2], fmaf(dxk[1] * dxk[1], col[1], (dxk[0] * dxk[0]) * col[0])));
             const float m4 = fmaf(dyk[3], wj[3], fmaf(dyk[2], wj[2], fmaf(dyk[1], wj[1], dyk[0] * wj[0])));
             const float m5 = fmaf(dyk[3] * dyk[3], row[3], fmaf(dyk[2] * dyk[2], row[2], fmaf(dyk[1] * dyk[1], row[1], (dyk[0] * dyk[0]) * row[0])));
+            if (COLORS) {
 #pragma unroll
-            for (int p = 0; p < 16; p++) {
-                const float4 gp = gq[p & 3];
-                if (p + 4 < 16) gq[p & 3] = gp_load(p + 4);
-                q0 = fmaf(ud[p].y, gp.x, q0); q1 = fmaf(ud[p].y, gp.y, q1); q2 = fmaf(ud[p].y, gp.z, q2);
-                if (DUAL) q3 = fmaf(ud[p].y, gp.w, q3);
+                for (int p = 0; p < 16; p++) {
+                    const float4 gp = gq[p & 3];
+                    if (p + 4 < 16) gq[p & 3] = gp_load(p + 4);
+                    q0 = fmaf(ud[p].y, gp.x, q0); q1 = fmaf(ud[p].y, gp.y, q1); q2 = fmaf(ud[p].y, gp.z, q2);
+                    if (DUAL) q3 = fmaf(ud[p].y, gp.w, q3);
+                }
             }
             lds_turn(); // every lane has read its column of the ring: the block turns into ST
             ST[0 * 64 + lane] = make_float4(m0, m1, m2, m3);
             ST[1 * 64 + lane] = make_float4(m4, m5, q0, q1);
-            ST[2 * 64 + lane] = make_float4(q2, q3, 0.f, 0.f);
+            if (COLORS) ST[2 * 64 + lane] = make_float4(q2, q3, 0.f, 0.f);
             INV[lane] = GSR_INV_NONE * 0x01010101u;
             if (lane < 4) INV[64 + lane] = GSR_INV_NONE * 0x01010101u;
             if (l < nb) reinterpret_cast<uint8_t*>(INV)[(o >> 2) + r] = (uint8_t)l; // o >> 2 = entry * 4; the dummy (index Q) lands in the slack
@@ -446,15 +454,18 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
                 const uint32_t q = rr * GSR_RING + ((inv >> (8 * rr)) & 15u);
-                s0[rr] = ST[0 * 64 + q]; s1[rr] = ST[1 * 64 + q]; s2[rr] = ST[2 * 64 + q];
+                s0[rr] = ST[0 * 64 + q]; s1[rr] = ST[1 * 64 + q];
+                if (COLORS) s2[rr] = ST[2 * 64 + q];
             }
 #pragma unroll
             for (int rr = 0; rr < 4; rr++) {
                 const float f = ((inv >> (8 * rr)) & GSR_INV_NONE) == 0u ? 1.f : 0.f;
                 t0 = fmaf(f, s0[rr].x, t0); t1 = fmaf(f, s0[rr].y, t1); t2 = fmaf(f, s0[rr].z, t2); t3 = fmaf(f, s0[rr].w, t3);
-                t4 = fmaf(f, s1[rr].x, t4); t5 = fmaf(f, s1[rr].y, t5); t6 = fmaf(f, s1[rr].z, t6); t7 = fmaf(f, s1[rr].w, t7);
-                t8 = fmaf(f, s2[rr].x, t8);
-                if (DUAL) t9 = fmaf(f, s2[rr].y, t9);
+                t4 = fmaf(f, s1[rr].x, t4); t5 = fmaf(f, s1[rr].y, t5);
+                if (COLORS) {
+                    t6 = fmaf(f, s1[rr].z, t6); t7 = fmaf(f, s1[rr].w, t7); t8 = fmaf(f, s2[rr].x, t8);
+                    if (DUAL) t9 = fmaf(f, s2[rr].y, t9);
+                }
             }
             lds_turn(); // the block is the ring again
         };
