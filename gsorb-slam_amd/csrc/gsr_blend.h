@@ -177,9 +177,10 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     // LDS budget: gfx950 hands LDS out in blocks of 1280 bytes (scripts/lds_granule.hip: 12 800 bytes per workgroup -> 12 single-wave
     // workgroups per CU, 12 816 -> 11), so the kernel is held at exactly ten blocks — the 12 waves per CU its registers allow.
     // The fused pair pays for its fourth dL/dpixel channel with byte-sized list entries (one shift per entry read).
-    using blist_t = typename std::conditional<DUAL, uint8_t, uint16_t>::type;
-    constexpr uint32_t LUNIT = DUAL ? 1u : 16u;
-    auto loff = [](const blist_t x) -> uint32_t { return DUAL ? (uint32_t)x << 4 : (uint32_t)x; };
+    constexpr bool BYTE_LISTS = DUAL;
+    using blist_t = typename std::conditional<BYTE_LISTS, uint8_t, uint16_t>::type;
+    constexpr uint32_t LUNIT = BYTE_LISTS ? 1u : 16u;
+    auto loff = [](const blist_t x) -> uint32_t { return BYTE_LISTS ? (uint32_t)x << 4 : (uint32_t)x; };
     __shared__ blist_t LIST[4 * (Q + 4)];
     // One block of LDS used three ways, one after the other:
     //  UD  the ring: (u, dcol) of pixel p of pair q = row * 16 + (iteration % 16) at float2 UD[p * 65 + q]. A blend iteration
@@ -391,6 +392,8 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
         //      entries sit (INV); (3) lane e collects the sums of entry e from the (at most four) rows that hold it.
         //      No read-modify-write on shared data anywhere: nothing to serialise, nothing to make atomic.
         auto gp_load = [&](const int p) -> float4 {
+            // (measured and dropped in round 4: pixel-major float4 entries, one ds_read_b128 per pixel instead of three or four ds_read_b32, with
+            // byte-sized lists to stay inside ten LDS blocks: plain kernel 221 -> 238 us (8 spills), fused pair 266 -> 266)
             return make_float4(GP[0][r * 17 + p], GP[1][r * 17 + p], GP[2][r * 17 + p], DUAL ? GP[DUAL ? 3 : 0][r * 17 + p] : 0.f);
         };
         auto reduce = [&](const int b0, const int nb) {
