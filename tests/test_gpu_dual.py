@@ -80,3 +80,24 @@ def test_fused_pair_equals_two_renders(gsr, syn, name):
     g0 = gsr.backward(plain, gA * ok[None])
     g1 = gsr.backward(st, gA * ok[None])
     assert rel_err(g1.dL_dmeans3D.cpu().numpy(), g0.dL_dmeans3D.cpu().numpy()) < 1e-5
+
+
+def test_pose_only_backward_without_the_colour_sums_gives_the_same_mean_gradient(gsr, syn):
+    """A tracking iteration hands gsr_backward a buffer for dL/dmean3D only, with the depth channel's colour detached: the blend stage then
+    runs without its colour sums (K_blend_bwd<..., COLORS = false>) and the per-splat stage skips the scale / rotation chain. The mean
+    gradient must be the one of the full backward (the sums it needs are accumulated by the same arithmetic; float atomics order aside)."""
+    import torch
+    cam = syn.make_camera(373, 251, 300.0, 305.0)
+    sc = syn.make_scene(20000, cam, seed=9, scale_mult=2.0)
+    s = gsr.capi.Settings.from_camera(cam)
+    rng = np.random.default_rng(1)
+    gA = rng.standard_normal((3, 251, 373)).astype(np.float32); gB = rng.standard_normal((2, 251, 373)).astype(np.float32)
+    gB[1] = 0.0   # (the loops never differentiate the silhouette: it is a detached mask)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations, dual=True)
+    full = gsr.backward(st, gA, dL_dds=gB, detach_depth_color=True)
+    ref = full.dL_dmeans3D.clone()
+    only = gsr.capi.Grads(None, None, None, None, torch.empty_like(ref), None, None, None, None)
+    st2 = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations, dual=True)
+    gsr.backward(st2, gA, grads=only, dL_dds=gB, detach_depth_color=True, once=True)
+    scale = float(ref.abs().max())
+    assert scale > 0 and float((only.dL_dmeans3D - ref).abs().max()) <= 2e-6 * scale
