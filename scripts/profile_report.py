@@ -19,8 +19,11 @@ def short(name):
     if "gsr::" not in name:
         return name.split("<")[0]
     name = name.replace("gsr::", "")
-    if name.startswith("K_blend"):
-        return name.split("<")[0] + ("_dual" if name.rstrip().endswith("true>") else "")
+    if name.startswith("K_blend"):   # K_blend_fwd<64, DUAL>, K_blend_bwd<64, DUAL, COLORS>
+        args = [x.strip() for x in name[name.index("<") + 1:name.rindex(">")].split(",")] if "<" in name else []
+        dual = len(args) > 1 and args[1] == "true"
+        nocol = len(args) > 2 and args[2] == "false"
+        return name.split("<")[0] + ("_dual" if dual else "") + ("_nocolour" if nocol else "")
     return name.split("<")[0]
 
 
