@@ -60,7 +60,7 @@ class BackwardArgs(C.Structure):
                 ("dL_dcolor", C.c_void_p), ("dL_dmean3D", C.c_void_p), ("dL_dcov3D", C.c_void_p),
                 ("dL_dsh", C.c_void_p), ("dL_dscale", C.c_void_p), ("dL_drot", C.c_void_p),
                 ("profile_events", C.POINTER(C.c_void_p)), ("band_y0", C.c_int), ("band_y1", C.c_int),
-                ("stages", C.c_int), ("dL_dds", C.c_void_p), ("ds_detach_depth", C.c_int)]
+                ("stages", C.c_int), ("dL_dds", C.c_void_p), ("ds_detach_depth", C.c_int), ("fused_map_update", C.c_void_p)]
 
 
 class DebugArrays(C.Structure):
@@ -356,7 +356,7 @@ def alloc_grads(P: int, M: int, dev, intermediates: bool = True) -> Grads:
 
 
 def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None, stages: int = 0, once: bool = False,
-             dL_dds=None, detach_depth_color: bool = False) -> Grads:
+             dL_dds=None, detach_depth_color: bool = False, fused_map_update=None) -> Grads:
     """gsr_backward; output shapes follow src/Rasterizer.cu:253-261. `once`: the caller runs one backward per
     forward (blend + per-splat without the re-zero of the accumulators); a later call on the same state
     is then started with a clear. dL_dds [2,H,W]: upstream gradient of the fused depth / silhouette channels."""
@@ -382,7 +382,8 @@ def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None,
                      _p(out.dL_dmeans2D), _p(out.dL_dconic), _p(out.dL_dopacity), _p(out.dL_dcolors),
                      _p(out.dL_dmeans3D), _p(out.dL_dcov3D), _p(out.dL_dsh) if M > 0 else None,
                      _p(out.dL_dscales) if has_sr else None, _p(out.dL_drotations) if has_sr else None, events,
-                     int(st.band[0]), int(st.band[1]), int(stages), _p(gds), int(bool(detach_depth_color)))
+                     int(st.band[0]), int(st.band[1]), int(stages), _p(gds), int(bool(detach_depth_color)),
+                     C.c_void_p(C.addressof(fused_map_update)) if fused_map_update is not None else None)   # (a MapUpdateArgs: map_update_args())
     if stages & 4:
         st.dirty = not (stages & 8)
     with torch.cuda.device(dev):
@@ -645,20 +646,29 @@ def map_update(params, moments, grads, acts, Tcw, lrs, steps, reg=None, geom=Non
     """gsr_map_update, in place: params = (xyz, rgb, unnorm_quat, logit, log_scales), moments = ((exp_avg,) * 5, (exp_avg_sq,) * 5),
     grads = (dL_dmeans_cam, dL_dcolors, dL_drotations, dL_dopacities, dL_dscales), acts = (opacities, scales) of gsr_map_prepare;
     reg = (reg_out, limit, w_long, w_scalar)."""
+    a = map_update_args(params, moments, grads, acts, Tcw, lrs, steps, reg, geom, betas, eps)
+    with torch.cuda.device(params[0].device):
+        _check(lib().gsr_map_update(C.byref(a), _stream()))
+
+
+def map_update_args(params, moments, grads, acts, Tcw, lrs, steps, reg=None, geom=None, betas=(0.9, 0.999), eps=1e-15):
+    """The gsr_map_update_args of map_update's arguments (grads may be None: gsr_backward_args.fused_map_update ignores them). The returned
+    struct keeps the tensors alive through `_keep`."""
     a = MapUpdateArgs()
+    a._keep = (params, moments, grads, acts, Tcw, reg, geom)
     a.n = int(params[0].shape[0])
     a.xyz, a.rgb, a.unnorm_quat, a.logit, a.log_scales = (_p(t) for t in params)
     for g in range(5):
         a.exp_avg[g] = _p(moments[0][g]); a.exp_avg_sq[g] = _p(moments[1][g]); a.lr[g] = float(lrs[g]); a.step[g] = int(steps[g])
-    a.dL_dmeans_cam, a.dL_dcolors, a.dL_drotations, a.dL_dopacities, a.dL_dscales = (_p(t) for t in grads)
+    if grads is not None:
+        a.dL_dmeans_cam, a.dL_dcolors, a.dL_drotations, a.dL_dopacities, a.dL_dscales = (_p(t) for t in grads)
     a.opacities, a.scales = _p(acts[0]), _p(acts[1])
     a.Tcw = _p(Tcw)
     if reg:
         a.reg_out = _p(reg[0]); a.reg_limit, a.w_long, a.w_scalar = float(reg[1]), float(reg[2]), float(reg[3])
     a.geom = _p(geom) if geom is not None else None
     a.beta1, a.beta2, a.eps = float(betas[0]), float(betas[1]), float(eps)
-    with torch.cuda.device(params[0].device):
-        _check(lib().gsr_map_update(C.byref(a), _stream()))
+    return a
 
 
 def pose_update(quat_trans, moments, best, history_slot, Tcw, partial, loss, lr, step, geom=None, betas=(0.9, 0.999), eps=1e-15):

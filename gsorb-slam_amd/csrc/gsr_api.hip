@@ -317,6 +317,35 @@ int gsr_ws_status(const char* geom, void* stream, int* num_rendered, int* overfl
     return GSR_OK;
 }
 
+namespace {
+const uint32_t* overflow_flag(const char* geom)
+{
+    return geom ? &reinterpret_cast<const GeomHeader*>(geom)->overflow : nullptr;
+}
+// gsr_map_update_args -> the kernels' view of it; grads = false: the gradient tensors are not needed (gsr_backward_args.fused_map_update)
+int make_map_update(const gsr_map_update_args* a, bool grads, gsr::MapUpdate* out)
+{
+    if (!a->xyz || !a->rgb || !a->unnorm_quat || !a->logit || !a->log_scales || !a->opacities || !a->scales || !a->Tcw || (a->n + 255) / 256 > 0x7FFFFFFFu)
+        return GSR_EINVAL;
+    if (grads && (!a->dL_dmeans_cam || !a->dL_dcolors || !a->dL_drotations || !a->dL_dopacities || !a->dL_dscales)) return GSR_EINVAL;
+    gsr::MapUpdate u;
+    u.xyz = a->xyz; u.rgb = a->rgb; u.quat = a->unnorm_quat; u.logit = a->logit; u.ls = a->log_scales;
+    for (int g = 0; g < 5; g++) {
+        if (!a->exp_avg[g] || !a->exp_avg_sq[g] || a->step[g] < 1) return GSR_EINVAL;
+        u.m[g] = a->exp_avg[g]; u.v[g] = a->exp_avg_sq[g];
+        // (bias corrections in double, like gsr_adam_step)
+        const double bc1 = 1.0 - std::pow(a->beta1, (double)a->step[g]), bc2 = 1.0 - std::pow(a->beta2, (double)a->step[g]);
+        u.step_size[g] = (float)(a->lr[g] / bc1); u.sqrt_bias2[g] = (float)std::sqrt(bc2);
+    }
+    u.dmc = a->dL_dmeans_cam; u.dcol = a->dL_dcolors; u.drot = a->dL_drotations; u.dopac = a->dL_dopacities; u.dscale = a->dL_dscales;
+    u.opac = a->opacities; u.scales = a->scales; u.Tcw = a->Tcw; u.reg_out = a->reg_out; u.overflow = overflow_flag(a->geom);
+    u.limit = a->reg_limit; u.w_long = a->w_long; u.w_scalar = a->w_scalar;
+    u.w1 = (float)(1.0 - a->beta1); u.b2 = (float)a->beta2; u.w2 = (float)(1.0 - a->beta2); u.eps = (float)a->eps;
+    *out = u;
+    return GSR_OK;
+}
+} // namespace
+
 int gsr_backward(const gsr_backward_args* a, void* stream)
 {
     if (!a || a->P < 0 || a->width <= 0 || a->height <= 0) return GSR_EINVAL;
@@ -369,8 +398,15 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
         o.dL_dcolor = a->dL_dcolor; o.dL_dmean3D = a->dL_dmean3D; o.dL_dcov3D = a->dL_dcov3D;
         o.dL_dsh = a->dL_dsh; o.dL_dscale = a->dL_dscale; o.dL_drot = a->dL_drot;
         tm.begin(GSR_BWD_SPLAT);
-        if (stages & GSR_STAGE_REZERO) hipLaunchKernelGGL(gsr::K_splat_bwd<true>, dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o);
-        else hipLaunchKernelGGL(gsr::K_splat_bwd<false>, dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o);
+        gsr::MapUpdate mu{};
+        if (a->fused_map_update) { // the per-splat stage takes the Adam step itself (include/gsr.h)
+            if (!a->scales || a->shs || a->fused_map_update->n != (size_t)P) return GSR_EINVAL;
+            const int rc = make_map_update(a->fused_map_update, false, &mu);
+            if (rc != GSR_OK) return rc;
+            if (stages & GSR_STAGE_REZERO) hipLaunchKernelGGL((gsr::K_splat_bwd<true, true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
+            else hipLaunchKernelGGL((gsr::K_splat_bwd<false, true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
+        } else if (stages & GSR_STAGE_REZERO) hipLaunchKernelGGL((gsr::K_splat_bwd<true, false>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
+        else hipLaunchKernelGGL((gsr::K_splat_bwd<false, false>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
         GSR_LAUNCHED();
         tm.end(GSR_BWD_SPLAT);
     }
@@ -579,13 +615,6 @@ int gsr_pixel_loss_backward_add(const float* image, const float* depth, const fl
     return GSR_OK;
 }
 
-namespace {
-const uint32_t* overflow_flag(const char* geom)
-{
-    return geom ? &reinterpret_cast<const GeomHeader*>(geom)->overflow : nullptr;
-}
-} // namespace
-
 int gsr_map_prepare(size_t n, const float* xyz, const float* logit, const float* log_scales, const float* unnorm_quat, const float* Tcw,
                     float* means_cam, float* opacities, float* scales, float* rotations, float reg_limit, float w_long, float w_scalar,
                     float* reg_partial, float* reg_out, void* stream)
@@ -609,22 +638,9 @@ int gsr_map_update(const gsr_map_update_args* a, void* stream)
 {
     if (!a) return GSR_EINVAL;
     if (a->n == 0) return GSR_OK;
-    if (!a->xyz || !a->rgb || !a->unnorm_quat || !a->logit || !a->log_scales || !a->dL_dmeans_cam || !a->dL_dcolors || !a->dL_drotations ||
-        !a->dL_dopacities || !a->dL_dscales || !a->opacities || !a->scales || !a->Tcw || (a->n + 255) / 256 > 0x7FFFFFFFu)
-        return GSR_EINVAL;
     gsr::MapUpdate u;
-    u.xyz = a->xyz; u.rgb = a->rgb; u.quat = a->unnorm_quat; u.logit = a->logit; u.ls = a->log_scales;
-    for (int g = 0; g < 5; g++) {
-        if (!a->exp_avg[g] || !a->exp_avg_sq[g] || a->step[g] < 1) return GSR_EINVAL;
-        u.m[g] = a->exp_avg[g]; u.v[g] = a->exp_avg_sq[g];
-        // (bias corrections in double, like gsr_adam_step)
-        const double bc1 = 1.0 - std::pow(a->beta1, (double)a->step[g]), bc2 = 1.0 - std::pow(a->beta2, (double)a->step[g]);
-        u.step_size[g] = (float)(a->lr[g] / bc1); u.sqrt_bias2[g] = (float)std::sqrt(bc2);
-    }
-    u.dmc = a->dL_dmeans_cam; u.dcol = a->dL_dcolors; u.drot = a->dL_drotations; u.dopac = a->dL_dopacities; u.dscale = a->dL_dscales;
-    u.opac = a->opacities; u.scales = a->scales; u.Tcw = a->Tcw; u.reg_out = a->reg_out; u.overflow = overflow_flag(a->geom);
-    u.limit = a->reg_limit; u.w_long = a->w_long; u.w_scalar = a->w_scalar;
-    u.w1 = (float)(1.0 - a->beta1); u.b2 = (float)a->beta2; u.w2 = (float)(1.0 - a->beta2); u.eps = (float)a->eps;
+    const int rc = make_map_update(a, true, &u);
+    if (rc != GSR_OK) return rc;
     if (a->n < (size_t)1 << 18) hipLaunchKernelGGL(gsr::K_map_update_small, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a->n, u);
     else hipLaunchKernelGGL(gsr::K_map_update, dim3((unsigned)((a->n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, a->n, u); // four splats per thread
     GSR_LAUNCHED();

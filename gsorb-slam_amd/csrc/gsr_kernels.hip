@@ -28,6 +28,7 @@
 #include "gsr_device.h"
 #include "gsr_splat_math.h"
 #include "gsr_blend.h"
+#include "gsr_train.h"
 
 namespace gsr {
 
@@ -1122,14 +1123,23 @@ __device__ __forceinline__ void st3(float* p, size_t i, float a, float b, float 
     if (p) { p[3 * i] = a; p[3 * i + 1] = b; p[3 * i + 2] = c; }
 }
 
-template <bool REZERO>
+// FUSED (gsr_backward_args.fused_map_update): the gradients are not written — the Gaussian's raw parameters take their Adam step right
+// here (map_update_with, csrc/gsr_train.h: the activations' backward, the camera transform's, the regularisers' gradient), from registers:
+// 56 bytes written and 56 read per Gaussian and one launch less per mapping iteration than gsr_backward + gsr_map_update.
+template <bool REZERO, bool FUSED = false>
 __global__ void __launch_bounds__(256)
-K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o)
+K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, MapUpdate mu)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= f.P) return;
+    if (FUSED && mu.overflow && *mu.overflow) return; // (the forward rendered nothing: no step)
     const size_t i = (size_t)idx;
     const int radius = __float_as_int(g.g1[idx].w);
+    if (FUSED && radius <= 0) { // invisible: zero gradients, but Adam still steps on its moments
+        const float z3[3] = {0.f, 0.f, 0.f};
+        map_update_with(i, mu, load_pose(mu.Tcw), z3, z3, make_float4(0.f, 0.f, 0.f, 0.f), 0.f, z3);
+        return;
+    }
     if (radius <= 0) { // invisible: every gradient is zero (the reference leaves its zero-fill)
         st3(o.dL_dmean2D, i, 0.f, 0.f, 0.f);
         if (o.dL_dconic) reinterpret_cast<float4*>(o.dL_dconic)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1253,7 +1263,9 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o)
     st3(o.dL_dmean3D, i, dmean.x, dmean.y, dmean.z);
 
     // ---- 3D covariance -> scale, rotation (backward.cu:278-341) ----
-    if (in.scales && o.dL_dscale && o.dL_drot) {
+    float ds3[3] = {0.f, 0.f, 0.f};
+    float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in.scales && (FUSED || (o.dL_dscale && o.dL_drot))) {
         const float3 sc = make_float3(in.scales[3 * i], in.scales[3 * i + 1], in.scales[3 * i + 2]);
         const float4 q = reinterpret_cast<const float4*>(in.rotations)[i];
         const float r = q.x, x = q.y, y = q.z, z = q.w;
@@ -1274,21 +1286,23 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o)
         const float dsx = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
         const float dsy = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
         const float dsz = Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2];
-        st3(o.dL_dscale, i, dsx, dsy, dsz);
+        ds3[0] = dsx; ds3[1] = dsy; ds3[2] = dsz;
 #pragma unroll
         for (int n = 0; n < 3; n++) { dMt.m[0][n] *= s.x; dMt.m[1][n] *= s.y; dMt.m[2][n] *= s.z; }
 #define GSR_D(cc3, rr3) dMt.m[cc3][rr3]
-        float4 dq;
         dq.x = 2 * z * (GSR_D(0, 1) - GSR_D(1, 0)) + 2 * y * (GSR_D(2, 0) - GSR_D(0, 2)) + 2 * x * (GSR_D(1, 2) - GSR_D(2, 1));
         dq.y = 2 * y * (GSR_D(1, 0) + GSR_D(0, 1)) + 2 * z * (GSR_D(2, 0) + GSR_D(0, 2)) + 2 * r * (GSR_D(1, 2) - GSR_D(2, 1)) - 4 * x * (GSR_D(2, 2) + GSR_D(1, 1));
         dq.z = 2 * x * (GSR_D(1, 0) + GSR_D(0, 1)) + 2 * r * (GSR_D(2, 0) - GSR_D(0, 2)) + 2 * z * (GSR_D(1, 2) + GSR_D(2, 1)) - 4 * y * (GSR_D(2, 2) + GSR_D(0, 0));
         dq.w = 2 * r * (GSR_D(0, 1) - GSR_D(1, 0)) + 2 * x * (GSR_D(2, 0) + GSR_D(0, 2)) + 2 * y * (GSR_D(1, 2) + GSR_D(2, 1)) - 4 * z * (GSR_D(1, 1) + GSR_D(0, 0));
 #undef GSR_D
-        reinterpret_cast<float4*>(o.dL_drot)[i] = dq;
-    } else {
-        st3(o.dL_dscale, i, 0.f, 0.f, 0.f);
-        if (o.dL_drot) reinterpret_cast<float4*>(o.dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (FUSED) {
+        const float gx[3] = {dmean.x, dmean.y, dmean.z}, gc[3] = {dcol.x, dcol.y, dcol.z};
+        map_update_with(i, mu, load_pose(mu.Tcw), gx, gc, dq, dopac, ds3);
+        return;
+    }
+    st3(o.dL_dscale, i, ds3[0], ds3[1], ds3[2]);
+    if (o.dL_drot) reinterpret_cast<float4*>(o.dL_drot)[i] = dq;
 }
 
 // ===================================================================================

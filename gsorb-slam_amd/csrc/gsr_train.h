@@ -521,22 +521,24 @@ __device__ __forceinline__ void adam_one(float& pp, const float gg, float& mm, f
     const float denom = sqrtf(vv) / u.sqrt_bias2[g] + u.eps;
     pp = fmaf(-u.step_size[g], mm / denom, pp);
 }
-// One Gaussian. Every load is issued before the first store (the tensors may alias as far as the compiler knows: section by section
-// it would wait for each section's round trip — at 10 k Gaussians, where nothing else hides it, the launch took 19 us for 0.4 MB).
-__device__ __forceinline__ void map_update_one(const size_t i, const MapUpdate& u, const Pose34& T)
+// One Gaussian, its gradients w.r.t. the rasterizer's inputs given in registers (K_map_update_small loads them; the per-splat stage of
+// the backward has just computed them: gsr_backward_args.fused_map_update). Every load is issued before the first store (the tensors may
+// alias as far as the compiler knows: section by section it would wait for each section's round trip — at 10 k Gaussians, where nothing
+// else hides it, the launch took 19 us for 0.4 MB).
+__device__ __forceinline__ void map_update_with(const size_t i, const MapUpdate& u, const Pose34& T, const float (&GX)[3], const float (&GC)[3],
+                                                const float4 dr, const float gop, const float (&GS)[3])
 {
-    float X[3], GX[3], M0[3], V0[3], C[3], GC[3], M1[3], V1[3], LS[3], GS[3], M4[3], V4[3], S[3];
+    float X[3], M0[3], V0[3], C[3], M1[3], V1[3], LS[3], M4[3], V4[3], S[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        X[k] = u.xyz[3 * i + k]; GX[k] = u.dmc[3 * i + k]; M0[k] = u.m[0][3 * i + k]; V0[k] = u.v[0][3 * i + k];
-        C[k] = u.rgb[3 * i + k]; GC[k] = u.dcol[3 * i + k]; M1[k] = u.m[1][3 * i + k]; V1[k] = u.v[1][3 * i + k];
-        LS[k] = u.ls[3 * i + k]; GS[k] = u.dscale[3 * i + k]; M4[k] = u.m[4][3 * i + k]; V4[k] = u.v[4][3 * i + k]; S[k] = u.scales[3 * i + k];
+        X[k] = u.xyz[3 * i + k]; M0[k] = u.m[0][3 * i + k]; V0[k] = u.v[0][3 * i + k];
+        C[k] = u.rgb[3 * i + k]; M1[k] = u.m[1][3 * i + k]; V1[k] = u.v[1][3 * i + k];
+        LS[k] = u.ls[3 * i + k]; M4[k] = u.m[4][3 * i + k]; V4[k] = u.v[4][3 * i + k]; S[k] = u.scales[3 * i + k];
     }
     float4 q = reinterpret_cast<const float4*>(u.quat)[i];
-    const float4 dr = reinterpret_cast<const float4*>(u.drot)[i];
     float4 M2 = reinterpret_cast<const float4*>(u.m[2])[i], V2 = reinterpret_cast<const float4*>(u.v[2])[i];
     float L = u.logit[i], M3 = u.m[3][i], V3 = u.v[3][i];
-    const float gop = u.dopac[i], o = u.opac[i];
+    const float o = u.opac[i];
     const float cnt = u.reg_out ? u.reg_out[0] : 0.f;
     { // means: mc = X R^T + t  =>  dL/dX = dmc R
         const float d[3] = {fmaf(GX[2], T.r[6], fmaf(GX[1], T.r[3], GX[0] * T.r[0])), fmaf(GX[2], T.r[7], fmaf(GX[1], T.r[4], GX[0] * T.r[1])),
@@ -580,6 +582,12 @@ __device__ __forceinline__ void map_update_one(const size_t i, const MapUpdate& 
     }
     reinterpret_cast<float4*>(u.quat)[i] = q; reinterpret_cast<float4*>(u.m[2])[i] = M2; reinterpret_cast<float4*>(u.v[2])[i] = V2;
     u.logit[i] = L; u.m[3][i] = M3; u.v[3][i] = V3;
+}
+__device__ __forceinline__ void map_update_one(const size_t i, const MapUpdate& u, const Pose34& T)
+{
+    const float GX[3] = {u.dmc[3 * i], u.dmc[3 * i + 1], u.dmc[3 * i + 2]}, GC[3] = {u.dcol[3 * i], u.dcol[3 * i + 1], u.dcol[3 * i + 2]};
+    const float GS[3] = {u.dscale[3 * i], u.dscale[3 * i + 1], u.dscale[3 * i + 2]};
+    map_update_with(i, u, T, GX, GC, reinterpret_cast<const float4*>(u.drot)[i], u.dopac[i], GS);
 }
 // small maps: one Gaussian per thread (four per thread leaves a 10 k map with ten workgroups)
 __global__ void __launch_bounds__(256)

@@ -6,7 +6,7 @@
 // (profiles/r04_loop.md). Here nothing inside an iteration goes through a tensor library: libtorch owns the memory (the
 // parameters, the Adam moments, one workspace that lives as long as the map's size), and an iteration is
 //   mapping : gsr_map_prepare -> gsr_forward_ws (fused pair) -> gsr_pixel_loss -> gsr_ssim_forward / _backward ->
-//             gsr_pixel_loss_backward_add -> gsr_map_loss_total -> gsr_backward -> gsr_map_update                       (18 launches)
+//             gsr_pixel_loss_backward_add -> gsr_map_loss_total -> gsr_backward [with gsr_map_update fused into its per-splat stage]  (17 launches)
 //   tracking: gsr_to_camera -> gsr_forward_ws -> gsr_pixel_loss -> gsr_pixel_loss_backward_add -> gsr_backward ->
 //             gsr_pose_grad -> gsr_pose_update                                                                          (13 launches)
 // with no allocation, no gradient tensor of a raw parameter, and no host synchronisation except where the reference has one
@@ -112,7 +112,7 @@ void SlamLoop::direct_forward_()
     chk(gsr_forward_ws(&a, b(d.geom), b(d.binning), d.binning_bytes, b(d.image), stream_()), "gsr_forward_ws");
 }
 
-void SlamLoop::direct_backward_(bool detach_depth_colour, bool means_only)
+void SlamLoop::direct_backward_(bool detach_depth_colour, bool means_only, const ::gsr_map_update_args* fused)
 {
     Direct& d = *d_;
     const auto& s = rasterizer_.raster_settings_;
@@ -124,8 +124,9 @@ void SlamLoop::direct_backward_(bool detach_depth_colour, bool means_only)
     a.radii = d.radii.data_ptr<int>();
     a.geom_buffer = b(d.geom); a.binning_buffer = b(d.binning); a.image_buffer = b(d.image);
     a.dL_dpix = f(d.g_image); a.dL_dds = f(d.g_ds); a.ds_detach_depth = detach_depth_colour ? 1 : 0;
-    a.dL_dmean3D = f(d.d_mc);
-    if (!means_only) { // (tracking optimises the pose only: the per-splat stage then skips the covariance -> scale / rotation chain and 56 bytes of stores per Gaussian)
+    a.fused_map_update = fused; // (the per-splat stage then takes the Adam step itself and writes no gradient)
+    if (!fused) a.dL_dmean3D = f(d.d_mc);
+    if (!means_only && !fused) { // (tracking optimises the pose only: the per-splat stage then skips the covariance -> scale / rotation chain and 56 bytes of stores per Gaussian)
         a.dL_dmean2D = f(d.d_m2d); a.dL_dopacity = f(d.d_opac); a.dL_dcolor = f(d.d_col);
         a.dL_dscale = f(d.d_scale); a.dL_drot = f(d.d_rot);
     }
@@ -161,8 +162,7 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
         "gsr_pixel_loss_backward_add");
     chk(gsr_map_loss_total(f(d.sums), f(d.ssim_partial), (int)d.ssim_partial.numel(), (size_t)3 * H_ * W_, (float)(cfg_.im_weight_mapping * (1 - cfg_.lam)),
                            f(d.reg_out), b(d.geom), loss_slot, st), "gsr_map_loss_total");
-    direct_backward_(false, false);
-    gsr_map_update_args u{};
+    ::gsr_map_update_args u{};
     u.n = n; u.xyz = f(xyz); u.rgb = f(rgb); u.unnorm_quat = f(unnorm_quat); u.logit = f(logit_opacities); u.log_scales = f(log_scales);
     for (int g = 0; g < 5; g++) {
         u.exp_avg[g] = f(fopt_->exp_avg(g)); u.exp_avg_sq[g] = f(fopt_->exp_avg_sq(g));
@@ -172,7 +172,12 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
     u.opacities = f(d.opac); u.scales = f(d.scales); u.Tcw = f(d.Tcw);
     u.reg_out = f(d.reg_out); u.reg_limit = limit; u.w_long = wl; u.w_scalar = wsc;
     u.geom = b(d.geom); u.beta1 = 0.9; u.beta2 = 0.999; u.eps = fopt_->eps();
-    chk(gsr_map_update(&u, st), "gsr_map_update");
+    if (cfg_.fused_update) {
+        direct_backward_(false, false, &u); // backward and update in the same per-splat pass (gsr_backward_args.fused_map_update)
+    } else {
+        direct_backward_(false, false, nullptr);
+        chk(gsr_map_update(&u, st), "gsr_map_update");
+    }
 }
 
 std::vector<double> SlamLoop::MapFrame(const LoopFrame& fr, int iters)
@@ -242,7 +247,7 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
         chk(gsr_pixel_loss(img, dep, sur, sil, f(frame.rgb), f(frame.depth), H_, W_, 0, 0.99f, w3, f(d.loss_partial), f(d.sums), st), "gsr_pixel_loss"); // Render.cc:1088-1105
         chk(gsr_pixel_loss_backward_add(img, dep, sil, f(frame.rgb), f(frame.depth), H_, W_, 0, 0.99f, w3, f(d.sums), nullptr, nullptr, f(d.g_image), f(d.g_ds), st),
             "gsr_pixel_loss_backward_add");
-        direct_backward_(true, true); // the [z, 1, 0] colours are detached while tracking (Render.cc:949-981)
+        direct_backward_(true, true, nullptr); // the [z, 1, 0] colours are detached while tracking (Render.cc:949-981)
         chk(gsr_pose_grad(f(xyz), f(d.d_mc), (size_t)d.n, f(d.Tcw), f(d.pose_partial), nullptr, st), "gsr_pose_grad");
         gsr_pose_update_args u{};
         u.quat_trans = f(d.pose); u.moments = f(d.pose_moments); u.best = f(d.best); u.history = f(d.history) + it; u.Tcw = f(d.Tcw);

@@ -14,6 +14,8 @@
 #include "FusedOps.h"
 #include "Rasterizer.h"
 
+struct gsr_map_update_args; // include/gsr.h
+
 namespace ORB_SLAM2 {
 
 // Examples/RGB-D/replica.yaml:87-117 (Mapping / Tracking blocks)
@@ -33,6 +35,8 @@ struct LoopConfig {
     bool direct = true;     // (with fused_pair and fused_ops) an iteration is a fixed sequence of C-ABI launches on a persistent workspace
                             // — no autograd graph, no allocation, no gradient tensors of the raw parameters (DirectLoop.cpp);
                             // false: the same kernels through libtorch autograd
+    bool fused_update = true; // (direct) the backward's per-splat stage takes the Adam step itself (gsr_backward_args.fused_map_update);
+                              // false: gsr_backward writes the gradients, gsr_map_update reads them
 };
 
 struct LoopFrame {
@@ -96,7 +100,7 @@ private:
     void ensure_direct_(int64_t history_len);
     void grow_binning_(size_t capacity);
     void direct_forward_();
-    void direct_backward_(bool detach_depth_colour, bool means_only);
+    void direct_backward_(bool detach_depth_colour, bool means_only, const ::gsr_map_update_args* fused);
     bool direct_overflowed_();
     void direct_map_iteration_(const LoopFrame& frame, float* loss_slot);
     std::vector<double> direct_track_(const LoopFrame& frame, const torch::Tensor& Tcw_init, int iters, torch::Tensor* Tcw_best);

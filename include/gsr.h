@@ -115,6 +115,8 @@ int gsr_forward_ws(const gsr_forward_args* args, char* geom, char* binning, size
 /* Blocking: copies {num_rendered, overflow} of the last forward on `geom` to the host. */
 int gsr_ws_status(const char* geom, void* stream, int* num_rendered, int* overflow);
 
+struct gsr_map_update_args; /* (below: the loops' fused update) */
+
 /* Arguments of Rasterizer::backward (rasterizer.h:60-88). R is what gsr_forward
  * returned; pass R < 0 after gsr_forward_ws (num_rendered stays on the device). The layout of the binning
  * blob follows the capacity the forward ran with, which the kernels read from the geometry header: R and
@@ -171,6 +173,13 @@ typedef struct gsr_backward_args {
     /* non-zero: the depth channel's colour z_i is a constant for this backward (GSORB-SLAM's tracking iterations detach the
      * [z, 1, 0] colours, src/Render.cc:949-981): its gradient is NOT folded into dL_dmean3D */
     int ds_detach_depth;
+    /* Optional (NULL: off). The per-splat stage then writes NO gradient (the dL_d* outputs are ignored and may be NULL): every Gaussian's
+     * raw parameters take gsr_map_update's step right there, from the gradients in registers — for a mapping iteration whose rasterizer
+     * inputs are gsr_map_prepare's outputs (means3D = means_cam with an identity view matrix, colors_precomp = the rgb parameter, scales,
+     * rotations, opacities the activations). Fields of the struct that name gradient tensors (dL_dmeans_cam ... dL_dscales) are ignored.
+     * Needs scales + rotations, no SH, and a call that runs the per-splat stage. 112 bytes of traffic per Gaussian and one launch less
+     * than gsr_backward followed by gsr_map_update. */
+    const struct gsr_map_update_args* fused_map_update;
 } gsr_backward_args;
 
 #define GSR_STAGE_CLEAR 1

@@ -106,6 +106,11 @@ def test_cpp_loop_follows_the_python_harness(gsr, syn, tmp_path, P):
     da_t = np.abs(np.asarray(ta[:k]) - np.asarray(tc[:k])).max() / abs(tc[0]); da_m = np.abs(np.asarray(ma[:20]) - np.asarray(mc[:20])).max() / abs(mc[0])
     print("      through autograd: tracking %.2f ms, mapping %.2f ms per iteration; direct vs autograd curves: tracking %.1e, mapping %.1e" % (tta, tma, da_t, da_m))
     assert da_t < 1e-3 and da_m < 1e-3 and np.abs(Ta - Tc).max() < 1e-3
+    # the Adam step fused into the backward's per-splat stage (the default) against gsr_backward + gsr_map_update as two launches (flags bit 5)
+    tu, Tu, mu, ttu, tmu = _cpp_run(str(tmp_path / "scene_unfused.bin"), params, frgb, fdepth, T_true, T_init, fused=3 | 32)
+    du = np.abs(np.asarray(mu[:20]) - np.asarray(mc[:20])).max() / abs(mc[0])
+    print("      unfused update: mapping %.2f ms per iteration; fused vs unfused mapping curve %.1e" % (tmu, du))
+    assert du < 1e-4
     if P == 10000:   # the reference's structure — two passes, plain libtorch arithmetic (matmul, conv2d SSIM, torch::optim::Adam) — gives the same curve
         t2, T2, m2, tt2, tm2 = _cpp_run(str(tmp_path / "scene2.bin"), params, frgb, fdepth, T_true, T_init, fused=0)
         print("      two passes + plain libtorch ops: tracking %.2f ms, mapping %.2f ms per iteration" % (tt2, tm2))
