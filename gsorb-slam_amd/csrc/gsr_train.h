@@ -28,9 +28,15 @@ K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int H
            float* __restrict__ partial, float* __restrict__ dmaps)
 {
     constexpr int TS = GSR_SSIM_TILE, HS = GSR_SSIM_HALO, R = GSR_SSIM_R;
-    __shared__ float a[HS][HS + 1], b[HS][HS + 1];
+    // Both passes slide a register window (round 4): a thread forms FOUR neighbouring outputs from 14 inputs it reads once — 3.1 LDS reads
+    // per output and tap-window instead of 11; the kernel is bound by LDS reads (one output per thread and pass: 40 us at 1200x680x3).
+    __shared__ float ab[2][HS][HS + 1];        // the two images' tile + halo; dead after the row pass: the column sums vv alias it
     __shared__ float h[5][HS][TS + 1];
     __shared__ float wsum[TS * TS / 64];
+    float (*const a)[HS + 1] = ab[0];
+    float (*const b)[HS + 1] = ab[1];
+    float* const vv = &ab[0][0][0];           // [5][TS][TS] (1280 floats of the 1404)
+    static_assert(5 * TS * TS <= 2 * HS * (HS + 1) && TS % 4 == 0, "the column sums fit the dead halo tiles");
     const int tid = threadIdx.x, tx = tid % TS, ty = tid / TS;
     const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS, c = blockIdx.z;
     const size_t plane = (size_t)H * W;
@@ -43,25 +49,41 @@ K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int H
         b[y][x] = in ? p2[(size_t)gy * W + gx] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < HS * TS; i += TS * TS) { // row pass: five window sums per (halo row, column)
-        const int y = i / TS, x = i - y * TS;
-        float s1 = 0.f, s2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+    for (int i = tid; i < HS * (TS / 4); i += TS * TS) { // row pass: five window sums per (halo row, column), four columns per thread
+        const int y = i / (TS / 4), xg = (i - y * (TS / 4)) * 4;
+        float pa[2 * R + 4], pb[2 * R + 4];
 #pragma unroll
-        for (int k = 0; k <= 2 * R; k++) {
-            const float p = a[y][x + k], q = b[y][x + k], g = taps.g[k];
-            s1 = fmaf(g, p, s1); s2 = fmaf(g, q, s2);
-            s11 = fmaf(g, p * p, s11); s22 = fmaf(g, q * q, s22); s12 = fmaf(g, p * q, s12);
+        for (int k = 0; k < 2 * R + 4; k++) { pa[k] = a[y][xg + k]; pb[k] = b[y][xg + k]; }
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float s1 = 0.f, s2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+#pragma unroll
+            for (int k = 0; k <= 2 * R; k++) {
+                const float p = pa[o + k], q = pb[o + k], g = taps.g[k];
+                s1 = fmaf(g, p, s1); s2 = fmaf(g, q, s2);
+                s11 = fmaf(g, p * p, s11); s22 = fmaf(g, q * q, s22); s12 = fmaf(g, p * q, s12);
+            }
+            h[0][y][xg + o] = s1; h[1][y][xg + o] = s2; h[2][y][xg + o] = s11; h[3][y][xg + o] = s22; h[4][y][xg + o] = s12;
         }
-        h[0][y][x] = s1; h[1][y][x] = s2; h[2][y][x] = s11; h[3][y][x] = s22; h[4][y][x] = s12;
     }
     __syncthreads();
-    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 5 * TS * (TS / 4); i += TS * TS) { // column pass: (quantity, column, four rows) per thread
+        const int q = i / (TS * (TS / 4)), rem = i - q * (TS * (TS / 4)), cx = rem % TS, yg = (rem / TS) * 4;
+        float cv[2 * R + 4];
 #pragma unroll
-    for (int k = 0; k <= 2 * R; k++) {
-        const float g = taps.g[k];
+        for (int k = 0; k < 2 * R + 4; k++) cv[k] = h[q][yg + k][cx];
 #pragma unroll
-        for (int q = 0; q < 5; q++) v[q] = fmaf(g, h[q][ty + k][tx], v[q]);
+        for (int o = 0; o < 4; o++) {
+            float sv = 0.f;
+#pragma unroll
+            for (int k = 0; k <= 2 * R; k++) sv = fmaf(taps.g[k], cv[o + k], sv);
+            vv[(q * TS + yg + o) * TS + cx] = sv;
+        }
     }
+    __syncthreads();
+    float v[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) v[q] = vv[(q * TS + ty) * TS + tx];
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     const float mu1 = v[0], mu2 = v[1], mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
     const float s1 = v[2] - mu1_sq, s2 = v[3] - mu2_sq, s12 = v[4] - mu12;
@@ -96,8 +118,9 @@ K_ssim_bwd(const float* __restrict__ img1, const float* __restrict__ img2, const
            SsimTaps taps, const float* __restrict__ dL_dmean, float* __restrict__ dL_dimg1)
 {
     constexpr int TS = GSR_SSIM_TILE, HS = GSR_SSIM_HALO, R = GSR_SSIM_R;
-    __shared__ float d[3][HS][HS + 1];
+    __shared__ float d[3][HS][HS + 1];         // (dead after the row pass: the column sums vv alias it; sliding windows as in K_ssim_fwd)
     __shared__ float h[3][HS][TS + 1];
+    float* const vv = &d[0][0][0];            // [3][TS][TS]
     const int tid = threadIdx.x, tx = tid % TS, ty = tid / TS;
     const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS, c = blockIdx.z;
     const size_t plane = (size_t)H * W, N = (size_t)gridDim.z * plane;
@@ -109,26 +132,37 @@ K_ssim_bwd(const float* __restrict__ img1, const float* __restrict__ img2, const
         for (int q = 0; q < 3; q++) d[q][y][x] = in ? dmaps[q * N + o] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < HS * TS; i += TS * TS) {
-        const int y = i / TS, x = i - y * TS;
-        float s[3] = {0.f, 0.f, 0.f};
+    for (int i = tid; i < 3 * HS * (TS / 4); i += TS * TS) { // row pass: (map, halo row, four columns) per thread
+        const int q = i / (HS * (TS / 4)), rem = i - q * (HS * (TS / 4)), y = rem / (TS / 4), xg = (rem - y * (TS / 4)) * 4;
+        float dv[2 * R + 4];
 #pragma unroll
-        for (int k = 0; k <= 2 * R; k++) {
-            const float g = taps.g[2 * R - k]; // transposed: tap k meets d[x - k + 5] = halo column x + (10 - k)
+        for (int k = 0; k < 2 * R + 4; k++) dv[k] = d[q][y][xg + k];
 #pragma unroll
-            for (int q = 0; q < 3; q++) s[q] = fmaf(g, d[q][y][x + k], s[q]);
+        for (int o = 0; o < 4; o++) {
+            float sv = 0.f;
+#pragma unroll
+            for (int k = 0; k <= 2 * R; k++) sv = fmaf(taps.g[2 * R - k], dv[o + k], sv); // transposed: tap k meets d[x - k + 5] = halo column x + (10 - k)
+            h[q][y][xg + o] = sv;
         }
-#pragma unroll
-        for (int q = 0; q < 3; q++) h[q][y][x] = s[q];
     }
     __syncthreads();
-    float v[3] = {0.f, 0.f, 0.f};
+    for (int i = tid; i < 3 * TS * (TS / 4); i += TS * TS) { // column pass: (map, column, four rows) per thread
+        const int q = i / (TS * (TS / 4)), rem = i - q * (TS * (TS / 4)), cx = rem % TS, yg = (rem / TS) * 4;
+        float cv[2 * R + 4];
 #pragma unroll
-    for (int k = 0; k <= 2 * R; k++) {
-        const float g = taps.g[2 * R - k];
+        for (int k = 0; k < 2 * R + 4; k++) cv[k] = h[q][yg + k][cx];
 #pragma unroll
-        for (int q = 0; q < 3; q++) v[q] = fmaf(g, h[q][ty + k][tx], v[q]);
+        for (int o = 0; o < 4; o++) {
+            float sv = 0.f;
+#pragma unroll
+            for (int k = 0; k <= 2 * R; k++) sv = fmaf(taps.g[2 * R - k], cv[o + k], sv);
+            vv[(q * TS + yg + o) * TS + cx] = sv;
+        }
     }
+    __syncthreads();
+    float v[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) v[q] = vv[(q * TS + ty) * TS + tx];
     const int gx = x0 + tx, gy = y0 + ty;
     if (gx < W && gy < H) {
         const size_t o = c * plane + (size_t)gy * W + gx;
