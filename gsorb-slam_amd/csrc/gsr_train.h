@@ -766,6 +766,13 @@ __global__ void __launch_bounds__(64)
 K_pose_update(PoseUpdate u)
 {
     const int lane = threadIdx.x;
+    // everything the single-thread tail needs is requested before the partial rows are summed (the tail's loads and stores may alias as
+    // far as the compiler knows: left where they are used, they are ~40 dependent round trips: 9.5 us for a kernel that moves 25 KB)
+    float pq[7], mm[7], vv[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) { pq[k] = u.quat_trans[k]; mm[k] = u.moments[k]; vv[k] = u.moments[7 + k]; }
+    const float best0 = u.best[0], loss_in = u.loss[0];
+    const bool skip = u.overflow && *u.overflow;
     float a[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int b = lane; b < GSR_POSE_BLOCKS; b += 64) {
 #pragma unroll
@@ -777,11 +784,10 @@ K_pose_update(PoseUpdate u)
         for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off, 64);
     }
     if (lane != 0) return;
-    const bool skip = u.overflow && *u.overflow;
-    float q[4] = {u.quat_trans[0], u.quat_trans[1], u.quat_trans[2], u.quat_trans[3]}, t[3] = {u.quat_trans[4], u.quat_trans[5], u.quat_trans[6]};
-    const float lv = skip ? __builtin_nanf("") : u.loss[0];
+    float q[4] = {pq[0], pq[1], pq[2], pq[3]}, t[3] = {pq[4], pq[5], pq[6]};
+    const float lv = skip ? __builtin_nanf("") : loss_in;
     u.history[0] = lv;
-    if (lv == lv && lv < u.best[0]) {
+    if (lv == lv && lv < best0) {
         u.best[0] = lv;
 #pragma unroll
         for (int k = 0; k < 4; k++) u.best[1 + k] = q[k];
@@ -801,13 +807,14 @@ K_pose_update(PoseUpdate u)
         const float g[7] = {(dr - r * dot) / n, (dx - x * dot) / n, (dy - y * dot) / n, (dz - z * dot) / n, a[9], a[10], a[11]};
 #pragma unroll
         for (int k = 0; k < 7; k++) {
-            float p = k < 4 ? q[k] : t[k - 4], mm = u.moments[k], vv = u.moments[7 + k];
-            mm = fmaf(u.w1, g[k] - mm, mm);
-            vv = fmaf(u.w2 * g[k], g[k], vv * u.b2);
-            p = fmaf(-u.step_size, mm / (sqrtf(vv) / u.sqrt_bias2 + u.eps), p);
-            u.moments[k] = mm; u.moments[7 + k] = vv; u.quat_trans[k] = p;
+            float p = k < 4 ? q[k] : t[k - 4];
+            mm[k] = fmaf(u.w1, g[k] - mm[k], mm[k]);
+            vv[k] = fmaf(u.w2 * g[k], g[k], vv[k] * u.b2);
+            p = fmaf(-u.step_size, mm[k] / (sqrtf(vv[k]) / u.sqrt_bias2 + u.eps), p);
             if (k < 4) q[k] = p; else t[k - 4] = p;
         }
+#pragma unroll
+        for (int k = 0; k < 7; k++) { u.moments[k] = mm[k]; u.moments[7 + k] = vv[k]; u.quat_trans[k] = k < 4 ? q[k] : t[k - 4]; }
     }
     { // the next iteration's pose matrix (K_rt2T)
         const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
