@@ -378,12 +378,13 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
         // nobody consumes the colour sums (this call also runs the per-splat stage, which is handed no colour / SH output, and the fused depth
         // channel's colour is a constant): the fused pair's kernel without them (a tracking iteration)
         const bool no_colour = (stages & GSR_STAGE_SPLAT) && !a->dL_dcolor && !a->dL_dsh && a->dL_dds && a->ds_detach_depth;
-        if (no_colour)
-            hipLaunchKernelGGL((gsr::K_blend_bwd<GSR_ROWQ, true, false>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, W, H, f.grid_x,
-                               Tb, f.band_y0 * f.grid_x, a->dL_dpix, a->dL_dds);
-        else if (a->dL_dds)
-            hipLaunchKernelGGL((gsr::K_blend_bwd<GSR_ROWQ, true>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, W, H, f.grid_x, Tb,
-                               f.band_y0 * f.grid_x, a->dL_dpix, a->dL_dds);
+#define GSR_BWD_DUAL(COL, SIL) hipLaunchKernelGGL((gsr::K_blend_bwd<GSR_ROWQ, true, COL, SIL>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, \
+                                                  W, H, f.grid_x, Tb, f.band_y0 * f.grid_x, a->dL_dpix, a->dL_dds)
+        if (no_colour && a->dds_depth_only) GSR_BWD_DUAL(false, false);
+        else if (no_colour) GSR_BWD_DUAL(false, true);
+        else if (a->dL_dds && a->dds_depth_only) GSR_BWD_DUAL(true, false);
+        else if (a->dL_dds) GSR_BWD_DUAL(true, true);
+#undef GSR_BWD_DUAL
         else
             hipLaunchKernelGGL((gsr::K_blend_bwd<GSR_ROWQ, false>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, W, H, f.grid_x, Tb,
                                f.band_y0 * f.grid_x, a->dL_dpix, (const float*)nullptr);

@@ -164,7 +164,9 @@ struct TimelineMark {
 // (quad, splat): dL/dz-colour, which K_splat_bwd folds into the mean.
 // COLORS = false: nobody consumes the colour sums (a tracking iteration: the pose is the only parameter, the colours and the depth channel's
 // colour are constants) — the reduce phase then skips its dL/dpixel reads and three or four of its nine or ten sums, the records are six floats.
-template <int Q, bool DUAL, bool COLORS = true>
+// SIL = false (with DUAL): dL_dds holds the depth plane only, the silhouette's upstream gradient is zero (both loops use the silhouette as a
+// detached mask): its accum_rec recursion and its term of dL/dalpha leave the loop.
+template <int Q, bool DUAL, bool COLORS = true, bool SIL = true>
 __attribute__((amdgpu_waves_per_eu(3, 3))) __global__ void __launch_bounds__(64)
 K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* __restrict__ bg, int W, int H,
                  int grid_x, int ntiles, int tile0, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dds)
@@ -225,7 +227,7 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     const uint32_t last = inside ? im.n_contrib[pix] : 0u;
     const float g0 = inside ? dL_dpix[pix] : 0.f, g1 = inside ? dL_dpix[HW + pix] : 0.f,
                 g2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
-    const float g3 = DUAL && inside ? dL_dds[pix] : 0.f, g4 = DUAL && inside ? dL_dds[HW + pix] : 0.f; // (their background is 0)
+    const float g3 = DUAL && inside ? dL_dds[pix] : 0.f, g4 = DUAL && SIL && inside ? dL_dds[HW + pix] : 0.f; // (their background is 0)
     const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
     const float nTf_bg = -T_final * bg_dot;
     // colour accumulated behind the current splat (the reference's accum_rec, updated eagerly:
@@ -376,9 +378,14 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
             const float e0 = B.z - S0, e1 = B.w - S1, e2 = Cz.x - S2;
             float eg = fmaf(e2, g2, fmaf(e1, g1, e0 * g0)); // (colour - accum_rec) . dL_dpix
             if (DUAL) { // the depth and silhouette channels: colours (z, 1)
-                const float e3 = Cz.z - S3, e4 = 1.0f - S4;
-                eg = fmaf(e4, g4, fmaf(e3, g3, eg));
-                S3 = fmaf(alpha, e3, S3); S4 = fmaf(alpha, e4, S4);
+                const float e3 = Cz.z - S3;
+                eg = fmaf(e3, g3, eg);
+                S3 = fmaf(alpha, e3, S3);
+                if (SIL) {
+                    const float e4 = 1.0f - S4;
+                    eg = fmaf(e4, g4, eg);
+                    S4 = fmaf(alpha, e4, S4);
+                }
             }
             const float dL_dalpha = fmaf(nTf_bg, ia, eg * T); // - T_final/(1-alpha) * (bg . dL_dpix)
             S0 = fmaf(alpha, e0, S0); S1 = fmaf(alpha, e1, S1); S2 = fmaf(alpha, e2, S2);

@@ -124,6 +124,7 @@ void SlamLoop::direct_backward_(bool detach_depth_colour, bool means_only, const
     a.radii = d.radii.data_ptr<int>();
     a.geom_buffer = b(d.geom); a.binning_buffer = b(d.binning); a.image_buffer = b(d.image);
     a.dL_dpix = f(d.g_image); a.dL_dds = f(d.g_ds); a.ds_detach_depth = detach_depth_colour ? 1 : 0;
+    a.dds_depth_only = 1; // (the silhouette is a detached mask in both losses: plane 1 of g_ds would be zeros)
     a.fused_map_update = fused; // (the per-splat stage then takes the Adam step itself and writes no gradient)
     if (!fused) a.dL_dmean3D = f(d.d_mc);
     if (!means_only && !fused) { // (tracking optimises the pose only: the per-splat stage then skips the covariance -> scale / rotation chain and 56 bytes of stores per Gaussian)

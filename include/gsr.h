@@ -180,6 +180,9 @@ typedef struct gsr_backward_args {
      * Needs scales + rotations, no SH, and a call that runs the per-splat stage. 112 bytes of traffic per Gaussian and one launch less
      * than gsr_backward followed by gsr_map_update. */
     const struct gsr_map_update_args* fused_map_update;
+    /* non-zero: dL_dds holds ONE plane [1,H,W], the depth channel's upstream gradient; the silhouette's is zero (GSORB-SLAM's losses use the
+     * silhouette only as a detached mask, src/Render.cc:436-471, :1088-1090): its recursion leaves the blend kernel's loop */
+    int dds_depth_only;
 } gsr_backward_args;
 
 #define GSR_STAGE_CLEAR 1

@@ -101,3 +101,12 @@ def test_pose_only_backward_without_the_colour_sums_gives_the_same_mean_gradient
     gsr.backward(st2, gA, grads=only, dL_dds=gB, detach_depth_color=True, once=True)
     scale = float(ref.abs().max())
     assert scale > 0 and float((only.dL_dmeans3D - ref).abs().max()) <= 2e-6 * scale
+    # ... and with the depth plane alone (gsr_backward_args.dds_depth_only: the silhouette's recursion leaves the loop), with and without the colour sums
+    for grads in (gsr.capi.Grads(None, None, None, None, torch.empty_like(ref), None, None, None, None), None):
+        st3 = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations, dual=True)
+        out = gsr.backward(st3, gA, grads=grads, dL_dds=gB[0:1].copy(), detach_depth_color=True, once=True, dds_depth_only=True)
+        assert float((out.dL_dmeans3D - ref).abs().max()) <= 2e-6 * scale
+        if grads is None:
+            for n in ("dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations"):
+                a, b = getattr(out, n), getattr(full, n)
+                assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), n
