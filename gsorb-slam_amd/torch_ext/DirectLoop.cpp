@@ -83,7 +83,8 @@ void SlamLoop::ensure_direct_(int64_t history_len)
         d.d_mc = torch::empty({n, 3}, fo); d.d_m2d = torch::empty({n, 3}, fo); d.d_col = torch::empty({n, 3}, fo); d.d_opac = torch::empty({n}, fo);
         d.d_scale = torch::empty({n, 3}, fo); d.d_rot = torch::empty({n, 4}, fo);
         d.reg_partial = torch::empty({3 * ((n + 255) / 256) + 3}, fo);
-        grow_binning_(4 * (size_t)n + 65536); // refined after the first synchronised look at num_rendered
+        d.binning = torch::Tensor(); d.binning_bytes = 0;
+        grow_binning_(cfg_.binning_capacity > 0 ? (size_t)cfg_.binning_capacity : 4 * (size_t)n + 65536); // grows at the first synchronised look at an overflow
     }
     if (d.history_len < history_len) { d.history = torch::empty({history_len}, fo); d.history_len = history_len; }
 }

@@ -35,6 +35,9 @@ struct LoopConfig {
     bool direct = true;     // (with fused_pair and fused_ops) an iteration is a fixed sequence of C-ABI launches on a persistent workspace
                             // — no autograd graph, no allocation, no gradient tensors of the raw parameters (DirectLoop.cpp);
                             // false: the same kernels through libtorch autograd
+    int64_t binning_capacity = 0; // (direct) tile instances the rasterizer's binning workspace starts with; 0 = 4 x the map's size + 65536. A forward
+                                  // that needs more skips its iteration's step on the device, the host grows the workspace at its next read and takes
+                                  // the iteration again: any value gives the same results
     bool fused_update = true; // (direct) the backward's per-splat stage takes the Adam step itself (gsr_backward_args.fused_map_update);
                               // false: gsr_backward writes the gradients, gsr_map_update reads them
 };

@@ -3,7 +3,7 @@
 // best pose, the loss of every mapping iteration, and the time per iteration. Test infrastructure (the product is SlamLoop).
 //   file: int32 P, W, H, track_iters, map_iters, flags (bit 0 fused pair, bit 1 fused loop kernels, bit 2 growth run: AddGaussians /
 //         PruneLowOpacity on a map of the first P/2 rows, bit 3 prune threshold 0.6, bit 4 the iterations through libtorch autograd instead of
-//         the direct launch sequences of DirectLoop.cpp, bit 5 gsr_backward + gsr_map_update as two launches); float32 fx, fy; then float32 arrays xyz[P,3] rgb[P,3] quat[P,4] logit[P,1]
+//         the direct launch sequences of DirectLoop.cpp, bit 5 gsr_backward + gsr_map_update as two launches, bit 6 a binning workspace that is too small at first); float32 fx, fy; then float32 arrays xyz[P,3] rgb[P,3] quat[P,4] logit[P,1]
 //         logs[P,3] frame_rgb[3,H,W] frame_depth[H,W] Tcw[4,4] T_init[4,4]
 #include <chrono>
 #include <cstdio>
@@ -38,6 +38,7 @@ int main(int argc, char** argv)
     cfg.fused_ops = (hdr[5] & 2) != 0;
     cfg.direct = (hdr[5] & 16) == 0;
     cfg.fused_update = (hdr[5] & 32) == 0;
+    if (hdr[5] & 64) cfg.binning_capacity = 1024; // (far too small: the first iteration of every loop overflows, is skipped on the device and taken again)
     ORB_SLAM2::SlamLoop loop(cfg, W, H, ff[0], ff[1], dev);
     auto xyz = rd(f, {P, 3}), rgb = rd(f, {P, 3}), quat = rd(f, {P, 4}), logit = rd(f, {P, 1}), logs = rd(f, {P, 3});
     loop.SetMap(xyz, rgb, quat, logit, logs);
