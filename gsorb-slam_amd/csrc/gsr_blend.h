@@ -627,7 +627,10 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
             // the LAST entry that updated a pixel are looked up once per round through the iteration index instead of being
             // carried through every iteration (the forward is bound by the LDS pipe: 0.81 busy, profiles/r03a_pmc.md)
             int li = -1, di = -1;
-            auto step = [&](const int it, const float4 A, const float4 B, const float Cb) {
+            // MEDIAN: some pixel of the quad still has T > 0.5 at the start of the round (T only falls: decided once per round, wave-uniform). Once
+            // none has, the median-depth bookkeeping (a compare and a select, both half-rate) leaves the loop — on the bench frame a pixel is below
+            // 0.5 after one or two of its ~50 contributors.
+            auto step = [&](auto MEDIAN, const int it, const float4 A, const float4 B, const float Cb) {
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 const float power2 = pair_power2(dx, dy, A.z, A.w, B.x); // = power * log2(e): same sign as power
                 const float alpha = fminf(0.99f, B.y * __builtin_amdgcn_exp2f(power2));
@@ -641,7 +644,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                 C1 = fmaf(B.w, wgt, C1);
                 C2 = fmaf(Cb, wgt, C2);
                 if (DUAL) C4 += wgt;                              // accumulated opacity (the depth channel: below, per round)
-                di = lane_of(upd & wm(T > 0.5f)) ? it : di;       // median depth (forward.cu:374-379)
+                if (decltype(MEDIAN)::value) di = lane_of(upd & wm(T > 0.5f)) ? it : di; // median depth (forward.cu:374-379)
                 T = u ? test_T : T;
                 li = u ? it : li;
                 return wgt;
@@ -654,6 +657,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                 if (DUAL) Zd0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(E2) + o0 + 4);
                 float4 A1, B1;
                 float Z1;
+                auto run = [&](auto MED) {
                 for (int it = 0; it < maxc; it += 2) {
                     A1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o1);
                     B1 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o1);
@@ -661,7 +665,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                     if (DUAL) Zd1 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(E2) + o1 + 4);
                     o0 = mylist[it + 2];
                     __builtin_amdgcn_sched_barrier(0); // keep the prefetch above the iteration it overlaps with
-                    const float w0 = step(it, A0, B0, Z0);
+                    const float w0 = step(MED, it, A0, B0, Z0);
                     if (DUAL) C3 = fmaf(Zd0, w0, C3);             // alpha-blended view depth
                     A0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E0) + o0);
                     B0 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(E1) + o0);
@@ -669,9 +673,12 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
                     if (DUAL) Zd0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(E2) + o0 + 4);
                     o1 = mylist[it + 3];
                     __builtin_amdgcn_sched_barrier(0);
-                    const float w1 = step(it + 1, A1, B1, Z1);
+                    const float w1 = step(MED, it + 1, A1, B1, Z1);
                     if (DUAL) C3 = fmaf(Zd1, w1, C3);
                 }
+                };
+                if (wm(T > 0.5f) & ~m_done) run(std::true_type{});
+                else run(std::false_type{});
                 // the round's last updates: list position + 1 and depth of the entries behind the two indices
                 const uint32_t ol = mylist[max(li, 0)], od = mylist[max(di, 0)];
                 const uint32_t lpos = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(E2) + ol + 8);
