@@ -499,7 +499,7 @@ int gsr_ssim_forward(const float* img1, const float* img2, int C, int H, int W, 
     gsr::SsimTaps t;
     for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
     const dim3 grid((W + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, (H + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, C);
-    hipLaunchKernelGGL(gsr::K_ssim_fwd, grid, dim3(GSR_SSIM_TILE * GSR_SSIM_TILE), 0, (hipStream_t)stream, img1, img2, H, W, t, partial, dmaps);
+    hipLaunchKernelGGL(gsr::K_ssim_fwd<false>, grid, dim3(GSR_SSIM_TILE * GSR_SSIM_TILE), 0, (hipStream_t)stream, img1, img2, H, W, t, partial, dmaps, gsr::MapLossPlanes{});
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -511,7 +511,7 @@ int gsr_ssim_backward(const float* img1, const float* img2, const float* dmaps, 
     gsr::SsimTaps t;
     for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
     const dim3 grid((W + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, (H + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, C);
-    hipLaunchKernelGGL(gsr::K_ssim_bwd, grid, dim3(GSR_SSIM_TILE * GSR_SSIM_TILE), 0, (hipStream_t)stream, img1, img2, dmaps, H, W, t, dL_dmean, dL_dimg1);
+    hipLaunchKernelGGL(gsr::K_ssim_bwd<false>, grid, dim3(GSR_SSIM_TILE * GSR_SSIM_TILE), 0, (hipStream_t)stream, img1, img2, dmaps, H, W, t, dL_dmean, dL_dimg1, gsr::MapLossGrad{});
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -621,14 +621,14 @@ int gsr_map_prepare(size_t n, const float* xyz, const float* logit, const float*
                     float* reg_partial, float* reg_out, void* stream)
 {
     if ((means_cam && (!xyz || !Tcw)) || (opacities && !logit) || ((scales || reg_partial) && !log_scales) || (rotations && !unnorm_quat) ||
-        ((reg_partial != nullptr) != (reg_out != nullptr)) || (n + 255) / 256 > 0x7FFFFFFFu)
+        (reg_out && !reg_partial) || (n + 255) / 256 > 0x7FFFFFFFu)
         return GSR_EINVAL;
     const unsigned rows = (unsigned)((n + 255) / 256);
     if (n > 0)
         hipLaunchKernelGGL(gsr::K_map_prepare, dim3(rows), dim3(256), 0, (hipStream_t)stream, n, xyz, logit, log_scales, unnorm_quat, Tcw, means_cam,
                            opacities, scales, rotations, reg_limit, reg_partial);
     GSR_LAUNCHED();
-    if (reg_partial) {
+    if (reg_partial && reg_out) {
         hipLaunchKernelGGL(gsr::K_scale_reg_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, reg_partial, (int)rows, w_long, w_scalar, reg_out);
         GSR_LAUNCHED();
     }
@@ -687,6 +687,48 @@ int gsr_composite_backward_occlusion(int world, int rank, const long long* order
     const size_t N = (size_t)H * W;
     hipLaunchKernelGGL(gsr::K_composite_bwd_occlusion, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, gathered,
                        c_all, g_sil, N, dS);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_map_loss_forward(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb, const float* frame_depth,
+                         int H, int W, const float* taps11, float sil_thr, float* partial6, float* dmaps, void* stream)
+{
+    if (!image || !frame_rgb || !frame_depth || !taps11 || !partial6 || !dmaps || H <= 0 || W <= 0) return GSR_EINVAL;
+    gsr::SsimTaps t;
+    for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
+    const dim3 grid((W + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, (H + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, 3);
+    const gsr::MapLossPlanes ml{depth, sur, sil, frame_depth, sil_thr, partial6};
+    hipLaunchKernelGGL(gsr::K_ssim_fwd<true>, grid, dim3(GSR_SSIM_TILE * GSR_SSIM_TILE), 0, (hipStream_t)stream, image, frame_rgb, H, W, t, (float*)nullptr, dmaps, ml);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_map_loss_finish(const float* partial6, const float* reg_partial, size_t n_gaussians, int H, int W, const float* w3, float c_ssim, float w_long,
+                        float w_scalar, const char* geom, float* sums, float* reg_out, float* loss, void* stream)
+{
+    if (!partial6 || !w3 || !sums || !loss || H <= 0 || W <= 0 || (reg_partial && !reg_out)) return GSR_EINVAL;
+    gsr::MapFinish m;
+    m.partial6 = partial6; m.n6 = (int)gsr_ssim_partials(3, H, W);
+    m.reg_partial = reg_partial; m.n_reg = reg_partial ? (int)((n_gaussians + 255) / 256) : 0;
+    m.inv_pixels3 = 1.f / (3.f * (float)((size_t)H * W)); m.inv_count_ssim = 1.f / (float)((size_t)3 * H * W);
+    m.w[0] = w3[0]; m.w[1] = w3[1]; m.w[2] = w3[2]; m.c_ssim = c_ssim; m.w_long = w_long; m.w_scalar = w_scalar;
+    m.overflow = overflow_flag(geom); m.sums = sums; m.reg_out = reg_out; m.loss = loss;
+    hipLaunchKernelGGL(gsr::K_map_finish, dim3(1), dim3(GSR_MAP_FINISH_THREADS), 0, (hipStream_t)stream, m);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_map_loss_backward(const float* image, const float* depth, const float* frame_rgb, const float* frame_depth, const float* dmaps, int H, int W,
+                          const float* taps11, const float* w3, const float* neg_c_ssim, const float* sums, float* dL_dimage, float* dL_ddepth, void* stream)
+{
+    if (!image || !frame_rgb || !frame_depth || !dmaps || !taps11 || !w3 || !neg_c_ssim || !sums || !dL_dimage || H <= 0 || W <= 0) return GSR_EINVAL;
+    gsr::SsimTaps t;
+    for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
+    const dim3 grid((W + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, (H + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, 3);
+    const gsr::MapLossGrad mg{depth, frame_depth, sums, w3[0] / (3.f * (float)((size_t)H * W)), w3[1], dL_ddepth};
+    hipLaunchKernelGGL(gsr::K_ssim_bwd<true>, grid, dim3(GSR_SSIM_TILE * GSR_SSIM_TILE), 0, (hipStream_t)stream, image, frame_rgb, dmaps, H, W, t, neg_c_ssim,
+                       dL_dimage, mg);
     GSR_LAUNCHED();
     return GSR_OK;
 }

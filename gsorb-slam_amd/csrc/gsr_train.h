@@ -21,11 +21,34 @@ namespace gsr {
 struct SsimTaps {
     float g[2 * GSR_SSIM_R + 1];
 };
+// sum over the wave in eight DPP adds (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, row_bcast15 / row_bcast31 across them): the total is in
+// lane 63. (__shfl_xor is six ds_bpermute round trips through the LDS pipe, which is what the SSIM kernels are short of.)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_add_f(float v)
+{
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_lane63(float v)
+{
+    v = dpp_add_f<0x111, 0xf>(v); v = dpp_add_f<0x112, 0xf>(v); v = dpp_add_f<0x114, 0xf>(v); v = dpp_add_f<0x118, 0xf>(v);
+    v = dpp_add_f<0x142, 0xa>(v); v = dpp_add_f<0x143, 0xc>(v);
+    return v;
+}
 
+// MAPLOSS (round 4): the pixel terms of the mapping loss (K_loss_sums, mode 1: colour L1, masked depth L1, masked surface-depth L1 and their
+// counts) ride on the SSIM pass, which has both images' pixels in its hands anyway: a row of six partial sums per workgroup
+// {SSIM map, |image - rgb|, |depth - fd| over fd > 0, its count, |sur - fd| over fd > 0 && sil > thr, its count} (the depth planes by the
+// workgroups of channel 0), one launch instead of two and one pass over the render instead of two.
+struct MapLossPlanes {
+    const float *depth, *sur, *sil, *fdepth; // [H,W] each (image / frame_rgb are the SSIM kernel's img1 / img2)
+    float thr;
+    float* partial6;                         // [6][workgroups]
+};
 // zero-padded "same" cross-correlation, like conv2d(padding = 5): out[y][x] = sum_k sum_l g[k] g[l] in[y + k - 5][x + l - 5]
+template <bool MAPLOSS>
 __global__ void __launch_bounds__(GSR_SSIM_TILE* GSR_SSIM_TILE)
 K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W, SsimTaps taps,
-           float* __restrict__ partial, float* __restrict__ dmaps)
+           float* __restrict__ partial, float* __restrict__ dmaps, MapLossPlanes ml)
 {
     constexpr int TS = GSR_SSIM_TILE, HS = GSR_SSIM_HALO, R = GSR_SSIM_R;
     // Both passes slide a register window (round 4): a thread forms FOUR neighbouring outputs from 14 inputs it reads once — 3.1 LDS reads
@@ -42,6 +65,17 @@ K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int H
     const size_t plane = (size_t)H * W;
     const float* __restrict__ p1 = img1 + c * plane;
     const float* __restrict__ p2 = img2 + c * plane;
+    // (MAPLOSS: the depth planes of this thread's pixel are requested first: their latency hides behind the whole SSIM computation)
+    float l_fd = 0.f, l_dep = 0.f, l_sur = 0.f, l_sil = 1.0e30f;
+    // the depth term rides on channel 0's workgroups, the surface-depth term on channel 1's (two and three more loads per thread: on one channel's
+    // workgroups alone the four were 9 us of a 41 us kernel)
+    if (MAPLOSS && c < 2 && x0 + tx < W && y0 + ty < H) {
+        const size_t pix = (size_t)(y0 + ty) * W + (x0 + tx);
+        l_fd = ml.fdepth[pix];
+        if (c == 0 && ml.depth) l_dep = ml.depth[pix];
+        if (c == 1 && ml.sur) l_sur = ml.sur[pix];
+        if (c == 1 && ml.sil) l_sil = ml.sil[pix];
+    }
     for (int i = tid; i < HS * HS; i += TS * TS) {
         const int y = i / HS, x = i - y * HS, gy = y0 + y - R, gx = x0 + x - R;
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -49,6 +83,7 @@ K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int H
         b[y][x] = in ? p2[(size_t)gy * W + gx] : 0.f;
     }
     __syncthreads();
+    const float own1 = MAPLOSS ? a[ty + R][tx + R] : 0.f, own2 = MAPLOSS ? b[ty + R][tx + R] : 0.f; // (the tiles are overwritten below)
     for (int i = tid; i < HS * (TS / 4); i += TS * TS) { // row pass: five window sums per (halo row, column), four columns per thread
         const int y = i / (TS / 4), xg = (i - y * (TS / 4)) * 4;
         float pa[2 * R + 4], pb[2 * R + 4];
@@ -99,6 +134,25 @@ K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int H
         dmaps[2 * N + o] = 2.f * A * inv;
     }
     float sum = inside ? m : 0.f;
+    const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (MAPLOSS) {
+        __shared__ float wl[TS * TS / 64][6];
+        float l[6] = {sum, inside ? fabsf(own1 - own2) : 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (c == 0 && inside && l_fd > 0.f) {
+            if (ml.depth) l[2] = fabsf(l_dep - l_fd);
+            l[3] = 1.f;
+        }
+        if (c == 1 && inside && l_fd > 0.f && ml.sur && l_sil > ml.thr) { l[4] = fabsf(l_sur - l_fd); l[5] = 1.f; }
+#pragma unroll
+        for (int q = 0; q < 6; q++) l[q] = wave_sum_lane63(l[q]);
+        if ((tid & 63) == 63) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) wl[tid >> 6][q] = l[q];
+        }
+        __syncthreads();
+        if (tid < 6) ml.partial6[(size_t)tid * ((size_t)gridDim.x * gridDim.y * gridDim.z) + wg] = (wl[0][tid] + wl[1][tid]) + (wl[2][tid] + wl[3][tid]); // six planes
+        return;
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
     if ((tid & 63) == 0) wsum[tid >> 6] = sum;
@@ -107,15 +161,24 @@ K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int H
         float t = 0.f;
 #pragma unroll
         for (int q = 0; q < TS * TS / 64; q++) t += wsum[q];
-        partial[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t;
+        partial[wg] = t;
     }
 }
 
 // dL/dimg1 = scale * ( corrT(dmu1) + 2 img1 corrT(dE11) + img2 corrT(dE12) ), corrT = the transposed window:
 // out[x] = sum_k g[k] d[x - k + 5]; scale = *dL_dmean / (C H W)
+// MAPLOSS: the gradient of the mapping loss's pixel terms (K_loss_grad, mode 1) is added where the SSIM term's is written, and the
+// workgroups of channel 0 write the depth plane's: dL/dimage and dL/ddepth of the whole image loss in one launch.
+struct MapLossGrad {
+    const float *depth, *fdepth; // [H,W]
+    const float* sums;           // K_map_finish's (the depth term divides by its count)
+    float ci, w_depth;           // w_colour / (3 H W), w_depth
+    float* ddepth;               // [H,W]
+};
+template <bool MAPLOSS>
 __global__ void __launch_bounds__(GSR_SSIM_TILE* GSR_SSIM_TILE)
 K_ssim_bwd(const float* __restrict__ img1, const float* __restrict__ img2, const float* __restrict__ dmaps, int H, int W,
-           SsimTaps taps, const float* __restrict__ dL_dmean, float* __restrict__ dL_dimg1)
+           SsimTaps taps, const float* __restrict__ dL_dmean, float* __restrict__ dL_dimg1, MapLossGrad mg)
 {
     constexpr int TS = GSR_SSIM_TILE, HS = GSR_SSIM_HALO, R = GSR_SSIM_R;
     __shared__ float d[3][HS][HS + 1];         // (dead after the row pass: the column sums vv alias it; sliding windows as in K_ssim_fwd)
@@ -124,6 +187,13 @@ K_ssim_bwd(const float* __restrict__ img1, const float* __restrict__ img2, const
     const int tid = threadIdx.x, tx = tid % TS, ty = tid / TS;
     const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS, c = blockIdx.z;
     const size_t plane = (size_t)H * W, N = (size_t)gridDim.z * plane;
+    float l_fd = 0.f, l_dep = 0.f, l_cnt = 1.f; // (MAPLOSS: requested first, used last)
+    if (MAPLOSS && c == 0 && mg.ddepth && x0 + tx < W && y0 + ty < H) {
+        const size_t pix = (size_t)(y0 + ty) * W + (x0 + tx);
+        l_fd = mg.fdepth[pix];
+        if (mg.depth) l_dep = mg.depth[pix];
+        l_cnt = mg.sums[2];
+    }
     for (int i = tid; i < HS * HS; i += TS * TS) {
         const int y = i / HS, x = i - y * HS, gy = y0 + y - R, gx = x0 + x - R;
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -167,7 +237,17 @@ K_ssim_bwd(const float* __restrict__ img1, const float* __restrict__ img2, const
     if (gx < W && gy < H) {
         const size_t o = c * plane + (size_t)gy * W + gx;
         const float scale = dL_dmean[0] / (float)N;
-        dL_dimg1[o] = scale * (v[0] + 2.f * img1[o] * v[1] + img2[o] * v[2]);
+        const float i1 = img1[o], i2 = img2[o];
+        float gval = scale * (v[0] + 2.f * i1 * v[1] + i2 * v[2]);
+        if (MAPLOSS) {
+            gval += mg.ci * ((float)(i1 - i2 > 0.f) - (float)(i1 - i2 < 0.f));
+            if (c == 0 && mg.ddepth) {
+                const size_t pix = (size_t)gy * W + gx;
+                const float dd = mg.depth ? l_dep - l_fd : 0.f;
+                mg.ddepth[pix] = l_fd > 0.f ? (mg.w_depth / fmaxf(l_cnt, 1.f)) * ((float)(dd > 0.f) - (float)(dd < 0.f)) : 0.f;
+            }
+        }
+        dL_dimg1[o] = gval;
     }
 }
 
@@ -746,6 +826,81 @@ K_map_loss_total(const float* __restrict__ sums, const float* __restrict__ ssim_
     const float t = (a[0] + a[1]) + (a[2] + a[3]);
     if (threadIdx.x == 0) // (an iteration whose forward overflowed its workspace rendered nothing: NaN, and K_map_update skipped its step)
         loss[0] = (overflow && *overflow) ? __builtin_nanf("") : sums[5] + c_ssim * (1.f - t * inv_count) + (reg_out ? reg_out[3] : 0.f);
+}
+
+// The one single-workgroup kernel between the mapping loss's two passes: adds the rows of K_ssim_fwd<true> (six sums per workgroup) and of
+// K_map_prepare (the regularisers' three), forms sums[8] as K_loss_finish (mode 1), reg_out[4] as K_scale_reg_finish and the iteration's loss as
+// K_map_loss_total — three launches of a few microseconds of latency each before.
+struct MapFinish {
+    const float* partial6; int n6;
+    const float* reg_partial; int n_reg;    // nullptr / 0: no regularisers
+    float inv_pixels3, inv_count_ssim;      // 1 / (3 H W) twice over: the colour L1 mean and the SSIM mean
+    float w[3], c_ssim, w_long, w_scalar;
+    const uint32_t* overflow;
+    float *sums, *reg_out, *loss;
+};
+#define GSR_MAP_FINISH_THREADS 1024
+__global__ void __launch_bounds__(GSR_MAP_FINISH_THREADS)
+K_map_finish(MapFinish m)
+{
+    constexpr int NT = GSR_MAP_FINISH_THREADS, NW = NT / 64;
+    __shared__ float ws[NW][9];
+    float a[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; // six sums of the loss rows, three of the regularisers'
+    // (1024 threads and every load of a trip requested before the first is used: one workgroup has to pull 0.3 MB through its own latency —
+    // 256 threads with one load outstanding per accumulator took 20 us at 1200x680)
+    for (int b0 = 0; b0 < m.n6; b0 += 2 * NT) {
+        float t[2][6];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int b = b0 + u * NT + (int)threadIdx.x;
+#pragma unroll
+            for (int q = 0; q < 6; q++) t[u][q] = b < m.n6 ? m.partial6[(size_t)q * m.n6 + b] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) a[q] += t[u][q];
+    }
+    for (int b0 = 0; b0 < m.n_reg; b0 += 2 * NT) {
+        float t[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int b = b0 + u * NT + (int)threadIdx.x;
+#pragma unroll
+            for (int q = 0; q < 3; q++) t[u][q] = b < m.n_reg ? m.reg_partial[(size_t)b * 3 + q] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) a[6 + q] += t[u][q];
+    }
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) ws[threadIdx.x >> 6][q] = a[q];
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float r[3];
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        float t = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NW; wv++) t += ws[wv][q];
+        if (q < 6) a[q] = t; else r[q - 6] = t;
+    }
+    const float pix = m.w[0] * (a[1] * m.inv_pixels3) + m.w[1] * (a[2] / fmaxf(a[3], 1.f)) + m.w[2] * (a[4] / fmaxf(a[5], 1.f));
+    m.sums[0] = a[1]; m.sums[1] = a[2]; m.sums[2] = a[3]; m.sums[3] = a[4]; m.sums[4] = a[5]; m.sums[5] = pix; m.sums[6] = a[0]; m.sums[7] = 0.f;
+    float reg = 0.f;
+    if (m.reg_partial) {
+        reg = m.w_long * (r[0] > 0.f ? r[2] / r[0] : 0.f) + m.w_scalar * r[1];
+        m.reg_out[0] = r[0]; m.reg_out[1] = r[1]; m.reg_out[2] = r[2]; m.reg_out[3] = reg;
+    }
+    m.loss[0] = (m.overflow && *m.overflow) ? __builtin_nanf("") : pix + m.c_ssim * (1.f - a[0] * m.inv_count_ssim) + reg;
 }
 
 // End of a tracking iteration, one workgroup. state[16]: {quat[4], trans[3], 0, m_quat[4], m_trans[3], 0}; state2[8]: {v_quat[4], v_trans[3], 0};

@@ -5,8 +5,8 @@
 // Adam launches, allocations of every intermediate — 1.08-1.30 ms per iteration of which the rasterizer pair is 0.55
 // (profiles/r04_loop.md). Here nothing inside an iteration goes through a tensor library: libtorch owns the memory (the
 // parameters, the Adam moments, one workspace that lives as long as the map's size), and an iteration is
-//   mapping : gsr_map_prepare -> gsr_forward_ws (fused pair) -> gsr_pixel_loss -> gsr_ssim_forward / _backward ->
-//             gsr_pixel_loss_backward_add -> gsr_map_loss_total -> gsr_backward [with gsr_map_update fused into its per-splat stage]  (17 launches)
+//   mapping : gsr_map_prepare -> gsr_forward_ws (fused pair) -> gsr_map_loss_forward -> gsr_map_loss_finish -> gsr_map_loss_backward ->
+//             gsr_backward [with gsr_map_update fused into its per-splat stage]                                           (13 launches)
 //   tracking: gsr_to_camera -> gsr_forward_ws -> gsr_pixel_loss -> gsr_pixel_loss_backward_add -> gsr_backward ->
 //             gsr_pose_grad -> gsr_pose_update                                                                          (13 launches)
 // with no allocation, no gradient tensor of a raw parameter, and no host synchronisation except where the reference has one
@@ -43,7 +43,7 @@ struct SlamLoop::Direct {
     torch::Tensor geom, image, binning;                                  // the rasterizer's three workspaces
     torch::Tensor mc, opac, scales, rots, radii;                         // what the rasterizer takes
     torch::Tensor out_color, out_sur, out_ds;                            // what it renders
-    torch::Tensor g_image, g_ds, g_ssim, dmaps, ssim_partial;            // upstream gradients of the renders, SSIM scratch
+    torch::Tensor g_image, g_ds, g_ssim, dmaps, ssim_partial, partial6;  // upstream gradients of the renders, SSIM / loss scratch
     torch::Tensor d_mc, d_m2d, d_col, d_opac, d_scale, d_rot;            // the rasterizer's gradients
     torch::Tensor loss_partial, sums, reg_partial, reg_out, neg_c, Tcw, bg, view, proj, campos, history;
     torch::Tensor pose, pose_moments, best, pose_partial;                // tracking: [7], [14], [8], [GSR_POSE_PARTIALS, 12]
@@ -67,7 +67,7 @@ void SlamLoop::ensure_direct_(int64_t history_len)
         d.image = torch::empty({(int64_t)gsr_image_bytes(W_, H_)}, bo);
         d.out_color = torch::empty({3, H_, W_}, fo); d.out_sur = torch::empty({1, H_, W_}, fo); d.out_ds = torch::empty({2, H_, W_}, fo);
         d.g_image = torch::empty({3, H_, W_}, fo); d.g_ds = torch::zeros({2, H_, W_}, fo); // (the silhouette plane's gradient stays zero: its mask is detached)
-        d.g_ssim = torch::empty({3, H_, W_}, fo); d.dmaps = torch::empty({3, 3, H_, W_}, fo); d.ssim_partial = torch::empty({np}, fo);
+        d.g_ssim = torch::empty({3, H_, W_}, fo); d.dmaps = torch::empty({3, 3, H_, W_}, fo); d.ssim_partial = torch::empty({np}, fo); d.partial6 = torch::empty({np * 6}, fo);
         d.loss_partial = torch::empty({GSR_LOSS_PARTIALS * 5}, fo); d.sums = torch::empty({8}, fo); d.reg_out = torch::empty({4}, fo);
         d.neg_c = torch::full({1}, -(cfg_.im_weight_mapping * (1 - cfg_.lam)), fo);
         d.Tcw = torch::eye(4, fo); d.bg = torch::zeros({3}, fo); d.view = torch::eye(4, fo); d.campos = torch::zeros({3}, fo);
@@ -152,18 +152,26 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
     const size_t n = (size_t)d.n;
     const float limit = (float)(0.1 * cfg_.scene_radius), wl = (float)cfg_.reg_long_weight, wsc = (float)cfg_.reg_scalar_weight;
     chk(gsr_map_prepare(n, f(xyz), f(logit_opacities), f(log_scales), f(unnorm_quat), f(d.Tcw), f(d.mc), f(d.opac), f(d.scales), f(d.rots), limit, wl, wsc,
-                        f(d.reg_partial), f(d.reg_out), st), "gsr_map_prepare");
+                        f(d.reg_partial), cfg_.fused_loss ? nullptr : f(d.reg_out), st), "gsr_map_prepare");
     direct_forward_();
     // Render.cc:436-471: lam * L1 + (1 - lam) * (1 - SSIM), masked depth L1, masked surface-depth L1 (no gradient), the regularisers
     const float w3[3] = {(float)(cfg_.im_weight_mapping * cfg_.lam), (float)cfg_.depth_weight_mapping, (float)cfg_.sur_depth_weight_mapping};
+    const float c_ssim = (float)(cfg_.im_weight_mapping * (1 - cfg_.lam));
     const float *img = f(d.out_color), *dep = f(d.out_ds), *sil = f(d.out_ds) + (size_t)H_ * W_, *sur = f(d.out_sur);
-    chk(gsr_pixel_loss(img, dep, sur, sil, f(fr.rgb), f(fr.depth), H_, W_, 1, 0.99f, w3, f(d.loss_partial), f(d.sums), st), "gsr_pixel_loss");
-    chk(gsr_ssim_forward(img, f(fr.rgb), 3, H_, W_, taps_host_.data(), f(d.ssim_partial), f(d.dmaps), st), "gsr_ssim_forward");
-    chk(gsr_ssim_backward(img, f(fr.rgb), f(d.dmaps), 3, H_, W_, taps_host_.data(), f(d.neg_c), f(d.g_ssim), st), "gsr_ssim_backward");
-    chk(gsr_pixel_loss_backward_add(img, dep, sil, f(fr.rgb), f(fr.depth), H_, W_, 1, 0.99f, w3, f(d.sums), nullptr, f(d.g_ssim), f(d.g_image), f(d.g_ds), st),
-        "gsr_pixel_loss_backward_add");
-    chk(gsr_map_loss_total(f(d.sums), f(d.ssim_partial), (int)d.ssim_partial.numel(), (size_t)3 * H_ * W_, (float)(cfg_.im_weight_mapping * (1 - cfg_.lam)),
-                           f(d.reg_out), b(d.geom), loss_slot, st), "gsr_map_loss_total");
+    if (cfg_.fused_loss) { // two passes over the image and one single-workgroup kernel between them
+        chk(gsr_map_loss_forward(img, dep, sur, sil, f(fr.rgb), f(fr.depth), H_, W_, taps_host_.data(), 0.99f, f(d.partial6), f(d.dmaps), st), "gsr_map_loss_forward");
+        chk(gsr_map_loss_finish(f(d.partial6), f(d.reg_partial), n, H_, W_, w3, c_ssim, wl, wsc, b(d.geom), f(d.sums), f(d.reg_out), loss_slot, st), "gsr_map_loss_finish");
+        chk(gsr_map_loss_backward(img, dep, f(fr.rgb), f(fr.depth), f(d.dmaps), H_, W_, taps_host_.data(), w3, f(d.neg_c), f(d.sums), f(d.g_image), f(d.g_ds), st),
+            "gsr_map_loss_backward");
+    } else {
+        chk(gsr_pixel_loss(img, dep, sur, sil, f(fr.rgb), f(fr.depth), H_, W_, 1, 0.99f, w3, f(d.loss_partial), f(d.sums), st), "gsr_pixel_loss");
+        chk(gsr_ssim_forward(img, f(fr.rgb), 3, H_, W_, taps_host_.data(), f(d.ssim_partial), f(d.dmaps), st), "gsr_ssim_forward");
+        chk(gsr_ssim_backward(img, f(fr.rgb), f(d.dmaps), 3, H_, W_, taps_host_.data(), f(d.neg_c), f(d.g_ssim), st), "gsr_ssim_backward");
+        chk(gsr_pixel_loss_backward_add(img, dep, sil, f(fr.rgb), f(fr.depth), H_, W_, 1, 0.99f, w3, f(d.sums), nullptr, f(d.g_ssim), f(d.g_image), f(d.g_ds), st),
+            "gsr_pixel_loss_backward_add");
+        chk(gsr_map_loss_total(f(d.sums), f(d.ssim_partial), (int)d.ssim_partial.numel(), (size_t)3 * H_ * W_, c_ssim, f(d.reg_out), b(d.geom), loss_slot, st),
+            "gsr_map_loss_total");
+    }
     ::gsr_map_update_args u{};
     u.n = n; u.xyz = f(xyz); u.rgb = f(rgb); u.unnorm_quat = f(unnorm_quat); u.logit = f(logit_opacities); u.log_scales = f(log_scales);
     for (int g = 0; g < 5; g++) {

@@ -38,6 +38,8 @@ struct LoopConfig {
     int64_t binning_capacity = 0; // (direct) tile instances the rasterizer's binning workspace starts with; 0 = 4 x the map's size + 65536. A forward
                                   // that needs more skips its iteration's step on the device, the host grows the workspace at its next read and takes
                                   // the iteration again: any value gives the same results
+    bool fused_loss = true;   // (direct) the mapping loss as gsr_map_loss_forward / _finish / _backward (SSIM and the pixel terms in the same two passes);
+                              // false: gsr_pixel_loss, gsr_ssim_*, gsr_pixel_loss_backward_add, gsr_map_loss_total as six launches
     bool fused_update = true; // (direct) the backward's per-splat stage takes the Adam step itself (gsr_backward_args.fused_map_update);
                               // false: gsr_backward writes the gradients, gsr_map_update reads them
 };

@@ -294,7 +294,7 @@ int gsr_pixel_loss_backward_add(const float* image, const float* depth, const fl
  * nothing allocates or synchronises.
  *   gsr_map_prepare  n raw Gaussians -> means_cam [n,3] = xyz R^T + t (Tcw: device 4x4 row-major), opacities [n] = sigmoid(logit),
  *                    scales [n,3] = exp(log_scales), rotations [n,4] = q / max(|q|, 1e-12); any output may be NULL. With
- *                    reg_partial (scratch of 3 * ((n + 255) / 256) floats) and reg_out [4] it also evaluates the two scale
+ *                    reg_partial (scratch of 3 * ((n + 255) / 256) floats; reg_out = NULL: the rows only, for gsr_map_loss_finish) and reg_out [4] it also evaluates the two scale
  *                    regularisers (gsr_scale_reg's out: {sum w, reg_scalar, sum w (max - min), w_long * reg_long + w_scalar * reg_scalar}).
  *   gsr_map_update   from the rasterizer's gradients (gsr_backward on camera-frame means with an identity view matrix: dL_dmean3D is
  *                    dL/dmeans_cam) to an Adam step of the five raw tensors, in place: dL/dxyz = dmc R; dL/dlogit = dopac * o (1 - o);
@@ -329,6 +329,23 @@ typedef struct gsr_map_update_args {
 int gsr_map_update(const gsr_map_update_args* args, void* stream);
 int gsr_map_loss_total(const float* sums, const float* ssim_partial, int n_partial, size_t count, float c_ssim, const float* reg_out,
                        const char* geom, float* loss, void* stream);
+/* The mapping loss as two passes over the image with one single-workgroup kernel between them (instead of gsr_pixel_loss, gsr_ssim_forward,
+ * gsr_ssim_backward, gsr_pixel_loss_backward_add, gsr_map_loss_total and the finish launch of gsr_map_prepare): reference src/Render.cc:436-471.
+ *   gsr_map_loss_forward   SSIM forward of image vs frame_rgb ([3,H,W]; dmaps [3,3,H,W] for the backward) with gsr_pixel_loss's mode-1 sums
+ *                          riding along: partial6 [6][gsr_ssim_partials(3,H,W)] = six planes of per-workgroup sums {SSIM map, |image - rgb|, |depth - fd| over fd > 0,
+ *                          its count, |sur - fd| over fd > 0 && sil > sil_thr, its count} (depth / sur / sil may be NULL as in gsr_pixel_loss)
+ *   gsr_map_loss_finish    sums [8] as gsr_pixel_loss (sums[6] = the SSIM map's sum), reg_out [4] as gsr_scale_reg from gsr_map_prepare's
+ *                          reg_partial rows (NULL: no regularisers; call gsr_map_prepare with reg_out = NULL then), and
+ *                          loss[0] = sums[5] + c_ssim * (1 - sums[6] / (3 H W)) + reg_out[3]   (NaN when the forward on `geom` overflowed)
+ *   gsr_map_loss_backward  dL_dimage [3,H,W] = the SSIM term's gradient (*neg_c_ssim: DEVICE scalar, -c_ssim) + the colour L1 term's;
+ *                          dL_ddepth [H,W] (NULL: not wanted) = the masked depth term's (divides by sums[2]) */
+int gsr_map_loss_forward(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb, const float* frame_depth,
+                         int H, int W, const float* taps11 /* host */, float sil_thr, float* partial6, float* dmaps, void* stream);
+int gsr_map_loss_finish(const float* partial6, const float* reg_partial, size_t n_gaussians, int H, int W, const float* w3 /* host */, float c_ssim,
+                        float w_long, float w_scalar, const char* geom, float* sums, float* reg_out, float* loss, void* stream);
+int gsr_map_loss_backward(const float* image, const float* depth, const float* frame_rgb, const float* frame_depth, const float* dmaps, int H, int W,
+                          const float* taps11 /* host */, const float* w3 /* host */, const float* neg_c_ssim, const float* sums, float* dL_dimage,
+                          float* dL_ddepth, void* stream);
 typedef struct gsr_pose_update_args {
     float* quat_trans;    /* [7] */
     float* moments;       /* [14] */

@@ -38,6 +38,7 @@ int main(int argc, char** argv)
     cfg.fused_ops = (hdr[5] & 2) != 0;
     cfg.direct = (hdr[5] & 16) == 0;
     cfg.fused_update = (hdr[5] & 32) == 0;
+    cfg.fused_loss = (hdr[5] & 32) == 0; // (bit 5 switches both fusions of the mapping iteration off)
     if (hdr[5] & 64) cfg.binning_capacity = 1024; // (far too small: the first iteration of every loop overflows, is skipped on the device and taken again)
     ORB_SLAM2::SlamLoop loop(cfg, W, H, ff[0], ff[1], dev);
     auto xyz = rd(f, {P, 3}), rgb = rd(f, {P, 3}), quat = rd(f, {P, 4}), logit = rd(f, {P, 1}), logs = rd(f, {P, 3});

@@ -364,3 +364,50 @@ def test_pose_update_is_rt2T_backward_plus_adam_and_keeps_the_best_pose(gsr, hz)
     h = hist.cpu()
     assert float(h[0]) == 3.0 and float(h[1]) == 2.0 and bool(torch.isnan(h[2])) and float(h[3]) == 2.5
     assert float(best[0]) == 2.0 and (best[1:].cpu().double() - poses_before[1]).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(37, 53), (680, 1200)])
+def test_fused_mapping_loss_equals_its_separate_kernels(gsr, hz, shape):
+    """gsr_map_loss_forward / _finish / _backward (SSIM and the pixel terms of the mapping loss in the same two passes, one finish kernel that
+    also closes the regularisers and forms the iteration's loss) against the kernels they replace: capi.mapping_pixel_loss, capi.ssim_mean (both
+    through autograd) and capi.scale_regularisers."""
+    import ctypes as C
+    H, W = shape
+    g = torch.Generator().manual_seed(H)
+    image = torch.rand((3, H, W), generator=g).cuda().requires_grad_(True)
+    frgb = torch.rand((3, H, W), generator=g).cuda()
+    fd = (0.5 + 3 * torch.rand((H, W), generator=g)); fd[::5, ::3] = 0.0; fd = fd.cuda()
+    depth = (fd + 0.1 * torch.randn((H, W), generator=g).cuda()).requires_grad_(True)
+    sur = (fd + 0.1 * torch.randn((H, W), generator=g).cuda())
+    sil = torch.rand((H, W), generator=g).cuda() * 0.2 + 0.85
+    taps = hz._ssim_taps().tolist() if hasattr(hz, "_ssim_taps") else None
+    assert taps is not None
+    n = 5000
+    ls = torch.log(0.01 + 0.3 * torch.rand((n, 3), generator=g)).cuda()
+    w = (0.8, 0.7, 0.35); c_ssim = 0.2; limit, wl, ws = 0.2, 5.0, 10.0
+    # separate kernels
+    pix, sums_ref = gsr.capi.mapping_pixel_loss(image, depth, sur, sil, frgb, fd, *w)
+    ssim = gsr.capi.ssim_mean(image, frgb, taps)
+    reg, reg_ref = gsr.capi.scale_regularisers(ls, limit, wl, ws)
+    total = pix + c_ssim * (1.0 - ssim) + reg
+    total.backward()
+    # fused
+    L = gsr.lib()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    np6 = int(L.gsr_ssim_partials(3, H, W))
+    partial6 = torch.empty((np6 * 6,), device="cuda"); dmaps = torch.empty((3, 3, H, W), device="cuda")
+    t11 = (C.c_float * 11)(*taps); w3 = (C.c_float * 3)(*w)
+    img = image.detach().contiguous(); dep = depth.detach().contiguous()
+    gsr.capi._check(L.gsr_map_loss_forward(p(img), p(dep), p(sur), p(sil), p(frgb), p(fd), H, W, t11, 0.99, p(partial6), p(dmaps), None))
+    xyz = torch.zeros((n, 3), device="cuda"); q = torch.ones((n, 4), device="cuda"); lg = torch.zeros((n, 1), device="cuda")
+    reg_partial = torch.empty((3 * ((n + 255) // 256),), device="cuda")
+    gsr.capi._check(L.gsr_map_prepare(n, None, None, p(ls), None, None, None, None, None, None, limit, wl, ws, p(reg_partial), None, None))
+    sums = torch.empty((8,), device="cuda"); reg_out = torch.empty((4,), device="cuda"); loss = torch.empty((1,), device="cuda")
+    gsr.capi._check(L.gsr_map_loss_finish(p(partial6), p(reg_partial), n, H, W, w3, c_ssim, wl, ws, None, p(sums), p(reg_out), p(loss), None))
+    neg_c = torch.tensor([-c_ssim], device="cuda"); gi = torch.empty_like(img); gd = torch.empty_like(dep)
+    gsr.capi._check(L.gsr_map_loss_backward(p(img), p(dep), p(frgb), p(fd), p(dmaps), H, W, t11, w3, p(neg_c), p(sums), p(gi), p(gd), None))
+    assert abs(float(loss) - float(total)) <= 2e-6 * abs(float(total))
+    assert (sums[:6].cpu() - sums_ref[:6].cpu()).abs().max() <= 2e-5 * float(sums_ref[:5].abs().max())
+    assert (reg_out.cpu() - reg_ref.cpu()).abs().max() <= 2e-5 * max(float(reg_ref.abs().max()), 1e-12)
+    assert (gi - image.grad).abs().max() <= 2e-6 * float(image.grad.abs().max())
+    assert (gd - depth.grad).abs().max() <= 2e-6 * float(depth.grad.abs().max())
