@@ -63,16 +63,57 @@ __device__ __forceinline__ void load_cov3d(const SplatInputs& in, const FramePar
 #ifndef GSR_PRE_THREADS
 #define GSR_PRE_THREADS 256
 #endif
+// Every per-splat input is requested before the first one is used (round 4): written in the order the reference computes, a
+// wave made five dependent trips to memory — means; scales + rotations; the view matrix; the projection matrix behind the
+// near-plane test; colour + opacity behind the visibility test (a compiler does not move a load above the branch that guards
+// it). pin() keeps the requests where they are written. What the kernel's time is made of (scripts/pre_only.py, variant builds
+// -DGSR_EXP_PRE2 / -DGSR_EXP_NOREACH; HIP-event pairs, ~2 us above rocprof's figure): loads alone 16 us, loads + stores without
+// the arithmetic 25.5 (132 MB: 5.2 TB/s), loads + arithmetic without the stores 25, everything 32 — the three phases of a wave
+// add up instead of overlapping (2.5 rounds of waves that start together), and neither the exact reach test (44 % of the
+// instructions: 32.3 -> 32.3 us without it) nor the order of the requests (33.1 -> 32.3) is what it waits for.
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 __global__ void __launch_bounds__(GSR_PRE_THREADS)
 K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomView g)
 {
     const int idx = blockIdx.x * GSR_PRE_THREADS + threadIdx.x;
     if (idx >= f.P) return;
-    const float3 p = make_float3(in.means3D[3 * (size_t)idx], in.means3D[3 * (size_t)idx + 1], in.means3D[3 * (size_t)idx + 2]);
+    float3 p = make_float3(in.means3D[3 * (size_t)idx], in.means3D[3 * (size_t)idx + 1], in.means3D[3 * (size_t)idx + 2]);
     float cov[6];
-    load_cov3d(in, f, idx, cov);
+    float3 sc = make_float3(0.f, 0.f, 0.f);
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cov[k] = in.cov3D_precomp[6 * (size_t)idx + k];
+    } else {
+        sc = make_float3(in.scales[3 * (size_t)idx], in.scales[3 * (size_t)idx + 1], in.scales[3 * (size_t)idx + 2]);
+        q = reinterpret_cast<const float4*>(in.rotations)[idx];
+    }
+    float opac = in.opacities[idx];
+    float3 cp = make_float3(0.f, 0.f, 0.f);
+    if (in.colors_precomp) cp = make_float3(in.colors_precomp[3 * (size_t)idx], in.colors_precomp[3 * (size_t)idx + 1], in.colors_precomp[3 * (size_t)idx + 2]);
+    float vm[16], pm[16]; // the two matrices: scalar loads, requested with the rest
+#pragma unroll
+    for (int k = 0; k < 16; k++) { vm[k] = in.view[k]; pm[k] = in.proj[k]; }
+    pin(p.x); pin(p.y); pin(p.z); pin(opac); pin(cp.x); pin(cp.y); pin(cp.z);
+    if (in.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) pin(cov[k]);
+    } else {
+        pin(sc.x); pin(sc.y); pin(sc.z); pin(q.x); pin(q.y); pin(q.z); pin(q.w);
+        cov3d_from_scale_rot(sc, f.scale_modifier, q, cov);
+    }
+#ifdef GSR_EXP_PRE2 // timing experiments: 1 = loads only, 2 = loads and stores without the arithmetic
+    if (GSR_EXP_PRE2 == 1) { if (p.x + cov[0] + opac + cp.x + vm[0] + pm[0] == 1.2345e30f) g.g1[idx] = make_float4(p.x, p.y, p.z, 0.f); return; }
+    if (GSR_EXP_PRE2 == 2) {
+        g.reach[idx] = make_uint2(__float_as_uint(p.x), __float_as_uint(p.y));
+        g.g0[idx] = make_float4(p.x, p.y, cov[0], cov[1]); g.g1[idx] = make_float4(cov[2], opac, p.z, cov[3]); g.col[idx] = make_float4(cp.x, cp.y, cp.z, vm[0] + pm[0]);
+        if (radii_out) radii_out[idx] = (int)cov[4];
+        g.slots[idx] = make_uint4(__float_as_uint(cov[5]), 1u, 2u, 3u);
+        return;
+    }
+#endif
     Projected pr;
-    const bool vis = project_splat(p, cov, f, in.view, in.proj, pr);
+    const bool vis = project_splat(p, cov, f, vm, pm, pr);
     if (!vis) {
         g.g1[idx] = make_float4(0.f, 0.f, 0.f, 0.f); // radius 0 marks the splat invisible
         g.slots[idx] = make_uint4(0u, 0u, 0u, 0u);
@@ -81,8 +122,7 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
     }
     float4 c;
     if (in.colors_precomp) {
-        c = make_float4(in.colors_precomp[3 * (size_t)idx], in.colors_precomp[3 * (size_t)idx + 1],
-                        in.colors_precomp[3 * (size_t)idx + 2], 0.f);
+        c = make_float4(cp.x, cp.y, cp.z, 0.f);
     } else {
         float3 raw;
         const float3 d = unit_dir(p, in.campos, raw);
@@ -91,7 +131,6 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
         const uint32_t flags = (r < 0 ? 1u : 0u) | (gg < 0 ? 2u : 0u) | (b < 0 ? 4u : 0u);
         c = make_float4(fmaxf(r, 0.f), fmaxf(gg, 0.f), fmaxf(b, 0.f), __uint_as_float(flags));
     }
-    const float opac = in.opacities[idx];
     // the exact patch reach of a small splat, once per splat instead of once per (tile entry, quad) in the blend (gsr_device.h)
     const uint32_t reach = splat_reach25(pr.px, pr.py, pr.conic_a, pr.conic_b, pr.conic_c, opac);
     g.reach[idx] = reach_entry(reach, pr.px, pr.py);
@@ -1134,10 +1173,25 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, MapUpdate m
     if (idx >= f.P) return;
     if (FUSED && mu.overflow && *mu.overflow) return; // (the forward rendered nothing: no step)
     const size_t i = (size_t)idx;
-    const int radius = __float_as_int(g.g1[idx].w);
+    // Two trips to memory per wave instead of six (round 4; see K_preprocess): the matrices are requested first — uniform
+    // addresses, read before the kernel's first store: scalar loads (behind a store the compiler has to fetch them per lane) —
+    // and everything a visible splat needs is requested in one go once its radius is known.
+    float vm[16], pm[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { vm[k] = in.view[k]; pm[k] = in.proj[k]; }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { asm volatile("" : "+s"(vm[k])); asm volatile("" : "+s"(pm[k])); }
+    Pose34 Tp; // (fused update: the pose the means were taken to the camera frame with)
+    if (FUSED) {
+        Tp = load_pose(mu.Tcw);
+#pragma unroll
+        for (int k = 0; k < 9; k++) Tp.r[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, Tp.r[k]))); // (uniform: scalar registers)
+    }
+    float4 gb = g.g1[idx];
+    const int radius = __float_as_int(gb.w);
     if (FUSED && radius <= 0) { // invisible: zero gradients, but Adam still steps on its moments
         const float z3[3] = {0.f, 0.f, 0.f};
-        map_update_with(i, mu, load_pose(mu.Tcw), z3, z3, make_float4(0.f, 0.f, 0.f, 0.f), 0.f, z3);
+        map_update_with(i, mu, Tp, z3, z3, make_float4(0.f, 0.f, 0.f, 0.f), 0.f, z3);
         return;
     }
     if (radius <= 0) { // invisible: every gradient is zero (the reference leaves its zero-fill)
@@ -1153,15 +1207,39 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, MapUpdate m
         return;
     }
     float* const acc = g.acc + i * GSR_ACC_STRIDE;
-    const float4 q0 = reinterpret_cast<const float4*>(acc)[0], q1 = reinterpret_cast<const float4*>(acc)[1];
-    const float q8 = acc[8], q9 = acc[9]; // q9: dL/d(view depth as a colour) of the fused depth channel (zero without it)
+    float4 q0 = reinterpret_cast<const float4*>(acc)[0], q1 = reinterpret_cast<const float4*>(acc)[1];
+    float q8 = acc[8], q9 = acc[9]; // q9: dL/d(view depth as a colour) of the fused depth channel (zero without it)
+    float4 ga = g.g0[idx];
+    float3 mean = make_float3(in.means3D[3 * i], in.means3D[3 * i + 1], in.means3D[3 * i + 2]);
+    float cov3D[6];
+    float3 sc = make_float3(0.f, 0.f, 0.f);
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) cov3D[k] = in.cov3D_precomp[6 * i + k];
+    }
+    if (in.scales) {
+        sc = make_float3(in.scales[3 * i], in.scales[3 * i + 1], in.scales[3 * i + 2]);
+        q = reinterpret_cast<const float4*>(in.rotations)[i];
+    }
+    pin(q0.x); pin(q0.y); pin(q0.z); pin(q0.w); pin(q1.x); pin(q1.y); pin(q1.z); pin(q1.w); pin(q8); pin(q9);
+    pin(ga.x); pin(ga.y); pin(ga.z); pin(ga.w); pin(mean.x); pin(mean.y); pin(mean.z);
+    if (in.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) pin(cov3D[k]);
+    }
+    if (in.scales) { pin(sc.x); pin(sc.y); pin(sc.z); pin(q.x); pin(q.y); pin(q.z); pin(q.w); }
+    MapRegs mr; // (fused update: the Gaussian's raw parameters and moments travel with the same request: 168 of its 408 bytes)
+#ifndef GSR_EXP_NOMAPHOIST
+    if (FUSED) { map_load(i, mu, mr); map_pin(mr); }
+#endif
+    if (!in.cov3D_precomp) cov3d_from_scale_rot(sc, f.scale_modifier, q, cov3D);
     if (REZERO) { // consumed: leave the record clean for the next backward on this geometry blob
         float4* const ap = reinterpret_cast<float4*>(acc);
         ap[0] = ap[1] = ap[2] = ap[3] = make_float4(0.f, 0.f, 0.f, 0.f); // the whole 64-byte line
     }
     // K_blend_bwd accumulated the raw moments of u = G*dL/dalpha: {u, u dx, u dy, u dx^2, u dx dy, u dy^2};
     // the reference's per-pixel terms (backward.cu:536-554) are these moments times conic / opacity:
-    const float4 ga = g.g0[idx], gb = g.g1[idx];
     const float ca = ga.z, cb = ga.w, cc = gb.x, op = gb.y;
     const float dmx = (op * -(ca * q0.y + cb * q0.z)) * (float)(0.5 * f.W);
     const float dmy = (op * -(cc * q0.z + cb * q0.y)) * (float)(0.5 * f.H);
@@ -1174,12 +1252,8 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, MapUpdate m
     if (o.dL_dopacity) o.dL_dopacity[i] = dopac;
     st3(o.dL_dcolor, i, dcol.x, dcol.y, dcol.z);
 
-    const float3 mean = make_float3(in.means3D[3 * i], in.means3D[3 * i + 1], in.means3D[3 * i + 2]);
-    float cov3D[6];
-    load_cov3d(in, f, idx, cov3D);
-
     // ---- conic -> 2D covariance -> 3D covariance and mean (backward.cu:144-274) ----
-    const Cov2D k = cov2d_forward(mean, f.focal_x, f.focal_y, f.tan_fovx, f.tan_fovy, cov3D, in.view);
+    const Cov2D k = cov2d_forward(mean, f.focal_x, f.focal_y, f.tan_fovx, f.tan_fovy, cov3D, vm);
     const float x_grad_mul = (k.txtz < -k.limx || k.txtz > k.limx) ? 0.f : 1.f;
     const float y_grad_mul = (k.tytz < -k.limy || k.tytz > k.limy) ? 0.f : 1.f;
     const M3& T = k.T; const M3& Vrk = k.Vrk; const M3& Wm = k.W;
@@ -1223,7 +1297,6 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, MapUpdate m
     const float dL_dtx = x_grad_mul * -hx * tz2 * dL_dJ02;
     const float dL_dty = y_grad_mul * -hy * tz2 * dL_dJ12;
     const float dL_dtz = -hx * tz2 * dL_dJ00 - hy * tz2 * dL_dJ11 + (2 * hx * k.t.x) * tz3 * dL_dJ02 + (2 * hy * k.t.y) * tz3 * dL_dJ12;
-    const float* vm = in.view;
     float3 dmean = make_float3(vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz,
                                vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz,
                                vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz);
@@ -1233,7 +1306,7 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, MapUpdate m
 
     // ---- screen-space mean -> 3D mean (backward.cu:366-387) ----
     {
-        const float* pj = in.proj;
+        const float* pj = pm;
         const float4 m_hom = xform4x4(mean, pj);
         const float m_w = 1.0f / (m_hom.w + 0.0000001f);
         const float mul1 = (pj[0] * mean.x + pj[4] * mean.y + pj[8] * mean.z + pj[12]) * m_w * m_w;
@@ -1266,8 +1339,6 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, MapUpdate m
     float ds3[3] = {0.f, 0.f, 0.f};
     float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
     if (in.scales && (FUSED || (o.dL_dscale && o.dL_drot))) {
-        const float3 sc = make_float3(in.scales[3 * i], in.scales[3 * i + 1], in.scales[3 * i + 2]);
-        const float4 q = reinterpret_cast<const float4*>(in.rotations)[i];
         const float r = q.x, x = q.y, y = q.z, z = q.w;
         const M3 R = quat_R(q);
         const float3 s = make_float3(f.scale_modifier * sc.x, f.scale_modifier * sc.y, f.scale_modifier * sc.z);
@@ -1298,7 +1369,11 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, MapUpdate m
     }
     if (FUSED) {
         const float gx[3] = {dmean.x, dmean.y, dmean.z}, gc[3] = {dcol.x, dcol.y, dcol.z};
-        map_update_with(i, mu, load_pose(mu.Tcw), gx, gc, dq, dopac, ds3);
+#ifndef GSR_EXP_NOMAPHOIST
+        map_apply(i, mu, Tp, mr, gx, gc, dq, dopac, ds3);
+#else
+        map_update_with(i, mu, Tp, gx, gc, dq, dopac, ds3);
+#endif
         return;
     }
     st3(o.dL_dscale, i, ds3[0], ds3[1], ds3[2]);

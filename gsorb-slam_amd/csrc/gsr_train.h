@@ -639,21 +639,45 @@ __device__ __forceinline__ void adam_one(float& pp, const float gg, float& mm, f
 // the backward has just computed them: gsr_backward_args.fused_map_update). Every load is issued before the first store (the tensors may
 // alias as far as the compiler knows: section by section it would wait for each section's round trip — at 10 k Gaussians, where nothing
 // else hides it, the launch took 19 us for 0.4 MB).
-__device__ __forceinline__ void map_update_with(const size_t i, const MapUpdate& u, const Pose34& T, const float (&GX)[3], const float (&GC)[3],
-                                                const float4 dr, const float gop, const float (&GS)[3])
-{
+struct MapRegs { // the raw parameters of one Gaussian, their Adam moments and the activations the chain rule needs
     float X[3], M0[3], V0[3], C[3], M1[3], V1[3], LS[3], M4[3], V4[3], S[3];
+    float4 q, M2, V2;
+    float L, M3, V3, o, cnt;
+};
+__device__ __forceinline__ void map_load(const size_t i, const MapUpdate& u, MapRegs& r)
+{
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        X[k] = u.xyz[3 * i + k]; M0[k] = u.m[0][3 * i + k]; V0[k] = u.v[0][3 * i + k];
-        C[k] = u.rgb[3 * i + k]; M1[k] = u.m[1][3 * i + k]; V1[k] = u.v[1][3 * i + k];
-        LS[k] = u.ls[3 * i + k]; M4[k] = u.m[4][3 * i + k]; V4[k] = u.v[4][3 * i + k]; S[k] = u.scales[3 * i + k];
+        r.X[k] = u.xyz[3 * i + k]; r.M0[k] = u.m[0][3 * i + k]; r.V0[k] = u.v[0][3 * i + k];
+        r.C[k] = u.rgb[3 * i + k]; r.M1[k] = u.m[1][3 * i + k]; r.V1[k] = u.v[1][3 * i + k];
+        r.LS[k] = u.ls[3 * i + k]; r.M4[k] = u.m[4][3 * i + k]; r.V4[k] = u.v[4][3 * i + k]; r.S[k] = u.scales[3 * i + k];
     }
-    float4 q = reinterpret_cast<const float4*>(u.quat)[i];
-    float4 M2 = reinterpret_cast<const float4*>(u.m[2])[i], V2 = reinterpret_cast<const float4*>(u.v[2])[i];
-    float L = u.logit[i], M3 = u.m[3][i], V3 = u.v[3][i];
-    const float o = u.opac[i];
-    const float cnt = u.reg_out ? u.reg_out[0] : 0.f;
+    r.q = reinterpret_cast<const float4*>(u.quat)[i];
+    r.M2 = reinterpret_cast<const float4*>(u.m[2])[i]; r.V2 = reinterpret_cast<const float4*>(u.v[2])[i];
+    r.L = u.logit[i]; r.M3 = u.m[3][i]; r.V3 = u.v[3][i];
+    r.o = u.opac[i];
+    r.cnt = u.reg_out ? u.reg_out[0] : 0.f;
+}
+// keeps the requests of map_load where they are written (a value the compiler may not assume unchanged has to be there)
+__device__ __forceinline__ void map_pin(MapRegs& r)
+{
+#define GSR_PIN(x) asm volatile("" : "+v"(x))
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        GSR_PIN(r.X[k]); GSR_PIN(r.M0[k]); GSR_PIN(r.V0[k]); GSR_PIN(r.C[k]); GSR_PIN(r.M1[k]); GSR_PIN(r.V1[k]);
+        GSR_PIN(r.LS[k]); GSR_PIN(r.M4[k]); GSR_PIN(r.V4[k]); GSR_PIN(r.S[k]);
+    }
+    GSR_PIN(r.q.x); GSR_PIN(r.q.y); GSR_PIN(r.q.z); GSR_PIN(r.q.w); GSR_PIN(r.M2.x); GSR_PIN(r.M2.y); GSR_PIN(r.M2.z); GSR_PIN(r.M2.w);
+    GSR_PIN(r.V2.x); GSR_PIN(r.V2.y); GSR_PIN(r.V2.z); GSR_PIN(r.V2.w); GSR_PIN(r.L); GSR_PIN(r.M3); GSR_PIN(r.V3); GSR_PIN(r.o);
+#undef GSR_PIN
+}
+__device__ __forceinline__ void map_apply(const size_t i, const MapUpdate& u, const Pose34& T, MapRegs& r, const float (&GX)[3], const float (&GC)[3],
+                                          const float4 dr, const float gop, const float (&GS)[3])
+{
+    float (&X)[3] = r.X, (&M0)[3] = r.M0, (&V0)[3] = r.V0, (&C)[3] = r.C, (&M1)[3] = r.M1, (&V1)[3] = r.V1, (&LS)[3] = r.LS, (&M4)[3] = r.M4, (&V4)[3] = r.V4, (&S)[3] = r.S;
+    float4 &q = r.q, &M2 = r.M2, &V2 = r.V2;
+    float &L = r.L, &M3 = r.M3, &V3 = r.V3;
+    const float o = r.o, cnt = r.cnt;
     { // means: mc = X R^T + t  =>  dL/dX = dmc R
         const float d[3] = {fmaf(GX[2], T.r[6], fmaf(GX[1], T.r[3], GX[0] * T.r[0])), fmaf(GX[2], T.r[7], fmaf(GX[1], T.r[4], GX[0] * T.r[1])),
                             fmaf(GX[2], T.r[8], fmaf(GX[1], T.r[5], GX[0] * T.r[2]))};
@@ -696,6 +720,13 @@ __device__ __forceinline__ void map_update_with(const size_t i, const MapUpdate&
     }
     reinterpret_cast<float4*>(u.quat)[i] = q; reinterpret_cast<float4*>(u.m[2])[i] = M2; reinterpret_cast<float4*>(u.v[2])[i] = V2;
     u.logit[i] = L; u.m[3][i] = M3; u.v[3][i] = V3;
+}
+__device__ __forceinline__ void map_update_with(const size_t i, const MapUpdate& u, const Pose34& T, const float (&GX)[3], const float (&GC)[3],
+                                                const float4 dr, const float gop, const float (&GS)[3])
+{
+    MapRegs r;
+    map_load(i, u, r);
+    map_apply(i, u, T, r, GX, GC, dr, gop, GS);
 }
 __device__ __forceinline__ void map_update_one(const size_t i, const MapUpdate& u, const Pose34& T)
 {

@@ -623,6 +623,122 @@ void gsro_geometry_census(int W, int H, const uint32_t* ranges, const uint32_t* 
     }
 }
 
+/* Measurement instrumentation (round 4, second census): what the forward could tell the backward. For the shipped 4x4 patches:
+ * how many pixels a patch hit really blends (the reach test is geometric: an ellipse that clips a corner of the patch's rectangle may
+ * contain no pixel centre; pixels already finished blend nothing), and what the blend loop would run with
+ *   Z: lists without the patch hits that blend no pixel (the forward would log the live mask),
+ *   P: per-PIXEL lists inside every 16-entry window of a row's list (each lane walks the entries that blend ITS pixel).
+ * out[0..16]: patch hits by blended pixels; out[17]: quad hits (parked records); out[18]: quad hits without any blended pixel;
+ * out[19]: wave iterations today; out[20]: reduce phases today; out[21]: wave iterations Z; out[22]: reduce phases Z;
+ * out[23]: wave iterations P (sum over windows of the max over the 64 lanes); out[24]: windows P; out[25]: rounds;
+ * out[26]: wave iterations of P on Z's lists; out[27]: per-round max over lanes of the pixel's count (no windows) */
+void gsro_pixlist_census(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
+                         const float* conic_opacity, const uint32_t* n_contrib, unsigned long long* out)
+{
+    const int gx = (W + GSRO_BLOCK_X - 1) / GSRO_BLOCK_X, gy = (H + GSRO_BLOCK_Y - 1) / GSRO_BLOCK_Y;
+    unsigned long long acc[28];
+    for (int i = 0; i < 28; i++) acc[i] = 0;
+#ifdef GSRO_OMP
+#pragma omp parallel for schedule(dynamic, 1) collapse(2) reduction(+ : acc[:28])
+#endif
+    for (int ty = 0; ty < gy; ty++)
+        for (int tx = 0; tx < gx; tx++) {
+            const uint32_t r0 = ranges[2 * (ty * gx + tx)], r1 = ranges[2 * (ty * gx + tx) + 1];
+            const int n = (int)(r1 - r0);
+            if (n <= 0) continue;
+            uint32_t* pm = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
+            uint32_t* ppos = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
+            for (int quad = 0; quad < 4; quad++) {
+                const int X0 = tx * 16 + (quad & 1) * 8, Y0 = ty * 16 + (quad >> 1) * 8;
+                uint32_t ntodo = 0;
+                for (int j = 0; j < 8; j++)
+                    for (int i = 0; i < 8; i++)
+                        if (X0 + i < W && Y0 + j < H && n_contrib[W * (Y0 + j) + X0 + i] > ntodo) ntodo = n_contrib[W * (Y0 + j) + X0 + i];
+                if (ntodo == 0) continue;
+                int nq = 0, nlive = 0;
+                for (int k = 0; k < n; k++) {
+                    const uint32_t id = point_list[r0 + k];
+                    const float* co = conic_opacity + 4 * id;
+                    uint32_t m = 0;
+                    for (int c = 0; c < 4; c++)
+                        if (gsro_rect_reach(means2D[2 * id], means2D[2 * id + 1], co[0], co[1], co[2], co[3], (float)(X0 + (c & 1) * 4), (float)(Y0 + (c >> 1) * 4), 4.f, 4.f))
+                            m |= 1u << c;
+                    if (!m) continue;
+                    pm[nq] = m; ppos[nq] = (uint32_t)k; nq++;
+                    if ((uint32_t)k < ntodo) nlive = nq;
+                }
+                int cq = ((nlive + 63) / 64) * 64;
+                if (cq > nq) cq = nq;
+                for (int top = cq; top > 0; top -= 64) {
+                    int c[4] = {0, 0, 0, 0}, cz[4] = {0, 0, 0, 0}, count = 0;
+                    static __thread uint16_t bm[4][64], bmz[4][64]; /* blended-pixel masks of the rows' list entries, in walking order */
+                    for (int e = top - 1; e >= 0 && e >= top - 64; e--) {
+                        if (ppos[e] >= ntodo) continue;
+                        count++;
+                        const uint32_t id = point_list[r0 + ppos[e]];
+                        const float* co = conic_opacity + 4 * id;
+                        int any = 0;
+                        for (int r = 0; r < 4; r++)
+                            if ((pm[e] >> r) & 1) {
+                                const int px0 = X0 + (r & 1) * 4, py0 = Y0 + (r >> 1) * 4;
+                                uint32_t mask = 0;
+                                for (int p = 0; p < 16; p++) {
+                                    const int px = px0 + (p & 3), py = py0 + (p >> 2);
+                                    if (!(px < W && py < H) || ppos[e] >= n_contrib[W * py + px]) continue;
+                                    const float dx = means2D[2 * id] - (float)px, dy = means2D[2 * id + 1] - (float)py;
+                                    const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                                    if (power > 0.0f) continue;
+                                    if (fminf(0.99f, co[3] * expf(power)) < 1.0f / 255.0f) continue;
+                                    mask |= 1u << p;
+                                }
+                                acc[__builtin_popcount(mask)]++;
+                                bm[r][c[r]++] = (uint16_t)mask;
+                                if (mask) { bmz[r][cz[r]++] = (uint16_t)mask; any = 1; }
+                            }
+                        acc[17]++;
+                        if (!any) acc[18]++;
+                    }
+                    if (count == 0) continue;
+                    acc[25]++;
+                    int maxc = 0, maxz = 0;
+                    for (int r = 0; r < 4; r++) { if (c[r] > maxc) maxc = c[r]; if (cz[r] > maxz) maxz = cz[r]; }
+                    maxc = (maxc + 1) & ~1; maxz = (maxz + 1) & ~1;
+                    acc[19] += (unsigned long long)maxc; acc[20] += (unsigned long long)((maxc + 15) / 16);
+                    acc[21] += (unsigned long long)maxz; acc[22] += (unsigned long long)((maxz + 15) / 16);
+                    for (int variant = 0; variant < 2; variant++) { /* P on today's lists, P on Z's lists */
+                        const int mx = variant ? maxz : maxc;
+                        for (int w0 = 0; w0 < mx; w0 += 16) {
+                            int best = 0;
+                            for (int r = 0; r < 4; r++) {
+                                const int cr = variant ? cz[r] : c[r];
+                                for (int p = 0; p < 16; p++) {
+                                    int cnt = 0;
+                                    for (int k = w0; k < w0 + 16 && k < cr; k++) cnt += ((variant ? bmz[r][k] : bm[r][k]) >> p) & 1;
+                                    if (cnt > best) best = cnt;
+                                }
+                            }
+                            best = (best + 1) & ~1;
+                            if (variant) acc[26] += (unsigned long long)best;
+                            else { acc[23] += (unsigned long long)best; acc[24]++; }
+                        }
+                    }
+                    {
+                        int best = 0;
+                        for (int r = 0; r < 4; r++)
+                            for (int p = 0; p < 16; p++) {
+                                int cnt = 0;
+                                for (int k = 0; k < c[r]; k++) cnt += (bm[r][k] >> p) & 1;
+                                if (cnt > best) best = cnt;
+                            }
+                        acc[27] += (unsigned long long)((best + 1) & ~1);
+                    }
+                }
+            }
+            free(pm); free(ppos);
+        }
+    for (int i = 0; i < 28; i++) out[i] = acc[i];
+}
+
 /* Test instrumentation (not in the reference): smallest relative distance of any
  * data-dependent branch of forward.cu:346-379 from flipping, per pixel. exp() is not
  * bit-reproducible across libm/CUDA/HIP, so a pixel whose margin is below the

@@ -72,6 +72,8 @@ def _load(omp: bool):
     lib.gsro_blend_census.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 7
     lib.gsro_geometry_census.restype = None
     lib.gsro_geometry_census.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p]
+    lib.gsro_pixlist_census.restype = None
+    lib.gsro_pixlist_census.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 6
     lib.gsro_set_threads.restype = None
     lib.gsro_set_threads.argtypes = [C.c_int]
     lib.gsro_higher_msb.restype = C.c_uint32
@@ -214,6 +216,16 @@ class Oracle:
                                       ptr(_STAGES["conic_opacity"][0]), ptr(_STAGES["n_contrib"][0]), len(ga), _ptr(ga), _ptr(out))
         names = ("quad_hits", "patch_hits", "wave_iterations", "reduce_phases", "rounds", "lane_slots", "blended_pairs", "pairs_in_reached_patches")
         return [dict(zip(names, (int(x) for x in row))) for row in out]
+
+    def pixlist_census(self):
+        """What the forward could tell the backward (gsro_pixlist_census): blended pixels per patch hit, loop lengths with lists
+        that drop the patch hits blending nothing and with per-pixel lists."""
+        s = self._s
+        ptr = lambda idx: C.c_void_p(self.lib.gsro_stage(self.state, idx, C.byref(C.c_size_t(0))))
+        out = np.zeros(28, np.uint64)
+        self.lib.gsro_pixlist_census(s.W, s.H, ptr(_STAGES["ranges"][0]), ptr(_STAGES["point_list"][0]), ptr(_STAGES["means2D"][0]),
+                                     ptr(_STAGES["conic_opacity"][0]), ptr(_STAGES["n_contrib"][0]), _ptr(out))
+        return [int(x) for x in out]
 
     def backward(self, dL_dpix, accum_double: bool = True) -> Backward:
         P, M = self._P, self._M
