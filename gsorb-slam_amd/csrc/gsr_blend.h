@@ -216,12 +216,20 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     const int px = X0p + (l & 3), py = Y0p + (l >> 2);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
+    // The job's first trips to memory (round 4: four dependent ones instead of six — at ~2.4 waves per SIMD nothing hides them): the tile's
+    // range, the header words and the quad's record count are asked for together, the pixel's own words with them, and the first records
+    // as soon as those scalars are there (clamped, always valid addresses) — not behind the wait for the pixel words that ntodo needs.
     const uint2 range = im.ranges[tile];
-    const int n = g.hdr->overflow ? 0 : (int)(range.y - range.x);
+    const uint32_t ovf = g.hdr->overflow;
+    const int cq = (int)im.qdone[4 * tile + quad]; // the records the forward took: every contributor is among them
+    const int n = ovf ? 0 : (int)(range.y - range.x);
     BinView bn; // the layout of the binning blob follows the capacity the forward ran with (kept in the header)
     binning_layout(binning, (size_t)g.hdr->capacity, &bn);
+    const uint2* __restrict__ qh = bn.qhits + (ovf ? (size_t)0 : 4 * (size_t)range.x + (size_t)quad * (size_t)n);
     const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
 
+    uint2 rec_c = qh[max(cq - 1 - lane, 0)];
+    uint2 rec_n = qh[max(cq - 1 - (lane + GSR_BSTEP), 0)];
     const float T_final = inside ? im.final_T[pix] : 0.f;
     float T = T_final;
     const uint32_t last = inside ? im.n_contrib[pix] : 0u;
@@ -256,12 +264,8 @@ K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* _
     // back to front. Gather pipeline: the records of the next two steps and the geometry of the next step
     // are in flight (unconditional loads from clamped, always valid addresses so that the compiler can
     // count them: the colour gather must not wait for the loads issued after it).
-    const int cq = (int)im.qdone[4 * tile + quad]; // the records the forward took: every contributor is among them
-    const uint2* __restrict__ qh = bn.qhits + 4 * (size_t)range.x + (size_t)quad * (size_t)n;
     if (ntodo <= 0 || cq <= 0) return;
     int k0 = 0;
-    uint2 rec_c = qh[max(cq - 1 - lane, 0)];
-    uint2 rec_n = qh[max(cq - 1 - (lane + GSR_BSTEP), 0)];
     float4 a_c = g.g0[rec_c.y & GSR_ID_MASK], b_c = g.g1[rec_c.y & GSR_ID_MASK], c_c = g.col[rec_c.y & GSR_ID_MASK];
     // ---- flush: a round leaves the totals of its entries staged in the block (12 words per entry: NC sums, the splat id in
     //      the last one); they are sent seven entries per instruction, NC consecutive lanes per 64-byte accumulator record:
@@ -559,13 +563,16 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
     const int px = X0 + (r & 1) * 4 + (l & 3), py = Y0 + (r >> 1) * 4 + (l >> 2);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
+    // (the range, the overflow flag and the quad's record count are asked for together: one trip to memory before the records, not two)
     const uint2 range = im.ranges[tile];
-    const int n = g.hdr->overflow ? 0 : (int)(range.y - range.x);
+    const uint32_t ovf = g.hdr->overflow;
+    const int cq0 = (int)im.qcount[4 * tile + quad];
+    const int n = ovf ? 0 : (int)(range.y - range.x);
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, C3 = 0.f, C4 = 0.f, Dp = 0.f;
     uint32_t last = 0u;
     wmask m_done = wm(!inside); // lanes whose pixel is finished (or outside the image)
-    const int cq = n > 0 ? (int)im.qcount[4 * tile + quad] : 0;
+    const int cq = n > 0 ? cq0 : 0;
     const uint2* __restrict__ qh = bn.qhits + 4 * (size_t)range.x + (size_t)quad * (size_t)n;
     constexpr uint32_t DUMMY = (uint32_t)Q * 16u;
     if (lane == 0) {
