@@ -76,27 +76,45 @@ K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int H
         if (c == 1 && ml.sur) l_sur = ml.sur[pix];
         if (c == 1 && ml.sil) l_sil = ml.sil[pix];
     }
-    for (int i = tid; i < HS * HS; i += TS * TS) {
-        const int y = i / HS, x = i - y * HS, gy = y0 + y - R, gx = x0 + x - R;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        a[y][x] = in ? p1[(size_t)gy * W + gx] : 0.f;
-        b[y][x] = in ? p2[(size_t)gy * W + gx] : 0.f;
+    { // tile + halo: every load of the thread is requested before the first LDS store (three trips to memory otherwise)
+        constexpr int NI = (HS * HS + TS * TS - 1) / (TS * TS);
+        float va[NI], vb[NI];
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            const int i = tid + j * TS * TS, y = i / HS, x = i - y * HS, gy = y0 + y - R, gx = x0 + x - R;
+            const bool in = i < HS * HS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            va[j] = in ? p1[(size_t)gy * W + gx] : 0.f;
+            vb[j] = in ? p2[(size_t)gy * W + gx] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            const int i = tid + j * TS * TS, y = i / HS, x = i - y * HS;
+            if (i < HS * HS) { a[y][x] = va[j]; b[y][x] = vb[j]; }
+        }
     }
     __syncthreads();
     const float own1 = MAPLOSS ? a[ty + R][tx + R] : 0.f, own2 = MAPLOSS ? b[ty + R][tx + R] : 0.f; // (the tiles are overwritten below)
-    for (int i = tid; i < HS * (TS / 4); i += TS * TS) { // row pass: five window sums per (halo row, column), four columns per thread
-        const int y = i / (TS / 4), xg = (i - y * (TS / 4)) * 4;
-        float pa[2 * R + 4], pb[2 * R + 4];
+    // row pass: five window sums per (halo row, column). GSR_SSIM_RO neighbouring columns per thread from one sliding register window
+    // (four: 104 work items, two of the workgroup's four waves; two: 208, all four), the three products formed once per input.
+#ifndef GSR_SSIM_RO
+#define GSR_SSIM_RO 4 // (plain kernel at 1200x680x3: 32.4 us with four, 33.1 with two; 34.7 before the products were hoisted and the loads batched)
+#endif
+    constexpr int RO = GSR_SSIM_RO;
+    for (int i = tid; i < HS * (TS / RO); i += TS * TS) {
+        const int y = i / (TS / RO), xg = (i - y * (TS / RO)) * RO;
+        float pa[2 * R + RO], pb[2 * R + RO], paa[2 * R + RO], pbb[2 * R + RO], pab[2 * R + RO];
 #pragma unroll
-        for (int k = 0; k < 2 * R + 4; k++) { pa[k] = a[y][xg + k]; pb[k] = b[y][xg + k]; }
+        for (int k = 0; k < 2 * R + RO; k++) { pa[k] = a[y][xg + k]; pb[k] = b[y][xg + k]; }
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
+        for (int k = 0; k < 2 * R + RO; k++) { paa[k] = pa[k] * pa[k]; pbb[k] = pb[k] * pb[k]; pab[k] = pa[k] * pb[k]; }
+#pragma unroll
+        for (int o = 0; o < RO; o++) {
             float s1 = 0.f, s2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
 #pragma unroll
             for (int k = 0; k <= 2 * R; k++) {
-                const float p = pa[o + k], q = pb[o + k], g = taps.g[k];
-                s1 = fmaf(g, p, s1); s2 = fmaf(g, q, s2);
-                s11 = fmaf(g, p * p, s11); s22 = fmaf(g, q * q, s22); s12 = fmaf(g, p * q, s12);
+                const float g = taps.g[k];
+                s1 = fmaf(g, pa[o + k], s1); s2 = fmaf(g, pb[o + k], s2);
+                s11 = fmaf(g, paa[o + k], s11); s22 = fmaf(g, pbb[o + k], s22); s12 = fmaf(g, pab[o + k], s12);
             }
             h[0][y][xg + o] = s1; h[1][y][xg + o] = s2; h[2][y][xg + o] = s11; h[3][y][xg + o] = s22; h[4][y][xg + o] = s12;
         }
@@ -194,12 +212,25 @@ K_ssim_bwd(const float* __restrict__ img1, const float* __restrict__ img2, const
         if (mg.depth) l_dep = mg.depth[pix];
         l_cnt = mg.sums[2];
     }
-    for (int i = tid; i < HS * HS; i += TS * TS) {
-        const int y = i / HS, x = i - y * HS, gy = y0 + y - R, gx = x0 + x - R;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const size_t o = c * plane + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+    { // tile + halo of the three maps: every load of the thread is requested before the first LDS store
+        constexpr int NI = (HS * HS + TS * TS - 1) / (TS * TS);
+        float vd[NI][3];
 #pragma unroll
-        for (int q = 0; q < 3; q++) d[q][y][x] = in ? dmaps[q * N + o] : 0.f;
+        for (int j = 0; j < NI; j++) {
+            const int i = tid + j * TS * TS, y = i / HS, x = i - y * HS, gy = y0 + y - R, gx = x0 + x - R;
+            const bool in = i < HS * HS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const size_t o = c * plane + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
+#pragma unroll
+            for (int q = 0; q < 3; q++) vd[j][q] = in ? dmaps[q * N + o] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            const int i = tid + j * TS * TS, y = i / HS, x = i - y * HS;
+            if (i < HS * HS) {
+#pragma unroll
+                for (int q = 0; q < 3; q++) d[q][y][x] = vd[j][q];
+            }
+        }
     }
     __syncthreads();
     for (int i = tid; i < 3 * HS * (TS / 4); i += TS * TS) { // row pass: (map, halo row, four columns) per thread

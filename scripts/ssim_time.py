@@ -1,0 +1,26 @@
+"""The SSIM kernels alone at 1200x680x3 (the plain pair gsr_ssim_forward / gsr_ssim_backward through capi.ssim_mean's pieces): us per launch
+between torch events over 200 launches each, clocks up first. GSR_LIB_OVERRIDE picks the library."""
+import sys, os, ctypes as C, numpy as np, torch
+R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,R); sys.path.insert(0,R+'/tests')
+from conftest import load_package
+gsr=load_package(); capi=gsr.capi; L=capi.lib()
+H,W,Cc=680,1200,3
+torch.manual_seed(0)
+a=torch.rand(Cc,H,W,device='cuda'); b=(a+0.1*torch.randn_like(a)).clamp(0,1)
+taps=gsr.harness._ssim_taps() if hasattr(gsr,'harness') and hasattr(gsr.harness,'_ssim_taps') else None
+if taps is None:
+    x=np.arange(11)-5; g=np.exp(-x**2/(2*1.5**2)); taps=(g/g.sum()).tolist()
+tp=(C.c_float*11)(*[float(x) for x in taps])
+partial=torch.empty((int(L.gsr_ssim_partials(Cc,H,W)),),device='cuda'); dmaps=torch.empty(3,Cc,H,W,device='cuda'); out=torch.empty_like(a); g1=torch.ones(1,device='cuda')
+p=capi._p; st=capi._stream
+def fwd(): capi._check(L.gsr_ssim_forward(p(a),p(b),Cc,H,W,tp,p(partial),p(dmaps),st()))
+def bwd(): capi._check(L.gsr_ssim_backward(p(a),p(b),p(dmaps),Cc,H,W,tp,p(g1),p(out),st()))
+for _ in range(300): fwd(); bwd()
+torch.cuda.synchronize()
+res={}
+for name,fn in (("fwd",fwd),("bwd",bwd)):
+    e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(200): fn()
+    e1.record(); torch.cuda.synchronize(); res[name]=e0.elapsed_time(e1)/200*1e3
+print(os.environ.get('GSR_LIB_OVERRIDE','default'), "ssim fwd %.1f us  bwd %.1f us   (sum %.6f)"%(res['fwd'],res['bwd'],float(partial.sum())/(Cc*H*W)))
