@@ -149,8 +149,12 @@ int forward_head(const gsr_forward_args* a, char* geom, char* image, hipStream_t
     tm.begin(GSR_FWD_SCAN);
     const BinGrid bg = bin_grid(P, T, 1, GSR_BIN_WINDOW);
     hipLaunchKernelGGL(gsr::K_bin_count, bg.grid, dim3(GSR_BIN_THREADS), (size_t)bg.twmax * 4, st, P, bg.per, T, f.grid_x, bg.wx, bg.nwin, *gv, iv->binmat);
-    hipLaunchKernelGGL(gsr::K_bin_colscan, dim3((T + 31) / 32), dim3(1024), 0, st, bg.rows, T, iv->binmat, iv->tile_cnt);
+#ifdef GSR_SEPARATE_SCAN // (the two-launch form)
+    hipLaunchKernelGGL(gsr::K_bin_colscan, dim3((T + 31) / 32), dim3(1024), 0, st, bg.rows, T, iv->binmat, iv->tile_cnt, (uint32_t*)nullptr, (uint2*)nullptr, gv->hdr, capacity);
     hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, T, iv->tile_cnt, 1, iv->tile_start, 1, iv->ranges, gv->hdr, capacity);
+#else
+    hipLaunchKernelGGL(gsr::K_bin_colscan, dim3((T + 31) / 32), dim3(1024), 0, st, bg.rows, T, iv->binmat, iv->tile_cnt, iv->tile_start, iv->ranges, gv->hdr, capacity);
+#endif
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SCAN);
     *fo = f;

@@ -43,7 +43,9 @@ struct GeomHeader {
     uint32_t num_rendered;
     uint32_t overflow;
     uint32_t capacity;
-    uint32_t pad[61];
+    uint32_t pad[8];   // (the instrumented builds count here)
+    uint32_t ticket;   // K_bin_colscan's arrival counter (zeroed by K_preprocess): the last workgroup to arrive scans the tile counts
+    uint32_t pad2[52];
 };
 static_assert(sizeof(GeomHeader) == 256, "header is one aligned slot");
 

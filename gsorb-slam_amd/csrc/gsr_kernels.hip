@@ -6,8 +6,7 @@
 //   K_bin_count    per range : LDS histogram of the tiles a contiguous range of splats covers -> one row of the
 //                              count matrix (gsr_device.h)
 //   K_bin_colscan  per column: exclusive scan down the matrix columns, column totals = tile counts
-//   K_scan_tiles   1 block   : counts -> segment starts, ranges, num_rendered, overflow flag, queues of the tiles with
-//                              more than 1024 / 4096 list entries
+//   (tile scan)    last workgroup of K_bin_colscan: counts -> segment starts, ranges, num_rendered, overflow flag
 //   K_bin_fill     per range : (depth bits<<32 | id) into the list slot an LDS cursor hands out (no global atomics)
 //   K_tile_sort_all per tile : one launch: bucket sort by depth in LDS with exact in-bin ranking (one wave per short
 //                              list, 256 threads for the queued longer ones, lists over 4096 through global scratch),
@@ -77,6 +76,7 @@ __global__ void __launch_bounds__(GSR_PRE_THREADS)
 K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomView g)
 {
     const int idx = blockIdx.x * GSR_PRE_THREADS + threadIdx.x;
+    if (idx == 0) g.hdr->ticket = 0u; // (K_bin_colscan's arrival counter: a launch boundary lies between this store and its first use)
     if (idx >= f.P) return;
     float3 p = make_float3(in.means3D[3 * (size_t)idx], in.means3D[3 * (size_t)idx + 1], in.means3D[3 * (size_t)idx + 2]);
     float cov[6];
@@ -261,43 +261,19 @@ K_bin_fill(int P, int per, int T, int grid_x, int wx, int nwin, GeomView g, cons
     bin_walk(P, per, grid_x, w, g.slots, [&](int t, uint64_t key) { pairs[lds_take(&s_bin[t])] = key; });
 }
 
-// Exclusive scan down the columns of the count matrix, in place; column totals -> tile_cnt. One workgroup takes
-// 32 tiles x 32 row groups (a wave reads two 128-byte row segments per load), every thread keeps its <= 16 rows
-// in registers between the two passes.
-__global__ void __launch_bounds__(1024)
-K_bin_colscan(int rows, int T, uint32_t* __restrict__ binmat, uint32_t* __restrict__ tile_cnt)
-{
-    __shared__ uint32_t part[32][33];
-    static_assert(GSR_BIN_ROWS <= 32 * 16, "rows per thread");
-    const int c = threadIdx.x & 31, q = threadIdx.x >> 5, t = blockIdx.x * 32 + c;
-    const int rper = (rows + 31) / 32, r0 = q * rper, r1 = min(rows, r0 + rper);
-    uint32_t v[16];
-    uint32_t sum = 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        v[j] = (t < T && r0 + j < r1) ? binmat[(size_t)(r0 + j) * T + t] : 0u;
-        sum += v[j];
-    }
-    part[q][c] = sum;
-    __syncthreads();
-    uint32_t run = 0;
-    for (int k = 0; k < q; k++) run += part[k][c];
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        if (t < T && r0 + j < r1) binmat[(size_t)(r0 + j) * T + t] = run;
-        run += v[j];
-    }
-    if (q == 31 && t < T) tile_cnt[t] = run;
-}
-
 // One block: per-tile counts -> list segments (start), ranges, num_rendered and the overflow flag. Shared with the
 // k-NN path (buckets instead of tiles; its counters sit in padded records, hence the strides, in words).
-// (Measured and dropped: letting the last workgroup of K_bin_colscan run this scan — the device-scope release / acquire
-// fences of the hand-over cost 45 us, the separate launch 5.)
-__global__ void __launch_bounds__(1024)
-K_scan_tiles(int T, const uint32_t* __restrict__ cnt, int cnt_stride, uint32_t* __restrict__ start, int start_stride,
-             uint2* __restrict__ ranges, GeomHeader* __restrict__ hdr, uint32_t capacity)
+// (The rasterizer runs this scan inside K_bin_colscan's last workgroup since round 4 — write-through stores and a ticket instead of the
+// release / acquire fences whose L2 write-back cost the first attempt 45 us; this kernel serves the k-NN path and -DGSR_SEPARATE_SCAN.)
+// COHERENT: the counts were written by other workgroups of the SAME launch with write-through (sc1) stores: read them with agent-scope
+// loads (K_bin_colscan's last workgroup, above).
+template <bool COHERENT>
+__device__ __forceinline__ void scan_tiles_body(int T, const uint32_t* cnt, int cnt_stride, uint32_t* __restrict__ start, int start_stride,
+                                                uint2* __restrict__ ranges, GeomHeader* __restrict__ hdr, uint32_t capacity)
 {
+    auto ld = [&](size_t i) -> uint32_t {
+        return COHERENT ? __hip_atomic_load(cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : cnt[i];
+    };
     // each thread owns `per` consecutive tiles (its counts stay in registers when per <= 8), the block
     // scan is one shuffle scan per wave plus one over the 16 wave totals: two barriers in all
     __shared__ uint32_t wsum[16];
@@ -309,11 +285,11 @@ K_scan_tiles(int T, const uint32_t* __restrict__ cnt, int cnt_stride, uint32_t* 
     if (per <= 8) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            ks[j] = (j < per && b + j < e) ? cnt[(size_t)(b + j) * cnt_stride] : 0u;
+            ks[j] = (j < per && b + j < e) ? ld((size_t)(b + j) * cnt_stride) : 0u;
             s += ks[j];
         }
     } else {
-        for (int i = b; i < e; i++) s += cnt[(size_t)i * cnt_stride];
+        for (int i = b; i < e; i++) s += ld((size_t)i * cnt_stride);
     }
     uint32_t inc = s; // inclusive scan inside the wave
 #pragma unroll
@@ -341,7 +317,7 @@ K_scan_tiles(int T, const uint32_t* __restrict__ cnt, int cnt_stride, uint32_t* 
         for (int j = 0; j < 8; j++)
             if (j < per && b + j < e) emit(b + j, ks[j]);
     } else {
-        for (int i = b; i < e; i++) emit(i, cnt[(size_t)i * cnt_stride]);
+        for (int i = b; i < e; i++) emit(i, ld((size_t)i * cnt_stride));
     }
 #ifdef GSR_EXP_ROWFILL
     if (tid < 8) hdr->pad[tid] = 0u;
@@ -351,6 +327,58 @@ K_scan_tiles(int T, const uint32_t* __restrict__ cnt, int cnt_stride, uint32_t* 
         hdr->overflow = total > capacity ? 1u : 0u;
         hdr->capacity = capacity;
     }
+}
+
+__global__ void __launch_bounds__(1024)
+K_scan_tiles(int T, const uint32_t* __restrict__ cnt, int cnt_stride, uint32_t* __restrict__ start, int start_stride,
+             uint2* __restrict__ ranges, GeomHeader* __restrict__ hdr, uint32_t capacity)
+{
+    scan_tiles_body<false>(T, cnt, cnt_stride, start, start_stride, ranges, hdr, capacity);
+}
+
+// Exclusive scan down the columns of the count matrix, in place; column totals -> tile_cnt. One workgroup takes
+// 32 tiles x 32 row groups (a wave reads two 128-byte row segments per load), every thread keeps its <= 16 rows
+// in registers between the two passes.
+__global__ void __launch_bounds__(1024)
+K_bin_colscan(int rows, int T, uint32_t* __restrict__ binmat, uint32_t* tile_cnt, uint32_t* __restrict__ tile_start, uint2* __restrict__ ranges,
+              GeomHeader* hdr, uint32_t capacity)
+{
+    __shared__ uint32_t part[32][33];
+    __shared__ uint32_t s_ticket;
+    static_assert(GSR_BIN_ROWS <= 32 * 16, "rows per thread");
+    const int c = threadIdx.x & 31, q = threadIdx.x >> 5, t = blockIdx.x * 32 + c;
+    const int rper = (rows + 31) / 32, r0 = q * rper, r1 = min(rows, r0 + rper);
+    uint32_t v[16];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        v[j] = (t < T && r0 + j < r1) ? binmat[(size_t)(r0 + j) * T + t] : 0u;
+        sum += v[j];
+    }
+    part[q][c] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int k = 0; k < q; k++) run += part[k][c];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (t < T && r0 + j < r1) binmat[(size_t)(r0 + j) * T + t] = run;
+        run += v[j];
+    }
+    // The workgroup that finishes LAST also turns the tile counts into list segments (K_scan_tiles' work: one launch and its 5 us less). The hand-over
+    // follows the chip's rules for data that crosses workgroups inside a launch (8 XCDs, private L2s; MI355X guide, "inter-workgroup communication"): the counts
+    // are stored write-through at agent scope (sc1), every storing wave drains its stores, then ONE lane takes a ticket from a device-scope counter (zeroed by
+    // K_preprocess of the same forward); the workgroup holding the last ticket acquires once and reads the counts with agent-scope loads. No release fence
+    // (it would write back the XCD's L2: the 45 us of the first attempt at this fusion), and the matrix itself goes out with plain stores: the next LAUNCH reads it.
+    if (q == 31 && t < T) __hip_atomic_store(tile_cnt + t, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!tile_start) return; // (no scan wanted)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&hdr->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1u) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    scan_tiles_body<true>(T, tile_cnt, 1, tile_start, 1, ranges, hdr, capacity);
 }
 
 // the forward's capacity guess was too small: switch the header to the exact capacity before the tail re-runs
