@@ -590,6 +590,21 @@ int gsr_pixel_loss(const float* image, const float* depth, const float* sur, con
     return GSR_OK;
 }
 
+int gsr_track_loss(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb, const float* frame_depth,
+                   int H, int W, float sil_thr, const float* w3, float* partial, float* sums, float* dL_dimage, float* dL_ddepth, void* stream)
+{
+    if (!image || !frame_rgb || !frame_depth || !w3 || !partial || !sums || !dL_dimage || H <= 0 || W <= 0 || (!depth && !sur)) return GSR_EINVAL;
+    const size_t N = (size_t)H * W;
+    const gsr::LossPlanes p{image, depth, sur, sil, frame_rgb, frame_depth};
+    gsr::LossWeights w{{w3[0], w3[1], w3[2]}};
+    const int nb = (int)std::min<size_t>(GSR_LOSS_BLOCKS, (N + 255) / 256);
+    hipLaunchKernelGGL(gsr::K_track_loss, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, N, sil_thr, w, partial, dL_dimage, dL_ddepth);
+    GSR_LAUNCHED();
+    hipLaunchKernelGGL(gsr::K_loss_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, partial, nb, 0, N, w, depth ? 0 : 1, sums);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
 int gsr_pixel_loss_backward(const float* image, const float* depth, const float* sil, const float* frame_rgb, const float* frame_depth,
                             int H, int W, int mode, float sil_thr, const float* w3, const float* sums, const float* dL_dloss,
                             float* dL_dimage, float* dL_ddepth, void* stream)

@@ -254,9 +254,8 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
     for (int it = 0; it < iters; it++) {
         chk(gsr_to_camera(f(xyz), (size_t)d.n, f(d.Tcw), f(d.mc), st), "gsr_to_camera");
         direct_forward_();
-        chk(gsr_pixel_loss(img, dep, sur, sil, f(frame.rgb), f(frame.depth), H_, W_, 0, 0.99f, w3, f(d.loss_partial), f(d.sums), st), "gsr_pixel_loss"); // Render.cc:1088-1105
-        chk(gsr_pixel_loss_backward_add(img, dep, sil, f(frame.rgb), f(frame.depth), H_, W_, 0, 0.99f, w3, f(d.sums), nullptr, nullptr, f(d.g_image), f(d.g_ds), st),
-            "gsr_pixel_loss_backward_add");
+        // Render.cc:1088-1105: the masked L1 sums and their gradient planes, one pass over the render
+        chk(gsr_track_loss(img, dep, sur, sil, f(frame.rgb), f(frame.depth), H_, W_, 0.99f, w3, f(d.loss_partial), f(d.sums), f(d.g_image), f(d.g_ds), st), "gsr_track_loss");
         direct_backward_(true, true, nullptr); // the [z, 1, 0] colours are detached while tracking (Render.cc:949-981)
         chk(gsr_pose_grad(f(xyz), f(d.d_mc), (size_t)d.n, f(d.Tcw), f(d.pose_partial), nullptr, st), "gsr_pose_grad");
         gsr_pose_update_args u{};

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 5 /* 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
+#define GSR_ABI_VERSION 6 /* 6: gsr_track_loss added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
                            * 5: gsr_map_prepare / gsr_map_update / gsr_map_loss_total / gsr_pose_update / gsr_pixel_loss_backward_add / gsr_composite_* added, GSR_LOSS_PARTIALS 256 -> 1024 */
 
 #define GSR_OK 0
@@ -273,6 +273,11 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int gsr_pixel_loss(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb,
                    const float* frame_depth, int H, int W, int mode, float sil_thr, const float* w3 /* host, 3 floats */,
                    float* partial, float* sums, void* stream);
+/* gsr_pixel_loss (mode 0) and gsr_pixel_loss_backward (mode 0, upstream gradient 1) in ONE pass over the render: a tracking iteration's loss and its gradient
+ * planes from the same loads (src/Render.cc:1088-1105: masked L1 SUMS; the gradient needs no total). sums [8] as gsr_pixel_loss, dL_dimage [3,H,W],
+ * dL_ddepth [H,W] (NULL: not wanted; zeros when depth == NULL: the median depth carries no gradient). */
+int gsr_track_loss(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb, const float* frame_depth,
+                   int H, int W, float sil_thr, const float* w3 /* host */, float* partial, float* sums, float* dL_dimage, float* dL_ddepth, void* stream);
 int gsr_pixel_loss_backward(const float* image, const float* depth, const float* sil, const float* frame_rgb, const float* frame_depth,
                             int H, int W, int mode, float sil_thr, const float* w3 /* host */, const float* sums,
                             const float* dL_dloss, float* dL_dimage, float* dL_ddepth, void* stream);

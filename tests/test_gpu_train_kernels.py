@@ -197,6 +197,33 @@ def test_fused_tracking_loss_matches_the_masked_l1_sums(gsr, shape, surface):
         assert torch.equal(di.grad.cpu(), (2.0 * d.grad).float())
 
 
+@pytest.mark.parametrize("surface", [False, True])
+def test_one_pass_tracking_loss_equals_the_two_kernels(gsr, surface):
+    """gsr_track_loss (the direct tracking loop's: sums and gradient planes from one pass over the render) against gsr_pixel_loss +
+    gsr_pixel_loss_backward_add, and against the float64 tensor expression."""
+    import ctypes as C
+    H, W = 680, 1200
+    img, dep, sur, sil, frgb, fd = (t.cuda().contiguous() for t in _loss_inputs(H, W, 5))
+    fd[::7, ::5] = float("nan")
+    L = gsr.lib(); p = gsr.capi._p; st = gsr.capi._stream
+    w3 = (C.c_float * 3)(0.5, 1.25, 0.0)
+    z = lambda *sh: torch.full(sh, 7.0, device="cuda")               # (garbage in every output)
+    part_a, sums_a, gi_a, gd_a = z(1024 * 5), z(8), z(3, H, W), z(H, W)
+    part_b, sums_b, gi_b, gd_b = z(1024 * 5), z(8), z(3, H, W), z(H, W)
+    d_ptr, s_ptr = (None, p(sur)) if surface else (p(dep), None)
+    gsr.capi._check(L.gsr_pixel_loss(p(img), d_ptr, s_ptr, p(sil), p(frgb), p(fd), H, W, 0, 0.99, w3, p(part_a), p(sums_a), st()))
+    gsr.capi._check(L.gsr_pixel_loss_backward_add(p(img), d_ptr, p(sil), p(frgb), p(fd), H, W, 0, 0.99, w3, p(sums_a), None, None, p(gi_a), p(gd_a), st()))
+    gsr.capi._check(L.gsr_track_loss(p(img), d_ptr, s_ptr, p(sil), p(frgb), p(fd), H, W, 0.99, w3, p(part_b), p(sums_b), p(gi_b), p(gd_b), st()))
+    torch.cuda.synchronize()
+    assert torch.equal(sums_a, sums_b) and torch.equal(gi_a, gi_b) and torch.equal(gd_a, gd_b)
+    certain = (sil.double() > 0.99) & ~torch.isnan(fd)
+    dd = (sur if surface else dep).double()
+    ref = 0.5 * torch.where(certain.unsqueeze(0).expand(3, H, W), (img.double() - frgb.double()).abs(), torch.zeros(3, H, W, device="cuda", dtype=torch.float64)).sum() \
+        + 1.25 * torch.where(certain, (dd - fd.double()).abs(), torch.zeros_like(dd)).sum()
+    assert abs(float(sums_b[5]) - float(ref)) <= 2e-5 * abs(float(ref))
+    assert float(gd_b.abs().max()) == (0.0 if surface else 1.25)
+
+
 @pytest.mark.parametrize("shape", [(37, 53), (680, 1200)])
 def test_fused_mapping_pixel_loss_matches_the_masked_means(gsr, shape):
     H, W = shape
