@@ -52,7 +52,10 @@ K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int H
 {
     constexpr int TS = GSR_SSIM_TILE, HS = GSR_SSIM_HALO, R = GSR_SSIM_R;
     // Both passes slide a register window (round 4): a thread forms FOUR neighbouring outputs from 14 inputs it reads once — 3.1 LDS reads
-    // per output and tap-window instead of 11; the kernel is bound by LDS reads (one output per thread and pass: 40 us at 1200x680x3).
+    // per output and tap-window instead of 11 (one output per thread and pass: 40 us at 1200x680x3). Where the 32.4 us of today go (variant
+    // builds, scripts/ssim_time.py): without the tile loads 24.8, without the row pass 27.5, without the column pass 29.9, without all three
+    // 12.5 — the skeleton (LDS fill, barriers, the SSIM map and its three derivative maps: 29 MB of stores) is the largest part, the two
+    // passes together cost 7 us: a better convolution cannot halve this kernel.
     __shared__ float ab[2][HS][HS + 1];        // the two images' tile + halo; dead after the row pass: the column sums vv alias it
     __shared__ float h[5][HS][TS + 1];
     __shared__ float wsum[TS * TS / 64];
