@@ -591,17 +591,21 @@ int gsr_pixel_loss(const float* image, const float* depth, const float* sur, con
 }
 
 int gsr_track_loss(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb, const float* frame_depth,
-                   int H, int W, float sil_thr, const float* w3, float* partial, float* sums, float* dL_dimage, float* dL_ddepth, void* stream)
+                   int H, int W, float sil_thr, const float* w3, float* partial, float* sums, float* dL_dimage, float* dL_ddepth, uint32_t* ticket,
+                   void* stream)
 {
     if (!image || !frame_rgb || !frame_depth || !w3 || !partial || !sums || !dL_dimage || H <= 0 || W <= 0 || (!depth && !sur)) return GSR_EINVAL;
     const size_t N = (size_t)H * W;
     const gsr::LossPlanes p{image, depth, sur, sil, frame_rgb, frame_depth};
     gsr::LossWeights w{{w3[0], w3[1], w3[2]}};
     const int nb = (int)std::min<size_t>(GSR_LOSS_BLOCKS, (N + 255) / 256);
-    hipLaunchKernelGGL(gsr::K_track_loss, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, N, sil_thr, w, partial, dL_dimage, dL_ddepth);
+    static_assert(GSR_FINISH_THREADS == 256, "the last workgroup of K_track_loss runs the finish");
+    hipLaunchKernelGGL(gsr::K_track_loss, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, N, sil_thr, w, partial, dL_dimage, dL_ddepth, ticket, depth ? 0 : 1, sums);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_loss_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, partial, nb, 0, N, w, depth ? 0 : 1, sums);
-    GSR_LAUNCHED();
+    if (!ticket) {
+        hipLaunchKernelGGL(gsr::K_loss_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, partial, nb, 0, N, w, depth ? 0 : 1, sums);
+        GSR_LAUNCHED();
+    }
     return GSR_OK;
 }
 
@@ -752,7 +756,8 @@ int gsr_map_loss_backward(const float* image, const float* depth, const float* f
     return GSR_OK;
 }
 
-int gsr_pose_update(const gsr_pose_update_args* a, void* stream)
+namespace {
+int make_pose_update(const gsr_pose_update_args* a, gsr::PoseUpdate* out)
 {
     if (!a || !a->quat_trans || !a->moments || !a->best || !a->history || !a->Tcw || !a->partial || !a->loss || a->step < 1) return GSR_EINVAL;
     gsr::PoseUpdate u;
@@ -761,7 +766,28 @@ int gsr_pose_update(const gsr_pose_update_args* a, void* stream)
     const double bc1 = 1.0 - std::pow(a->beta1, (double)a->step), bc2 = 1.0 - std::pow(a->beta2, (double)a->step);
     u.w1 = (float)(1.0 - a->beta1); u.b2 = (float)a->beta2; u.w2 = (float)(1.0 - a->beta2); u.eps = (float)a->eps;
     u.step_size = (float)(a->lr / bc1); u.sqrt_bias2 = (float)std::sqrt(bc2);
+    *out = u;
+    return GSR_OK;
+}
+} // namespace
+
+int gsr_pose_update(const gsr_pose_update_args* a, void* stream)
+{
+    gsr::PoseUpdate u;
+    const int rc = make_pose_update(a, &u);
+    if (rc != GSR_OK) return rc;
     hipLaunchKernelGGL(gsr::K_pose_update, dim3(1), dim3(64), 0, (hipStream_t)stream, u);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_pose_step(const float* means3D, const float* dL_dmeans_cam, size_t n, const gsr_pose_update_args* a, uint32_t* ticket, void* stream)
+{
+    gsr::PoseUpdate u;
+    const int rc = make_pose_update(a, &u);
+    if (rc != GSR_OK) return rc;
+    if (!ticket || (n > 0 && (!means3D || !dL_dmeans_cam))) return GSR_EINVAL;
+    hipLaunchKernelGGL(gsr::K_pose_step, dim3(GSR_POSE_BLOCKS), dim3(256), 0, (hipStream_t)stream, means3D, dL_dmeans_cam, n, const_cast<float*>(a->partial), ticket, u);
     GSR_LAUNCHED();
     return GSR_OK;
 }

@@ -35,6 +35,24 @@ __device__ __forceinline__ float wave_sum_lane63(float v)
     return v;
 }
 
+// "Am I the last workgroup of this launch to arrive?" for kernels that finish their own partial sums (K_track_loss, K_pose_step). Called by ONE
+// thread after the workgroup's write-through stores have drained (s_waitcnt vmcnt(0) in every storing wave + __syncthreads()). One counter word
+// takes ~11 ns per arrival (512-1024 workgroups on one word: 6-11 us, measured), so the arrivals are sharded: the workgroups with the same
+// blockIdx.x % 8 (one XCD's, as the dispatcher places them) share a word, the last of each shard arrives at the top word. tickets: GSR_TICKET_WORDS
+// device words, zero between launches (the last arrivers put them back); words 64 bytes apart.
+#define GSR_TICKET_STRIDE 16
+#define GSR_TICKET_WORDS (9 * GSR_TICKET_STRIDE)
+__device__ __forceinline__ bool last_arriver(uint32_t* tickets, const uint32_t nblocks)
+{
+    const uint32_t grp = blockIdx.x & 7u, members = (nblocks - grp + 7u) >> 3, ngroups = nblocks < 8u ? nblocks : 8u;
+    uint32_t* const mine = tickets + (1u + grp) * GSR_TICKET_STRIDE;
+    if (__hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != members - 1u) return false;
+    __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_fetch_add(tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ngroups - 1u) return false;
+    __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 // MAPLOSS (round 4): the pixel terms of the mapping loss (K_loss_sums, mode 1: colour L1, masked depth L1, masked surface-depth L1 and their
 // counts) ride on the SSIM pass, which has both images' pixels in its hands anyway: a row of six partial sums per workgroup
 // {SSIM map, |image - rgb|, |depth - fd| over fd > 0, its count, |sur - fd| over fd > 0 && sil > thr, its count} (the depth planes by the
@@ -344,9 +362,12 @@ K_to_camera(const float* __restrict__ X, size_t n, const float* __restrict__ Tcw
     mc[3 * i + 2] = fmaf(T.r[8], z, fmaf(T.r[7], y, T.r[6] * x)) + T.t[2];
 }
 // backward: twelve pose sums per workgroup (if partial) and dL/dX = dmc R (if dX)
-__global__ void __launch_bounds__(256)
-K_pose_grad(const float* __restrict__ X, const float* __restrict__ dmc, size_t n, const float* __restrict__ Tcw,
-            float* __restrict__ partial, float* __restrict__ dX)
+struct PoseUpdate;
+template <bool COHERENT>
+__device__ void pose_update_body(const PoseUpdate& u, int nrows);
+template <bool STEP>
+__device__ __forceinline__ void pose_grad_body(const float* __restrict__ X, const float* __restrict__ dmc, size_t n, const float* Tcw,
+                                               float* partial, float* __restrict__ dX, uint32_t* ticket, const PoseUpdate* u)
 {
     const Pose34 T = load_pose(Tcw);
     __shared__ float ws[4][12];
@@ -391,7 +412,30 @@ K_pose_grad(const float* __restrict__ X, const float* __restrict__ dmc, size_t n
         for (int q = 0; q < 12; q++) ws[threadIdx.x >> 6][q] = a[q];
     }
     __syncthreads();
-    if (threadIdx.x < 12) partial[blockIdx.x * 12 + threadIdx.x] = (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]);
+    const float row = threadIdx.x < 12 ? (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]) : 0.f;
+    if (!STEP) {
+        if (threadIdx.x < 12) partial[blockIdx.x * 12 + threadIdx.x] = row;
+        return;
+    }
+    // STEP: the workgroup that arrives last takes the pose step (K_pose_update's work, one launch less) — write-through stores of the rows, every
+    // storing wave drains them, a ticket per workgroup, one acquire by the holder of the last one: the hand-over of K_bin_colscan (gsr_kernels.hip).
+    // Every workgroup has read Tcw by then (it arrives after its sums): the next iteration's matrix can be written.
+    __shared__ uint32_t s_ticket;
+    if (threadIdx.x < 12) __hip_atomic_store(partial + blockIdx.x * 12 + threadIdx.x, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = last_arriver(ticket, gridDim.x) ? 1u : 0u;
+    __syncthreads();
+    if (!s_ticket) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    if (threadIdx.x < 64) pose_update_body<true>(*u, (int)gridDim.x);
+}
+__global__ void __launch_bounds__(256)
+K_pose_grad(const float* __restrict__ X, const float* __restrict__ dmc, size_t n, const float* __restrict__ Tcw,
+            float* __restrict__ partial, float* __restrict__ dX)
+{
+    pose_grad_body<false>(X, dmc, n, Tcw, partial, dX, nullptr, nullptr);
 }
 
 // Pose from the optimiser's parameters, rt2T of the reference (include/Utils.h:56-77, src/Utils.cc:170-179): an
@@ -505,13 +549,41 @@ K_loss_sums(LossPlanes p, size_t N, int mode, float thr, float* __restrict__ par
 struct LossWeights {
     float w[3];
 };
+// COHERENT: the rows were written by other workgroups of the SAME launch with write-through (agent-scope) stores — the last workgroup of
+// K_track_loss to arrive runs this (the hand-over of K_bin_colscan, gsr_kernels.hip): read them with agent-scope loads.
+template <bool COHERENT>
+__device__ __forceinline__ void loss_finish_body(const float* partial, int nblocks, int mode, size_t N, LossWeights w, int depth_from_sur, float* __restrict__ sums,
+                                                 float (*ws)[5])
+{
+    const int lane = threadIdx.x;
+    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = lane; b < nblocks; b += GSR_FINISH_THREADS) {
+#pragma unroll
+        for (int q = 0; q < 5; q++) a[q] += COHERENT ? __hip_atomic_load(partial + b * 5 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : partial[b * 5 + q];
+    }
+    finish_sum<5>(a, ws);
+    if (lane == 0) {
+        float loss;
+        if (mode == 0) loss = w.w[0] * a[0] + w.w[1] * (depth_from_sur ? a[3] : a[1]);
+        else loss = w.w[0] * (a[0] / (3.f * (float)N)) + w.w[1] * (a[1] / fmaxf(a[2], 1.f)) + w.w[2] * (a[3] / fmaxf(a[4], 1.f)); // (an empty mask: 0, in the loss and in its gradient)
+        sums[0] = a[0]; sums[1] = a[1]; sums[2] = a[2]; sums[3] = a[3]; sums[4] = a[4]; sums[5] = loss; sums[6] = 0.f; sums[7] = 0.f;
+    }
+}
+__global__ void __launch_bounds__(GSR_FINISH_THREADS)
+K_loss_finish(const float* __restrict__ partial, int nblocks, int mode, size_t N, LossWeights w, int depth_from_sur, float* __restrict__ sums)
+{
+    __shared__ float ws[4][5];
+    loss_finish_body<false>(partial, nblocks, mode, N, w, depth_from_sur, sums, ws);
+}
 // A tracking iteration's loss in ONE pass over the render (round 4): K_loss_sums (mode 0) and K_loss_grad (mode 0, upstream gradient 1) read the same
 // planes — the tracking loss is a masked SUM, its gradient needs no total — so the partial sums and the gradient planes come out of the same loads
 // (one launch and 30 MB of reads less per iteration). Same expressions, same order of a thread's additions as the two kernels.
 __global__ void __launch_bounds__(256)
-K_track_loss(LossPlanes p, size_t N, float thr, LossWeights w, float* __restrict__ partial, float* __restrict__ dimage, float* __restrict__ ddepth)
+K_track_loss(LossPlanes p, size_t N, float thr, LossWeights w, float* partial, float* __restrict__ dimage, float* __restrict__ ddepth,
+             uint32_t* ticket, int depth_from_sur, float* __restrict__ sums)
 {
     __shared__ float ws[4][5];
+    __shared__ uint32_t s_ticket;
     float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (size_t)gridDim.x * 256) {
         const float fd = p.fdepth[i];
@@ -541,25 +613,23 @@ K_track_loss(LossPlanes p, size_t N, float thr, LossWeights w, float* __restrict
         for (int q = 0; q < 5; q++) ws[threadIdx.x >> 6][q] = a[q];
     }
     __syncthreads();
-    if (threadIdx.x < 5) partial[blockIdx.x * 5 + threadIdx.x] = (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]);
-}
-__global__ void __launch_bounds__(GSR_FINISH_THREADS)
-K_loss_finish(const float* __restrict__ partial, int nblocks, int mode, size_t N, LossWeights w, int depth_from_sur, float* __restrict__ sums)
-{
-    __shared__ float ws[4][5];
-    const int lane = threadIdx.x;
-    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int b = lane; b < nblocks; b += GSR_FINISH_THREADS) {
-#pragma unroll
-        for (int q = 0; q < 5; q++) a[q] += partial[b * 5 + q];
+    const float row = threadIdx.x < 5 ? (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]) : 0.f;
+    if (!ticket) { // the finish is a launch of its own (K_loss_finish)
+        if (threadIdx.x < 5) partial[blockIdx.x * 5 + threadIdx.x] = row;
+        return;
     }
-    finish_sum<5>(a, ws);
-    if (lane == 0) {
-        float loss;
-        if (mode == 0) loss = w.w[0] * a[0] + w.w[1] * (depth_from_sur ? a[3] : a[1]);
-        else loss = w.w[0] * (a[0] / (3.f * (float)N)) + w.w[1] * (a[1] / fmaxf(a[2], 1.f)) + w.w[2] * (a[3] / fmaxf(a[4], 1.f)); // (an empty mask: 0, in the loss and in its gradient)
-        sums[0] = a[0]; sums[1] = a[1]; sums[2] = a[2]; sums[3] = a[3]; sums[4] = a[4]; sums[5] = loss; sums[6] = 0.f; sums[7] = 0.f;
-    }
+    // The workgroup that arrives last adds the rows up (K_loss_finish's work, one launch less): write-through stores of the rows, every storing
+    // wave drains them, one ticket per workgroup from a device-scope counter, one acquire by the holder of the last one — the hand-over of
+    // K_bin_colscan (gsr_kernels.hip). The counter is zero between launches: the last arriver puts it back.
+    if (threadIdx.x < 5) __hip_atomic_store(partial + blockIdx.x * 5 + threadIdx.x, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = last_arriver(ticket, gridDim.x) ? 1u : 0u;
+    __syncthreads();
+    if (!s_ticket) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    loss_finish_body<true>(partial, (int)gridDim.x, 0, N, w, depth_from_sur, sums, ws);
 }
 // gradient planes: dL/dimage [3,H,W] and dL/ddepth [H,W] (nullptr: not wanted), times the upstream gradient *go
 __global__ void __launch_bounds__(256)
@@ -1051,10 +1121,10 @@ struct PoseUpdate {
     const uint32_t* overflow;
     float w1, b2, w2, eps, step_size, sqrt_bias2;
 };
-__global__ void __launch_bounds__(64)
-K_pose_update(PoseUpdate u)
+template <bool COHERENT>
+__device__ void pose_update_body(const PoseUpdate& u, const int nrows)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x; // (one wave: the threads 0..63 of the workgroup)
     // everything the single-thread tail needs is requested before the partial rows are summed (the tail's loads and stores may alias as
     // far as the compiler knows: left where they are used, they are ~40 dependent round trips: 9.5 us for a kernel that moves 25 KB)
     float pq[7], mm[7], vv[7];
@@ -1063,9 +1133,9 @@ K_pose_update(PoseUpdate u)
     const float best0 = u.best[0], loss_in = u.loss[0];
     const bool skip = u.overflow && *u.overflow;
     float a[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int b = lane; b < GSR_POSE_BLOCKS; b += 64) {
+    for (int b = lane; b < nrows; b += 64) {
 #pragma unroll
-        for (int q = 0; q < 12; q++) a[q] += u.partial[b * 12 + q];
+        for (int q = 0; q < 12; q++) a[q] += COHERENT ? __hip_atomic_load(u.partial + b * 12 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : u.partial[b * 12 + q];
     }
 #pragma unroll
     for (int q = 0; q < 12; q++) {
@@ -1114,6 +1184,17 @@ K_pose_update(PoseUpdate u)
         T[8] = 2.f * (x * z - r * y); T[9] = 2.f * (y * z + r * x); T[10] = 1.f - 2.f * (x * x + y * y); T[11] = t[2];
         T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
     }
+}
+__global__ void __launch_bounds__(64)
+K_pose_update(PoseUpdate u)
+{
+    pose_update_body<false>(u, GSR_POSE_BLOCKS);
+}
+// gsr_pose_grad and gsr_pose_update in one launch (the last workgroup of the sums takes the step)
+__global__ void __launch_bounds__(256)
+K_pose_step(const float* __restrict__ X, const float* __restrict__ dmc, size_t n, float* partial, uint32_t* ticket, PoseUpdate u)
+{
+    pose_grad_body<true>(X, dmc, n, u.Tcw, partial, nullptr, ticket, &u);
 }
 
 } // namespace gsr

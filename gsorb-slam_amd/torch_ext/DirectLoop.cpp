@@ -47,6 +47,7 @@ struct SlamLoop::Direct {
     torch::Tensor d_mc, d_m2d, d_col, d_opac, d_scale, d_rot;            // the rasterizer's gradients
     torch::Tensor loss_partial, sums, reg_partial, reg_out, neg_c, Tcw, bg, view, proj, campos, history;
     torch::Tensor pose, pose_moments, best, pose_partial;                // tracking: [7], [14], [8], [GSR_POSE_PARTIALS, 12]
+    torch::Tensor tickets;                                               // [2 * GSR_TICKET_WORDS] arrival counters of the kernels that finish their own sums (zero between launches)
     int64_t history_len = 0;
 };
 
@@ -74,6 +75,7 @@ void SlamLoop::ensure_direct_(int64_t history_len)
         d.proj = rasterizer_.raster_settings_.projmatrix.to(dev_, torch::kFloat32).contiguous();
         d.pose = torch::zeros({7}, fo); d.pose_moments = torch::zeros({14}, fo); d.best = torch::zeros({8}, fo);
         d.pose_partial = torch::empty({GSR_POSE_PARTIALS, 12}, fo);
+        d.tickets = torch::zeros({2 * GSR_TICKET_WORDS}, fo.dtype(torch::kInt32));
     }
     if (d.n != n) { // per map size
         d.n = n;
@@ -255,14 +257,15 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
         chk(gsr_to_camera(f(xyz), (size_t)d.n, f(d.Tcw), f(d.mc), st), "gsr_to_camera");
         direct_forward_();
         // Render.cc:1088-1105: the masked L1 sums and their gradient planes, one pass over the render
-        chk(gsr_track_loss(img, dep, sur, sil, f(frame.rgb), f(frame.depth), H_, W_, 0.99f, w3, f(d.loss_partial), f(d.sums), f(d.g_image), f(d.g_ds), st), "gsr_track_loss");
+        chk(gsr_track_loss(img, dep, sur, sil, f(frame.rgb), f(frame.depth), H_, W_, 0.99f, w3, f(d.loss_partial), f(d.sums), f(d.g_image), f(d.g_ds),
+                           reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()), st), "gsr_track_loss");
         direct_backward_(true, true, nullptr); // the [z, 1, 0] colours are detached while tracking (Render.cc:949-981)
-        chk(gsr_pose_grad(f(xyz), f(d.d_mc), (size_t)d.n, f(d.Tcw), f(d.pose_partial), nullptr, st), "gsr_pose_grad");
         gsr_pose_update_args u{};
         u.quat_trans = f(d.pose); u.moments = f(d.pose_moments); u.best = f(d.best); u.history = f(d.history) + it; u.Tcw = f(d.Tcw);
         u.partial = f(d.pose_partial); u.loss = f(d.sums) + 5; u.geom = b(d.geom);
         u.lr = cfg_.lr_cam_quat; u.beta1 = 0.9; u.beta2 = 0.999; u.eps = 1e-15; u.step = ++step;
-        chk(gsr_pose_update(&u, st), "gsr_pose_update");
+        // the pose sums and the step in one launch (the last workgroup of the sums takes the step)
+        chk(gsr_pose_step(f(xyz), f(d.d_mc), (size_t)d.n, &u, reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()) + GSR_TICKET_WORDS, st), "gsr_pose_step");
         const double lv = d.history.slice(0, it, it + 1).item<float>(); // Render.cc:1107: the loop looks at every loss
         if (std::isnan(lv) && direct_overflowed_()) { --step; --it; continue; } // the workspace has grown: take the iteration again
         history.push_back(lv);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 6 /* 6: gsr_track_loss added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
+#define GSR_ABI_VERSION 6 /* 6: gsr_track_loss, gsr_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
                            * 5: gsr_map_prepare / gsr_map_update / gsr_map_loss_total / gsr_pose_update / gsr_pixel_loss_backward_add / gsr_composite_* added, GSR_LOSS_PARTIALS 256 -> 1024 */
 
 #define GSR_OK 0
@@ -277,7 +277,9 @@ int gsr_pixel_loss(const float* image, const float* depth, const float* sur, con
  * planes from the same loads (src/Render.cc:1088-1105: masked L1 SUMS; the gradient needs no total). sums [8] as gsr_pixel_loss, dL_dimage [3,H,W],
  * dL_ddepth [H,W] (NULL: not wanted; zeros when depth == NULL: the median depth carries no gradient). */
 int gsr_track_loss(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb, const float* frame_depth,
-                   int H, int W, float sil_thr, const float* w3 /* host */, float* partial, float* sums, float* dL_dimage, float* dL_ddepth, void* stream);
+                   int H, int W, float sil_thr, const float* w3 /* host */, float* partial, float* sums, float* dL_dimage, float* dL_ddepth,
+                   uint32_t* ticket /* NULL, or GSR_TICKET_WORDS DEVICE words that are zero between calls (zero them once): the sums are then finished inside the same launch */,
+                   void* stream);
 int gsr_pixel_loss_backward(const float* image, const float* depth, const float* sil, const float* frame_rgb, const float* frame_depth,
                             int H, int W, int mode, float sil_thr, const float* w3 /* host */, const float* sums,
                             const float* dL_dloss, float* dL_dimage, float* dL_ddepth, void* stream);
@@ -364,6 +366,10 @@ typedef struct gsr_pose_update_args {
     int step;
 } gsr_pose_update_args;
 int gsr_pose_update(const gsr_pose_update_args* args, void* stream);
+/* gsr_pose_grad (the twelve pose sums of dL/dmeans_cam against the world-frame means) and gsr_pose_update in ONE launch: the workgroup of the sums
+ * that finishes last takes the step. args->partial: scratch [GSR_POSE_PARTIALS][12]; ticket: GSR_TICKET_WORDS DEVICE words that are zero between calls (zero them once). */
+#define GSR_TICKET_WORDS 144
+int gsr_pose_step(const float* means3D, const float* dL_dmeans_cam, size_t n, const gsr_pose_update_args* args, uint32_t* ticket, void* stream);
 
 /* ---- multi-GPU scheme B (scene shards; gsorb-slam_amd/sharded.py): compositing of the ranks' layers around the
  * two collectives of the forward and the one of the backward. The reference is single-GPU; north_star: "shard Gaussians across the GPUs,

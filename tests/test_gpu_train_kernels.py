@@ -213,9 +213,16 @@ def test_one_pass_tracking_loss_equals_the_two_kernels(gsr, surface):
     d_ptr, s_ptr = (None, p(sur)) if surface else (p(dep), None)
     gsr.capi._check(L.gsr_pixel_loss(p(img), d_ptr, s_ptr, p(sil), p(frgb), p(fd), H, W, 0, 0.99, w3, p(part_a), p(sums_a), st()))
     gsr.capi._check(L.gsr_pixel_loss_backward_add(p(img), d_ptr, p(sil), p(frgb), p(fd), H, W, 0, 0.99, w3, p(sums_a), None, None, p(gi_a), p(gd_a), st()))
-    gsr.capi._check(L.gsr_track_loss(p(img), d_ptr, s_ptr, p(sil), p(frgb), p(fd), H, W, 0.99, w3, p(part_b), p(sums_b), p(gi_b), p(gd_b), st()))
+    gsr.capi._check(L.gsr_track_loss(p(img), d_ptr, s_ptr, p(sil), p(frgb), p(fd), H, W, 0.99, w3, p(part_b), p(sums_b), p(gi_b), p(gd_b), None, st()))
     torch.cuda.synchronize()
     assert torch.equal(sums_a, sums_b) and torch.equal(gi_a, gi_b) and torch.equal(gd_a, gd_b)
+    # the sums finished inside the same launch (a ticket word that is zero between calls): three calls in a row, the word is put back every time
+    ticket = torch.zeros(144, dtype=torch.int32, device="cuda")   # GSR_TICKET_WORDS
+    for _ in range(3):
+        sums_c, part_c = z(8), z(1024 * 5)
+        gsr.capi._check(L.gsr_track_loss(p(img), d_ptr, s_ptr, p(sil), p(frgb), p(fd), H, W, 0.99, w3, p(part_c), p(sums_c), p(gi_b), p(gd_b), p(ticket), st()))
+        torch.cuda.synchronize()
+        assert torch.equal(sums_a, sums_c) and int(ticket.abs().sum()) == 0
     certain = (sil.double() > 0.99) & ~torch.isnan(fd)
     dd = (sur if surface else dep).double()
     ref = 0.5 * torch.where(certain.unsqueeze(0).expand(3, H, W), (img.double() - frgb.double()).abs(), torch.zeros(3, H, W, device="cuda", dtype=torch.float64)).sum() \
@@ -391,6 +398,33 @@ def test_pose_update_is_rt2T_backward_plus_adam_and_keeps_the_best_pose(gsr, hz)
     h = hist.cpu()
     assert float(h[0]) == 3.0 and float(h[1]) == 2.0 and bool(torch.isnan(h[2])) and float(h[3]) == 2.5
     assert float(best[0]) == 2.0 and (best[1:].cpu().double() - poses_before[1]).abs().max() < 2e-6
+
+
+def test_pose_step_equals_pose_grad_plus_pose_update(gsr):
+    """gsr_pose_step (the pose sums and the step in one launch: the last workgroup of the sums takes the step) against gsr_pose_grad followed by
+    gsr_pose_update on the same state, four iterations (a NaN loss among them): bit-identical pose, moments, best pose, history and matrix."""
+    import ctypes as C
+    L = gsr.lib(); p = gsr.capi._p; st = gsr.capi._stream
+    g = torch.Generator().manual_seed(11)
+    n = 300_001
+    X = torch.randn((n, 3), generator=g).cuda()
+    q0 = torch.tensor([0.9, 0.1, -0.2, 0.05]); t0 = torch.tensor([0.1, -0.2, 0.3])
+    mk = lambda: dict(pose=torch.cat([q0, t0]).cuda(), mom=torch.zeros(14, device="cuda"), best=torch.tensor([float("inf")] + [0.0] * 7, device="cuda"),
+                      hist=torch.zeros(4, device="cuda"), Tcw=torch.eye(4, device="cuda").reshape(16).clone(), part=torch.full((512, 12), 9.0, device="cuda"))
+    A, B = mk(), mk()
+    ticket = torch.zeros(144, dtype=torch.int32, device="cuda")   # GSR_TICKET_WORDS
+    for it, lv in enumerate([3.0, 2.0, float("nan"), 2.5]):
+        dmc = (torch.randn((n, 3), generator=g) * 1e-3).cuda()
+        loss = torch.tensor([lv], device="cuda")
+        gsr.capi._check(L.gsr_pose_grad(p(X), p(dmc), n, p(A["Tcw"]), p(A["part"]), None, st()))
+        gsr.capi.pose_update(A["pose"], A["mom"], A["best"], A["hist"][it:], A["Tcw"], A["part"], loss, 4e-4, it + 1)
+        a = gsr.capi.PoseUpdateArgs(p(B["pose"]), p(B["mom"]), p(B["best"]), p(B["hist"][it:]), p(B["Tcw"]), p(B["part"]), p(loss), None, 4e-4, 0.9, 0.999, 1e-15, it + 1)
+        gsr.capi._check(L.gsr_pose_step(p(X), p(dmc), n, C.byref(a), p(ticket), st()))
+        torch.cuda.synchronize()
+        assert int(ticket.abs().sum()) == 0
+        for k in ("pose", "mom", "best", "Tcw"):
+            assert torch.equal(A[k], B[k]), (it, k)
+    assert torch.equal(A["hist"].isnan(), B["hist"].isnan()) and torch.equal(A["hist"].nan_to_num(0.0), B["hist"].nan_to_num(0.0))
 
 
 @pytest.mark.parametrize("shape", [(37, 53), (680, 1200)])
