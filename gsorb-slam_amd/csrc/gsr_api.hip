@@ -600,6 +600,7 @@ int gsr_track_loss(const float* image, const float* depth, const float* sur, con
     gsr::LossWeights w{{w3[0], w3[1], w3[2]}};
     const int nb = (int)std::min<size_t>(GSR_LOSS_BLOCKS, (N + 255) / 256);
     static_assert(GSR_FINISH_THREADS == 256, "the last workgroup of K_track_loss runs the finish");
+    static_assert(GSR_TICKET_WORDS == GSR_TICKET_WORDS_DEV, "header and kernels agree on the arrival counters");
     hipLaunchKernelGGL(gsr::K_track_loss, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, N, sil_thr, w, partial, dL_dimage, dL_ddepth, ticket, depth ? 0 : 1, sums);
     GSR_LAUNCHED();
     if (!ticket) {

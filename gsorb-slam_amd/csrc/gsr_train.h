@@ -39,9 +39,9 @@ __device__ __forceinline__ float wave_sum_lane63(float v)
 // thread after the workgroup's write-through stores have drained (s_waitcnt vmcnt(0) in every storing wave + __syncthreads()). One counter word
 // takes ~11 ns per arrival (512-1024 workgroups on one word: 6-11 us, measured), so the arrivals are sharded: the workgroups with the same
 // blockIdx.x % 8 (one XCD's, as the dispatcher places them) share a word, the last of each shard arrives at the top word. tickets: GSR_TICKET_WORDS
-// device words, zero between launches (the last arrivers put them back); words 64 bytes apart.
+// (include/gsr.h) device words, zero between launches (the last arrivers put them back); words 64 bytes apart.
 #define GSR_TICKET_STRIDE 16
-#define GSR_TICKET_WORDS (9 * GSR_TICKET_STRIDE)
+#define GSR_TICKET_WORDS_DEV (9 * GSR_TICKET_STRIDE) // == GSR_TICKET_WORDS of include/gsr.h (checked in gsr_api.hip)
 __device__ __forceinline__ bool last_arriver(uint32_t* tickets, const uint32_t nblocks)
 {
     const uint32_t grp = blockIdx.x & 7u, members = (nblocks - grp + 7u) >> 3, ngroups = nblocks < 8u ? nblocks : 8u;
