@@ -60,7 +60,8 @@ class BackwardArgs(C.Structure):
                 ("dL_dcolor", C.c_void_p), ("dL_dmean3D", C.c_void_p), ("dL_dcov3D", C.c_void_p),
                 ("dL_dsh", C.c_void_p), ("dL_dscale", C.c_void_p), ("dL_drot", C.c_void_p),
                 ("profile_events", C.POINTER(C.c_void_p)), ("band_y0", C.c_int), ("band_y1", C.c_int),
-                ("stages", C.c_int), ("dL_dds", C.c_void_p), ("ds_detach_depth", C.c_int), ("fused_map_update", C.c_void_p), ("dds_depth_only", C.c_int)]
+                ("stages", C.c_int), ("dL_dds", C.c_void_p), ("ds_detach_depth", C.c_int), ("fused_map_update", C.c_void_p), ("dds_depth_only", C.c_int),
+                ("fused_pose_step", C.c_void_p)]
 
 
 class DebugArrays(C.Structure):
@@ -77,6 +78,10 @@ class MapUpdateArgs(C.Structure):
                 ("opacities", C.c_void_p), ("scales", C.c_void_p), ("Tcw", C.c_void_p), ("reg_out", C.c_void_p), ("reg_limit", C.c_float),
                 ("w_long", C.c_float), ("w_scalar", C.c_float), ("geom", C.c_void_p), ("lr", C.c_double * 5), ("beta1", C.c_double),
                 ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int * 5)]
+
+
+class PoseStepArgs(C.Structure):
+    _fields_ = [("means_world", C.c_void_p), ("update", C.c_void_p)]
 
 
 class PoseUpdateArgs(C.Structure):
@@ -366,7 +371,7 @@ def alloc_grads(P: int, M: int, dev, intermediates: bool = True) -> Grads:
 
 
 def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None, stages: int = 0, once: bool = False,
-             dL_dds=None, detach_depth_color: bool = False, fused_map_update=None, dds_depth_only: bool = False) -> Grads:
+             dL_dds=None, detach_depth_color: bool = False, fused_map_update=None, dds_depth_only: bool = False, fused_pose_step=None) -> Grads:
     """gsr_backward; output shapes follow src/Rasterizer.cu:253-261. `once`: the caller runs one backward per
     forward (blend + per-splat without the re-zero of the accumulators); a later call on the same state
     is then started with a clear. dL_dds [2,H,W]: upstream gradient of the fused depth / silhouette channels."""
@@ -394,7 +399,8 @@ def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None,
                      _p(out.dL_dscales) if has_sr else None, _p(out.dL_drotations) if has_sr else None, events,
                      int(st.band[0]), int(st.band[1]), int(stages), _p(gds), int(bool(detach_depth_color)),
                      C.c_void_p(C.addressof(fused_map_update)) if fused_map_update is not None else None,   # (a MapUpdateArgs: map_update_args())
-                     int(bool(dds_depth_only)))
+                     int(bool(dds_depth_only)),
+                     C.c_void_p(C.addressof(fused_pose_step)) if fused_pose_step is not None else None)       # (a PoseStepArgs)
     if stages & 4:
         st.dirty = not (stages & 8)
     with torch.cuda.device(dev):

@@ -322,6 +322,7 @@ int gsr_ws_status(const char* geom, void* stream, int* num_rendered, int* overfl
 }
 
 namespace {
+int make_pose_update(const gsr_pose_update_args* a, gsr::PoseUpdate* out);
 const uint32_t* overflow_flag(const char* geom)
 {
     return geom ? &reinterpret_cast<const GeomHeader*>(geom)->overflow : nullptr;
@@ -410,6 +411,18 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
             if (rc != GSR_OK) return rc;
             if (stages & GSR_STAGE_REZERO) hipLaunchKernelGGL((gsr::K_splat_bwd<true, true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
             else hipLaunchKernelGGL((gsr::K_splat_bwd<false, true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
+        } else if (a->fused_pose_step) { // the per-splat stage forms the pose sums and its last workgroup takes the pose step (include/gsr.h)
+            const gsr_pose_step_args* ps = a->fused_pose_step;
+            static_assert(GSR_POSE_ACC_ROWS * 12 <= GSR_POSE_PARTIALS * 12, "gsr_pose_grad's scratch holds the accumulator rows");
+            if (!ps->means_world) return GSR_EINVAL;
+            gsr::PoseUpdate u;
+            const int rc = make_pose_update(ps->update, &u);
+            if (rc != GSR_OK) return rc;
+            gsr::PoseStep k;
+            k.X = ps->means_world; k.acc = const_cast<float*>(ps->update->partial);
+            if (stages & GSR_STAGE_REZERO) hipLaunchKernelGGL((gsr::K_splat_bwd_pose<true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, k);
+            else hipLaunchKernelGGL((gsr::K_splat_bwd_pose<false>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, k);
+            hipLaunchKernelGGL(gsr::K_pose_finish, dim3(1), dim3(64), 0, st, u, k.acc);
         } else if (stages & GSR_STAGE_REZERO) hipLaunchKernelGGL((gsr::K_splat_bwd<true, false>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
         else hipLaunchKernelGGL((gsr::K_splat_bwd<false, false>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
         GSR_LAUNCHED();

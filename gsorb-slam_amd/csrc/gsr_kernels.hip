@@ -1196,10 +1196,11 @@ __device__ __forceinline__ void st3(float* p, size_t i, float a, float b, float 
 // FUSED (gsr_backward_args.fused_map_update): the gradients are not written — the Gaussian's raw parameters take their Adam step right
 // here (map_update_with, csrc/gsr_train.h: the activations' backward, the camera transform's, the regularisers' gradient), from registers:
 // 56 bytes written and 56 read per Gaussian and one launch less per mapping iteration than gsr_backward + gsr_map_update.
-template <bool REZERO, bool FUSED = false>
-__global__ void __launch_bounds__(256)
-K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, MapUpdate mu)
+// (the body of one thread; gmean: the splat's dL/dmean3D — zero for a splat that is culled or out of range — for K_splat_bwd_pose)
+template <bool REZERO, bool FUSED>
+__device__ __forceinline__ void splat_bwd_thread(const FrameParams& f, const SplatInputs& in, const GeomView& g, const SplatGrads& o, const MapUpdate& mu, float3& gmean)
 {
+    gmean = make_float3(0.f, 0.f, 0.f);
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= f.P) return;
     if (FUSED && mu.overflow && *mu.overflow) return; // (the forward rendered nothing: no step)
@@ -1365,6 +1366,7 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, MapUpdate m
         dmean.x += dm.x; dmean.y += dm.y; dmean.z += dm.z;
     }
     st3(o.dL_dmean3D, i, dmean.x, dmean.y, dmean.z);
+    gmean = dmean;
 
     // ---- 3D covariance -> scale, rotation (backward.cu:278-341) ----
     float ds3[3] = {0.f, 0.f, 0.f};
@@ -1409,6 +1411,64 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, MapUpdate m
     }
     st3(o.dL_dscale, i, ds3[0], ds3[1], ds3[2]);
     if (o.dL_drot) reinterpret_cast<float4*>(o.dL_drot)[i] = dq;
+}
+
+template <bool REZERO, bool FUSED = false>
+__global__ void __launch_bounds__(256)
+K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, MapUpdate mu)
+{
+    float3 gm;
+    splat_bwd_thread<REZERO, FUSED>(f, in, g, o, mu, gm);
+}
+
+// gsr_backward_args.fused_pose_step (a tracking iteration: the pose is the only parameter): the per-splat stage also forms the twelve pose sums of
+// dL/dmeans_cam against the WORLD-frame means (K_pose_grad's: dL/dR[i][j] = sum dmc[i] X[j], dL/dt = sum dmc) — the gradient is in registers, the
+// sums cost 12 bytes of loads per splat where gsr_pose_grad re-read 24 and this kernel wrote 12. Every workgroup ADDS its twelve sums to one of
+// GSR_POSE_ACC_ROWS accumulator rows (float atomics, fire and forget: the backward's sums are atomics' anyway), K_pose_finish adds the rows up, takes the
+// pose step (gsr_pose_update) and leaves the rows zero. (Measured first: the last workgroup taking the step — write-through rows, a ticket per
+// workgroup: 49 us against 28 + 17 for the two launches; 3 907 short-lived workgroups each wait for their stores and their ticket.)
+#define GSR_POSE_ACC_ROWS 64
+struct PoseStep {
+    const float* X;      // [P,3] world-frame means
+    float* acc;          // [GSR_POSE_ACC_ROWS][12], zero between launches
+};
+template <bool REZERO>
+__global__ void __launch_bounds__(256)
+K_splat_bwd_pose(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, PoseStep ps)
+{
+    __shared__ float ws[4][12];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    float x[3] = {0.f, 0.f, 0.f};
+    if (idx < f.P) { x[0] = ps.X[3 * (size_t)idx]; x[1] = ps.X[3 * (size_t)idx + 1]; x[2] = ps.X[3 * (size_t)idx + 2]; } // (requested before the body's loads)
+    float3 gm;
+    splat_bwd_thread<REZERO, false>(f, in, g, o, MapUpdate{}, gm);
+    float a[12] = {gm.x * x[0], gm.x * x[1], gm.x * x[2], gm.y * x[0], gm.y * x[1], gm.y * x[2], gm.z * x[0], gm.z * x[1], gm.z * x[2], gm.x, gm.y, gm.z};
+#pragma unroll
+    for (int q = 0; q < 12; q++) a[q] = wave_sum_lane63(a[q]);
+    if ((threadIdx.x & 63) == 63) {
+#pragma unroll
+        for (int q = 0; q < 12; q++) ws[threadIdx.x >> 6][q] = a[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const float row = (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]);
+        if (row != 0.f) unsafeAtomicAdd(ps.acc + (size_t)(blockIdx.x % GSR_POSE_ACC_ROWS) * 12 + threadIdx.x, row);
+    }
+}
+// adds the accumulator rows up, takes the pose step, leaves the rows zero for the next backward
+__global__ void __launch_bounds__(64)
+K_pose_finish(PoseUpdate u, float* acc)
+{
+    static_assert(GSR_POSE_ACC_ROWS == 64, "one accumulator row per lane");
+    float r[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) r[q] = acc[threadIdx.x * 12 + q];
+#pragma unroll
+    for (int q = 0; q < 12; q++) { acc[threadIdx.x * 12 + q] = 0.f; r[q] = wave_sum_lane63(r[q]); }
+    float tot[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) tot[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r[q]), 63));
+    pose_update_body<false>(u, 0, tot);
 }
 
 // ===================================================================================

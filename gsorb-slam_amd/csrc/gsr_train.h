@@ -364,7 +364,7 @@ K_to_camera(const float* __restrict__ X, size_t n, const float* __restrict__ Tcw
 // backward: twelve pose sums per workgroup (if partial) and dL/dX = dmc R (if dX)
 struct PoseUpdate;
 template <bool COHERENT>
-__device__ void pose_update_body(const PoseUpdate& u, int nrows);
+__device__ void pose_update_body(const PoseUpdate& u, int nrows, const float* presum = nullptr);
 template <bool STEP>
 __device__ __forceinline__ void pose_grad_body(const float* __restrict__ X, const float* __restrict__ dmc, size_t n, const float* Tcw,
                                                float* partial, float* __restrict__ dX, uint32_t* ticket, const PoseUpdate* u)
@@ -1121,8 +1121,9 @@ struct PoseUpdate {
     const uint32_t* overflow;
     float w1, b2, w2, eps, step_size, sqrt_bias2;
 };
+// presum: the twelve sums already added up (K_splat_bwd_pose's last workgroup), or nullptr: this wave adds the nrows rows of u.partial
 template <bool COHERENT>
-__device__ void pose_update_body(const PoseUpdate& u, const int nrows)
+__device__ void pose_update_body(const PoseUpdate& u, const int nrows, const float* presum)
 {
     const int lane = threadIdx.x; // (one wave: the threads 0..63 of the workgroup)
     // everything the single-thread tail needs is requested before the partial rows are summed (the tail's loads and stores may alias as
@@ -1141,6 +1142,10 @@ __device__ void pose_update_body(const PoseUpdate& u, const int nrows)
     for (int q = 0; q < 12; q++) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) a[q] += __shfl_xor(a[q], off, 64);
+    }
+    if (presum) {
+#pragma unroll
+        for (int q = 0; q < 12; q++) a[q] = presum[q];
     }
     if (lane != 0) return;
     float q[4] = {pq[0], pq[1], pq[2], pq[3]}, t[3] = {pq[4], pq[5], pq[6]};

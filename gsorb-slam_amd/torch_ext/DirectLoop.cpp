@@ -47,6 +47,7 @@ struct SlamLoop::Direct {
     torch::Tensor d_mc, d_m2d, d_col, d_opac, d_scale, d_rot;            // the rasterizer's gradients
     torch::Tensor loss_partial, sums, reg_partial, reg_out, neg_c, Tcw, bg, view, proj, campos, history;
     torch::Tensor pose, pose_moments, best, pose_partial;                // tracking: [7], [14], [8], [GSR_POSE_PARTIALS, 12]
+    torch::Tensor pose_acc;                                              // [64, 12] the fused pose step's accumulator rows (zero between launches)
     torch::Tensor tickets;                                               // [2 * GSR_TICKET_WORDS] arrival counters of the kernels that finish their own sums (zero between launches)
     int64_t history_len = 0;
 };
@@ -74,8 +75,8 @@ void SlamLoop::ensure_direct_(int64_t history_len)
         d.Tcw = torch::eye(4, fo); d.bg = torch::zeros({3}, fo); d.view = torch::eye(4, fo); d.campos = torch::zeros({3}, fo);
         d.proj = rasterizer_.raster_settings_.projmatrix.to(dev_, torch::kFloat32).contiguous();
         d.pose = torch::zeros({7}, fo); d.pose_moments = torch::zeros({14}, fo); d.best = torch::zeros({8}, fo);
-        d.pose_partial = torch::empty({GSR_POSE_PARTIALS, 12}, fo);
         d.tickets = torch::zeros({2 * GSR_TICKET_WORDS}, fo.dtype(torch::kInt32));
+        d.pose_acc = torch::zeros({64, 12}, fo);
     }
     if (d.n != n) { // per map size
         d.n = n;
@@ -85,6 +86,7 @@ void SlamLoop::ensure_direct_(int64_t history_len)
         d.d_mc = torch::empty({n, 3}, fo); d.d_m2d = torch::empty({n, 3}, fo); d.d_col = torch::empty({n, 3}, fo); d.d_opac = torch::empty({n}, fo);
         d.d_scale = torch::empty({n, 3}, fo); d.d_rot = torch::empty({n, 4}, fo);
         d.reg_partial = torch::empty({3 * ((n + 255) / 256) + 3}, fo);
+        d.pose_partial = torch::empty({GSR_POSE_PARTIALS, 12}, fo);
         d.binning = torch::Tensor(); d.binning_bytes = 0;
         grow_binning_(cfg_.binning_capacity > 0 ? (size_t)cfg_.binning_capacity : 4 * (size_t)n + 65536); // grows at the first synchronised look at an overflow
     }
@@ -115,7 +117,7 @@ void SlamLoop::direct_forward_()
     chk(gsr_forward_ws(&a, b(d.geom), b(d.binning), d.binning_bytes, b(d.image), stream_()), "gsr_forward_ws");
 }
 
-void SlamLoop::direct_backward_(bool detach_depth_colour, bool means_only, const ::gsr_map_update_args* fused)
+void SlamLoop::direct_backward_(bool detach_depth_colour, bool means_only, const ::gsr_map_update_args* fused, const ::gsr_pose_step_args* pose_step)
 {
     Direct& d = *d_;
     const auto& s = rasterizer_.raster_settings_;
@@ -129,7 +131,8 @@ void SlamLoop::direct_backward_(bool detach_depth_colour, bool means_only, const
     a.dL_dpix = f(d.g_image); a.dL_dds = f(d.g_ds); a.ds_detach_depth = detach_depth_colour ? 1 : 0;
     a.dds_depth_only = 1; // (the silhouette is a detached mask in both losses: plane 1 of g_ds would be zeros)
     a.fused_map_update = fused; // (the per-splat stage then takes the Adam step itself and writes no gradient)
-    if (!fused) a.dL_dmean3D = f(d.d_mc);
+    a.fused_pose_step = pose_step; // (tracking: the per-splat stage forms the pose sums and its last workgroup takes the pose step: no gradient tensor)
+    if (!fused && !pose_step) a.dL_dmean3D = f(d.d_mc);
     if (!means_only && !fused) { // (tracking optimises the pose only: the per-splat stage then skips the covariance -> scale / rotation chain and 56 bytes of stores per Gaussian)
         a.dL_dmean2D = f(d.d_m2d); a.dL_dopacity = f(d.d_opac); a.dL_dcolor = f(d.d_col);
         a.dL_dscale = f(d.d_scale); a.dL_drot = f(d.d_rot);
@@ -185,9 +188,9 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
     u.reg_out = f(d.reg_out); u.reg_limit = limit; u.w_long = wl; u.w_scalar = wsc;
     u.geom = b(d.geom); u.beta1 = 0.9; u.beta2 = 0.999; u.eps = fopt_->eps();
     if (cfg_.fused_update) {
-        direct_backward_(false, false, &u); // backward and update in the same per-splat pass (gsr_backward_args.fused_map_update)
+        direct_backward_(false, false, &u, nullptr); // backward and update in the same per-splat pass (gsr_backward_args.fused_map_update)
     } else {
-        direct_backward_(false, false, nullptr);
+        direct_backward_(false, false, nullptr, nullptr);
         chk(gsr_map_update(&u, st), "gsr_map_update");
     }
 }
@@ -259,13 +262,19 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
         // Render.cc:1088-1105: the masked L1 sums and their gradient planes, one pass over the render
         chk(gsr_track_loss(img, dep, sur, sil, f(frame.rgb), f(frame.depth), H_, W_, 0.99f, w3, f(d.loss_partial), f(d.sums), f(d.g_image), f(d.g_ds),
                            reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()), st), "gsr_track_loss");
-        direct_backward_(true, true, nullptr); // the [z, 1, 0] colours are detached while tracking (Render.cc:949-981)
         gsr_pose_update_args u{};
         u.quat_trans = f(d.pose); u.moments = f(d.pose_moments); u.best = f(d.best); u.history = f(d.history) + it; u.Tcw = f(d.Tcw);
         u.partial = f(d.pose_partial); u.loss = f(d.sums) + 5; u.geom = b(d.geom);
         u.lr = cfg_.lr_cam_quat; u.beta1 = 0.9; u.beta2 = 0.999; u.eps = 1e-15; u.step = ++step;
-        // the pose sums and the step in one launch (the last workgroup of the sums takes the step)
-        chk(gsr_pose_step(f(xyz), f(d.d_mc), (size_t)d.n, &u, reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()) + GSR_TICKET_WORDS, st), "gsr_pose_step");
+        uint32_t* const tickets = reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()) + GSR_TICKET_WORDS;
+        if (cfg_.fused_update) { // the backward's per-splat stage forms the pose sums (into accumulator rows that are zero between launches), a one-wave kernel takes the step: no dL/dmeans tensor
+            u.partial = f(d.pose_acc);
+            const gsr_pose_step_args ps{f(xyz), &u};
+            direct_backward_(true, true, nullptr, &ps); // the [z, 1, 0] colours are detached while tracking (Render.cc:949-981)
+        } else {
+            direct_backward_(true, true, nullptr, nullptr);
+            chk(gsr_pose_step(f(xyz), f(d.d_mc), (size_t)d.n, &u, tickets, st), "gsr_pose_step"); // the pose sums and the step in one launch
+        }
         const double lv = d.history.slice(0, it, it + 1).item<float>(); // Render.cc:1107: the loop looks at every loss
         if (std::isnan(lv) && direct_overflowed_()) { --step; --it; continue; } // the workspace has grown: take the iteration again
         history.push_back(lv);

@@ -15,6 +15,7 @@
 #include "Rasterizer.h"
 
 struct gsr_map_update_args; // include/gsr.h
+struct gsr_pose_step_args;  // include/gsr.h
 
 namespace ORB_SLAM2 {
 
@@ -105,7 +106,7 @@ private:
     void ensure_direct_(int64_t history_len);
     void grow_binning_(size_t capacity);
     void direct_forward_();
-    void direct_backward_(bool detach_depth_colour, bool means_only, const ::gsr_map_update_args* fused);
+    void direct_backward_(bool detach_depth_colour, bool means_only, const ::gsr_map_update_args* fused, const ::gsr_pose_step_args* pose_step);
     bool direct_overflowed_();
     void direct_map_iteration_(const LoopFrame& frame, float* loss_slot);
     std::vector<double> direct_track_(const LoopFrame& frame, const torch::Tensor& Tcw_init, int iters, torch::Tensor* Tcw_best);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 6 /* 6: gsr_track_loss, gsr_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
+#define GSR_ABI_VERSION 6 /* 6: gsr_track_loss, gsr_pose_step, gsr_backward_args.fused_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
                            * 5: gsr_map_prepare / gsr_map_update / gsr_map_loss_total / gsr_pose_update / gsr_pixel_loss_backward_add / gsr_composite_* added, GSR_LOSS_PARTIALS 256 -> 1024 */
 
 #define GSR_OK 0
@@ -183,6 +183,10 @@ typedef struct gsr_backward_args {
     /* non-zero: dL_dds holds ONE plane [1,H,W], the depth channel's upstream gradient; the silhouette's is zero (GSORB-SLAM's losses use the
      * silhouette only as a detached mask, src/Render.cc:436-471, :1088-1090): its recursion leaves the blend kernel's loop */
     int dds_depth_only;
+    /* Optional (NULL: off; not together with fused_map_update). A tracking iteration's backward (the pose is the only parameter; means3D = gsr_to_camera's
+     * means_cam with an identity view matrix): the per-splat stage also forms the pose sums of dL/dmeans_cam against the world-frame means (gsr_pose_grad)
+     * and a one-wave kernel behind it takes the pose step (gsr_pose_update): no dL_dmean3D tensor is needed (it is still written if given). */
+    const struct gsr_pose_step_args* fused_pose_step;
 } gsr_backward_args;
 
 #define GSR_STAGE_CLEAR 1
@@ -369,6 +373,12 @@ int gsr_pose_update(const gsr_pose_update_args* args, void* stream);
 /* gsr_pose_grad (the twelve pose sums of dL/dmeans_cam against the world-frame means) and gsr_pose_update in ONE launch: the workgroup of the sums
  * that finishes last takes the step. args->partial: scratch [GSR_POSE_PARTIALS][12]; ticket: GSR_TICKET_WORDS DEVICE words that are zero between calls (zero them once). */
 #define GSR_TICKET_WORDS 144
+/* gsr_backward_args.fused_pose_step */
+typedef struct gsr_pose_step_args {
+    const float* means_world;                  /* [P,3] the world-frame means (the rasterizer's means3D are their camera-frame images) */
+    const struct gsr_pose_update_args* update; /* as for gsr_pose_update; update->partial: 64 * 12 floats that are ZERO between calls (zero them once:
+                                                * the workgroups of the per-splat stage add their sums there, the step leaves them zero) */
+} gsr_pose_step_args;
 int gsr_pose_step(const float* means3D, const float* dL_dmeans_cam, size_t n, const gsr_pose_update_args* args, uint32_t* ticket, void* stream);
 
 /* ---- multi-GPU scheme B (scene shards; gsorb-slam_amd/sharded.py): compositing of the ranks' layers around the

@@ -428,6 +428,44 @@ def test_pose_step_equals_pose_grad_plus_pose_update(gsr):
     assert torch.equal(A["hist"].isnan(), B["hist"].isnan()) and torch.equal(A["hist"].nan_to_num(0.0), B["hist"].nan_to_num(0.0))
 
 
+def test_backward_with_the_pose_step_inside_equals_backward_plus_pose_step(gsr, syn):
+    """gsr_backward_args.fused_pose_step (a tracking iteration: the per-splat stage adds the pose sums to accumulator rows, a one-wave kernel behind it takes the pose step) against
+    gsr_backward writing dL_dmean3D followed by gsr_pose_step: the same pose, moments, best pose, history and matrix up to the order of the sums,
+    over three iterations on one workspace (the arrival counters go back to zero every time); with culled splats and a map size that is not a multiple of 256."""
+    import ctypes as C
+    cam = syn.make_camera(width=203, height=149, fx=150.0, fy=152.0)
+    sc = syn.make_scene(30_001, cam, seed=5, scale_mult=2.0, frac_behind=0.1, frac_offscreen=0.2)
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float32, device="cuda").contiguous()
+    X = t(sc.means3D) + 0.01                                                   # (the "world-frame" means: any [P,3] tensor)
+    p = gsr.capi._p
+    q0 = torch.tensor([0.9, 0.1, -0.2, 0.05]); t0 = torch.tensor([0.1, -0.2, 0.3])
+    mk = lambda: dict(pose=torch.cat([q0, t0]).cuda(), mom=torch.zeros(14, device="cuda"), best=torch.tensor([float("inf")] + [0.0] * 7, device="cuda"),
+                      hist=torch.zeros(4, device="cuda"), Tcw=torch.eye(4, device="cuda").reshape(16).clone(),
+                      part=torch.full((512, 12), 9.0, device="cuda"))
+    A, B = mk(), mk()
+    B["part"].zero_()                                                          # (the fused step's accumulator rows: zero between calls)
+    tickets = torch.zeros(144, dtype=torch.int32, device="cuda")
+    for it, lv in enumerate([3.0, float("nan"), 2.5]):
+        g = torch.Generator().manual_seed(it)
+        dpix = t(torch.randn((3, sc.cam.height, sc.cam.width), generator=g).numpy())
+        loss = torch.tensor([lv], device="cuda")
+        st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+        gr = gsr.backward(st, dpix)
+        a = gsr.capi.PoseUpdateArgs(p(A["pose"]), p(A["mom"]), p(A["best"]), p(A["hist"][it:]), p(A["Tcw"]), p(A["part"]), p(loss), None, 4e-4, 0.9, 0.999, 1e-15, it + 1)
+        gsr.capi._check(gsr.lib().gsr_pose_step(p(X), p(gr.dL_dmeans3D), sc.P, C.byref(a), p(tickets), gsr.capi._stream()))
+        b = gsr.capi.PoseUpdateArgs(p(B["pose"]), p(B["mom"]), p(B["best"]), p(B["hist"][it:]), p(B["Tcw"]), p(B["part"]), p(loss), None, 4e-4, 0.9, 0.999, 1e-15, it + 1)
+        ps = gsr.capi.PoseStepArgs(p(X), C.cast(C.pointer(b), C.c_void_p))
+        st2 = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+        gr2 = gsr.backward(st2, dpix, fused_pose_step=ps)
+        torch.cuda.synchronize()
+        assert int(tickets.abs().sum()) == 0 and float(B["part"][:64].abs().sum()) == 0.0
+        assert (gr2.dL_dmeans3D - gr.dL_dmeans3D).abs().max() <= 1e-5 * gr.dL_dmeans3D.abs().max()      # (still written when given; atomics' order only)
+        for k in ("pose", "mom", "Tcw", "best"):
+            assert (A[k] - B[k]).abs().max() <= 1e-5 * max(1e-6, float(A[k].abs().max())), (it, k)
+    assert torch.equal(A["hist"].isnan(), B["hist"].isnan()) and torch.equal(A["hist"].nan_to_num(0.0), B["hist"].nan_to_num(0.0))
+
+
 @pytest.mark.parametrize("shape", [(37, 53), (680, 1200)])
 def test_fused_mapping_loss_equals_its_separate_kernels(gsr, hz, shape):
     """gsr_map_loss_forward / _finish / _backward (SSIM and the pixel terms of the mapping loss in the same two passes, one finish kernel that
