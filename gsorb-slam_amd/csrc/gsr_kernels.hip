@@ -70,7 +70,8 @@ __device__ __forceinline__ void load_cov3d(const SplatInputs& in, const FramePar
 // the arithmetic 25.5 (132 MB: 5.2 TB/s), loads + arithmetic without the stores 25, everything 32 — the three phases of a wave
 // add up instead of overlapping (2.5 rounds of waves that start together), and neither the exact reach test (44 % of the
 // instructions: 32.3 -> 32.3 us without it) nor the order of the requests (33.1 -> 32.3) is what it waits for. Two and four splats
-// per thread, software-pipelined (the next splat's inputs requested before the current one's arithmetic): 33.1 / 35.6 us.
+// per thread, software-pipelined (the next splat's inputs requested before the current one's arithmetic): 33.1 / 35.6 us. Held to 72 / 64
+// VGPRs for seven / eight waves per SIMD instead of six (it spills 44 / 72 bytes): 41.9 / 82 us.
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 __global__ void __launch_bounds__(GSR_PRE_THREADS)
 K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomView g)
