@@ -354,14 +354,35 @@ int make_map_update(const gsr_map_update_args* a, bool grads, gsr::MapUpdate* ou
 int gsr_backward(const gsr_backward_args* a, void* stream)
 {
     if (!a || a->P < 0 || a->width <= 0 || a->height <= 0) return GSR_EINVAL;
-    if (a->P == 0) return GSR_OK; // src/Rasterizer.cu:263
+    hipStream_t st = (hipStream_t)stream;
+    // The fused steps are validated BEFORE anything is launched: an EINVAL must leave the accumulators as the forward left them (a retried
+    // backward would otherwise count the blend stage twice).
+    if (a->fused_map_update && a->fused_pose_step) return GSR_EINVAL; // one or the other (include/gsr.h)
+    gsr::MapUpdate mu{};
+    gsr::PoseUpdate pu{};
+    if (a->fused_map_update) {
+        if (!a->scales || a->shs || a->fused_map_update->n != (size_t)a->P) return GSR_EINVAL;
+        const int rc = make_map_update(a->fused_map_update, false, &mu);
+        if (rc != GSR_OK) return rc;
+    }
+    if (a->fused_pose_step) {
+        if (!a->fused_pose_step->update || (a->P > 0 && !a->fused_pose_step->means_world)) return GSR_EINVAL;
+        const int rc = make_pose_update(a->fused_pose_step->update, &pu);
+        if (rc != GSR_OK) return rc;
+    }
+    if (a->P == 0) { // src/Rasterizer.cu:263. An empty map still owes the tracking loop its bookkeeping: loss history, best pose, the next Tcw
+        if (a->fused_pose_step && ((a->stages ? a->stages : GSR_STAGE_SPLAT) & GSR_STAGE_SPLAT)) {
+            hipLaunchKernelGGL(gsr::K_pose_finish, dim3(1), dim3(64), 0, st, pu, const_cast<float*>(a->fused_pose_step->update->partial));
+            GSR_LAUNCHED();
+        }
+        return GSR_OK;
+    }
     if (!a->geom_buffer || !a->binning_buffer || !a->image_buffer || !a->dL_dpix || !a->means3D ||
         !a->viewmatrix || !a->projmatrix || !a->background)
         return GSR_EINVAL;
     if ((a->scales != nullptr && a->rotations != nullptr) == (a->cov3D_precomp != nullptr)) return GSR_EINVAL;
     // K_splat_bwd writes dL_dsh[0 .. (D+1)^2) per splat and zero-fills up to M: an inconsistent D / M would write out of bounds
     if (a->shs && (!a->dL_dsh || a->M <= 0 || !a->cam_pos || a->D < 0 || a->D > 3 || (a->D + 1) * (a->D + 1) > a->M)) return GSR_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
     const int P = a->P, W = a->width, H = a->height;
     FrameParams f = frame_params(P, a->D, a->M, W, H, a->tan_fovx, a->tan_fovy, a->scale_modifier, a->band_y0, a->band_y1);
     f.fold_depth_color = a->ds_detach_depth ? 0 : 1;
@@ -382,7 +403,8 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
         tm.begin(GSR_BWD_BLEND);
         // nobody consumes the colour sums (this call also runs the per-splat stage, which is handed no colour / SH output, and the fused depth
         // channel's colour is a constant): the fused pair's kernel without them (a tracking iteration)
-        const bool no_colour = (stages & GSR_STAGE_SPLAT) && !a->dL_dcolor && !a->dL_dsh && a->dL_dds && a->ds_detach_depth;
+        // (the fused map update steps the colours from those sums although it is handed no dL_dcolor buffer: ADVICE r4)
+        const bool no_colour = (stages & GSR_STAGE_SPLAT) && !a->dL_dcolor && !a->dL_dsh && a->dL_dds && a->ds_detach_depth && !a->fused_map_update;
 #define GSR_BWD_DUAL(COL, SIL) hipLaunchKernelGGL((gsr::K_blend_bwd<GSR_ROWQ, true, COL, SIL>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, \
                                                   W, H, f.grid_x, Tb, f.band_y0 * f.grid_x, a->dL_dpix, a->dL_dds)
         if (no_colour && a->dds_depth_only) GSR_BWD_DUAL(false, false);
@@ -404,20 +426,13 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
         o.dL_dcolor = a->dL_dcolor; o.dL_dmean3D = a->dL_dmean3D; o.dL_dcov3D = a->dL_dcov3D;
         o.dL_dsh = a->dL_dsh; o.dL_dscale = a->dL_dscale; o.dL_drot = a->dL_drot;
         tm.begin(GSR_BWD_SPLAT);
-        gsr::MapUpdate mu{};
-        if (a->fused_map_update) { // the per-splat stage takes the Adam step itself (include/gsr.h)
-            if (!a->scales || a->shs || a->fused_map_update->n != (size_t)P) return GSR_EINVAL;
-            const int rc = make_map_update(a->fused_map_update, false, &mu);
-            if (rc != GSR_OK) return rc;
+        if (a->fused_map_update) { // the per-splat stage takes the Adam step itself (include/gsr.h; arguments checked above, before the first launch)
             if (stages & GSR_STAGE_REZERO) hipLaunchKernelGGL((gsr::K_splat_bwd<true, true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
             else hipLaunchKernelGGL((gsr::K_splat_bwd<false, true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
         } else if (a->fused_pose_step) { // the per-splat stage forms the pose sums and its last workgroup takes the pose step (include/gsr.h)
             const gsr_pose_step_args* ps = a->fused_pose_step;
             static_assert(GSR_POSE_ACC_ROWS * 12 <= GSR_POSE_PARTIALS * 12, "gsr_pose_grad's scratch holds the accumulator rows");
-            if (!ps->means_world) return GSR_EINVAL;
-            gsr::PoseUpdate u;
-            const int rc = make_pose_update(ps->update, &u);
-            if (rc != GSR_OK) return rc;
+            const gsr::PoseUpdate& u = pu;
             gsr::PoseStep k;
             k.X = ps->means_world; k.acc = const_cast<float*>(ps->update->partial);
             if (stages & GSR_STAGE_REZERO) hipLaunchKernelGGL((gsr::K_splat_bwd_pose<true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, k);

@@ -466,6 +466,90 @@ def test_backward_with_the_pose_step_inside_equals_backward_plus_pose_step(gsr, 
     assert torch.equal(A["hist"].isnan(), B["hist"].isnan()) and torch.equal(A["hist"].nan_to_num(0.0), B["hist"].nan_to_num(0.0))
 
 
+def _fused_update_setup(gsr, syn, n=20_000):
+    """A fused-pair forward and a raw parameter set whose activations are the scene's (so that the rasterizer inputs and the update's
+    parameters belong together): returns a function that runs one backward with fused_map_update and hands back the stepped raw tensors."""
+    cam = syn.make_camera(203, 149, 150.0, 152.0)
+    sc = syn.make_scene(n, cam, seed=3, scale_mult=2.0)
+    s = gsr.capi.Settings.from_camera(cam)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float32, device="cuda").contiguous()
+    g = torch.Generator().manual_seed(5)
+    gA = t(torch.randn((3, 149, 203), generator=g)); gB = t(torch.randn((2, 149, 203), generator=g)); gB[1] = 0.0
+    T = torch.eye(4, device="cuda")
+    opac = t(sc.opacities).reshape(-1).clamp(1e-4, 1 - 1e-4)
+    raw0 = [t(sc.means3D), t(sc.colors), t(sc.rotations), torch.log(opac / (1 - opac)).reshape(-1, 1).contiguous(), torch.log(t(sc.scales))]
+
+    def run(detach, grads, n_override=None, also_pose=False, lrs=(1e-4, 2.5e-3, 1e-3, 5e-2, 1e-3)):
+        raw = [x.clone() for x in raw0]
+        m = [torch.zeros_like(x) for x in raw]; v = [torch.zeros_like(x) for x in raw]
+        mc, op, scl, rot = gsr.capi.map_prepare(raw[0], raw[3], raw[4], raw[2], T)
+        st = gsr.forward(s, mc, op, colors=raw[1], scales=scl, rotations=rot, dual=True)
+        a = gsr.capi.map_update_args(raw, (m, v), None, (op, scl), T, lrs, [1] * 5)
+        if n_override is not None:
+            a.n = n_override
+        kw = {}
+        if also_pose:
+            import ctypes as C
+            z = lambda k: torch.zeros(k, device="cuda")
+            pu = gsr.capi.PoseUpdateArgs(*(gsr.capi._p(x) for x in (z(7), z(14), z(8), z(4), z(16), z(64 * 12), z(1))), None, 4e-4, 0.9, 0.999, 1e-15, 1)
+            kw["fused_pose_step"] = gsr.capi.PoseStepArgs(gsr.capi._p(raw[0]), C.cast(C.pointer(pu), C.c_void_p))
+        gsr.backward(st, gA, grads=grads, dL_dds=gB, detach_depth_color=detach, once=True, fused_map_update=a, **kw)
+        torch.cuda.synchronize()
+        return raw, st
+    return run, raw0
+
+
+def test_fused_map_update_steps_the_colours_when_the_depth_colour_is_detached(gsr, syn):
+    """with fused_map_update the per-splat stage steps Adam on rgb from the blend stage's colour sums although no dL_dcolor buffer
+    is handed over. With ds_detach_depth = 1 and no gradient buffers at all the call used to pick the blend kernel WITHOUT those sums
+    (the tracking variant) and step the colours with a zero gradient. The colour update must not depend on the detach flag."""
+    run, raw0 = _fused_update_setup(gsr, syn)
+    none = gsr.capi.Grads(*([None] * 9))
+    a, _ = run(False, none)
+    b, _ = run(True, none)
+    moved = float((a[1] - raw0[1]).abs().max())
+    assert moved > 1e-3                                              # one Adam step of lr 2.5e-3 on the colours
+    assert float((b[1] - raw0[1]).abs().max()) > 1e-3                # ... also with the depth channel's colour detached
+    assert float((a[1] - b[1]).abs().max()) <= 1e-3 * moved          # (sign flips of ~0 gradients aside: the first Adam step is +-lr)
+    for k in (2, 3, 4):                                              # rotations, opacity, scales see no depth-colour term either
+        assert float((a[k] - b[k]).abs().max()) <= 2e-2 * float((a[k] - raw0[k]).abs().max())
+    assert float((a[0] - b[0]).abs().max()) > 0.0                    # the means do: that is what the flag detaches
+
+
+def test_backward_rejects_bad_fused_arguments_before_it_launches_anything(gsr, syn):
+    """fused_map_update / fused_pose_step are validated at the top of gsr_backward. A rejected call leaves the accumulators as
+    the forward left them: the same state then takes a correct backward (no double count of the blend stage); both fused steps at once
+    are an error."""
+    run, raw0 = _fused_update_setup(gsr, syn, n=5000)
+    none = gsr.capi.Grads(*([None] * 9))
+    good, _ = run(False, none)
+    with pytest.raises(Exception):
+        run(False, none, also_pose=True)
+    cam = syn.make_camera(203, 149, 150.0, 152.0)
+    # a wrong n: EINVAL, then the SAME forward state is taken back by a plain backward and must equal a clean one
+    sc = syn.make_scene(5000, cam, seed=3, scale_mult=2.0)
+    s = gsr.capi.Settings.from_camera(cam)
+    g = torch.Generator().manual_seed(5)
+    gA = torch.randn((3, 149, 203), generator=g).cuda()
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    ref = gsr.backward(st, gA)
+    st2 = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    t = lambda a: torch.as_tensor(a, dtype=torch.float32, device="cuda").contiguous()
+    raw = [t(sc.means3D), t(sc.colors), t(sc.rotations), torch.zeros((5000, 1), device="cuda"), torch.log(t(sc.scales))]
+    m = [torch.zeros_like(x) for x in raw]; v = [torch.zeros_like(x) for x in raw]
+    a = gsr.capi.map_update_args(raw, (m, v), None, (t(sc.opacities).reshape(-1), t(sc.scales)), torch.eye(4, device="cuda"), [1e-3] * 5, [1] * 5)
+    a.n = 4999
+    before = [x.clone() for x in raw]
+    with pytest.raises(Exception):
+        gsr.backward(st2, gA, fused_map_update=a)
+    st2.dirty = False                                                # (the rejected call launched nothing: the accumulators are still clean)
+    out = gsr.backward(st2, gA)
+    assert all(torch.equal(x, y) for x, y in zip(raw, before))
+    for nme in ("dL_dmeans3D", "dL_dcolors", "dL_dopacity", "dL_dscales"):
+        x, y = getattr(out, nme), getattr(ref, nme)
+        assert float((x - y).abs().max()) <= 2e-6 * float(y.abs().max()), nme
+
+
 @pytest.mark.parametrize("shape", [(37, 53), (680, 1200)])
 def test_fused_mapping_loss_equals_its_separate_kernels(gsr, hz, shape):
     """gsr_map_loss_forward / _finish / _backward (SSIM and the pixel terms of the mapping loss in the same two passes, one finish kernel that
