@@ -15,11 +15,11 @@ all-reduced inside the timed region. The collective-free replica figure (every r
 `replica_rasterize`.
 
 `shard_step` (same JSON line, --mode all | shard-step): the step that DOES exchange data — one sharded mapping
-iteration and one sharded tracking iteration of gsorb-slam_amd/sharded.py:ShardedMapper (src/Render.cc:420-483,
-:1054-1126 with the map split into depth slabs over the ranks; BASELINE.json config 4: --splats Gaussians in
-TOTAL, strong scaling). Its timed region contains the two rasterizer forwards + backwards of the rank's shard,
-the layer compositing (all-gather of 2 floats/pixel/rank, all-reduce of 4 channels, backward all-gather of 1), the
-losses, the scalar / pose-gradient all-reduce and the Adam step, over RCCL ("nccl") when N > 1.
+iteration and one sharded tracking iteration of the C++ loop (torch_ext/DirectLoop.cpp: ORB_SLAM2::SlamLoop with SetShard;
+src/Render.cc:420-483, :1054-1126 with the map cut into k-d cells over the ranks; BASELINE.json config 4: --splats Gaussians in
+TOTAL, strong scaling). Its timed region contains the fused rasterizer pair of the rank's cell forwards and backwards, the layer
+compositing (all-gather of 2 floats/pixel/rank, all-reduce of 4 channels, backward all-gather of 1), the fused losses, the
+regulariser / pose-row all-reduce and the Adam step, over RCCL ("nccl"; a one-rank RCCL group when N = 1).
 
 The JSON line also carries
   roofline     : the dominant kernel (backward blend) against the HBM roofline, timed live
@@ -345,77 +345,76 @@ def boundary_ms(gsr, sc, dev, steps=20):
 
 
 def shard_step(a, gsr, td, rank, world, dev):
-    """One sharded MAPPING iteration and one sharded TRACKING iteration (sharded.ShardedMapper) with every
-    collective inside the timed region. --splats Gaussians in TOTAL, split into depth slabs (strong scaling)."""
+    """One sharded MAPPING iteration and one sharded TRACKING iteration of the C++ loop (torch_ext/DirectLoop.cpp: SlamLoop::SetShard) with
+    every collective inside the timed region. --splats Gaussians in TOTAL, cut into `world` k-d cells (sharded.KdPartition: the partition
+    that holds while the view changes), one cell per rank; the loop's three collectives per iteration go through the process group on the
+    loop's stream (RCCL; with one rank a one-rank RCCL group so that the collectives are RCCL's launches, not copies)."""
     syn = gsr.synthetic
-    hz = __import__("gsorb_slam_amd.harness", fromlist=["x"])
     sharded = __import__("gsorb_slam_amd.sharded", fromlist=["x"])
+    sys.path.insert(0, os.path.join(ROOT, "gsorb-slam_amd"))
+    from diff_gaussian_rasterization import _C
     camd = syn.CAMERAS[a.camera]
     cam = syn.make_camera(**camd)
     W, H = cam.width, cam.height
     sc = syn.make_scene(a.splats, cam, seed=1234, scale_mult=a.scale_mult)      # the SAME scene on every rank
-    z = torch.tensor(sc.means3D[:, 2])
-    idx = sharded.shard_by_depth_slabs(z, world)[rank].numpy()
-    g = hz.GaussianMap(hz.Config(), camd["fx"], camd["fy"], device=dev)
-    g.add_points(torch.tensor(sc.means3D[idx]), torch.tensor(sc.colors[idx]))
-    op = torch.tensor(sc.opacities[idx])
-    with torch.no_grad():
-        g.log_scales.copy_(torch.log(torch.tensor(sc.scales[idx])))
-        g.unnorm_quat.copy_(torch.tensor(sc.rotations[idx]))
-        g.logit_opacities.copy_(torch.log(op / (1 - op)))
-    m = sharded.make_sharded_mapper(hz)(g, W, H)
+    t = lambda x: torch.tensor(x, dtype=torch.float32)
+    op = t(sc.opacities).reshape(-1, 1)
+    raw = [t(sc.means3D), t(sc.colors), t(sc.rotations), torch.log(op / (1 - op)), torch.log(t(sc.scales))]
+    part = sharded.KdPartition.build(raw[0], world)
+    idx = torch.nonzero(part.assign(raw[0]) == rank).squeeze(-1)
+    group, backend, own_group = None, "none (single process: the exchange is local copies)", False
+    if world > 1:
+        group, backend = td.group.WORLD, td.get_backend()
+    else:
+        try:                                                     # one rank: RCCL itself still runs the loop's collectives
+            import socket
+            import torch.distributed as td1
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+            td1.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            group, backend, own_group = td1.group.WORLD, "nccl (one rank)", True
+        except Exception as e:                                   # (stated in the record, never silent)
+            backend = f"none (single process: one-rank RCCL group failed: {type(e).__name__})"
+    loop = _C.SlamLoop(W, H, camd["fx"], camd["fy"], dev)
+    loop.set_map(*[x[idx] for x in raw])
+    loop.set_shard(group, rank, world, part.nodes)
     T = torch.eye(4, device=dev)
-    with torch.no_grad():
-        rgb, sur, _ = m.render_pair(T, tracking=True)
-        frame = hz.Frame((rgb * 0.9 + 0.05).clone(), sur[0].clone(), T.clone())
+    rgb, sur, _ = loop.render_composite(T)
+    rgb, depth = (rgb * 0.9 + 0.05).contiguous(), sur[0].contiguous()
+    T0 = T.clone(); T0[:3, 3] = torch.tensor([0.004, -0.003, 0.005], device=dev)
 
     def barrier():
         if world > 1:
             td.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn, n, warm=3):
-        for _ in range(warm):
-            fn()
+    def timed(fn):
+        fn(3)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
+        ran = fn(max(a.shard_steps, 1))
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt / max(n, 1) * 1e3
+        return dt / max(ran, 1) * 1e3, ran
 
-    n = max(a.shard_steps, 1)
-    map_ms = timed(lambda: m.mapping_iteration([frame]), n)
-    # tracking: one track() call of n pose iterations (it stops early only if the loss stalls: count what ran)
-    ran = {}
-    def track_once():
-        ran["n"] = len(m.track(frame, T, iters=n)[1])
-    track_once()
-    barrier()
-    t0 = time.perf_counter()
-    track_once()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
-        dt = float(tt.item())
-    track_ms = dt / max(ran["n"], 1) * 1e3
-    plane = W * H * 4              # sharded._CompositeFn: all-gather (silhouette, surface depth, key row), all-reduce 4 channels, backward all-gather 1
-    return {"what": "one sharded mapping iteration / one sharded tracking iteration (two rasterizer fwd+bwd of the rank's depth slab, "
-                    "layer all-gather, compositing, losses, scalar or pose-gradient all-reduce, Adam step) — collectives INSIDE the timed region",
-            "scaling": "strong", "total_splats": a.splats, "splats_per_rank": int(len(idx)), "width": W, "height": H,
-            "backend": (td.get_backend() if world > 1 else "none (single process)"),
-            "rccl_ranks": (td.get_world_size() if world > 1 else 1),
-            "mapping_ms_per_iter": map_ms, "tracking_ms_per_iter": track_ms,
+    map_ms, n = timed(lambda k: len(loop.map_frame(rgb, depth, T, k)))      # SlamLoop::MapFrame: the losses are read back once, like Render::RenderForFrame
+    track_ms, ran = timed(lambda k: len(loop.track(rgb, depth, T0, k)[0]))  # (it stops early only if the loss stalls: what ran is what is counted)
+    if own_group:
+        td1.destroy_process_group()
+    plane = W * H * 4              # DirectLoop.cpp: all-gather (silhouette, surface depth), all-reduce of the 4 premultiplied planes, backward all-gather of 1 plane
+    return {"what": "one sharded mapping iteration / one sharded tracking iteration of the C++ loop (ORB_SLAM2::SlamLoop with SetShard, torch_ext/DirectLoop.cpp): "
+                    "fused rasterizer pair on the rank's k-d cell, gsr_shard_order, layer all-gather, gsr_composite_forward, all-reduce, the fused loss kernels on the "
+                    "composite, gsr_composite_backward_* around an all-gather, backward with the Adam step fused (mapping: + all-reduce of three regulariser "
+                    "sums) or gsr_pose_grad + all-reduce of the pose rows + gsr_pose_update (tracking) — collectives INSIDE the timed region",
+            "scaling": "strong", "total_splats": a.splats, "splats_per_rank": int(idx.numel()), "width": W, "height": H,
+            "partition": f"k-d cells x{world} (sharded.KdPartition)", "backend": backend, "rccl_ranks": (td.get_world_size() if world > 1 else (1 if own_group else 0)),
+            "mapping_ms_per_iter": map_ms, "tracking_ms_per_iter": track_ms, "tracking_iterations_run": ran,
             "mapping_splats_pixels_per_s": 2 * a.splats * W * H / (map_ms * 1e-3),
-            "collectives_per_mapping_iter": {"all_gather_bytes_sent_per_rank": 4 * plane, "all_reduce_bytes": 4 * plane, "all_reduce_floats": 3},
-            "collectives_per_tracking_iter": {"all_gather_bytes_sent_per_rank": 4 * plane, "all_reduce_bytes": 4 * plane, "all_reduce_floats": 7},
+            "collectives_per_mapping_iter": {"all_gather_bytes_sent_per_rank": 3 * plane, "all_reduce_bytes": 4 * plane, "all_reduce_floats": 3},
+            "collectives_per_tracking_iter": {"all_gather_bytes_sent_per_rank": 3 * plane, "all_reduce_bytes": 4 * plane, "all_reduce_floats": 512 * 12},
             "timed_iters": n}
 
 
@@ -576,9 +575,10 @@ def main():
             out = {"metric": "ms per sharded mapping iteration (collectives in the timed region)", "value": ss["mapping_ms_per_iter"],
                    "unit": "ms", "n_gpus": world, "steps": ss["timed_iters"], "warmup": 3, "ms_per_step": ss["mapping_ms_per_iter"],
                    "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                   "config": {"workload": f"{a.splats} Gaussians in total, depth slabs over {world} rank(s), {ss['width']}x{ss['height']}"}}
+                   "config": {"workload": f"{a.splats} Gaussians in total, k-d cells over {world} rank(s), {ss['width']}x{ss['height']}"}}
         out["shard_step"] = ss
     if rank == 0:
+        C.CDLL(None).fflush(None)   # (RCCL prints a version banner through C stdio: out before the line, which must be the last one)
         print(json.dumps(out), flush=True)
     if dist:
         td.destroy_process_group()

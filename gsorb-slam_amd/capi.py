@@ -21,7 +21,7 @@ EXPORTS = ["gsr_forward", "gsr_forward_ws", "gsr_ws_status", "gsr_backward", "gs
            "gsr_adam_step", "gsr_pose_grad", "gsr_to_camera", "gsr_pose_from_quat", "gsr_pose_from_quat_backward",
            "gsr_pixel_loss", "gsr_pixel_loss_backward", "gsr_pixel_loss_backward_add", "gsr_track_loss", "gsr_scale_reg", "gsr_scale_reg_backward",
            "gsr_map_prepare", "gsr_map_update", "gsr_map_loss_total", "gsr_map_loss_forward", "gsr_map_loss_finish", "gsr_map_loss_backward", "gsr_pose_update", "gsr_pose_step", "gsr_composite_forward", "gsr_composite_backward_local",
-           "gsr_composite_backward_occlusion", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
+           "gsr_composite_backward_occlusion", "gsr_shard_order", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
 
 
 def library_path() -> str:
@@ -168,11 +168,13 @@ def lib():
     L.gsr_map_loss_total.restype = C.c_int
     L.gsr_map_loss_total.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gsr_composite_forward.restype = C.c_int
-    L.gsr_composite_forward.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gsr_composite_forward.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gsr_composite_backward_local.restype = C.c_int
-    L.gsr_composite_backward_local.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.gsr_composite_backward_local.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gsr_composite_backward_occlusion.restype = C.c_int
-    L.gsr_composite_backward_occlusion.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.gsr_composite_backward_occlusion.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.gsr_shard_order.restype = C.c_int
+    L.gsr_shard_order.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gsr_map_loss_forward.restype = C.c_int
     L.gsr_map_loss_forward.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gsr_map_loss_finish.restype = C.c_int
@@ -620,8 +622,8 @@ def composite_forward(world, rank, order, gathered, layer4, has_sur):
     sil = torch.empty((1, H, W), dtype=torch.float32, device=layer4.device)
     surf = torch.empty_like(sil)
     with torch.cuda.device(layer4.device):
-        _check(lib().gsr_composite_forward(int(world), int(rank), _p(order), _p(gathered), _p(layer4), H, W, int(bool(has_sur)), _p(contrib), _p(sil),
-                                           _p(surf), _stream()))
+        _check(lib().gsr_composite_forward(int(world), int(rank), _p(order), _p(gathered), int(gathered.shape[1]), _p(layer4), H, W, int(bool(has_sur)),
+                                           _p(contrib), _p(sil), _p(surf), _stream()))
     return contrib, sil, surf
 
 
@@ -630,8 +632,8 @@ def composite_backward_local(world, rank, order, gathered, layer4, g4):
     d_layer = torch.empty_like(layer4)
     c_own = torch.empty((1, H, W), dtype=torch.float32, device=layer4.device)
     with torch.cuda.device(layer4.device):
-        _check(lib().gsr_composite_backward_local(int(world), int(rank), _p(order), _p(gathered), _p(layer4), _p(g4) if g4 is not None else None, H, W,
-                                                  _p(d_layer), _p(c_own), _stream()))
+        _check(lib().gsr_composite_backward_local(int(world), int(rank), _p(order), _p(gathered), int(gathered.shape[1]), _p(layer4),
+                                                  _p(g4) if g4 is not None else None, H, W, _p(d_layer), _p(c_own), _stream()))
     return d_layer, c_own
 
 
@@ -639,9 +641,18 @@ def composite_backward_occlusion(world, rank, order, gathered, c_all, g_sil):
     H, W = int(gathered.shape[-2]), int(gathered.shape[-1])
     dS = torch.empty((1, H, W), dtype=torch.float32, device=gathered.device)
     with torch.cuda.device(gathered.device):
-        _check(lib().gsr_composite_backward_occlusion(int(world), int(rank), _p(order), _p(gathered), _p(c_all), _p(g_sil) if g_sil is not None else None,
-                                                      H, W, _p(dS), _stream()))
+        _check(lib().gsr_composite_backward_occlusion(int(world), int(rank), _p(order), _p(gathered), int(gathered.shape[1]), _p(c_all),
+                                                      _p(g_sil) if g_sil is not None else None, H, W, _p(dS), _stream()))
     return dS
+
+
+def shard_order(kd_nodes, Tcw):
+    """gsr_shard_order: the ranks of a k-d partition front to back for the camera of Tcw (device tensors; sharded.KdPartition.nodes)."""
+    world = int(kd_nodes.shape[0]) + 1
+    order = torch.empty((world,), dtype=torch.int64, device=Tcw.device)
+    with torch.cuda.device(Tcw.device):
+        _check(lib().gsr_shard_order(world, _p(_f32(kd_nodes, Tcw.device)), _p(_f32(Tcw, Tcw.device)), _p(order), _stream()))
+    return order
 
 
 def map_prepare(xyz, logit, log_scales, unnorm_quat, Tcw, reg=None):

@@ -710,35 +710,44 @@ int gsr_map_loss_total(const float* sums, const float* ssim_partial, int n_parti
     return GSR_OK;
 }
 
-int gsr_composite_forward(int world, int rank, const long long* order, const float* gathered, const float* layer4, int H, int W, int has_sur,
+int gsr_composite_forward(int world, int rank, const long long* order, const float* gathered, int gathered_planes, const float* layer4, int H, int W, int has_sur,
                           float* contrib, float* sil_total, float* surf, void* stream)
 {
     if (world < 1 || rank < 0 || rank >= world || !order || !gathered || !layer4 || !contrib || !sil_total || H <= 0 || W <= 0) return GSR_EINVAL;
+    if (gathered_planes < (has_sur ? 2 : 1)) return GSR_EINVAL;
     const size_t N = (size_t)H * W;
-    hipLaunchKernelGGL(gsr::K_composite_fwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, gathered, layer4, N,
-                       has_sur, contrib, sil_total, surf);
+    hipLaunchKernelGGL(gsr::K_composite_fwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, gathered, gathered_planes,
+                       layer4, N, has_sur, contrib, sil_total, surf);
     GSR_LAUNCHED();
     return GSR_OK;
 }
 
-int gsr_composite_backward_local(int world, int rank, const long long* order, const float* gathered, const float* layer4, const float* g4, int H, int W,
-                                 float* d_layer4, float* c_own, void* stream)
+int gsr_composite_backward_local(int world, int rank, const long long* order, const float* gathered, int gathered_planes, const float* layer4, const float* g4, int H,
+                                 int W, float* d_layer4, float* c_own, void* stream)
 {
-    if (world < 1 || rank < 0 || rank >= world || !order || !gathered || !layer4 || !d_layer4 || !c_own || H <= 0 || W <= 0) return GSR_EINVAL;
+    if (world < 1 || rank < 0 || rank >= world || !order || !gathered || !layer4 || !d_layer4 || !c_own || H <= 0 || W <= 0 || gathered_planes < 1) return GSR_EINVAL;
     const size_t N = (size_t)H * W;
-    hipLaunchKernelGGL(gsr::K_composite_bwd_local, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, gathered, layer4,
-                       g4, N, d_layer4, c_own);
+    hipLaunchKernelGGL(gsr::K_composite_bwd_local, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, gathered,
+                       gathered_planes, layer4, g4, N, d_layer4, c_own);
     GSR_LAUNCHED();
     return GSR_OK;
 }
 
-int gsr_composite_backward_occlusion(int world, int rank, const long long* order, const float* gathered, const float* c_all, const float* g_sil, int H,
-                                     int W, float* dS, void* stream)
+int gsr_composite_backward_occlusion(int world, int rank, const long long* order, const float* gathered, int gathered_planes, const float* c_all, const float* g_sil,
+                                     int H, int W, float* dS, void* stream)
 {
-    if (world < 1 || rank < 0 || rank >= world || !order || !gathered || !c_all || !dS || H <= 0 || W <= 0) return GSR_EINVAL;
+    if (world < 1 || rank < 0 || rank >= world || !order || !gathered || !c_all || !dS || H <= 0 || W <= 0 || gathered_planes < 1) return GSR_EINVAL;
     const size_t N = (size_t)H * W;
     hipLaunchKernelGGL(gsr::K_composite_bwd_occlusion, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, gathered,
-                       c_all, g_sil, N, dS);
+                       gathered_planes, c_all, g_sil, N, dS);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_shard_order(int world, const float* kd_nodes, const float* Tcw, long long* order, void* stream)
+{
+    if (world < 1 || world > 32 || !order || (world > 1 && (!kd_nodes || !Tcw))) return GSR_EINVAL;
+    hipLaunchKernelGGL(gsr::K_shard_order, dim3(1), dim3(1), 0, (hipStream_t)stream, world, kd_nodes, Tcw, order);
     GSR_LAUNCHED();
     return GSR_OK;
 }

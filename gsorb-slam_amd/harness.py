@@ -259,6 +259,25 @@ class GaussianMap:
             self.opt.param_groups[gi]["params"][0] = new
             setattr(self, n, new)
 
+    def append_rows(self, params, exp_avg, exp_avg_sq):
+        """Rows that arrive with their history (a sharded map re-balancing its cells): params / moments [k, 14] in NAMES order."""
+        if params.shape[0] == 0:
+            return
+        widths = [int(getattr(self, n)[0].numel()) for n in self.NAMES] if len(self) else [3, 3, 4, 1, 3]
+        off = 0
+        for gi, (n, w) in enumerate(zip(self.NAMES, widths)):
+            old = getattr(self, n)
+            shape = (params.shape[0],) + tuple(old.shape[1:])
+            st = self.opt.state.pop(old, None)
+            merged = torch.cat([old.detach(), params[:, off:off + w].reshape(shape)], 0).requires_grad_(True)
+            if st is not None and "exp_avg" in st:
+                st["exp_avg"] = torch.cat([st["exp_avg"], exp_avg[:, off:off + w].reshape(shape)], 0)
+                st["exp_avg_sq"] = torch.cat([st["exp_avg_sq"], exp_avg_sq[:, off:off + w].reshape(shape)], 0)
+                self.opt.state[merged] = st
+            self.opt.param_groups[gi]["params"][0] = merged
+            setattr(self, n, merged)
+            off += w
+
     def low_opacity_mask(self):
         return (torch.sigmoid(self.logit_opacities) < self.cfg.prune_opacities).squeeze(-1)   # Gaussian.cc:180-185
 
@@ -507,8 +526,7 @@ class SlamRenderer:
         g, c = self.map, self.map.cfg
         with torch.no_grad():
             Tcw = frame.Tcw.to(g.device)
-            rim, _, _ = self.render_rgb(Tcw, tracking=True)
-            rdep, _, _ = self.render_depth(Tcw, tracking=True)
+            rim, rdep = self._densify_renders(Tcw)
             gray = (rim[0] * 299 + rim[1] * 587 + rim[2] * 114) / 1000
             black = gray < 50 / 255.0
             diff = torch.abs(frame.depth - rdep[0])
@@ -529,8 +547,21 @@ class SlamRenderer:
             pc = torch.stack([(u.float() - cx) * z / g.fx, (v.float() - cy) * z / g.fy, z], 1)
             Twc = torch.inverse(Tcw)
             pw = pc @ Twc[:3, :3].t() + Twc[:3, 3]
-            g.add_points(pw, frame.rgb[:, v, u].t().contiguous())
-            return int(v.numel())
+            cols = frame.rgb[:, v, u].t().contiguous()
+            own = self._owned(pw)                                 # (a sharded map: only the points of this rank's cell)
+            if own is not None:
+                pw, cols = pw[own], cols[own]
+            if pw.shape[0]:
+                g.add_points(pw, cols)
+            return int(pw.shape[0])
+
+    def _densify_renders(self, Tcw):
+        rim, _, _ = self.render_rgb(Tcw, tracking=True)
+        rdep, _, _ = self.render_depth(Tcw, tracking=True)
+        return rim, rdep
+
+    def _owned(self, pw):
+        return None
 
     def remove_low_opacity(self):                              # Render.cc:598-616
         m = self.map.low_opacity_mask()

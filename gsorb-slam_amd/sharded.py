@@ -194,10 +194,132 @@ class LayerCompositor:
 
 
 def shard_by_depth_slabs(depths: torch.Tensor, world: int):
-    """Depth-separable partition for one view: rank g gets the g-th quantile slab of camera-space
-    depth. Returns a list of index tensors (front to back)."""
+    """Depth-separable partition for ONE view: rank g gets the g-th quantile slab of camera-space
+    depth. Returns a list of index tensors (front to back). The mapping loop of the reference draws a different keyframe every
+    iteration (src/Render.cc:406-425): use KdPartition there."""
     order = torch.argsort(depths)
     return list(torch.tensor_split(order, world))
+
+
+class KdPartition:
+    """A partition of the map that holds while the view changes: a k-d split of the Gaussians' centres into `world` convex cells
+    (axis-aligned boxes), balanced by count, one cell per rank. Convex cells of a BSP can be ordered front to back EXACTLY for any
+    camera (visit, at every split, the side that holds the camera centre first), which a partition by the depth of one view cannot.
+    What stays approximate is the extent of the splats: a Gaussian centred in one cell reaches into its neighbours, and the
+    compositor treats a cell's layer as one slab — report PSNR against the one-GPU render (tests/test_kd_partition_gloo.py).
+
+    nodes [world - 1, 4] float32 = {axis, split, left, right}: a child >= 0 is a node index, a child < 0 the leaf (rank) -1 - child;
+    node 0 is the root, parents are numbered before their children; a point goes LEFT when x[axis] < split. The same array drives
+    gsr_shard_order on the device (include/gsr.h) and SlamLoop::SetShard (torch_ext/SlamLoop.h).
+    Owner rule for map growth (src/Render.cc:557-594, src/Gaussian.cc:40-95): a new Gaussian belongs to the cell that holds its centre
+    (assign). After pruning (src/Gaussian.cc:180-258) the cells drift out of balance: rebalance_* below re-split and move the rows."""
+
+    def __init__(self, nodes: torch.Tensor, world: int):
+        self.world = int(world)
+        self.nodes = torch.as_tensor(nodes, dtype=torch.float32).reshape(max(self.world - 1, 0), 4).cpu().contiguous()
+
+    @classmethod
+    def build(cls, xyz: torch.Tensor, world: int) -> "KdPartition":
+        pts = torch.as_tensor(xyz, dtype=torch.float32).detach().cpu().reshape(-1, 3)
+        nodes: list = []
+
+        def rec(idx, lo, hi):
+            if hi - lo == 1:
+                return -1 - lo
+            me = len(nodes)
+            nodes.append(None)                                   # parents before children
+            k = (hi - lo) // 2
+            if idx.numel() == 0:
+                axis, split = 0, 0.0
+                left = right = idx
+            else:
+                sub = pts[idx]
+                axis = int(torch.argmax(sub.max(0).values - sub.min(0).values))
+                vals, perm = torch.sort(sub[:, axis], stable=True)
+                m = min(max(int(round(idx.numel() * k / (hi - lo))), 0), idx.numel())
+                if m == 0:
+                    split = float(vals[0])                        # everything goes right
+                elif m == idx.numel():
+                    split = float(torch.nextafter(vals[-1], torch.tensor(float("inf"))))
+                else:
+                    split = float(vals[m])
+                    m = int(torch.searchsorted(vals, vals[m]))    # ties with the split value go right together (x < split is the rule)
+                left, right = idx[perm[:m]], idx[perm[m:]]
+            l = rec(left, lo, lo + k)
+            r = rec(right, lo + k, hi)
+            nodes[me] = (float(axis), split, float(l), float(r))
+            return me
+
+        if world > 1:
+            rec(torch.arange(pts.shape[0]), 0, world)
+        return cls(torch.tensor(nodes, dtype=torch.float32).reshape(-1, 4) if nodes else torch.zeros((0, 4)), world)
+
+    def assign(self, xyz: torch.Tensor) -> torch.Tensor:
+        """[n] int64: the rank whose cell holds each point."""
+        pts = torch.as_tensor(xyz).detach()
+        node = torch.zeros((pts.shape[0],), dtype=torch.int64, device=pts.device)
+        for i in range(self.nodes.shape[0]):
+            axis, split, l, r = int(self.nodes[i, 0]), float(self.nodes[i, 1]), int(self.nodes[i, 2]), int(self.nodes[i, 3])
+            here, go_left = node == i, pts[:, axis] < split
+            node = torch.where(here & go_left, torch.full_like(node, l), torch.where(here & ~go_left, torch.full_like(node, r), node))
+        return -1 - node if self.world > 1 else node
+
+    def order(self, Tcw: torch.Tensor) -> list:
+        """The ranks front to back for the camera of Tcw (world -> camera): the CPU twin of gsr_shard_order."""
+        if self.world == 1:
+            return [0]
+        T = torch.as_tensor(Tcw, dtype=torch.float64).detach().cpu().reshape(4, 4)
+        c = -(T[:3, :3].t() @ T[:3, 3])
+        out, stack = [], [0]
+        while stack:
+            n = stack.pop()
+            if n < 0:
+                out.append(-1 - n)
+                continue
+            axis, split, l, r = int(self.nodes[n, 0]), float(self.nodes[n, 1]), int(self.nodes[n, 2]), int(self.nodes[n, 3])
+            near_left = float(c[axis]) < split
+            stack.append(r if near_left else l)                  # far side: popped second
+            stack.append(l if near_left else r)
+        return out
+
+    def key(self, Tcw: torch.Tensor, rank: int) -> float:
+        """An order key for LayerCompositor.composite: this rank's position in the front-to-back order."""
+        return float(self.order(Tcw).index(rank))
+
+
+def _gather_rows(rows: torch.Tensor, world: int, group=None):
+    """all-gather of row blocks of different lengths: returns the list of every rank's rows"""
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c) for c in counts]
+    mx = max(max(counts), 1)
+    pad = torch.zeros((mx,) + tuple(rows.shape[1:]), dtype=rows.dtype)
+    pad[:rows.shape[0]] = rows.detach().cpu()
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return [p[:c] for p, c in zip(parts, counts)]
+
+
+def rebalance_rows(xyz: torch.Tensor, payload: torch.Tensor, rank: int, world: int, group=None, tolerance: float = 1.25):
+    """Re-split of a sharded map whose cells have drifted out of balance (pruning removes where the scene is over-explained, growth adds
+    where it is not). Collective. xyz [n,3] the rank's centres, payload [n,k] everything that travels with a Gaussian (its raw
+    parameters and Adam moments). Returns (partition, keep, arrivals): the new KdPartition, the indices of the own rows that stay,
+    and the payload rows that arrive from the other ranks — or None when max(count) <= tolerance * mean(count) (nothing moves).
+    Exchange: one all-gather of the centres (12 B per Gaussian of the whole map) and one of the rows that change owner."""
+    mine = xyz.detach().cpu().to(torch.float32)
+    counts = [p.shape[0] for p in _gather_rows(torch.zeros((mine.shape[0], 0)), world, group)]
+    total = sum(counts)
+    if total == 0 or max(counts) <= tolerance * total / world:
+        return None
+    everyone = torch.cat(_gather_rows(mine, world, group), 0)
+    part = KdPartition.build(everyone, world)
+    owner = part.assign(mine)
+    stay = owner == rank
+    leaving = torch.cat([payload.detach().cpu().to(torch.float32)[~stay], owner[~stay].to(torch.float32).unsqueeze(1)], 1)
+    arrivals = torch.cat([p[p[:, -1] == rank][:, :-1] for r, p in enumerate(_gather_rows(leaving, world, group)) if r != rank] or
+                         [torch.zeros((0, payload.shape[1]))], 0)
+    return part, torch.nonzero(stay).squeeze(-1), arrivals
 
 
 def make_sharded_mapper(harness_mod):
@@ -217,15 +339,18 @@ def make_sharded_mapper(harness_mod):
         Exact for shards that are depth-separable for the view (up to the residual transmittance of pixels that
         stop early, forward.cu:360-364); otherwise report PSNR against the one-GPU render."""
 
-        def __init__(self, gmap, width, height, group=None, **kw):
+        def __init__(self, gmap, width, height, group=None, partition=None, **kw):
             super().__init__(gmap, width, height, **kw)
             self.comp = LayerCompositor(group)
+            self.partition = partition                           # KdPartition: the cells' order holds for every view; None: nearest depth of the shard
 
         def render_pair(self, Tcw, tracking=False):
             rimage, rsur, rdepth = super().render_pair(Tcw, tracking)
             with torch.no_grad():                                # the shard's nearest camera depth, as a device scalar
                 xyz = self.map.xyz
-                if len(self.map):
+                if self.partition is not None:                   # exact front-to-back order of the k-d cells for this camera
+                    key = self.partition.key(Tcw, self.comp.rank)
+                elif len(self.map):
                     z = (xyz * Tcw[2, :3]).sum(1) + Tcw[2, 3]      # (as a matrix-vector product rocBLAS takes 0.7 ms at 1 M rows)
                     key = torch.where(z > 0.2, z, torch.full_like(z, float("inf"))).min()   # what the rasterizer keeps (auxiliary.h:154)
                 else:
@@ -245,6 +370,41 @@ def make_sharded_mapper(harness_mod):
             # the pose gradients of the ranks are SUMMED (_sync_pose_grads): a term that does not depend on the shard
             # (harness.track's feature reprojection error) would otherwise be counted `world` times
             return 1.0 / self.comp.world
+
+        def _densify_renders(self, Tcw):
+            # the mask of Render::AddGaussian is taken on the composite of all ranks' layers: the same on every rank
+            rim, _, rds = self.render_pair(Tcw, tracking=True)
+            return rim, rds
+
+        def _owned(self, pw):
+            # owner rule: a new Gaussian belongs to the rank whose cell holds the back-projected point
+            if self.comp.world == 1:
+                return None
+            if self.partition is None:
+                raise RuntimeError("map growth on a sharded map needs a KdPartition")
+            return self.partition.assign(pw) == self.comp.rank
+
+        def rebalance(self, tolerance: float = 1.25):
+            """After pruning / growth: re-split the map when the cells are out of balance (collective). Returns True when rows moved."""
+            g = self.map
+            if self.comp.world == 1 or self.partition is None:
+                return False
+            state = [g.opt.state.get(getattr(g, n), {}) for n in g.NAMES]
+            rows = lambda ts: torch.cat([t.detach().reshape(len(g), -1) for t in ts], 1)
+            par = rows([getattr(g, n) for n in g.NAMES])
+            zeros = lambda n: torch.zeros_like(getattr(g, n))
+            m = rows([st.get("exp_avg", zeros(n)) for st, n in zip(state, g.NAMES)])
+            v = rows([st.get("exp_avg_sq", zeros(n)) for st, n in zip(state, g.NAMES)])
+            res = rebalance_rows(g.xyz, torch.cat([par, m, v], 1), self.comp.rank, self.comp.world, self.comp.group, tolerance)
+            if res is None:
+                return False
+            self.partition, keep, arr = res
+            mask = torch.ones(len(g), dtype=torch.bool, device=g.device)
+            mask[keep.to(g.device)] = False
+            g.prune(mask)
+            k = par.shape[1]
+            g.append_rows(arr[:, :k].to(g.device), arr[:, k:2 * k].to(g.device), arr[:, 2 * k:].to(g.device))
+            return True
 
         def _sync_pose_grads(self):
             g = self.map

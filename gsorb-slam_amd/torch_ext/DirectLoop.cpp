@@ -12,12 +12,26 @@
 // with no allocation, no gradient tensor of a raw parameter, and no host synchronisation except where the reference has one
 // (the tracking loop reads its loss every iteration, Render.cc:1107; the mapping loop of RenderForFrame never does: MapFrame
 // reads all losses back once, at the end). Reference: src/Render.cc:420-483, :1054-1126; src/Gaussian.cc:97-175.
+//
+// SHARDED (SetShard; multi-GPU scheme B): every rank holds a shard of the map — one cell of a k-d partition — with its Adam
+// moments and rasterizes only that shard; between the forward and the loss sit the compositor of csrc/gsr_shard.h and its collectives, issued
+// from here on the loop's stream through the c10d::ProcessGroup the caller hands over (backend "nccl" = RCCL over xGMI; "gloo" in the
+// two-processes-on-one-GPU test: staged through the host):
+//   gsr_shard_order (the cells front to back for this pose) -> gsr_forward_ws (own shard) -> ALL-GATHER (silhouette, surface depth: 2 planes) ->
+//   gsr_composite_forward -> ALL-REDUCE (the four premultiplied planes) -> the loss kernels on the composite [mapping: ALL-REDUCE of the three
+//   regulariser sums before gsr_map_loss_finish] -> gsr_composite_backward_local -> ALL-GATHER (g . L: 1 plane) -> gsr_composite_backward_occlusion
+//   -> gsr_backward on the layer's gradient [mapping: with the Adam step fused; tracking: gsr_pose_grad -> ALL-REDUCE of the pose rows (24 KB)
+//   -> gsr_pose_update]. No per-splat data crosses ranks: north_star's "all-reduce on pose / loss gradients only".
 #include "SlamLoop.h"
 
 #include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
+#include <rccl/rccl.h> // (types and prototypes only: the library is opened at run time, below)
+#include <dlfcn.h>
 
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <stdexcept>
 #include <string>
@@ -42,7 +56,9 @@ struct SlamLoop::Direct {
     size_t binning_bytes = 0;
     torch::Tensor geom, image, binning;                                  // the rasterizer's three workspaces
     torch::Tensor mc, opac, scales, rots, radii;                         // what the rasterizer takes
-    torch::Tensor out_color, out_sur, out_ds;                            // what it renders
+    torch::Tensor layers;                                                // [6,H,W] what it renders: rgb, depth, silhouette, surface depth — views below
+    torch::Tensor out_color, out_sur, out_ds;
+    torch::Tensor G;                                                     // [5,H,W] the loss's gradient: d/d rgb, d/d depth, d/d silhouette (zero) — views below
     torch::Tensor g_image, g_ds, g_ssim, dmaps, ssim_partial, partial6;  // upstream gradients of the renders, SSIM / loss scratch
     torch::Tensor d_mc, d_m2d, d_col, d_opac, d_scale, d_rot;            // the rasterizer's gradients
     torch::Tensor loss_partial, sums, reg_partial, reg_out, neg_c, Tcw, bg, view, proj, campos, history;
@@ -50,7 +66,128 @@ struct SlamLoop::Direct {
     torch::Tensor pose_acc;                                              // [64, 12] the fused pose step's accumulator rows (zero between launches)
     torch::Tensor tickets;                                               // [2 * GSR_TICKET_WORDS] arrival counters of the kernels that finish their own sums (zero between launches)
     int64_t history_len = 0;
+    // sharded (SetShard): the composite of all ranks' layers and what its backward needs
+    c10::intrusive_ptr<c10d::ProcessGroup> pg;
+    int rank = 0, world = 1;
+    bool order_stale = true;                                             // the pose changed since gsr_shard_order ran
+    bool staged = false;                                                 // the group cannot move device tensors (gloo): through the host
+    ncclComm_t comm = nullptr;                                           // backend "nccl": the loop's OWN RCCL communicator — its collectives are enqueued on the loop's
+                                                                         // stream like any kernel (the process group's run on its internal stream behind two event hops
+                                                                         // and ~25 us of host work each: 5 per mapping iteration); the group carries the bootstrap only
+    hipStream_t stream = nullptr;
+    torch::Tensor kd_nodes, order;                                       // [world - 1, 4] the partition (gsr_shard_order), [world] int64 the ranks front to back
+    torch::Tensor gathered, comp, D, c_own, c_all, reg_tot;              // [world,2,H,W]; [6,H,W] composite rgb, depth, silhouette, surface depth;
+                                                                         // [5,H,W] d/d own layer (4) and d/d own silhouette; [H,W]; [world,H,W]; [4]
+    ~Direct();
+    bool sharded() const { return world > 1 || pg; }
+    void all_gather(torch::Tensor out, const torch::Tensor& in);         // out [world, ...] <- every rank's `in`
+    void all_reduce(torch::Tensor t);                                    // in-place sum
 };
+
+namespace {
+// RCCL is resolved when the first sharded loop asks for it, from the library the process group's backend has already loaded
+// (torch/lib/librccl.so): programs that never shard never load it (linked in at build time its exit-time teardown raced libtorch's).
+struct Rccl {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    static const Rccl& get()
+    {
+        static const Rccl r = [] {
+            Rccl x;
+            void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) throw std::runtime_error(std::string("the sharded loop needs librccl.so: ") + dlerror());
+            auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) throw std::runtime_error(std::string("librccl.so lacks ") + n); return p; };
+            x.GetUniqueId = (decltype(x.GetUniqueId))sym("ncclGetUniqueId"); x.CommInitRank = (decltype(x.CommInitRank))sym("ncclCommInitRank");
+            x.CommDestroy = (decltype(x.CommDestroy))sym("ncclCommDestroy"); x.AllGather = (decltype(x.AllGather))sym("ncclAllGather");
+            x.AllReduce = (decltype(x.AllReduce))sym("ncclAllReduce"); x.GetErrorString = (decltype(x.GetErrorString))sym("ncclGetErrorString");
+            return x;
+        }();
+        return r;
+    }
+};
+void nccl_chk(ncclResult_t r, const char* what)
+{
+    if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + Rccl::get().GetErrorString(r));
+}
+} // namespace
+
+SlamLoop::Direct::~Direct()
+{
+    if (comm) (void)Rccl::get().CommDestroy(comm);
+}
+
+void SlamLoop::Direct::all_gather(torch::Tensor out, const torch::Tensor& in)
+{
+    if (!pg) { out.select(0, 0).copy_(in); return; }
+    if (comm) {
+        const auto src = in.contiguous();
+        nccl_chk(Rccl::get().AllGather(src.data_ptr<float>(), out.data_ptr<float>(), (size_t)src.numel(), ncclFloat, comm, stream), "ncclAllGather");
+        return;
+    }
+    if (staged) {
+        auto hin = in.to(torch::kCPU).contiguous().reshape({-1}), hout = torch::empty({out.numel()}, hin.options()); // (flat: the backends chunk the output by rank)
+        pg->_allgather_base(hout, hin)->wait();
+        out.copy_(hout.reshape(out.sizes()));
+        return;
+    }
+    auto src = in.contiguous().reshape({-1}), dst = out.reshape({-1}); // (views: `out` is contiguous)
+    pg->_allgather_base(dst, src)->wait(); // (RCCL: enqueued behind this stream's work; wait() orders the stream, not the host)
+}
+
+void SlamLoop::Direct::all_reduce(torch::Tensor t)
+{
+    if (!pg) return;
+    if (comm) {
+        nccl_chk(Rccl::get().AllReduce(t.data_ptr<float>(), t.data_ptr<float>(), (size_t)t.numel(), ncclFloat, ncclSum, comm, stream), "ncclAllReduce");
+        return;
+    }
+    if (staged) {
+        auto h = t.to(torch::kCPU).contiguous();
+        std::vector<torch::Tensor> v{h};
+        pg->allreduce(v)->wait();
+        t.copy_(h);
+        return;
+    }
+    std::vector<torch::Tensor> v{t};
+    pg->allreduce(v)->wait();
+}
+
+void SlamLoop::SetShard(c10::intrusive_ptr<c10d::ProcessGroup> pg, int rank, int world, const torch::Tensor& kd_nodes)
+{
+    if (!direct_()) throw std::runtime_error("SetShard needs LoopConfig::direct");
+    if (world < 1 || rank < 0 || rank >= world || world > 32) throw std::runtime_error("SetShard: bad rank / world");
+    if (pg && (pg->getRank() != rank || pg->getSize() != world)) throw std::runtime_error("SetShard: the group's rank / size differ");
+    if (!pg && world > 1) throw std::runtime_error("SetShard: world > 1 needs a process group");
+    if (kd_nodes.defined() && kd_nodes.numel() > 0 && (kd_nodes.dim() != 2 || kd_nodes.size(0) != world - 1 || kd_nodes.size(1) != 4))
+        throw std::runtime_error("SetShard: kd_nodes must be [world - 1, 4]");
+    if (!d_) d_ = std::make_shared<Direct>();
+    Direct& d = *d_;
+    d.pg = pg; d.rank = rank; d.world = world;
+    d.staged = pg && pg->getBackendName() != "nccl";
+    if (d.comm) { (void)Rccl::get().CommDestroy(d.comm); d.comm = nullptr; }
+    if (pg && !d.staged) { // the communicator's id travels through the group (a device tensor: the group's backend is RCCL too)
+        c10::DeviceGuard guard(dev_);
+        ncclUniqueId id;
+        if (rank == 0) nccl_chk(Rccl::get().GetUniqueId(&id), "ncclGetUniqueId");
+        auto bytes = torch::empty({(int64_t)sizeof(id)}, torch::kUInt8);
+        std::memcpy(bytes.data_ptr(), &id, sizeof(id));
+        auto on_dev = bytes.to(dev_);
+        std::vector<torch::Tensor> v{on_dev};
+        pg->broadcast(v)->wait();
+        bytes = on_dev.to(torch::kCPU);
+        std::memcpy(&id, bytes.data_ptr(), sizeof(id));
+        nccl_chk(Rccl::get().CommInitRank(&d.comm, world, id, rank), "ncclCommInitRank");
+    }
+    d.kd_nodes = (kd_nodes.defined() && kd_nodes.numel() > 0) ? kd_nodes.to(dev_, torch::kFloat32).contiguous() : torch::Tensor();
+    d.order = torch::arange(world, torch::TensorOptions().device(dev_).dtype(torch::kInt64)); // (no partition given: the ranks ARE the order, e.g. depth slabs)
+    shard_ = true;
+    d.gathered = torch::Tensor(); // (re-sized by ensure_direct_)
+}
 
 SlamLoop::~SlamLoop() = default;
 
@@ -67,8 +204,10 @@ void SlamLoop::ensure_direct_(int64_t history_len)
     if (!d.image.defined()) { // per image size: once
         const int64_t np = (int64_t)gsr_ssim_partials(3, H_, W_);
         d.image = torch::empty({(int64_t)gsr_image_bytes(W_, H_)}, bo);
-        d.out_color = torch::empty({3, H_, W_}, fo); d.out_sur = torch::empty({1, H_, W_}, fo); d.out_ds = torch::empty({2, H_, W_}, fo);
-        d.g_image = torch::empty({3, H_, W_}, fo); d.g_ds = torch::zeros({2, H_, W_}, fo); // (the silhouette plane's gradient stays zero: its mask is detached)
+        d.layers = torch::empty({6, H_, W_}, fo); // (one block: the compositor takes (rgb, depth) as four consecutive planes, the all-gather (silhouette, surface depth) as two)
+        d.out_color = d.layers.slice(0, 0, 3); d.out_ds = d.layers.slice(0, 3, 5); d.out_sur = d.layers.slice(0, 5, 6);
+        d.G = torch::zeros({5, H_, W_}, fo);
+        d.g_image = d.G.slice(0, 0, 3); d.g_ds = d.G.slice(0, 3, 5); // (the silhouette plane's gradient stays zero: its mask is detached)
         d.g_ssim = torch::empty({3, H_, W_}, fo); d.dmaps = torch::empty({3, 3, H_, W_}, fo); d.ssim_partial = torch::empty({np}, fo); d.partial6 = torch::empty({np * 6}, fo);
         d.loss_partial = torch::empty({GSR_LOSS_PARTIALS * 5}, fo); d.sums = torch::empty({8}, fo); d.reg_out = torch::empty({4}, fo);
         d.neg_c = torch::full({1}, -(cfg_.im_weight_mapping * (1 - cfg_.lam)), fo);
@@ -91,6 +230,45 @@ void SlamLoop::ensure_direct_(int64_t history_len)
         grow_binning_(cfg_.binning_capacity > 0 ? (size_t)cfg_.binning_capacity : 4 * (size_t)n + 65536); // grows at the first synchronised look at an overflow
     }
     if (d.history_len < history_len) { d.history = torch::empty({history_len}, fo); d.history_len = history_len; }
+    if (shard_ && !d.gathered.defined()) {
+        // comp: the four planes the all-reduce sums, the three regulariser sums right behind them (ONE all-reduce carries both), then the
+        // composite's silhouette and surface depth
+        const int64_t HW = (int64_t)H_ * W_;
+        d.gathered = torch::empty({d.world, 2, H_, W_}, fo); d.comp = torch::zeros({6 * HW + 4}, fo); d.D = torch::empty({5, H_, W_}, fo);
+        d.reg_tot = d.comp.slice(0, 4 * HW, 4 * HW + 4);
+        d.c_own = torch::empty({1, H_, W_}, fo); d.c_all = torch::empty({d.world, 1, H_, W_}, fo);
+    }
+}
+
+// (the collectives of an iteration go to the stream its kernels go to)
+// Sharded: the composite of all ranks' layers from this rank's render (layers) — comp = {rgb, depth, silhouette, surface depth} of the whole map.
+void SlamLoop::shard_composite_forward_(bool pose_moved, bool with_reg)
+{
+    Direct& d = *d_;
+    void* const st = stream_();
+    d.stream = (hipStream_t)st;
+    const size_t HW = (size_t)H_ * W_;
+    // (the cells' order depends on the pose alone: once per MapFrame call, every iteration while the pose is tracked)
+    if (pose_moved && d.kd_nodes.defined()) chk(gsr_shard_order(d.world, f(d.kd_nodes), f(d.Tcw), (long long*)d.order.data_ptr<int64_t>(), st), "gsr_shard_order");
+    d.all_gather(d.gathered, d.layers.slice(0, 4, 6));
+    chk(gsr_composite_forward(d.world, d.rank, (const long long*)d.order.data_ptr<int64_t>(), f(d.gathered), 2, f(d.layers), H_, W_, 1, f(d.comp),
+                              f(d.comp) + 4 * HW + 4, f(d.comp) + 5 * HW + 4, st), "gsr_composite_forward");
+    // mapping: the regularisers are a sum and a mean over the WHOLE map (Render.cc:449-462) — their three sums ride behind the planes
+    d.all_reduce(d.comp.slice(0, 0, (int64_t)(4 * HW + (with_reg ? 3 : 0))));
+}
+
+// Sharded: from the loss's gradient on the composite (G: rgb, depth; the silhouette's is zero — a detached mask in both losses) to the gradient
+// of this rank's own layer (D: rgb, depth, silhouette): its planes through its prefix transmittance, its silhouette through what it occludes.
+void SlamLoop::shard_composite_backward_()
+{
+    Direct& d = *d_;
+    void* const st = stream_();
+    d.stream = (hipStream_t)st;
+    const long long* const order = (const long long*)d.order.data_ptr<int64_t>();
+    chk(gsr_composite_backward_local(d.world, d.rank, order, f(d.gathered), 2, f(d.layers), f(d.G), H_, W_, f(d.D), f(d.c_own), st), "gsr_composite_backward_local");
+    d.all_gather(d.c_all, d.c_own);
+    chk(gsr_composite_backward_occlusion(d.world, d.rank, order, f(d.gathered), 2, f(d.c_all), nullptr, H_, W_, f(d.D) + (size_t)4 * H_ * W_, st),
+        "gsr_composite_backward_occlusion");
 }
 
 void SlamLoop::grow_binning_(size_t capacity)
@@ -106,6 +284,7 @@ void SlamLoop::grow_binning_(size_t capacity)
 void SlamLoop::direct_forward_()
 {
     Direct& d = *d_;
+    if (d.n == 0) { d.layers.zero_(); return; } // (an empty shard still takes part in the exchange: its layer is nothing)
     const auto& s = rasterizer_.raster_settings_;
     gsr_forward_args a{};
     a.P = (int)d.n; a.D = 0; a.M = 0;
@@ -120,6 +299,7 @@ void SlamLoop::direct_forward_()
 void SlamLoop::direct_backward_(bool detach_depth_colour, bool means_only, const ::gsr_map_update_args* fused, const ::gsr_pose_step_args* pose_step)
 {
     Direct& d = *d_;
+    if (d.n == 0 && !pose_step) return;
     const auto& s = rasterizer_.raster_settings_;
     gsr_backward_args a{};
     a.P = (int)d.n; a.D = 0; a.M = 0; a.R = -1;
@@ -130,6 +310,9 @@ void SlamLoop::direct_backward_(bool detach_depth_colour, bool means_only, const
     a.geom_buffer = b(d.geom); a.binning_buffer = b(d.binning); a.image_buffer = b(d.image);
     a.dL_dpix = f(d.g_image); a.dL_dds = f(d.g_ds); a.ds_detach_depth = detach_depth_colour ? 1 : 0;
     a.dds_depth_only = 1; // (the silhouette is a detached mask in both losses: plane 1 of g_ds would be zeros)
+    if (shard_) { // the own layer's gradient comes from the compositor, and the own silhouette has one: what the layer occludes
+        a.dL_dpix = f(d.D); a.dL_dds = f(d.D) + (size_t)3 * H_ * W_; a.dds_depth_only = 0;
+    }
     a.fused_map_update = fused; // (the per-splat stage then takes the Adam step itself and writes no gradient)
     a.fused_pose_step = pose_step; // (tracking: the per-splat stage forms the pose sums and its last workgroup takes the pose step: no gradient tensor)
     if (!fused && !pose_step) a.dL_dmean3D = f(d.d_mc);
@@ -156,16 +339,24 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
     void* const st = stream_();
     const size_t n = (size_t)d.n;
     const float limit = (float)(0.1 * cfg_.scene_radius), wl = (float)cfg_.reg_long_weight, wsc = (float)cfg_.reg_scalar_weight;
-    chk(gsr_map_prepare(n, f(xyz), f(logit_opacities), f(log_scales), f(unnorm_quat), f(d.Tcw), f(d.mc), f(d.opac), f(d.scales), f(d.rots), limit, wl, wsc,
-                        f(d.reg_partial), cfg_.fused_loss ? nullptr : f(d.reg_out), st), "gsr_map_prepare");
+    if (shard_ && !cfg_.fused_loss) throw std::runtime_error("the sharded loop needs LoopConfig::fused_loss");
+    if (n == 0) d.reg_tot.zero_();
+    else chk(gsr_map_prepare(n, f(xyz), f(logit_opacities), f(log_scales), f(unnorm_quat), f(d.Tcw), f(d.mc), f(d.opac), f(d.scales), f(d.rots), limit, wl, wsc,
+                        f(d.reg_partial), shard_ ? f(d.reg_tot) : cfg_.fused_loss ? nullptr : f(d.reg_out), st), "gsr_map_prepare");
     direct_forward_();
+    if (shard_) { shard_composite_forward_(d.order_stale, true); d.order_stale = false; }
     // Render.cc:436-471: lam * L1 + (1 - lam) * (1 - SSIM), masked depth L1, masked surface-depth L1 (no gradient), the regularisers
     const float w3[3] = {(float)(cfg_.im_weight_mapping * cfg_.lam), (float)cfg_.depth_weight_mapping, (float)cfg_.sur_depth_weight_mapping};
     const float c_ssim = (float)(cfg_.im_weight_mapping * (1 - cfg_.lam));
-    const float *img = f(d.out_color), *dep = f(d.out_ds), *sil = f(d.out_ds) + (size_t)H_ * W_, *sur = f(d.out_sur);
+    const size_t HW = (size_t)H_ * W_;
+    const float* const im0 = shard_ ? f(d.comp) : f(d.layers); // (both blocks: rgb, depth, silhouette, surface depth; comp keeps four floats between depth and silhouette)
+    const size_t gap = shard_ ? 4 : 0;
+    const float *img = im0, *dep = im0 + 3 * HW, *sil = im0 + 4 * HW + gap, *sur = im0 + 5 * HW + gap;
     if (cfg_.fused_loss) { // two passes over the image and one single-workgroup kernel between them
         chk(gsr_map_loss_forward(img, dep, sur, sil, f(fr.rgb), f(fr.depth), H_, W_, taps_host_.data(), 0.99f, f(d.partial6), f(d.dmaps), st), "gsr_map_loss_forward");
-        chk(gsr_map_loss_finish(f(d.partial6), f(d.reg_partial), n, H_, W_, w3, c_ssim, wl, wsc, b(d.geom), f(d.sums), f(d.reg_out), loss_slot, st), "gsr_map_loss_finish");
+        // (sharded: the regulariser sums of the whole map stand in as ONE row)
+        chk(gsr_map_loss_finish(f(d.partial6), shard_ ? f(d.reg_tot) : f(d.reg_partial), shard_ ? 1 : n, H_, W_, w3, c_ssim, wl, wsc, b(d.geom), f(d.sums), f(d.reg_out),
+                                loss_slot, st), "gsr_map_loss_finish");
         chk(gsr_map_loss_backward(img, dep, f(fr.rgb), f(fr.depth), f(d.dmaps), H_, W_, taps_host_.data(), w3, f(d.neg_c), f(d.sums), f(d.g_image), f(d.g_ds), st),
             "gsr_map_loss_backward");
     } else {
@@ -187,6 +378,8 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
     u.opacities = f(d.opac); u.scales = f(d.scales); u.Tcw = f(d.Tcw);
     u.reg_out = f(d.reg_out); u.reg_limit = limit; u.w_long = wl; u.w_scalar = wsc;
     u.geom = b(d.geom); u.beta1 = 0.9; u.beta2 = 0.999; u.eps = fopt_->eps();
+    if (shard_) shard_composite_backward_();
+    if (n == 0) return;
     if (cfg_.fused_update) {
         direct_backward_(false, false, &u, nullptr); // backward and update in the same per-splat pass (gsr_backward_args.fused_map_update)
     } else {
@@ -198,7 +391,7 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
 std::vector<double> SlamLoop::MapFrame(const LoopFrame& fr, int iters)
 {
     std::vector<double> losses;
-    if (iters <= 0 || size() == 0) return losses;
+    if (iters <= 0 || (size() == 0 && !shard_)) return losses;
     if (!direct_()) {
         for (int i = 0; i < iters; i++) losses.push_back(MappingIteration(fr));
         return losses;
@@ -209,6 +402,7 @@ std::vector<double> SlamLoop::MapFrame(const LoopFrame& fr, int iters)
     Direct& d = *d_;
     const LoopFrame frame{fr.rgb.to(dev_, torch::kFloat32).contiguous(), fr.depth.to(dev_, torch::kFloat32).contiguous(), fr.Tcw};
     d.Tcw.copy_(fr.Tcw.to(torch::kFloat32).reshape({4, 4}));
+    if (shard_) { shard_preflight_(); d.order_stale = true; }
     int done = 0;
     while (done < iters) {
         const int batch = iters - done;
@@ -217,6 +411,11 @@ std::vector<double> SlamLoop::MapFrame(const LoopFrame& fr, int iters)
         // an iteration whose forward ran out of workspace rendered nothing, wrote NaN and skipped its step: it is taken again
         // (its step count with it) once the workspace has grown. The first iteration on a new map size is where this can happen.
         const bool overflowed = direct_overflowed_();
+        if (shard_) { // the ranks step together or not at all: an overflow on ANY rank corrupted every rank's composite
+            if (shard_any_(overflowed)) throw std::runtime_error("sharded loop: a rank's binning workspace overflowed inside a batch of iterations; raise LoopConfig::binning_capacity");
+            for (int i = 0; i < batch; i++) losses.push_back(h[i].item<float>());
+            break;
+        }
         int kept = 0;
         for (int i = 0; i < batch; i++) {
             const double v = h[i].item<float>();
@@ -246,19 +445,24 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
     d.pose_moments.zero_();
     d.best.zero_(); d.best.slice(0, 0, 1).fill_(std::numeric_limits<float>::infinity());
     chk(gsr_pose_from_quat(f(d.pose), f(d.pose) + 4, f(d.Tcw), st), "gsr_pose_from_quat");
+    if (shard_) shard_preflight_();
     // the map does not move while the pose is tracked: its activations are formed once per call
-    chk(gsr_map_prepare((size_t)d.n, nullptr, f(logit_opacities), f(log_scales), f(unnorm_quat), nullptr, nullptr, f(d.opac), f(d.scales), f(d.rots), 0.f, 0.f, 0.f,
+    if (d.n > 0) chk(gsr_map_prepare((size_t)d.n, nullptr, f(logit_opacities), f(log_scales), f(unnorm_quat), nullptr, nullptr, f(d.opac), f(d.scales), f(d.rots), 0.f, 0.f, 0.f,
                         nullptr, nullptr, st), "gsr_map_prepare");
     const float w3[3] = {(float)cfg_.im_weight_tracking, (float)cfg_.depth_weight_tracking, 0.f};
-    const float *img = f(d.out_color), *sil = f(d.out_ds) + (size_t)H_ * W_;
-    const float* dep = cfg_.use_sur_depth ? nullptr : f(d.out_ds);
-    const float* sur = cfg_.use_sur_depth ? f(d.out_sur) : nullptr;
+    const size_t HW = (size_t)H_ * W_;
+    const float* const im0 = shard_ ? f(d.comp) : f(d.layers);
+    const size_t gap = shard_ ? 4 : 0;
+    const float *img = im0, *sil = im0 + 4 * HW + gap;
+    const float* dep = cfg_.use_sur_depth ? nullptr : im0 + 3 * HW;
+    const float* sur = cfg_.use_sur_depth ? im0 + 5 * HW + gap : nullptr;
     std::vector<double> history;
     double last_loss = 0.0;
     int step = 0;
     for (int it = 0; it < iters; it++) {
-        chk(gsr_to_camera(f(xyz), (size_t)d.n, f(d.Tcw), f(d.mc), st), "gsr_to_camera");
+        if (d.n > 0) chk(gsr_to_camera(f(xyz), (size_t)d.n, f(d.Tcw), f(d.mc), st), "gsr_to_camera");
         direct_forward_();
+        if (shard_) shard_composite_forward_(true, false);
         // Render.cc:1088-1105: the masked L1 sums and their gradient planes, one pass over the render
         chk(gsr_track_loss(img, dep, sur, sil, f(frame.rgb), f(frame.depth), H_, W_, 0.99f, w3, f(d.loss_partial), f(d.sums), f(d.g_image), f(d.g_ds),
                            reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()), st), "gsr_track_loss");
@@ -267,7 +471,14 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
         u.partial = f(d.pose_partial); u.loss = f(d.sums) + 5; u.geom = b(d.geom);
         u.lr = cfg_.lr_cam_quat; u.beta1 = 0.9; u.beta2 = 0.999; u.eps = 1e-15; u.step = ++step;
         uint32_t* const tickets = reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()) + GSR_TICKET_WORDS;
-        if (cfg_.fused_update) { // the backward's per-splat stage forms the pose sums (into accumulator rows that are zero between launches), a one-wave kernel takes the step: no dL/dmeans tensor
+        if (shard_) { // every rank holds the pose sums of its shard: the rows are summed over the ranks before the (replicated) pose step
+            shard_composite_backward_();
+            direct_backward_(true, true, nullptr, nullptr);
+            if (d.n > 0) chk(gsr_pose_grad(f(xyz), f(d.d_mc), (size_t)d.n, f(d.Tcw), f(d.pose_partial), nullptr, st), "gsr_pose_grad");
+            else d.pose_partial.zero_();
+            d_->all_reduce(d.pose_partial);
+            chk(gsr_pose_update(&u, st), "gsr_pose_update");
+        } else if (cfg_.fused_update) { // the backward's per-splat stage forms the pose sums (into accumulator rows that are zero between launches), a one-wave kernel takes the step: no dL/dmeans tensor
             u.partial = f(d.pose_acc);
             const gsr_pose_step_args ps{f(xyz), &u};
             direct_backward_(true, true, nullptr, &ps); // the [z, 1, 0] colours are detached while tracking (Render.cc:949-981)
@@ -276,7 +487,10 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
             chk(gsr_pose_step(f(xyz), f(d.d_mc), (size_t)d.n, &u, tickets, st), "gsr_pose_step"); // the pose sums and the step in one launch
         }
         const double lv = d.history.slice(0, it, it + 1).item<float>(); // Render.cc:1107: the loop looks at every loss
-        if (std::isnan(lv) && direct_overflowed_()) { --step; --it; continue; } // the workspace has grown: take the iteration again
+        if (shard_) {
+            if (std::isnan(lv) && shard_any_(direct_overflowed_()))
+                throw std::runtime_error("sharded loop: a rank's binning workspace overflowed while tracking; raise LoopConfig::binning_capacity");
+        } else if (std::isnan(lv) && direct_overflowed_()) { --step; --it; continue; } // the workspace has grown: take the iteration again
         history.push_back(lv);
         if (std::fabs(last_loss - lv) < 10e-4) break;                                                    // Render.cc:1113-1114
         last_loss = lv;
@@ -286,6 +500,86 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
         *Tcw_best = rt2T(bh.slice(0, 1, 5).reshape({4, 1}), bh.slice(0, 5, 8).reshape({3, 1})).to(dev_);
     }
     return history;
+}
+
+int SlamLoop::shard_rank_() const { return d_ ? d_->rank : 0; }
+
+torch::Tensor SlamLoop::LastPoseSums() const
+{
+    if (!d_ || !d_->pose_partial.defined()) throw std::runtime_error("LastPoseSums: no tracking iteration yet");
+    return d_->pose_partial.sum(0);
+}
+
+// Sharded: does ANY rank say yes? (a host-side decision every rank must take alike)
+bool SlamLoop::shard_any_(bool mine)
+{
+    Direct& d = *d_;
+    if (!d.pg) return mine;
+    auto t = torch::full({1}, mine ? 1.f : 0.f, torch::TensorOptions().dtype(torch::kFloat32).device(d.staged ? torch::Device(torch::kCPU) : dev_));
+    std::vector<torch::Tensor> v{t};
+    d.pg->allreduce(v)->wait();
+    return t.item<float>() > 0.f;
+}
+
+// Sharded: one forward of the shard under the current pose before the first iteration on a workspace, so that every rank's binning workspace holds its
+// frame with room to spare (inside a batch nobody looks, and an overflow on one rank would spoil every rank's composite).
+void SlamLoop::shard_preflight_()
+{
+    Direct& d = *d_;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        if (d.n > 0) {
+            chk(gsr_map_prepare((size_t)d.n, f(xyz), f(logit_opacities), f(log_scales), f(unnorm_quat), f(d.Tcw), f(d.mc), f(d.opac), f(d.scales), f(d.rots), 0.f, 0.f, 0.f,
+                                nullptr, nullptr, stream_()), "gsr_map_prepare");
+            direct_forward_();
+        }
+        int R = 0, ov = 0;
+        if (d.n > 0) chk(gsr_ws_status(b(d.geom), stream_(), &R, &ov), "gsr_ws_status");
+        const size_t want = 2 * (size_t)R + 65536;
+        const bool grow = d.n > 0 && gsr_binning_bytes(want) > d.binning_bytes && (ov || gsr_binning_bytes((size_t)R + (size_t)R / 2) > d.binning_bytes);
+        if (grow) grow_binning_(want);
+        if (!shard_any_(ov != 0)) return;
+    }
+    throw std::runtime_error("sharded loop: the binning workspace keeps overflowing");
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> SlamLoop::RenderComposite(const torch::Tensor& Tcw)
+{
+    if (!direct_()) throw std::runtime_error("RenderComposite needs LoopConfig::direct");
+    torch::NoGradGuard ng;
+    c10::DeviceGuard guard(dev_);
+    ensure_direct_(1);
+    Direct& d = *d_;
+    d.Tcw.copy_(Tcw.to(torch::kFloat32).reshape({4, 4}));
+    if (shard_) shard_preflight_();
+    if (d.n > 0)
+        chk(gsr_map_prepare((size_t)d.n, f(xyz), f(logit_opacities), f(log_scales), f(unnorm_quat), f(d.Tcw), f(d.mc), f(d.opac), f(d.scales), f(d.rots), 0.f, 0.f, 0.f,
+                            nullptr, nullptr, stream_()), "gsr_map_prepare");
+    direct_forward_();
+    if (!shard_) return {d.layers.slice(0, 0, 3).clone(), d.layers.slice(0, 5, 6).clone(), d.layers.slice(0, 3, 5).clone()};
+    shard_composite_forward_(true, false);
+    const int64_t HW = (int64_t)H_ * W_;
+    const auto plane = [&](int64_t off, int64_t n) { return d.comp.slice(0, off, off + n * HW).reshape({n, H_, W_}); };
+    return {plane(0, 3).clone(), plane(5 * HW + 4, 1).clone(), torch::cat({plane(3 * HW, 1), plane(4 * HW + 4, 1)}, 0)};
+}
+
+// Sharded: the cell of the k-d partition every point lies in ([n] int64 ranks) — the owner rule of map growth
+torch::Tensor SlamLoop::shard_cells_(const torch::Tensor& pts) const
+{
+    const Direct& d = *d_;
+    const int64_t n = pts.size(0);
+    if (d.world == 1) return torch::zeros({n}, torch::TensorOptions().device(pts.device()).dtype(torch::kInt64));
+    if (!d.kd_nodes.defined()) throw std::runtime_error("map growth on a sharded loop needs the k-d partition (SetShard's kd_nodes)");
+    const auto kd = d.kd_nodes.to(torch::kCPU);
+    auto node = torch::zeros({n}, torch::TensorOptions().device(pts.device()).dtype(torch::kInt64));
+    // (the nodes are numbered parents before children: one pass over them settles every point)
+    for (int64_t i = 0; i < kd.size(0); i++) {
+        const int axis = (int)kd[i][0].item<float>();
+        const float split = kd[i][1].item<float>();
+        const int64_t left = (int64_t)kd[i][2].item<float>(), right = (int64_t)kd[i][3].item<float>();
+        const auto here = node == i, go_left = pts.select(1, axis) < split;
+        node = torch::where(here & go_left, torch::full_like(node, left), torch::where(here & ~go_left, torch::full_like(node, right), node));
+    }
+    return -1 - node;
 }
 
 } // namespace ORB_SLAM2

@@ -315,7 +315,8 @@ int64_t SlamLoop::AddGaussians(const LoopFrame& frame)
 {
     torch::NoGradGuard ng;
     const auto Tcw = frame.Tcw.to(dev_, torch::kFloat32);
-    auto [rim, rsur, rdep] = RenderPair(Tcw, true);
+    // (sharded: the mask is taken on the composite of all ranks' layers — the same on every rank)
+    auto [rim, rsur, rdep] = shard_ ? RenderComposite(Tcw) : RenderPair(Tcw, true);
     (void)rsur;
     const auto gray = (rim[0] * 299 + rim[1] * 587 + rim[2] * 114) / 1000;                               // Render.cc:560-561
     const auto black = gray < 50 / 255.0;
@@ -339,6 +340,11 @@ int64_t SlamLoop::AddGaussians(const LoopFrame& frame)
     const auto Twc = torch::inverse(Tcw);
     const auto pw = pc.matmul(Twc.slice(0, 0, 3).slice(1, 0, 3).t()) + Twc.slice(0, 0, 3).slice(1, 3, 4).reshape({1, 3});
     const auto cols = frame.rgb.index({torch::indexing::Slice(), v, u}).t().contiguous();
+    if (shard_) { // owner rule: a new Gaussian belongs to the rank whose cell holds the back-projected point
+        const auto mine = torch::nonzero(shard_cells_(pw) == shard_rank_()).squeeze(-1);
+        AddPoints(pw.index_select(0, mine), cols.index_select(0, mine));
+        return mine.size(0);
+    }
     AddPoints(pw, cols);
     return n;
 }

@@ -14,6 +14,7 @@
 #include "FusedOps.h"
 #include "Rasterizer.h"
 
+namespace c10d { class ProcessGroup; }
 struct gsr_map_update_args; // include/gsr.h
 struct gsr_pose_step_args;  // include/gsr.h
 
@@ -81,6 +82,20 @@ public:
     int64_t PruneLowOpacity();
     int64_t size() const { return xyz.defined() ? xyz.size(0) : 0; }
 
+    // ---- the map sharded over the GPUs of one node (multi-GPU scheme B; DirectLoop.cpp) ----
+    // This loop then holds ONE SHARD of the map (SetMap with the shard's rows): every iteration rasterizes the shard and composites the ranks'
+    // layers front to back around three collectives of `group` (backend "nccl" = RCCL; any other backend is staged through the host); the loss is
+    // evaluated on the composite on every rank, the regulariser sums (mapping) and the pose rows (tracking) are all-reduced, Adam state stays
+    // local. kd_nodes [world - 1, 4] = the k-d partition whose cell `rank` this shard is (gsr_shard_order; sharded.KdPartition.nodes); undefined:
+    // the ranks are already in front-to-back order (depth slabs of one view). group = null with world 1: the same launch sequence, no exchange.
+    // The reference is single-GPU (src/Render.cc:402-483, :1054-1126): north_star's "shard Gaussians, all-reduce pose / loss gradients only".
+    void SetShard(c10::intrusive_ptr<c10d::ProcessGroup> group, int rank, int world, const torch::Tensor& kd_nodes);
+    // the whole map's render for a pose from every rank's shard: {colour [3,H,W], surface depth [1,H,W], depth / silhouette [2,H,W]} (collective call)
+    std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> RenderComposite(const torch::Tensor& Tcw);
+    // (inspection) the twelve pose sums dL/dR (row-major), dL/dt of the last tracking iteration that went through gsr_pose_grad's rows — the
+    // sharded loop (summed over the ranks) and the unsharded one with LoopConfig::fused_update = false
+    torch::Tensor LastPoseSums() const;
+
     // both renders of an iteration: {colour [3,H,W], surface (median) depth [1,H,W], depth/silhouette [2,H,W]}
     std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> RenderPair(const torch::Tensor& Tcw, bool tracking);
 
@@ -102,6 +117,13 @@ private:
     struct Direct;
     std::shared_ptr<Direct> d_; // (shared_ptr: its deleter is bound where the type is complete)
     bool direct_() const { return cfg_.direct && cfg_.fused_pair && cfg_.fused_ops; }
+    bool shard_ = false;
+    void shard_composite_forward_(bool pose_moved, bool with_reg);
+    void shard_composite_backward_();
+    void shard_preflight_();
+    bool shard_any_(bool mine);
+    torch::Tensor shard_cells_(const torch::Tensor& pts) const;
+    int shard_rank_() const;
     void* stream_() const;
     void ensure_direct_(int64_t history_len);
     void grow_binning_(size_t capacity);

@@ -55,7 +55,7 @@ def build_lib(force: bool = False) -> str:
         objs.append(obj)
     csrc = os.path.join(PKG, "csrc")
     subprocess.run(["g++", "-shared", "-o", LIB] + objs + [
-        f"-L{tlib}", f"-L{csrc}", "-lgsr_hip", "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_hip",
+        f"-L{tlib}", f"-L{csrc}", "-lgsr_hip", "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-ldl",
         f"-Wl,-rpath,{tlib}", "-Wl,-rpath,$ORIGIN/../csrc"], check=True)
     for o in objs:
         os.remove(o)

@@ -3,8 +3,10 @@
 // lists as rasterize_points.h:18-65: the Python twin has no device_num), plus the radii-only
 // filter pass GSORB added on the C++ side.
 #include <torch/extension.h>
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 
 #include "Rasterizer.h"
+#include "SlamLoop.h"
 
 namespace {
 
@@ -46,10 +48,62 @@ torch::Tensor FilterRadii(const torch::Tensor& means3D, const torch::Tensor& sca
                                                    dev_index_of(means3D));
 }
 
+// LoopConfig from keyword arguments (the field names of SlamLoop.h)
+ORB_SLAM2::LoopConfig loop_config(const py::dict& kw)
+{
+    ORB_SLAM2::LoopConfig c;
+    for (auto item : kw) {
+        const std::string k = py::cast<std::string>(item.first);
+        const py::handle v = item.second;
+#define GSR_F(name, T) if (k == #name) { c.name = py::cast<T>(v); continue; }
+        GSR_F(im_weight_mapping, double) GSR_F(depth_weight_mapping, double) GSR_F(sur_depth_weight_mapping, double) GSR_F(reg_long_weight, double)
+        GSR_F(reg_scalar_weight, double) GSR_F(lam, double) GSR_F(lr_mean3d, double) GSR_F(lr_rgb, double) GSR_F(lr_rotation, double)
+        GSR_F(lr_opacities, double) GSR_F(lr_scales, double) GSR_F(lr_cam_quat, double) GSR_F(im_weight_tracking, double) GSR_F(depth_weight_tracking, double)
+        GSR_F(scale_modifier, double) GSR_F(scene_radius, double) GSR_F(prune_opacities, double) GSR_F(median_mul, double) GSR_F(init_scalar_method, int)
+        GSR_F(use_sur_depth, bool) GSR_F(fused_pair, bool) GSR_F(fused_ops, bool) GSR_F(direct, bool) GSR_F(binning_capacity, int64_t) GSR_F(fused_loss, bool)
+        GSR_F(fused_update, bool)
+#undef GSR_F
+        throw std::invalid_argument("SlamLoop: unknown configuration field " + k);
+    }
+    return c;
+}
+
 } // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
+    // ORB_SLAM2::SlamLoop (torch_ext/SlamLoop.h): the tracking / mapping / map-growth loops of Render.cc as the C++ driver, for callers that hold
+    // their frames as tensors — and the way a torch.distributed process group reaches the sharded loop (SetShard)
+    py::class_<ORB_SLAM2::SlamLoop, std::shared_ptr<ORB_SLAM2::SlamLoop>>(m, "SlamLoop")
+        .def(py::init([](int width, int height, float fx, float fy, const torch::Device& device, const py::kwargs& kw) {
+                 return std::make_shared<ORB_SLAM2::SlamLoop>(loop_config(kw), width, height, fx, fy, device);
+             }), py::arg("width"), py::arg("height"), py::arg("fx"), py::arg("fy"), py::arg("device"))
+        .def("set_map", &ORB_SLAM2::SlamLoop::SetMap)
+        .def("set_shard", [](ORB_SLAM2::SlamLoop& l, const py::object& group, int rank, int world, const torch::Tensor& kd_nodes) {
+                 c10::intrusive_ptr<c10d::ProcessGroup> pg;
+                 if (!group.is_none()) pg = py::cast<c10::intrusive_ptr<c10d::ProcessGroup>>(group);
+                 l.SetShard(pg, rank, world, kd_nodes);
+             }, py::arg("group"), py::arg("rank"), py::arg("world"), py::arg("kd_nodes"))
+        .def("track", [](ORB_SLAM2::SlamLoop& l, const torch::Tensor& rgb, const torch::Tensor& depth, const torch::Tensor& Tcw_init, int iters) {
+                 torch::Tensor best;
+                 const auto h = l.Track(ORB_SLAM2::LoopFrame{rgb, depth, Tcw_init}, Tcw_init, iters, &best);
+                 return std::make_pair(h, best);
+             }, py::call_guard<py::gil_scoped_release>())
+        .def("map_frame", [](ORB_SLAM2::SlamLoop& l, const torch::Tensor& rgb, const torch::Tensor& depth, const torch::Tensor& Tcw, int iters) {
+                 return l.MapFrame(ORB_SLAM2::LoopFrame{rgb, depth, Tcw}, iters);
+             }, py::call_guard<py::gil_scoped_release>())
+        .def("mapping_iteration", [](ORB_SLAM2::SlamLoop& l, const torch::Tensor& rgb, const torch::Tensor& depth, const torch::Tensor& Tcw) {
+                 return l.MappingIteration(ORB_SLAM2::LoopFrame{rgb, depth, Tcw});
+             }, py::call_guard<py::gil_scoped_release>())
+        .def("add_gaussians", [](ORB_SLAM2::SlamLoop& l, const torch::Tensor& rgb, const torch::Tensor& depth, const torch::Tensor& Tcw) {
+                 return l.AddGaussians(ORB_SLAM2::LoopFrame{rgb, depth, Tcw});
+             }, py::call_guard<py::gil_scoped_release>())
+        .def("prune_low_opacity", &ORB_SLAM2::SlamLoop::PruneLowOpacity, py::call_guard<py::gil_scoped_release>())
+        .def("render_composite", &ORB_SLAM2::SlamLoop::RenderComposite, py::call_guard<py::gil_scoped_release>())
+        .def("last_pose_sums", &ORB_SLAM2::SlamLoop::LastPoseSums)
+        .def("size", &ORB_SLAM2::SlamLoop::size)
+        .def("params", [](ORB_SLAM2::SlamLoop& l) { return std::vector<torch::Tensor>{l.xyz, l.rgb, l.unnorm_quat, l.logit_opacities, l.log_scales}; });
+
     m.def("rasterize_gaussians", &RasterizeGaussians);
     m.def("rasterize_gaussians_backward", &ORB_SLAM2::RasterizeGaussiansBackwardCUDA);
     m.def("rasterize_gaussians_backward_staged", &ORB_SLAM2::RasterizeGaussiansBackwardStaged);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 6 /* 6: gsr_track_loss, gsr_pose_step, gsr_backward_args.fused_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
+#define GSR_ABI_VERSION 7 /* 7: gsr_composite_* take the plane count of the gathered buffer, gsr_shard_order added; 6: gsr_track_loss, gsr_pose_step, gsr_backward_args.fused_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
                            * 5: gsr_map_prepare / gsr_map_update / gsr_map_loss_total / gsr_pose_update / gsr_pixel_loss_backward_add / gsr_composite_* added, GSR_LOSS_PARTIALS 256 -> 1024 */
 
 #define GSR_OK 0
@@ -384,7 +384,7 @@ int gsr_pose_step(const float* means3D, const float* dL_dmeans_cam, size_t n, co
 /* ---- multi-GPU scheme B (scene shards; gsorb-slam_amd/sharded.py): compositing of the ranks' layers around the
  * two collectives of the forward and the one of the backward. The reference is single-GPU; north_star: "shard Gaussians across the GPUs,
  * RCCL all-reduce on pose / loss gradients only". All pointers are DEVICE pointers; N = H * W.
- *   gathered [world,3,H,W]  the all-gather of every rank's (silhouette S, surface depth, key row), in RANK order
+ *   gathered [world,gathered_planes,H,W]  the all-gather of every rank's (silhouette S, surface depth[, a plane that carries the order key]), in RANK order
  *   order    [world] int64  the ranks front to back (argsort of the keys)
  *   layer4   [4,H,W]        this rank's (rgb, depth) render
  * gsr_composite_forward: contrib [4,H,W] = P_own * layer4 with P_own = prod_{layers in front} (1 - S) (the caller all-reduces it),
@@ -393,12 +393,18 @@ int gsr_pose_step(const float* means3D, const float* dL_dmeans_cam, size_t n, co
  * gsr_composite_backward_local: d_layer4 = P_own * g4 (g4 NULL: zeros) and c_own [H,W] = g4 . layer4, which the caller all-gathers.
  * gsr_composite_backward_occlusion: dS [H,W] = - sum_{k behind own} (prod_{h before k, h != own} (1 - S_h)) c_k
  *   + g_sil * prod_{h != own} (1 - S_h)   (c_all [world,H,W] in rank order; g_sil NULL: no silhouette gradient). */
-int gsr_composite_forward(int world, int rank, const long long* order, const float* gathered, const float* layer4, int H, int W, int has_sur,
+int gsr_composite_forward(int world, int rank, const long long* order, const float* gathered, int gathered_planes, const float* layer4, int H, int W, int has_sur,
                           float* contrib, float* sil_total, float* surf, void* stream);
-int gsr_composite_backward_local(int world, int rank, const long long* order, const float* gathered, const float* layer4, const float* g4, int H, int W,
-                                 float* d_layer4, float* c_own, void* stream);
-int gsr_composite_backward_occlusion(int world, int rank, const long long* order, const float* gathered, const float* c_all, const float* g_sil, int H,
-                                     int W, float* dS, void* stream);
+int gsr_composite_backward_local(int world, int rank, const long long* order, const float* gathered, int gathered_planes, const float* layer4, const float* g4, int H,
+                                 int W, float* d_layer4, float* c_own, void* stream);
+int gsr_composite_backward_occlusion(int world, int rank, const long long* order, const float* gathered, int gathered_planes, const float* c_all, const float* g_sil,
+                                     int H, int W, float* dS, void* stream);
+/* Front-to-back order of the cells of a k-d partition of the map (gsorb-slam_amd/sharded.py: KdPartition; one cell per rank) for the camera of
+ * Tcw (DEVICE, row-major 4x4 world -> camera): order [world] (DEVICE int64) = the ranks, nearest cell first. The leaves of a BSP are ordered
+ * exactly by visiting the side of every split that holds the camera centre first — for ANY view, unlike an order by nearest depth.
+ * kd_nodes [world - 1][4] (DEVICE floats) = {axis 0..2, split, left, right}; a child >= 0 is a node index, a child < 0 the leaf (rank) -1 - child;
+ * node 0 is the root. world <= 32. The reference renders on one GPU (src/Render.cc:927-981): nothing to compare with. */
+int gsr_shard_order(int world, const float* kd_nodes, const float* Tcw, long long* order, void* stream);
 
 /* Workspace sizes: replace required<GeometryState/ImageState/BinningState>
  * (rasterizer_impl.h:67-73). */

@@ -1,0 +1,196 @@
+"""The sharded C++ loop (torch_ext/DirectLoop.cpp: SlamLoop::SetShard; multi-GPU scheme B) on the HIP kernels, driven through the `_C.SlamLoop`
+binding with real process groups:
+  * two processes on the one GPU of the test box, backend "gloo" (the loop stages its three collectives through the host there);
+  * one rank with backend "nccl": RCCL itself executes the all-gathers / all-reduces on the loop's stream.
+Every rank owns one cell of a k-d partition of the map (sharded.KdPartition). Compared with the UNSHARDED C++ loop on the whole map:
+the mapping loss curve, the tracking loss curve and the tracked pose, the twelve pose sums of the first tracking iteration (summed over
+the ranks by the loop's all-reduce), the composite render (PSNR), and map growth under the owner rule.
+Reference: src/Render.cc:402-483, :1054-1126 (the loops), :557-594 (growth); the reference itself is single-GPU.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, FX, FY = 320, 240, 260.0, 258.0
+P, MAP_ITERS, TRACK_ITERS = 30_000, 12, 10
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup():
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_package
+    gsr = load_package()
+    sys.path.insert(0, os.path.join(ROOT, "gsorb-slam_amd"))
+    from diff_gaussian_rasterization import _C
+    sharded = __import__("gsorb_slam_amd.sharded", fromlist=["x"])
+    return gsr, _C, sharded
+
+
+def _scene(gsr):
+    syn = gsr.synthetic
+    sc = syn.make_scene(P, syn.make_camera(W, H, FX, FY), seed=17, scale_mult=1.5)
+    t = lambda a: torch.tensor(a, dtype=torch.float32)
+    op = t(sc.opacities).reshape(-1, 1)
+    raw = [t(sc.means3D), t(sc.colors), t(sc.rotations), torch.log(op / (1 - op)), torch.log(t(sc.scales))]
+    return sc, raw
+
+
+def _poses():
+    from util import pose
+    t = lambda a, tr: torch.tensor(pose(a, tr), dtype=torch.float32)
+    return t(0.02, (0.01, -0.01, 0.015)), t(0.026, (0.02, -0.004, 0.03))
+
+
+def _loop(_C, raw, dev=0, **cfg):
+    loop = _C.SlamLoop(W, H, FX, FY, torch.device("cuda", dev), **cfg)
+    loop.set_map(*raw)
+    return loop
+
+
+def _frame(_C, raw, dev=0):
+    """the observation: the whole map with perturbed colours under the true pose"""
+    T, _ = _poses()
+    obs = [x.clone() for x in raw]
+    obs[1] = obs[1] * 0.8 + 0.1
+    rgb, sur, _ = _loop(_C, obs, dev).render_composite(T.cuda(dev))
+    return rgb.contiguous(), sur[0].contiguous(), T.cuda(dev)
+
+
+def _schedule(loop, frame, T0, cfg_note):
+    rgb, depth, T = frame
+    res = {"note": cfg_note}
+    comp = loop.render_composite(T)
+    res["render"] = comp[0].cpu().numpy()
+    res["map"] = loop.map_frame(rgb, depth, T, MAP_ITERS)
+    hist, best = loop.track(rgb, depth, T0, 1)
+    res["pose_sums"] = loop.last_pose_sums().cpu().numpy()
+    res["track1"] = hist
+    hist, best = loop.track(rgb, depth, T0, TRACK_ITERS)
+    res["track"], res["pose"] = hist, best.cpu().numpy()
+    res["added"] = loop.add_gaussians(rgb * 0.0 + 0.9, depth, T)     # a bright frame nobody explains: the dark-pixel rule adds nothing, the silhouette rule might
+    res["size"] = loop.size()
+    return res
+
+
+def _worker(rank, world, port, backend, q):
+    gsr, _C, sharded = _setup()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = rank if backend == "nccl" and world > 1 else 0               # (gloo: both ranks share the test box's one GPU)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        sc, raw = _scene(gsr)
+        part = sharded.KdPartition.build(raw[0], world)
+        idx = torch.nonzero(part.assign(raw[0]) == rank).squeeze(-1)
+        frame = _frame(_C, raw, dev)
+        loop = _loop(_C, [x[idx] for x in raw], dev, fused_update=True)
+        loop.set_shard(dist.group.WORLD, rank, world, part.nodes)
+        res = _schedule(loop, frame, _poses()[1].cuda(dev), "sharded %s world %d" % (backend, world))
+        res.update(count=int(idx.numel()), order_dev=gsr.capi.shard_order(part.nodes.cuda(), frame[2]).cpu().tolist() if world > 1 else [0],
+                   order_cpu=part.order(frame[2]))
+        torch.cuda.synchronize()
+        q.put((rank, res))
+    except Exception:                                                      # (the parent must not wait for a rank that died)
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def _reference():
+    gsr, _C, sharded = _setup()
+    sc, raw = _scene(gsr)
+    frame = _frame(_C, raw)
+    # (fused_update = False: the unsharded tracking iteration then goes through gsr_pose_step's rows, which LastPoseSums reads)
+    return _schedule(_loop(_C, raw, fused_update=False), frame, _poses()[1].cuda(), "unsharded")
+
+
+def _psnr(a, b):
+    mse = float(((a - b) ** 2).mean())
+    return 99.0 if mse == 0 else float(10 * np.log10(1.0 / mse))
+
+
+def _run(backend, world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    got, t0 = {}, time.time()
+    while len(got) < world:
+        try:
+            r, res = q.get(timeout=2)
+            assert "error" not in res, "rank %d failed:\n%s" % (r, res.get("error"))
+            got[r] = res
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > 300:
+                for p in procs:
+                    p.kill()
+                raise AssertionError("ranks died or hung: exit codes %s after %.0f s" % ([p.exitcode for p in procs], time.time() - t0))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ref = _reference()
+    scale = lambda a: np.abs(np.asarray(a)).max() + 1e-30
+    for r in range(1, world):                                             # replicas: every rank evaluates the same loss on the same composite
+        np.testing.assert_allclose(got[r]["map"], got[0]["map"], rtol=1e-6)
+        np.testing.assert_allclose(got[r]["track"], got[0]["track"], rtol=1e-6)
+        np.testing.assert_allclose(got[r]["pose"], got[0]["pose"], atol=1e-7)
+    assert got[0]["order_dev"] == got[0]["order_cpu"] and sorted(got[0]["order_cpu"]) == list(range(world))
+    assert sum(got[r]["count"] for r in range(world)) == P
+    psnr = _psnr(got[0]["render"], ref["render"])
+    e_map = float(np.abs(np.array(got[0]["map"]) - np.array(ref["map"])).max() / scale(ref["map"]))
+    e_sum = float(np.abs(got[0]["pose_sums"] - ref["pose_sums"]).max() / scale(ref["pose_sums"]))
+    n = min(len(got[0]["track"]), len(ref["track"]))
+    e_track = float(np.abs(np.array(got[0]["track"][:n]) - np.array(ref["track"][:n])).max() / scale(ref["track"]))
+    e_pose = float(np.abs(got[0]["pose"] - ref["pose"]).max())
+    print("\n%s world %d: composite vs one-GPU render %.1f dB; mapping loss curve %.1e (first %.5f / %.5f, last %.5f / %.5f); pose sums %.1e; "
+          "tracking loss curve %.1e over %d iterations; tracked pose %.1e; growth %s vs %d" %
+          (backend, world, psnr, e_map, got[0]["map"][0], ref["map"][0], got[0]["map"][-1], ref["map"][-1], e_sum, e_track, n, e_pose,
+           [got[r]["added"] for r in range(world)], ref["added"]))
+    assert len(got[0]["map"]) == MAP_ITERS and got[0]["map"][-1] < got[0]["map"][0]
+    if world == 1:                                                         # one layer: the composite IS the render, the exchange changes nothing
+        assert psnr >= 90.0 and e_map < 1e-4 and e_sum < 2e-3 and e_track < 1e-3 and e_pose < 1e-4   # (the pose sums: float atomics in the backward, sums that cancel)
+    else:                                                                  # cells side by side: exact order, splats that straddle a boundary are what differs
+        assert psnr >= 38.0 and e_map < 1e-2 and e_sum < 5e-2 and e_track < 2e-2 and e_pose < 2e-3
+        assert n >= 3
+    added = sum(got[r]["added"] for r in range(world))
+    assert abs(added - ref["added"]) <= 0.02 * ref["added"] + 5
+    assert sum(got[r]["size"] for r in range(world)) == P + added
+
+
+@pytest.mark.gpu
+def test_two_processes_on_one_gpu_gloo_drive_the_sharded_cpp_loop():
+    _run("gloo", world=2)
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_drives_the_sharded_cpp_loop():
+    _run("nccl", world=1)
+
+
+@pytest.mark.gpu
+def test_two_gpus_rccl_drive_the_sharded_cpp_loop():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run("nccl", world=2)

@@ -169,7 +169,18 @@ def _run(backend, world=2):
     procs = [ctx.Process(target=_worker, args=(r, world, port, backend, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=600) for _ in range(world))
+    import queue
+    import time
+    got, t0 = {}, time.time()
+    while len(got) < world:                                   # (never wait for a rank that died)
+        try:
+            r, res = q.get(timeout=2)
+            got[r] = res
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs) or time.time() - t0 > 300:
+                for p in procs:
+                    p.kill()
+                raise AssertionError("ranks died or hung: exit codes %s after %.0f s" % ([p.exitcode for p in procs], time.time() - t0))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
