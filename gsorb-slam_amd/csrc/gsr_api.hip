@@ -52,6 +52,7 @@ int check_forward(const gsr_forward_args* a)
 {
     if (!a || a->P < 0 || a->width <= 0 || a->height <= 0) return GSR_EINVAL;
     if (a->P > (int)GSR_ID_MASK) return GSR_EINVAL; // the quad-hit log keeps ids in 28 bits (268 M splats = 30 GB of geometry blob)
+    if ((int64_t)((a->width + 15) / 16) * ((a->height + 15) / 16) > (int64_t)GSR_BIN_NWIN * (GSR_BIN_WINDOW - 2)) return GSR_EINVAL; // a tile window is counted in one CU's LDS
     if (!a->out_color || !a->out_depth) return GSR_EINVAL;
     if (a->P == 0) return GSR_OK;
     if (!a->means3D || !a->opacities || !a->viewmatrix || !a->projmatrix || !a->background) return GSR_EINVAL;
@@ -74,9 +75,7 @@ gsr::SplatInputs splat_inputs(const float* means3D, const float* scales, const f
     return in;
 }
 
-#ifndef GSR_FILL_WX
-#define GSR_FILL_WX 8
-#endif
+#define GSR_FILL_WX GSR_BIN_NWIN // the binning passes run one workgroup per (splat range, tile window): the layout of the bucketed records
 // launch shape of the two binning passes: one workgroup per splat range x tile window
 struct BinGrid {
     int rows, per, wx, nwin, twmax;
@@ -86,12 +85,12 @@ BinGrid bin_grid(int P, int T, int wx, int window)
 {
     BinGrid b;
     b.rows = bin_rows(P);
-    b.per = (P + b.rows - 1) / b.rows;
+    b.per = ((P + b.rows - 1) / b.rows + GSR_BIN_PIECE - 1) / GSR_BIN_PIECE * GSR_BIN_PIECE; // whole pieces of the bucketed records (K_preprocess workgroups)
+    b.rows = (P + b.per - 1) / b.per;
     b.wx = wx;
-    window -= 2; // the two words of slack below: a window never needs more than GSR_BIN_WINDOW words = 64 KB of LDS (T = 16384 did)
-    const int wy = (T + wx * window - 1) / (wx * window);
-    b.nwin = wx * wy;
-    b.grid = dim3(b.rows * wx, wy);
+    (void)window;
+    b.nwin = wx; // (check_forward refuses frames of more than GSR_BIN_NWIN * (GSR_BIN_WINDOW - 2) tiles)
+    b.grid = dim3(b.rows * wx, 1);
     b.twmax = ((T + b.nwin - 1) / b.nwin + 2) & ~1; // even: the staged keys behind the per-tile words stay 8-byte aligned
     return b;
 }
@@ -103,7 +102,7 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     const StageTimer tm{a->profile_events, st};
     tm.begin(GSR_FWD_FILL);
     const BinGrid bg = bin_grid(P, T, GSR_FILL_WX, GSR_BIN_WINDOW);
-    hipLaunchKernelGGL(gsr::K_bin_fill, bg.grid, dim3(GSR_BIN_THREADS), (size_t)bg.twmax * 4, st, P, bg.per, T, f.grid_x, bg.wx, bg.nwin, gv,
+    hipLaunchKernelGGL(gsr::K_bin_fill, bg.grid, dim3(GSR_BINF_THREADS), (size_t)bg.twmax * 4, st, P, bg.per, T, f.grid_x, bg.wx, bg.nwin, gv,
                        iv.binmat, iv.tile_start, bv.pairs);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_FILL);
@@ -147,8 +146,12 @@ int forward_head(const gsr_forward_args* a, char* geom, char* image, hipStream_t
     GSR_LAUNCHED();
     tm.end(GSR_FWD_PREPROCESS);
     tm.begin(GSR_FWD_SCAN);
-    const BinGrid bg = bin_grid(P, T, 1, GSR_BIN_WINDOW);
-    hipLaunchKernelGGL(gsr::K_bin_count, bg.grid, dim3(GSR_BIN_THREADS), (size_t)bg.twmax * 4, st, P, bg.per, T, f.grid_x, bg.wx, bg.nwin, *gv, iv->binmat);
+    const BinGrid bg = bin_grid(P, T, GSR_FILL_WX, GSR_BIN_WINDOW);
+    if ((size_t)bg.twmax * 4 > 65536) { // (only frames beyond 131 000 tiles need more than the default limit of dynamic LDS)
+        GSR_HIP(hipFuncSetAttribute((const void*)gsr::K_bin_count, hipFuncAttributeMaxDynamicSharedMemorySize, bg.twmax * 4));
+        GSR_HIP(hipFuncSetAttribute((const void*)gsr::K_bin_fill, hipFuncAttributeMaxDynamicSharedMemorySize, bg.twmax * 4));
+    }
+    hipLaunchKernelGGL(gsr::K_bin_count, bg.grid, dim3(GSR_BINC_THREADS), (size_t)bg.twmax * 4, st, P, bg.per, T, f.grid_x, bg.wx, bg.nwin, *gv, iv->binmat);
 #ifdef GSR_SEPARATE_SCAN // (the two-launch form)
     hipLaunchKernelGGL(gsr::K_bin_colscan, dim3((T + 31) / 32), dim3(1024), 0, st, bg.rows, T, iv->binmat, iv->tile_cnt, (uint32_t*)nullptr, (uint2*)nullptr, gv->hdr, capacity);
     hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, T, iv->tile_cnt, 1, iv->tile_start, 1, iv->ranges, gv->hdr, capacity);

@@ -2,7 +2,7 @@
 //
 // Data layout in HBM (all sub-arrays 256-byte aligned inside caller-owned blobs):
 //
-//   geometry blob  (gsr_geom_bytes(P)), 136 B per splat:
+//   geometry blob  (gsr_geom_bytes(P)), 248 B per splat:
 //     GeomHeader                         256 B   {num_rendered, overflow, capacity of the binning blob}
 //     rec  48 B[P]  the per-splat record the blend kernels gather, interleaved so that it costs one L2 line:
 //          g0  {x, y, conic_a, conic_b}            pixel centre + half of the conic
@@ -10,7 +10,9 @@
 //          col {r, g, b, clamp-flags}              colour the blend uses (SH result or copy of colors_precomp)
 //     reach uint2[P]     what culls the splat against the 4x4 patches of a tile, dense (8 bytes: one gather per tile instance
 //                        by the tile sort): {reach word (below), centre's patch column | patch row << 16 (int16 each)}
-//     slots uint4[P]     bin record for the count and fill passes: tile count, depth bits, band-clipped tile rectangle
+//     pool uint4[ceil(P/256)][8][256]  the bin records of the count and fill passes, BUCKETED: piece (K_preprocess workgroup j, tile window w)
+//                        holds, densely from its start, {splat id, depth bits, x0 | y0 << 16, x1 | y1 << 16} (band-clipped tile rectangle) of
+//                        the workgroup's splats that cover a tile of window w; pcnt uint16[ceil(P/256)][8] = how many
 //     acc  float[P][16]  backward accumulators, one 64-byte line per splat (48-byte records straddle lines and
 //                        the L2 atomic rate drops from 20 to 13 G records/s): moments of u = G*dL/dalpha
 //                        {sum u, u*dx, u*dy, u*dx^2, u*dx*dy, u*dy^2}, dcolor.rgb, 7 unused
@@ -60,11 +62,33 @@ static_assert(sizeof(GeomHeader) == 256, "header is one aligned slot");
 //   K_bin_fill     the same workgroup over the same splats: every (splat, tile) takes its slot from an LDS cursor
 //                  that starts at tile_start[t] + binmat[b][t] (returning LDS atomic) and its key goes there
 // The matrix has at most GSR_BIN_ROWS rows, so the image blob's size depends on the resolution only. Frames of
-// more than GSR_BIN_WINDOW tiles are histogrammed in windows of that many tiles (grid.y = windows); the fill pass
-// always works in (a multiple of) eight windows, one per XCD.
+// more than 8 x GSR_BIN_WINDOW tiles are refused. Round 5: the bin records leave K_preprocess bucketed by window (GeomView::pool), both
+// passes run one workgroup per (splat range, window) and read only the records of their window — one pass over 16P + 8R bytes each
+// instead of eight over the fill pass's 16P.
 #define GSR_BIN_ROWS 512
-#define GSR_BIN_THREADS 1024
-#define GSR_BIN_WINDOW 16384 // tiles per window: 64 KB of LDS
+// threads of a (splat range, window) workgroup of the count / fill pass: ~560 records in 16 pieces at 1 M splats, a wave per piece (measured,
+// count / fill at 128, 256, 512, 1024 threads: 14.3 / 22.5, 11.4 / 20.5, 12.3 / 19.0, 15.1 / 20.5 us)
+#ifndef GSR_BINC_THREADS
+#define GSR_BINC_THREADS 256
+#endif
+#ifndef GSR_BINF_THREADS
+#define GSR_BINF_THREADS 512
+#endif
+#define GSR_BIN_NWIN 8       // tile windows = XCDs: window w is tiles [T w / 8, T (w + 1) / 8), counted and filled by workgroups of XCD w
+#define GSR_BIN_PIECE 256    // splats per K_preprocess workgroup = bin records per piece of the pool
+#define GSR_BIN_WINDOW 40000 // tiles per window: 160 KB of LDS, the whole CU (frames of up to 320 000 tiles = 82 Mpixel; beyond: GSR_EINVAL)
+// the window of tile t (window w starts at floor(T w / 8))
+__host__ __device__ inline int tile_window(int t, int T) { return (int)((((int64_t)t + 1) * GSR_BIN_NWIN - 1) / T); }
+// does window w hold a tile of the rectangle [x0, x1) x [y0, y1)?
+__host__ __device__ inline bool window_meets_rect(int w, int T, int grid_x, int x0, int y0, int x1, int y1)
+{
+    const int a = (int)((int64_t)T * w / GSR_BIN_NWIN), b = (int)((int64_t)T * (w + 1) / GSR_BIN_NWIN); // tiles [a, b)
+    for (int y = a / grid_x > y0 ? a / grid_x : y0; y < y1 && y * grid_x + x0 < b; y++) { // the rectangle's row segments are ascending in tile index
+        const int lo = y * grid_x + x0 > a ? y * grid_x + x0 : a, hi = y * grid_x + x1 < b ? y * grid_x + x1 : b;
+        if (lo < hi) return true;
+    }
+    return false;
+}
 __host__ __device__ inline int bin_rows(int P)
 {
     // 4096 splats per range: 256 ranges at 1 M splats (measured fill / column scan: 28.5 / 6.7 us; 512 ranges 32.1 / 9.3, 128 ranges 32.7 / 5.1)
@@ -90,7 +114,8 @@ struct GeomView {
     Strided4 g1;
     Strided4 col;
     uint2* reach; // {reach word: bit 3 small, bits 4..28 the 5x5 patch window; (int16) floor(px/4) | (int16) floor(py/4) << 16}
-    uint4* slots; // {tiles covered, depth bits, x0 | y0 << 16, x1 | y1 << 16} (band-clipped tile rectangle; 0 tiles: not binned)
+    uint4* pool;    // [ceil(P/256)][8][256] {splat id, depth bits, x0 | y0 << 16, x1 | y1 << 16}: the bin records, bucketed by (K_preprocess workgroup, tile window)
+    uint16_t* pcnt; // [ceil(P/256)][8] records in each piece
     float* acc;
 };
 struct ImageView {
@@ -122,7 +147,9 @@ __host__ __device__ inline size_t geom_layout(char* base, int P, GeomView* v)
     g.col.p = g.g0.p + 2;
     off = gsr_align_up(off + Pz * 16 * GSR_GSTRIDE);
     g.reach = (uint2*)(base + off); off = gsr_align_up(off + Pz * 8);
-    g.slots = (uint4*)(base + off); off = gsr_align_up(off + Pz * 16);
+    const size_t pieces = (Pz + GSR_BIN_PIECE - 1) / GSR_BIN_PIECE * GSR_BIN_NWIN;
+    g.pool = (uint4*)(base + off); off = gsr_align_up(off + pieces * GSR_BIN_PIECE * 16);
+    g.pcnt = (uint16_t*)(base + off); off = gsr_align_up(off + pieces * 2);
     g.acc = (float*)(base + off); off = gsr_align_up(off + Pz * GSR_ACC_STRIDE * 4);
     if (v) *v = g;
     return off;

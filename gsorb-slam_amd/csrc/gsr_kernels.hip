@@ -59,26 +59,21 @@ __device__ __forceinline__ void load_cov3d(const SplatInputs& in, const FramePar
     }
 }
 
-#ifndef GSR_PRE_THREADS
-#define GSR_PRE_THREADS 256
-#endif
+#define GSR_PRE_THREADS GSR_BIN_PIECE // one workgroup = one piece of the bucketed bin records (gsr_device.h)
 // Every per-splat input is requested before the first one is used (round 4): written in the order the reference computes, a
 // wave made five dependent trips to memory — means; scales + rotations; the view matrix; the projection matrix behind the
 // near-plane test; colour + opacity behind the visibility test (a compiler does not move a load above the branch that guards
-// it). pin() keeps the requests where they are written. What the kernel's time is made of (scripts/pre_only.py, variant builds
-// -DGSR_EXP_PRE2 / -DGSR_EXP_NOREACH; HIP-event pairs, ~2 us above rocprof's figure): loads alone 16 us, loads + stores without
+// it). pin() keeps the requests where they are written. What the kernel's time is made of (round 4, variant builds; HIP-event
+// pairs, ~2 us above rocprof's figure): loads alone 16 us, loads + stores without
 // the arithmetic 25.5 (132 MB: 5.2 TB/s), loads + arithmetic without the stores 25, everything 32 — the three phases of a wave
 // add up instead of overlapping (2.5 rounds of waves that start together), and neither the exact reach test (44 % of the
 // instructions: 32.3 -> 32.3 us without it) nor the order of the requests (33.1 -> 32.3) is what it waits for. Two and four splats
 // per thread, software-pipelined (the next splat's inputs requested before the current one's arithmetic): 33.1 / 35.6 us. Held to 72 / 64
 // VGPRs for seven / eight waves per SIMD instead of six (it spills 44 / 72 bytes): 41.9 / 82 us.
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
-__global__ void __launch_bounds__(GSR_PRE_THREADS)
-K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomView g)
+// one splat: everything but its bin record, which is returned ({tiles of the band-clipped rectangle, depth bits, x0 | y0 << 16, x1 | y1 << 16})
+__device__ __forceinline__ uint4 preprocess_splat(const int idx, const FrameParams& f, const SplatInputs& in, int* __restrict__ radii_out, const GeomView& g)
 {
-    const int idx = blockIdx.x * GSR_PRE_THREADS + threadIdx.x;
-    if (idx == 0) g.hdr->ticket = 0u; // (K_bin_colscan's arrival counter: a launch boundary lies between this store and its first use)
-    if (idx >= f.P) return;
     float3 p = make_float3(in.means3D[3 * (size_t)idx], in.means3D[3 * (size_t)idx + 1], in.means3D[3 * (size_t)idx + 2]);
     float cov[6];
     float3 sc = make_float3(0.f, 0.f, 0.f);
@@ -104,23 +99,12 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
         pin(sc.x); pin(sc.y); pin(sc.z); pin(q.x); pin(q.y); pin(q.z); pin(q.w);
         cov3d_from_scale_rot(sc, f.scale_modifier, q, cov);
     }
-#ifdef GSR_EXP_PRE2 // timing experiments: 1 = loads only, 2 = loads and stores without the arithmetic
-    if (GSR_EXP_PRE2 == 1) { if (p.x + cov[0] + opac + cp.x + vm[0] + pm[0] == 1.2345e30f) g.g1[idx] = make_float4(p.x, p.y, p.z, 0.f); return; }
-    if (GSR_EXP_PRE2 == 2) {
-        g.reach[idx] = make_uint2(__float_as_uint(p.x), __float_as_uint(p.y));
-        g.g0[idx] = make_float4(p.x, p.y, cov[0], cov[1]); g.g1[idx] = make_float4(cov[2], opac, p.z, cov[3]); g.col[idx] = make_float4(cp.x, cp.y, cp.z, vm[0] + pm[0]);
-        if (radii_out) radii_out[idx] = (int)cov[4];
-        g.slots[idx] = make_uint4(__float_as_uint(cov[5]), 1u, 2u, 3u);
-        return;
-    }
-#endif
     Projected pr;
     const bool vis = project_splat(p, cov, f, vm, pm, pr);
     if (!vis) {
         g.g1[idx] = make_float4(0.f, 0.f, 0.f, 0.f); // radius 0 marks the splat invisible
-        g.slots[idx] = make_uint4(0u, 0u, 0u, 0u);
         if (radii_out) radii_out[idx] = 0;
-        return;
+        return make_uint4(0u, 0u, 0u, 0u);
     }
     float4 c;
     if (in.colors_precomp) {
@@ -140,11 +124,39 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
     g.g1[idx] = make_float4(pr.conic_c, opac, pr.p_view.z, __int_as_float(pr.radius));
     g.col[idx] = c;
     if (radii_out) radii_out[idx] = pr.radius;
-    // the bin record of the count and fill passes; only the band's tile rows are binned
+    // only the band's tile rows are binned
     pr.y0 = max(pr.y0, f.band_y0); pr.y1 = max(pr.y0, min(pr.y1, f.band_y1));
-    const uint32_t ntl = (uint32_t)((pr.x1 - pr.x0) * (pr.y1 - pr.y0));
-    g.slots[idx] = make_uint4(ntl, __float_as_uint(pr.p_view.z), (uint32_t)pr.x0 | ((uint32_t)pr.y0 << 16),
-                              (uint32_t)pr.x1 | ((uint32_t)pr.y1 << 16));
+    return make_uint4((uint32_t)((pr.x1 - pr.x0) * (pr.y1 - pr.y0)), __float_as_uint(pr.p_view.z), (uint32_t)pr.x0 | ((uint32_t)pr.y0 << 16),
+                      (uint32_t)pr.x1 | ((uint32_t)pr.y1 << 16));
+}
+
+// The bin records leave BUCKETED by tile window (round 5): the workgroup's records of window w go, densely, to the piece (workgroup, w) of the
+// pool, a splat whose rectangle crosses a window boundary to both pieces; the binning passes of window w then read what concerns them and
+// nothing else (gsr_device.h). A returning LDS atomic hands out the slot, one barrier before the eight counts are stored: no global atomic.
+__global__ void __launch_bounds__(GSR_PRE_THREADS)
+K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomView g)
+{
+    __shared__ uint32_t s_cnt[GSR_BIN_NWIN];
+    const int idx = blockIdx.x * GSR_PRE_THREADS + threadIdx.x;
+    if (threadIdx.x < GSR_BIN_NWIN) s_cnt[threadIdx.x] = 0u;
+    if (idx == 0) g.hdr->ticket = 0u; // (K_bin_colscan's arrival counter: a launch boundary lies between this store and its first use)
+    __syncthreads();
+    const uint4 br = idx < f.P ? preprocess_splat(idx, f, in, radii_out, g) : make_uint4(0u, 0u, 0u, 0u);
+    if (br.x != 0u) {
+        const int T = f.grid_x * f.grid_y;
+        const int x0 = (int)(br.z & 0xFFFFu), y0 = (int)(br.z >> 16), x1 = (int)(br.w & 0xFFFFu), y1 = (int)(br.w >> 16);
+        const int w0 = tile_window(y0 * f.grid_x + x0, T), w1 = tile_window((y1 - 1) * f.grid_x + x1 - 1, T);
+        const uint4 rec = make_uint4((uint32_t)idx, br.y, br.z, br.w);
+        for (int w = w0; w <= w1; w++) {
+            // (a window between the first and the last holds a tile of the rectangle unless it is narrower than a tile row: the exact test keeps
+            // every record worth at least one tile instance)
+            if (w != w0 && w != w1 && !window_meets_rect(w, T, f.grid_x, x0, y0, x1, y1)) continue;
+            const uint32_t slot = __hip_atomic_fetch_add(&s_cnt[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            g.pool[((size_t)blockIdx.x * GSR_BIN_NWIN + w) * GSR_BIN_PIECE + slot] = rec;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < GSR_BIN_NWIN) g.pcnt[(size_t)blockIdx.x * GSR_BIN_NWIN + threadIdx.x] = (uint16_t)s_cnt[threadIdx.x];
 }
 
 __global__ void __launch_bounds__(256)
@@ -176,50 +188,57 @@ K_mark_visible(int P, const float* __restrict__ means3D, const float* __restrict
 // the whole wave (a fat splat would otherwise hold 63 lanes idle for its whole walk). hit(window tile, key) is
 // called for every (splat, tile of the window).
 struct BinWindow {
-    int brow, t0, tw, wy0, wy1;
+    int brow, wi, t0, tw, wy0, wy1;
 };
 __device__ __forceinline__ BinWindow bin_window(int T, int grid_x, int wx, int nwin)
 {
     // consecutive workgroup ids go to consecutive XCDs: with wx = 8 all workgroups of one XCD work on the same eighth of the tiles
     BinWindow w;
     const int wi = blockIdx.x % wx + wx * blockIdx.y;
+    w.wi = wi;
     w.brow = blockIdx.x / wx;
     w.t0 = (int)((int64_t)T * wi / nwin);
     w.tw = (int)((int64_t)T * (wi + 1) / nwin) - w.t0;
     w.wy0 = w.t0 / grid_x; w.wy1 = (w.t0 + w.tw + grid_x - 1) / grid_x; // tile rows the window touches
     return w;
 }
-template <typename Hit>
-__device__ __forceinline__ void bin_walk(int P, int per, int grid_x, const BinWindow& w, const uint4* __restrict__ slots, Hit hit)
+template <int THREADS, typename Hit>
+__device__ __forceinline__ void bin_walk(int P, int per, int grid_x, const BinWindow& w, const GeomView& g, Hit hit)
 {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int b = w.brow * per, e = min(P, b + per);
-    // whole waves make the same number of trips. (Loading the records of several trips ahead was measured slower: fill 29 -> 32 us, count 7.3 -> 13 us;
-    // the first trip's record requested before the workgroup sets up its LDS words: fill 29.4 -> 30.3; 512 / 256 threads over the same ranges: fill 31 / 42.5,
-    // count 9.1 / 13.5 us.)
-    for (int base = b; base < e; base += GSR_BIN_THREADS) {
-        const int idx = base + tid;
-        const uint4 br = idx < e ? slots[idx] : make_uint4(0u, 0u, 0u, 0u);
-        const int x0 = (int)(br.z & 0xFFFFu), y0 = (int)(br.z >> 16), x1 = (int)(br.w & 0xFFFFu), y1 = (int)(br.w >> 16);
-        const uint64_t key = ((uint64_t)br.y << 32) | (uint32_t)idx;
-        const bool wide = br.x > 16u && y0 < w.wy1 && y1 > w.wy0;
-        if (br.x != 0u && br.x <= 16u)
-            for (int y = max(y0, w.wy0); y < min(y1, w.wy1); y++)
-                for (int x = x0; x < x1; x++) {
-                    const int t = y * grid_x + x - w.t0;
-                    if ((uint32_t)t < (uint32_t)w.tw) hit(t, key);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = THREADS / 64;
+    // the pieces of this range that belong to the window: one per K_preprocess workgroup, a wave each, densely packed — the records of the
+    // other seven windows are never touched (round 4 read all 4096 records of the range in each of the eight window workgroups: 125 MB of the
+    // fill pass's 149 MB of fabric traffic)
+    const int j0 = (int)(((int64_t)w.brow * per) / GSR_BIN_PIECE), j1 = min((P + GSR_BIN_PIECE - 1) / GSR_BIN_PIECE, (int)(((int64_t)(w.brow + 1) * per) / GSR_BIN_PIECE));
+    for (int j = j0 + wave; j < j1; j += nwaves) {
+        const size_t piece = (size_t)j * GSR_BIN_NWIN + w.wi;
+        const int n = (int)g.pcnt[piece];
+        const uint4* __restrict__ recs = g.pool + piece * GSR_BIN_PIECE;
+        for (int s0 = 0; s0 < n; s0 += 64) { // whole waves make the same number of trips
+            const int s = s0 + lane;
+            const uint4 br = s < n ? recs[s] : make_uint4(0u, 0u, 0u, 0u);
+            const int x0 = (int)(br.z & 0xFFFFu), y0 = (int)(br.z >> 16), x1 = (int)(br.w & 0xFFFFu), y1 = (int)(br.w >> 16);
+            const int ntl = (x1 - x0) * (y1 - y0);
+            const uint64_t key = ((uint64_t)br.y << 32) | br.x;
+            const bool wide = ntl > 16 && y0 < w.wy1 && y1 > w.wy0;
+            if (ntl != 0 && ntl <= 16)
+                for (int y = max(y0, w.wy0); y < min(y1, w.wy1); y++)
+                    for (int x = x0; x < x1; x++) {
+                        const int t = y * grid_x + x - w.t0;
+                        if ((uint32_t)t < (uint32_t)w.tw) hit(t, key);
+                    }
+            uint64_t todo = __ballot(wide);
+            while (todo) { // a rectangle of more than 16 tiles is walked by the whole wave (a fat splat would otherwise hold 63 lanes idle)
+                const int l = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int fx0 = __shfl(x0, l, 64), fy0 = __shfl(y0, l, 64), fw = __shfl(x1, l, 64) - fx0;
+                const int n2 = __shfl(ntl, l, 64);
+                const uint64_t fkey = ((uint64_t)(uint32_t)__shfl((int)br.y, l, 64) << 32) | (uint32_t)__shfl((int)br.x, l, 64);
+                for (int k = lane; k < n2; k += 64) {
+                    const int dy = k / fw;
+                    const int t = (fy0 + dy) * grid_x + fx0 + (k - dy * fw) - w.t0;
+                    if ((uint32_t)t < (uint32_t)w.tw) hit(t, fkey);
                 }
-        uint64_t todo = __ballot(wide);
-        while (todo) {
-            const int l = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const int fx0 = __shfl(x0, l, 64), fy0 = __shfl(y0, l, 64), fw = __shfl(x1, l, 64) - fx0;
-            const int n = __shfl((int)br.x, l, 64);
-            const uint64_t fkey = ((uint64_t)(uint32_t)__shfl((int)br.y, l, 64) << 32) | (uint32_t)(base + (tid & ~63) + l);
-            for (int k = lane; k < n; k += 64) {
-                const int dy = k / fw;
-                const int t = (fy0 + dy) * grid_x + fx0 + (k - dy * fw) - w.t0;
-                if ((uint32_t)t < (uint32_t)w.tw) hit(t, fkey);
             }
         }
     }
@@ -228,28 +247,28 @@ __device__ __forceinline__ uint32_t lds_take(uint32_t* p)
 {
     return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// Count pass: histogram of the window's tiles in LDS -> the range's row of the count matrix.
+// Count pass: histogram of the window's tiles in LDS -> the range's row of the count matrix (its columns of the window).
 // (Measured and dropped: K_preprocess and this pass in one launch, 1024-thread workgroups projecting four splats per
 // thread and counting as they go — 38 us against 28.5 + 7.5 us for the two launches.)
-__global__ void __launch_bounds__(GSR_BIN_THREADS)
+__global__ void __launch_bounds__(GSR_BINC_THREADS)
 K_bin_count(int P, int per, int T, int grid_x, int wx, int nwin, GeomView g, uint32_t* __restrict__ binmat)
 {
     extern __shared__ uint32_t s_bin[];
     const BinWindow w = bin_window(T, grid_x, wx, nwin);
-    for (int t = threadIdx.x; t < w.tw; t += GSR_BIN_THREADS) s_bin[t] = 0u;
+    for (int t = threadIdx.x; t < w.tw; t += GSR_BINC_THREADS) s_bin[t] = 0u;
     __syncthreads();
-    bin_walk(P, per, grid_x, w, g.slots, [&](int t, uint64_t) { (void)lds_take(&s_bin[t]); });
+    bin_walk<GSR_BINC_THREADS>(P, per, grid_x, w, g, [&](int t, uint64_t) { (void)lds_take(&s_bin[t]); });
     __syncthreads();
     uint32_t* const row = binmat + (size_t)w.brow * T + w.t0;
-    for (int t = threadIdx.x; t < w.tw; t += GSR_BIN_THREADS) row[t] = s_bin[t];
+    for (int t = threadIdx.x; t < w.tw; t += GSR_BINC_THREADS) row[t] = s_bin[t];
 }
 
 // Fill pass: the LDS words start as the range's cursors (segment start of the tile + instances of earlier ranges);
 // every (splat, tile) takes its slot with a returning LDS atomic and stores its key there. (Sorting the keys of a
 // workgroup by tile in LDS first, so that a wave stores to as few lines as possible, was measured slower — 36.6 vs
-// 28.5 us at 1 M splats: the pass is bound by the latency of its few dependent phases, not by L2 transactions.)
+// 28.5 us at 1 M splats: a (range, window) pair holds ~3 keys per tile, no run worth coalescing.)
 // (Non-temporal stores: 89 us — the keys of a segment do merge in L2 on the normal path.)
-__global__ void __launch_bounds__(GSR_BIN_THREADS)
+__global__ void __launch_bounds__(GSR_BINF_THREADS)
 K_bin_fill(int P, int per, int T, int grid_x, int wx, int nwin, GeomView g, const uint32_t* __restrict__ binmat,
            const uint32_t* __restrict__ tile_start, uint64_t* __restrict__ pairs)
 {
@@ -257,9 +276,9 @@ K_bin_fill(int P, int per, int T, int grid_x, int wx, int nwin, GeomView g, cons
     if (g.hdr->overflow) return;
     const BinWindow w = bin_window(T, grid_x, wx, nwin);
     const uint32_t* const row = binmat + (size_t)w.brow * T + w.t0;
-    for (int t = threadIdx.x; t < w.tw; t += GSR_BIN_THREADS) s_bin[t] = tile_start[w.t0 + t] + row[t];
+    for (int t = threadIdx.x; t < w.tw; t += GSR_BINF_THREADS) s_bin[t] = tile_start[w.t0 + t] + row[t];
     __syncthreads();
-    bin_walk(P, per, grid_x, w, g.slots, [&](int t, uint64_t key) { pairs[lds_take(&s_bin[t])] = key; });
+    bin_walk<GSR_BINF_THREADS>(P, per, grid_x, w, g, [&](int t, uint64_t key) { pairs[lds_take(&s_bin[t])] = key; });
 }
 
 // One block: per-tile counts -> list segments (start), ranges, num_rendered and the overflow flag. Shared with the

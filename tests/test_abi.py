@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(gsr):
 def test_workspace_sizes_are_sane(gsr):
     L = gsr.lib()
     assert L.gsr_geom_bytes(0) > 0 and L.gsr_geom_bytes(1000) >= 1000 * 112
-    assert L.gsr_geom_bytes(1_000_000) < 1_000_000 * 136 + 4096          # 48 B record + 8 B reach entry + 16 B bin record + 64 B backward accumulators
+    assert L.gsr_geom_bytes(1_000_000) < 1_000_000 * 248 + 200_000       # 48 B record + 8 B reach entry + 8 x 16 B bucketed bin records + 64 B backward accumulators
     assert L.gsr_binning_bytes(1_000_000) < 1_000_000 * 44 + 4096        # 12 B/instance + 32 B of quad-hit log (reference: 24 + sort temp)
     assert L.gsr_image_bytes(1200, 680) >= 1200 * 680 * 8
     assert L.gsr_error_string(-1).decode() == "invalid argument"
