@@ -249,7 +249,9 @@ __device__ __forceinline__ uint32_t lds_take(uint32_t* p)
 }
 // Count pass: histogram of the window's tiles in LDS -> the range's row of the count matrix (its columns of the window).
 // (Measured and dropped: K_preprocess and this pass in one launch, 1024-thread workgroups projecting four splats per
-// thread and counting as they go — 38 us against 28.5 + 7.5 us for the two launches.)
+// thread and counting as they go — 38 us against 28.5 + 7.5 us for the two launches. Round 5, on the bucketed records: one workgroup per
+// splat range that takes the eight windows' pieces one after the other, the whole matrix row in LDS — 16.1 / 20.6 us at 1024 / 512 threads
+// against 11.5 for one workgroup per (range, window).)
 __global__ void __launch_bounds__(GSR_BINC_THREADS)
 K_bin_count(int P, int per, int T, int grid_x, int wx, int nwin, GeomView g, uint32_t* __restrict__ binmat)
 {

@@ -322,6 +322,19 @@ def rebalance_rows(xyz: torch.Tensor, payload: torch.Tensor, rank: int, world: i
     return part, torch.nonzero(stay).squeeze(-1), arrivals
 
 
+def rebalance_loop(loop, rank: int, world: int, group=None, tolerance: float = 1.25):
+    """Re-balance of a sharded C++ loop (_C.SlamLoop with set_shard): the same exchange as ShardedMapper.rebalance on the loop's exported rows
+    (parameters and Adam moments travel together), then the loop is told its new cell. Collective; returns the new KdPartition or None."""
+    rows = loop.export_rows()
+    res = rebalance_rows(rows[:, 0:3], rows, rank, world, group, tolerance)
+    if res is None:
+        return None
+    part, keep, arrivals = res
+    loop.replace_rows(keep, arrivals)
+    loop.set_shard(group, rank, world, part.nodes)
+    return part
+
+
 def make_sharded_mapper(harness_mod):
     """Returns the ShardedMapper class bound to the harness module (gsorb-slam_amd/harness.py): the reference's
     mapping / tracking loops (src/Render.cc:420-483, :1054-1126) with the MAP sharded over the ranks — scheme B."""

@@ -349,6 +349,50 @@ int64_t SlamLoop::AddGaussians(const LoopFrame& frame)
     return n;
 }
 
+torch::Tensor SlamLoop::ExportRows()
+{
+    torch::NoGradGuard ng;
+    if (!fopt_) throw std::runtime_error("ExportRows needs LoopConfig::fused_ops");
+    const int64_t n = size();
+    std::vector<torch::Tensor> cols;
+    const auto ps = params_();
+    for (auto* p : ps) cols.push_back(p->detach().reshape({n, -1}));
+    for (size_t i = 0; i < ps.size(); i++) cols.push_back(fopt_->exp_avg(i).reshape({n, -1}));
+    for (size_t i = 0; i < ps.size(); i++) cols.push_back(fopt_->exp_avg_sq(i).reshape({n, -1}));
+    return torch::cat(cols, 1);
+}
+
+void SlamLoop::ReplaceRows(const torch::Tensor& keep_, const torch::Tensor& arrivals_)
+{
+    torch::NoGradGuard ng;
+    if (!fopt_) throw std::runtime_error("ReplaceRows needs LoopConfig::fused_ops");
+    const auto keep = keep_.to(dev_, torch::kInt64).contiguous();
+    const auto arr = arrivals_.to(dev_, torch::kFloat32).contiguous();
+    const int64_t k = arr.size(0), nk = keep.size(0);
+    const int64_t widths[5] = {3, 3, 4, 1, 3};
+    if (k > 0 && arr.size(1) != 42) throw std::runtime_error("ReplaceRows: arrivals must be [k, 42]");
+    std::vector<torch::Tensor> kept;
+    for (auto* p : params_()) kept.push_back(p->detach().index_select(0, keep));
+    replace_params_(kept, 0, &keep);                     // the rows that stay, with their moments
+    if (k == 0) return;
+    std::vector<torch::Tensor> grown;
+    int64_t off = 0;
+    const auto ps = params_();
+    for (size_t i = 0; i < ps.size(); i++) {
+        grown.push_back(torch::cat({ps[i]->detach(), arr.slice(1, off, off + widths[i]).reshape({k, widths[i]})}, 0));
+        off += widths[i];
+    }
+    replace_params_(grown, k, nullptr);                  // the rows that arrive (moments: zeros for now)
+    for (int part = 0; part < 2; part++) {               // ... and their own moments behind the zeros
+        off = 14 * (part + 1);
+        for (size_t i = 0; i < ps.size(); i++) {
+            auto& m = part == 0 ? fopt_->exp_avg(i) : fopt_->exp_avg_sq(i);
+            m.slice(0, nk, nk + k).copy_(arr.slice(1, off, off + widths[i]).reshape({k, widths[i]}));
+            off += widths[i];
+        }
+    }
+}
+
 int64_t SlamLoop::PruneLowOpacity()
 {
     torch::NoGradGuard ng;

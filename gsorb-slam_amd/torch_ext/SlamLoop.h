@@ -92,6 +92,11 @@ public:
     void SetShard(c10::intrusive_ptr<c10d::ProcessGroup> group, int rank, int world, const torch::Tensor& kd_nodes);
     // the whole map's render for a pose from every rank's shard: {colour [3,H,W], surface depth [1,H,W], depth / silhouette [2,H,W]} (collective call)
     std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> RenderComposite(const torch::Tensor& Tcw);
+    // Re-balance of a sharded map (sharded.rebalance_loop drives the exchange): every Gaussian of this loop with what travels with it — raw
+    // parameters (14 floats: xyz, rgb, quaternion, logit, log-scales), exp_avg (14), exp_avg_sq (14): [n, 42] —, and the surgery that keeps the
+    // rows `keep` and appends the rows that arrive from other ranks WITH their moments (Gaussian.cc:218-258 does the same with zeros / a selection)
+    torch::Tensor ExportRows();
+    void ReplaceRows(const torch::Tensor& keep, const torch::Tensor& arrivals);
     // (inspection) the twelve pose sums dL/dR (row-major), dL/dt of the last tracking iteration that went through gsr_pose_grad's rows — the
     // sharded loop (summed over the ranks) and the unsharded one with LoopConfig::fused_update = false
     torch::Tensor LastPoseSums() const;

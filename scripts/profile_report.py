@@ -53,6 +53,24 @@ with open(os.path.join(dst, tag + "_kernel_stats.md"), "w") as o:
         o.write("| %s | %s | %.1f | %.1f | %.1f | %s |\n" % (short(x["Name"]), x["Calls"], float(x["AverageNs"]) / 1e3,
                                                          float(x["MinNs"]) / 1e3, float(x["MaxNs"]) / 1e3, x["Percentage"]))
 
+# ---- per-kernel resources of the build (VERDICT r4 hygiene item: occupancy claims belong beside the timings)
+try:
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import kres
+    res = kres.resources()
+    with open(os.path.join(dst, tag + "_kernel_stats.md"), "a") as o:
+        o.write("\n## Kernel resources of this build (scripts/kres.py: metadata of the gfx950 code object)\n\n")
+        o.write("| kernel | VGPRs (unified file: 512 per SIMD lane) | SGPRs | LDS bytes | scratch bytes | spilled VGPRs | waves per SIMD the registers allow | single-wave or workgroup waves per CU the LDS allows |\n|---|---|---|---|---|---|---|---|\n")
+        for r in res:
+            if not r["name"].startswith(("K_preprocess", "K_bin", "K_tile_sort_cut", "K_blend", "K_splat_bwd", "K_map", "K_ssim", "K_track", "K_pose", "K_composite", "K_shard")):
+                continue
+            alloc = max(8, -(-r["vgpr"] // 8) * 8)
+            lds_blocks = -(-r["lds"] // 1280) if r["lds"] else 0
+            o.write("| `%s` | %d | %d | %d | %d | %d | %d | %s |\n" % (r["name"], r["vgpr"], r["sgpr"], r["lds"], r["scratch"], r["spill"], min(8, 512 // alloc),
+                                                                  ("%d workgroups" % (128 // lds_blocks)) if lds_blocks else "-"))
+except Exception as e:   # (no hipcc: the table is skipped, the timings stand)
+    print("kernel resources skipped:", e)
+
 # ---- PMC
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))

@@ -71,7 +71,12 @@ def _frame(_C, raw, dev=0):
     return rgb.contiguous(), sur[0].contiguous(), T.cuda(dev)
 
 
-def _schedule(loop, frame, T0, cfg_note):
+_RANK = {}
+def rank_of(loop):
+    return _RANK.get(id(loop), 0)
+
+
+def _schedule(loop, frame, T0, cfg_note, rebalance=None):
     rgb, depth, T = frame
     res = {"note": cfg_note}
     comp = loop.render_composite(T)
@@ -84,6 +89,16 @@ def _schedule(loop, frame, T0, cfg_note):
     res["track"], res["pose"] = hist, best.cpu().numpy()
     res["added"] = loop.add_gaussians(rgb * 0.0 + 0.9, depth, T)     # a bright frame nobody explains: the dark-pixel rule adds nothing, the silhouette rule might
     res["size"] = loop.size()
+    if rebalance is not None:                                         # growth left the cells out of balance: re-split, rows travel with their moments
+        before = loop.render_composite(T)[0].cpu().numpy()
+        rows0 = loop.export_rows().cpu()
+        part = rebalance(loop)
+        rows1 = loop.export_rows().cpu()
+        after = loop.render_composite(T)[0].cpu().numpy()
+        res.update(rebalanced=part is not None, size_rebalanced=loop.size(), psnr_rebalance=_psnr(after, before),
+                   rows_checksum=(float(rows0.double().sum()), float(rows1.double().sum())),
+                   misplaced=int((part.assign(rows1[:, 0:3]) != rank_of(loop)).sum()) if part is not None else 0,
+                   loss_after=loop.map_frame(rgb, depth, T, 2))
     return res
 
 
@@ -100,7 +115,9 @@ def _worker(rank, world, port, backend, q):
         frame = _frame(_C, raw, dev)
         loop = _loop(_C, [x[idx] for x in raw], dev, fused_update=True)
         loop.set_shard(dist.group.WORLD, rank, world, part.nodes)
-        res = _schedule(loop, frame, _poses()[1].cuda(dev), "sharded %s world %d" % (backend, world))
+        _RANK[id(loop)] = rank
+        res = _schedule(loop, frame, _poses()[1].cuda(dev), "sharded %s world %d" % (backend, world),
+                        rebalance=(lambda l: sharded.rebalance_loop(l, rank, world, dist.group.WORLD, tolerance=1.02)) if world > 1 else None)
         res.update(count=int(idx.numel()), order_dev=gsr.capi.shard_order(part.nodes.cuda(), frame[2]).cpu().tolist() if world > 1 else [0],
                    order_cpu=part.order(frame[2]))
         torch.cuda.synchronize()
@@ -177,6 +194,15 @@ def _run(backend, world):
     added = sum(got[r]["added"] for r in range(world))
     assert abs(added - ref["added"]) <= 0.02 * ref["added"] + 5
     assert sum(got[r]["size"] for r in range(world)) == P + added
+    if world > 1:       # the re-balance: rows move with their moments, none is lost, every Gaussian ends in its owner's cell, the composite is the same map
+        sizes = [got[r]["size_rebalanced"] for r in range(world)]
+        print("  re-balance: %s -> %s, composite after vs before %.1f dB, two more mapping iterations %s" %
+              ([got[r]["size"] for r in range(world)], sizes, got[0]["psnr_rebalance"], got[0]["loss_after"]))
+        assert all(got[r]["rebalanced"] for r in range(world)) and sum(sizes) == P + added and max(sizes) - min(sizes) <= world
+        assert all(got[r]["misplaced"] == 0 for r in range(world)) and got[0]["psnr_rebalance"] >= 35.0
+        tot0, tot1 = sum(got[r]["rows_checksum"][0] for r in range(world)), sum(got[r]["rows_checksum"][1] for r in range(world))
+        assert abs(tot0 - tot1) <= 1e-6 * abs(tot0)                      # parameters AND moments: the same multiset of rows
+        assert got[0]["loss_after"][-1] < 1.05 * got[0]["map"][-1]
 
 
 @pytest.mark.gpu
