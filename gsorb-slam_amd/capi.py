@@ -21,7 +21,7 @@ EXPORTS = ["gsr_forward", "gsr_forward_ws", "gsr_ws_status", "gsr_backward", "gs
            "gsr_adam_step", "gsr_pose_grad", "gsr_to_camera", "gsr_pose_from_quat", "gsr_pose_from_quat_backward",
            "gsr_pixel_loss", "gsr_pixel_loss_backward", "gsr_pixel_loss_backward_add", "gsr_track_loss", "gsr_scale_reg", "gsr_scale_reg_backward",
            "gsr_map_prepare", "gsr_map_update", "gsr_map_loss_total", "gsr_map_loss_forward", "gsr_map_loss_finish", "gsr_map_loss_backward", "gsr_pose_update", "gsr_pose_step", "gsr_composite_forward", "gsr_composite_backward_local",
-           "gsr_composite_backward_occlusion", "gsr_shard_order", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
+           "gsr_composite_backward_occlusion", "gsr_shard_order", "gsr_reproj_loss", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
 
 
 def library_path() -> str:
@@ -173,6 +173,9 @@ def lib():
     L.gsr_composite_backward_local.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gsr_composite_backward_occlusion.restype = C.c_int
     L.gsr_composite_backward_occlusion.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.gsr_reproj_loss.restype = C.c_int
+    L.gsr_reproj_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gsr_shard_order.restype = C.c_int
     L.gsr_shard_order.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gsr_map_loss_forward.restype = C.c_int
@@ -644,6 +647,14 @@ def composite_backward_occlusion(world, rank, order, gathered, c_all, g_sil):
         _check(lib().gsr_composite_backward_occlusion(int(world), int(rank), _p(order), _p(gathered), int(gathered.shape[1]), _p(c_all),
                                                       _p(g_sil) if g_sil is not None else None, H, W, _p(dS), _stream()))
     return dS
+
+
+def reproj_loss(obs, Xw, inv_sigma2, Tcw, fx, fy, cx, cy, weight, pose_row, loss, inliers=None, refresh=2, grad_scale=1.0):
+    """gsr_reproj_loss: adds the reprojection term's twelve pose sums to pose_row [12] and weight * Lrpj to loss [1] (device tensors)."""
+    M = int(obs.shape[0])
+    with torch.cuda.device(Tcw.device):
+        _check(lib().gsr_reproj_loss(_p(obs), _p(Xw), _p(inv_sigma2), M, _p(Tcw), float(fx), float(fy), float(cx), float(cy), float(weight), float(grad_scale),
+                                     int(refresh), _p(inliers) if inliers is not None else None, _p(pose_row), _p(loss), _stream()))
 
 
 def shard_order(kd_nodes, Tcw):

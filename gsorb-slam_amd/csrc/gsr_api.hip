@@ -822,6 +822,18 @@ int gsr_pose_update(const gsr_pose_update_args* a, void* stream)
     return GSR_OK;
 }
 
+int gsr_reproj_loss(const float* obs, const float* Xw, const float* inv_sigma2, size_t M, const float* Tcw, float fx, float fy, float cx, float cy,
+                    float weight, float grad_scale, int refresh_inliers, uint8_t* inliers, float* pose_row, float* loss, void* stream)
+{
+    if (M > 0x7FFFFFFFu || !Tcw || !pose_row || !loss || refresh_inliers < 0 || refresh_inliers > 2) return GSR_EINVAL;
+    if (M > 0 && (!obs || !Xw || !inv_sigma2 || (refresh_inliers != 2 && !inliers))) return GSR_EINVAL;
+    if (M == 0) return GSR_OK;
+    hipLaunchKernelGGL(gsr::K_reproj, dim3(1), dim3(256), 0, (hipStream_t)stream, obs, Xw, inv_sigma2, (int)M, Tcw, fx, fy, cx, cy, weight, weight * grad_scale,
+                       refresh_inliers, inliers, pose_row, loss);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
 int gsr_pose_step(const float* means3D, const float* dL_dmeans_cam, size_t n, const gsr_pose_update_args* a, uint32_t* ticket, void* stream)
 {
     gsr::PoseUpdate u;

@@ -438,6 +438,48 @@ K_pose_grad(const float* __restrict__ X, const float* __restrict__ dmc, size_t n
     pose_grad_body<false>(X, dmc, n, Tcw, partial, dX, nullptr, nullptr);
 }
 
+// The feature reprojection term of the tracking loss (src/Render.cc:1031-1096: the ORB matches' 3-D points under the pose being optimised against
+// their observed pixels, weighted by the keypoints' inverse level variances, outliers (chi-square 5.991) frozen out halfway through the iterations).
+// It depends on the pose alone: Xc = R Xw + t has the pose sums' own form, dL/dR = sum g (x) Xw, dL/dt = sum g, so the term ADDS its twelve sums to one
+// row of the pose rows (gsr_pose_grad's partial rows / the fused pose step's accumulator rows) and its value to the iteration's loss, and the pose step
+// that follows sees one objective. refresh: 0 use the stored inlier flags, 1 recompute them from the current errors and store them, 2 every match is one.
+__global__ void __launch_bounds__(256)
+K_reproj(const float* __restrict__ obs, const float* __restrict__ Xw, const float* __restrict__ inv_s2, int M, const float* __restrict__ Tcw,
+         float fx, float fy, float cx, float cy, float w_loss, float w_grad, int refresh, uint8_t* __restrict__ inl, float* row, float* loss)
+{
+    const Pose34 T = load_pose(Tcw);
+    __shared__ float ws[4][13];
+    float a[13] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < M; i += 256) {
+        const float x = Xw[3 * i], y = Xw[3 * i + 1], z = Xw[3 * i + 2];
+        const float cxx = fmaf(T.r[2], z, fmaf(T.r[1], y, T.r[0] * x)) + T.t[0], cyy = fmaf(T.r[5], z, fmaf(T.r[4], y, T.r[3] * x)) + T.t[1],
+                    czz = fmaf(T.r[8], z, fmaf(T.r[7], y, T.r[6] * x)) + T.t[2];
+        const float iz = 1.0f / czz;
+        const float ex = fmaf(fx, cxx * iz, cx) - obs[2 * i], ey = fmaf(fy, cyy * iz, cy) - obs[2 * i + 1], s = inv_s2[i];
+        const float werr = s * (ex * ex + ey * ey);
+        const bool in = refresh == 2 ? true : refresh == 1 ? werr < 5.991f : inl[i] != 0;
+        if (refresh == 1) inl[i] = in ? 1 : 0;
+        if (!in) continue;
+        const float gx = 2.f * s * ex * fx * iz, gy = 2.f * s * ey * fy * iz, gz = -(gx * cxx + gy * cyy) * iz;
+        a[0] = fmaf(gx, x, a[0]); a[1] = fmaf(gx, y, a[1]); a[2] = fmaf(gx, z, a[2]);
+        a[3] = fmaf(gy, x, a[3]); a[4] = fmaf(gy, y, a[4]); a[5] = fmaf(gy, z, a[5]);
+        a[6] = fmaf(gz, x, a[6]); a[7] = fmaf(gz, y, a[7]); a[8] = fmaf(gz, z, a[8]);
+        a[9] += gx; a[10] += gy; a[11] += gz; a[12] += werr;
+    }
+#pragma unroll
+    for (int q = 0; q < 13; q++) a[q] = wave_sum_lane63(a[q]);
+    if ((threadIdx.x & 63) == 63) {
+#pragma unroll
+        for (int q = 0; q < 13; q++) ws[threadIdx.x >> 6][q] = a[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 13) {
+        const float tot = (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]);
+        if (threadIdx.x < 12) row[threadIdx.x] += w_grad * tot;
+        else loss[0] += w_loss * tot;
+    }
+}
+
 // Pose from the optimiser's parameters, rt2T of the reference (include/Utils.h:56-77, src/Utils.cc:170-179): an
 // un-normalised quaternion (r, x, y, z) and a translation -> the 4x4 row-major Tcw, and its backward. In libtorch this
 // is ~40 scalar-tensor kernels forwards and ~80 backwards per tracking iteration (0.4 ms of launches); one thread does it.

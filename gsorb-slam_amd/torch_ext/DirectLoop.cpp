@@ -430,7 +430,7 @@ std::vector<double> SlamLoop::MapFrame(const LoopFrame& fr, int iters)
     return losses;
 }
 
-std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Tensor& Tcw_init, int iters, torch::Tensor* Tcw_best)
+std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Tensor& Tcw_init, int iters, torch::Tensor* Tcw_best, const LoopMatches* matches)
 {
     torch::NoGradGuard ng;
     c10::DeviceGuard guard(dev_);
@@ -456,6 +456,24 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
     const float *img = im0, *sil = im0 + 4 * HW + gap;
     const float* dep = cfg_.use_sur_depth ? nullptr : im0 + 3 * HW;
     const float* sur = cfg_.use_sur_depth ? im0 + 5 * HW + gap : nullptr;
+    // the feature front end's matches: the reprojection term is added to the loss and to one pose row by one launch per iteration
+    torch::Tensor m_obs, m_X, m_s2, m_inl;
+    float m_cx = 0.f, m_cy = 0.f;
+    if (matches && matches->obs.defined() && matches->obs.size(0) > 0) {
+        m_obs = matches->obs.to(dev_, torch::kFloat32).reshape({-1, 2}).contiguous(); m_X = matches->Xw.to(dev_, torch::kFloat32).reshape({-1, 3}).contiguous();
+        m_s2 = matches->inv_sigma2.to(dev_, torch::kFloat32).reshape({-1}).contiguous();
+        if (m_X.size(0) != m_obs.size(0) || m_s2.size(0) != m_obs.size(0)) throw std::runtime_error("Track: matches of different lengths");
+        m_inl = torch::ones({m_obs.size(0)}, torch::TensorOptions().device(dev_).dtype(torch::kUInt8));
+        m_cx = (float)(matches->cx >= 0 ? matches->cx : (W_ - 1) / 2.0); m_cy = (float)(matches->cy >= 0 ? matches->cy : (H_ - 1) / 2.0);
+    }
+    const int feature_clear = (int)(iters / 2.0);                                                       // Render.cc:1051
+    // (a sharded run sums the ranks' pose rows: a term every rank holds in full enters each rank's row with weight 1 / world)
+    auto reproj = [&](int it, float* row) {
+        if (!m_obs.defined()) return;
+        chk(gsr_reproj_loss(f(m_obs), f(m_X), f(m_s2), (size_t)m_obs.size(0), f(d.Tcw), fx_, fy_, m_cx, m_cy, (float)cfg_.feature_weight_tracking,
+                            shard_ ? 1.f / (float)d.world : 1.f, it < feature_clear ? 2 : it == feature_clear ? 1 : 0, m_inl.data_ptr<uint8_t>(), row,
+                            f(d.sums) + 5, st), "gsr_reproj_loss");
+    };
     std::vector<double> history;
     double last_loss = 0.0;
     int step = 0;
@@ -476,15 +494,22 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
             direct_backward_(true, true, nullptr, nullptr);
             if (d.n > 0) chk(gsr_pose_grad(f(xyz), f(d.d_mc), (size_t)d.n, f(d.Tcw), f(d.pose_partial), nullptr, st), "gsr_pose_grad");
             else d.pose_partial.zero_();
+            reproj(it, f(d.pose_partial));
             d_->all_reduce(d.pose_partial);
             chk(gsr_pose_update(&u, st), "gsr_pose_update");
         } else if (cfg_.fused_update) { // the backward's per-splat stage forms the pose sums (into accumulator rows that are zero between launches), a one-wave kernel takes the step: no dL/dmeans tensor
             u.partial = f(d.pose_acc);
+            reproj(it, f(d.pose_acc)); // (the accumulator rows are zero here: the per-splat stage adds to them, the one-wave kernel behind it sums them)
             const gsr_pose_step_args ps{f(xyz), &u};
             direct_backward_(true, true, nullptr, &ps); // the [z, 1, 0] colours are detached while tracking (Render.cc:949-981)
         } else {
             direct_backward_(true, true, nullptr, nullptr);
-            chk(gsr_pose_step(f(xyz), f(d.d_mc), (size_t)d.n, &u, tickets, st), "gsr_pose_step"); // the pose sums and the step in one launch
+            if (m_obs.defined()) { // (the term goes between the rows and the step: two launches instead of gsr_pose_step's one)
+                chk(gsr_pose_grad(f(xyz), f(d.d_mc), (size_t)d.n, f(d.Tcw), f(d.pose_partial), nullptr, st), "gsr_pose_grad");
+                reproj(it, f(d.pose_partial));
+                chk(gsr_pose_update(&u, st), "gsr_pose_update");
+            } else
+                chk(gsr_pose_step(f(xyz), f(d.d_mc), (size_t)d.n, &u, tickets, st), "gsr_pose_step"); // the pose sums and the step in one launch
         }
         const double lv = d.history.slice(0, it, it + 1).item<float>(); // Render.cc:1107: the loop looks at every loss
         if (shard_) {

@@ -157,9 +157,17 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> SlamLoop::RenderPair(con
     return {image, sur, dimg.slice(0, 0, 2)};
 }
 
-std::vector<double> SlamLoop::Track(const LoopFrame& frame, const torch::Tensor& Tcw_init, int iters, torch::Tensor* Tcw_best)
+std::vector<double> SlamLoop::Track(const LoopFrame& frame, const torch::Tensor& Tcw_init, int iters, torch::Tensor* Tcw_best, const LoopMatches* matches)
 {
-    if (direct_()) return direct_track_(frame, Tcw_init, iters, Tcw_best);
+    if (direct_()) return direct_track_(frame, Tcw_init, iters, Tcw_best, matches);
+    // (the autograd path: the reprojection term as the reference's tensor expressions, Render.cc:1060-1086)
+    torch::Tensor m_obs, m_X, m_s2, m_inl;
+    double m_cx = 0, m_cy = 0;
+    if (matches && matches->obs.defined() && matches->obs.size(0) > 0) {
+        m_obs = matches->obs.to(dev_, torch::kFloat32).reshape({-1, 2}); m_X = matches->Xw.to(dev_, torch::kFloat32).reshape({-1, 3});
+        m_s2 = matches->inv_sigma2.to(dev_, torch::kFloat32).reshape({-1});
+        m_cx = matches->cx >= 0 ? matches->cx : (W_ - 1) / 2.0; m_cy = matches->cy >= 0 ? matches->cy : (H_ - 1) / 2.0;
+    }
     // Gaussian::InitCameraPose (Gaussian.cc:97-150)
     const auto T0 = Tcw_init.to(dev_, torch::kFloat32);
     cam_quat_ = rot_to_quat(T0.slice(0, 0, 3).slice(1, 0, 3)).reshape({4, 1}).to(dev_).requires_grad_(true);
@@ -184,6 +192,13 @@ std::vector<double> SlamLoop::Track(const LoopFrame& frame, const torch::Tensor&
             const auto image_l1 = l1_sum(rimage, frame.rgb, certain.unsqueeze(0).repeat({3, 1, 1}));
             const auto depth_l1 = l1_sum(cfg_.use_sur_depth ? rsur[0] : rdepth[0], frame.depth, certain);
             loss = cfg_.im_weight_tracking * image_l1 + cfg_.depth_weight_tracking * depth_l1;
+        }
+        if (m_obs.defined()) {
+            const auto Xc = m_X.matmul(Tcw.slice(0, 0, 3).slice(1, 0, 3).t()) + Tcw.slice(0, 0, 3).slice(1, 3, 4).reshape({1, 3});
+            const auto ex = fx_ * Xc.select(1, 0) / Xc.select(1, 2) + m_cx - m_obs.select(1, 0), ey = fy_ * Xc.select(1, 1) / Xc.select(1, 2) + m_cy - m_obs.select(1, 1);
+            const auto werr = m_s2 * (ex * ex + ey * ey);
+            if (it == (int)(iters / 2.0)) m_inl = (werr < 5.991).detach();
+            loss = loss + cfg_.feature_weight_tracking * (m_inl.defined() ? werr.masked_select(m_inl).sum() : werr.sum());
         }
         loss.backward();
         torch::NoGradGuard ng;

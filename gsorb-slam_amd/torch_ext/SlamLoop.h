@@ -27,6 +27,7 @@ struct LoopConfig {
     double lr_mean3d = 0.0001, lr_rgb = 0.0025, lr_rotation = 0.001, lr_opacities = 0.05, lr_scales = 0.001;
     double lr_cam_quat = 0.0004; // used for BOTH pose groups, like the reference (Gaussian.cc:149-150)
     double im_weight_tracking = 0.7, depth_weight_tracking = 1.0;
+    double feature_weight_tracking = 0.1; // Tracking.FeatureWeight (replica.yaml, scannet.yaml): weight of the ORB matches' reprojection term (Render.cc:1096)
     double scale_modifier = 1.0, scene_radius = 1.0;
     double prune_opacities = 0.005, median_mul = 40.0; // Mapping.PruneOpcities / Mapping.MedianMul
     int init_scalar_method = 2;                        // 0 Distance, 1 DistanceMean, 2 SinglePixel (Gaussian.cc:59-79)
@@ -51,6 +52,13 @@ struct LoopFrame {
     torch::Tensor depth; // [H,W], 0 = invalid
     torch::Tensor Tcw;   // [4,4]
 };
+// The feature front end's matches for a tracking call (Render.cc:1005-1043: map points matched to the frame's keypoints)
+struct LoopMatches {
+    torch::Tensor obs;        // [M,2] observed pixels (u, v)
+    torch::Tensor Xw;         // [M,3] world points
+    torch::Tensor inv_sigma2; // [M] inverse level variance of the keypoints
+    double cx = -1, cy = -1;  // principal point (< 0: the image centre the loop's other back-projections use, (W - 1) / 2, (H - 1) / 2)
+};
 
 class SlamLoop {
 public:
@@ -62,7 +70,9 @@ public:
 
     // Render.cc:1054-1126: pose-only optimisation against one frame; returns the loss of every iteration that ran and the
     // best pose (lowest loss) in *Tcw_best
-    std::vector<double> Track(const LoopFrame& frame, const torch::Tensor& Tcw_init, int iters, torch::Tensor* Tcw_best);
+    // With `matches` the objective is the reference's whole tracking loss: + feature_weight_tracking * Lrpj, the reprojection error of the matches
+    // under the pose being optimised, outliers frozen out halfway through (Render.cc:1031-1096; gsr_reproj_loss).
+    std::vector<double> Track(const LoopFrame& frame, const torch::Tensor& Tcw_init, int iters, torch::Tensor* Tcw_best, const LoopMatches* matches = nullptr);
 
     // Render.cc:420-483: one mapping iteration on one keyframe (loss, backward, Adam step); returns the loss
     double MappingIteration(const LoopFrame& frame);
@@ -136,7 +146,7 @@ private:
     void direct_backward_(bool detach_depth_colour, bool means_only, const ::gsr_map_update_args* fused, const ::gsr_pose_step_args* pose_step);
     bool direct_overflowed_();
     void direct_map_iteration_(const LoopFrame& frame, float* loss_slot);
-    std::vector<double> direct_track_(const LoopFrame& frame, const torch::Tensor& Tcw_init, int iters, torch::Tensor* Tcw_best);
+    std::vector<double> direct_track_(const LoopFrame& frame, const torch::Tensor& Tcw_init, int iters, torch::Tensor* Tcw_best, const LoopMatches* matches);
     void replace_params_(const std::vector<torch::Tensor>& fresh, int64_t added, const torch::Tensor* keep);
 };
 

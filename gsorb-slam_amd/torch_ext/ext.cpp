@@ -58,7 +58,7 @@ ORB_SLAM2::LoopConfig loop_config(const py::dict& kw)
 #define GSR_F(name, T) if (k == #name) { c.name = py::cast<T>(v); continue; }
         GSR_F(im_weight_mapping, double) GSR_F(depth_weight_mapping, double) GSR_F(sur_depth_weight_mapping, double) GSR_F(reg_long_weight, double)
         GSR_F(reg_scalar_weight, double) GSR_F(lam, double) GSR_F(lr_mean3d, double) GSR_F(lr_rgb, double) GSR_F(lr_rotation, double)
-        GSR_F(lr_opacities, double) GSR_F(lr_scales, double) GSR_F(lr_cam_quat, double) GSR_F(im_weight_tracking, double) GSR_F(depth_weight_tracking, double)
+        GSR_F(lr_opacities, double) GSR_F(lr_scales, double) GSR_F(lr_cam_quat, double) GSR_F(im_weight_tracking, double) GSR_F(depth_weight_tracking, double) GSR_F(feature_weight_tracking, double)
         GSR_F(scale_modifier, double) GSR_F(scene_radius, double) GSR_F(prune_opacities, double) GSR_F(median_mul, double) GSR_F(init_scalar_method, int)
         GSR_F(use_sur_depth, bool) GSR_F(fused_pair, bool) GSR_F(fused_ops, bool) GSR_F(direct, bool) GSR_F(binning_capacity, int64_t) GSR_F(fused_loss, bool)
         GSR_F(fused_update, bool)
@@ -84,11 +84,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
                  if (!group.is_none()) pg = py::cast<c10::intrusive_ptr<c10d::ProcessGroup>>(group);
                  l.SetShard(pg, rank, world, kd_nodes);
              }, py::arg("group"), py::arg("rank"), py::arg("world"), py::arg("kd_nodes"))
-        .def("track", [](ORB_SLAM2::SlamLoop& l, const torch::Tensor& rgb, const torch::Tensor& depth, const torch::Tensor& Tcw_init, int iters) {
+        .def("track", [](ORB_SLAM2::SlamLoop& l, const torch::Tensor& rgb, const torch::Tensor& depth, const torch::Tensor& Tcw_init, int iters,
+                         const std::optional<torch::Tensor>& obs, const std::optional<torch::Tensor>& Xw, const std::optional<torch::Tensor>& inv_sigma2,
+                         double cx, double cy) {
                  torch::Tensor best;
-                 const auto h = l.Track(ORB_SLAM2::LoopFrame{rgb, depth, Tcw_init}, Tcw_init, iters, &best);
+                 const bool with = obs.has_value() && Xw.has_value() && inv_sigma2.has_value() && obs->numel() > 0;
+                 const ORB_SLAM2::LoopMatches m{with ? *obs : torch::Tensor(), with ? *Xw : torch::Tensor(), with ? *inv_sigma2 : torch::Tensor(), cx, cy};
+                 const auto h = l.Track(ORB_SLAM2::LoopFrame{rgb, depth, Tcw_init}, Tcw_init, iters, &best, with ? &m : nullptr);
                  return std::make_pair(h, best);
-             }, py::call_guard<py::gil_scoped_release>())
+             }, py::arg("rgb"), py::arg("depth"), py::arg("Tcw_init"), py::arg("iters"), py::arg("obs") = py::none(), py::arg("Xw") = py::none(),
+             py::arg("inv_sigma2") = py::none(), py::arg("cx") = -1.0, py::arg("cy") = -1.0, py::call_guard<py::gil_scoped_release>())
         .def("map_frame", [](ORB_SLAM2::SlamLoop& l, const torch::Tensor& rgb, const torch::Tensor& depth, const torch::Tensor& Tcw, int iters) {
                  return l.MapFrame(ORB_SLAM2::LoopFrame{rgb, depth, Tcw}, iters);
              }, py::call_guard<py::gil_scoped_release>())

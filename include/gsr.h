@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 7 /* 7: gsr_composite_* take the plane count of the gathered buffer, gsr_shard_order added; 6: gsr_track_loss, gsr_pose_step, gsr_backward_args.fused_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
+#define GSR_ABI_VERSION 7 /* 7: gsr_composite_* take the plane count of the gathered buffer, gsr_shard_order and gsr_reproj_loss added; 6: gsr_track_loss, gsr_pose_step, gsr_backward_args.fused_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
                            * 5: gsr_map_prepare / gsr_map_update / gsr_map_loss_total / gsr_pose_update / gsr_pixel_loss_backward_add / gsr_composite_* added, GSR_LOSS_PARTIALS 256 -> 1024 */
 
 #define GSR_OK 0
@@ -380,6 +380,16 @@ typedef struct gsr_pose_step_args {
                                                 * the workgroups of the per-splat stage add their sums there, the step leaves them zero) */
 } gsr_pose_step_args;
 int gsr_pose_step(const float* means3D, const float* dL_dmeans_cam, size_t n, const gsr_pose_update_args* args, uint32_t* ticket, void* stream);
+/* The feature reprojection term of the tracking loss, weight * Lrpj (src/Render.cc:1031-1096, _featureWeightTracking; Examples/RGB-D/replica.yaml: 0.1):
+ * Lrpj = sum over the inlier matches of inv_sigma2 * |K (Xc / Xc.z) - obs|^2, Xc = R Xw + t under the DEVICE pose Tcw (the reference freezes its
+ * inliers — chi-square < 5.991 — halfway through the iterations). The term depends on the pose alone and its gradient has the pose sums' own form, so it
+ * is ADDED to what the pose step reads: pose_row [12] += weight * grad_scale * (dLrpj/dR row-major, dLrpj/dt) — any row of gsr_pose_grad's partial rows
+ * (after that call) or of the fused pose step's accumulator rows (before gsr_backward) — and loss[0] += weight * Lrpj (gsr_track_loss's sums + 5, after
+ * that call). grad_scale: 1, or 1 / world when the ranks of a sharded loop each add the term and their rows are then summed.
+ * obs [M,2] pixels, Xw [M,3] world points, inv_sigma2 [M]; refresh_inliers: 0 use inliers [M] as stored, 1 recompute them from the current
+ * errors and store them, 2 every match counts (inliers may be NULL). One launch, nothing allocates or synchronises. (ABI 7) */
+int gsr_reproj_loss(const float* obs, const float* Xw, const float* inv_sigma2, size_t M, const float* Tcw, float fx, float fy, float cx, float cy,
+                    float weight, float grad_scale, int refresh_inliers, uint8_t* inliers, float* pose_row, float* loss, void* stream);
 
 /* ---- multi-GPU scheme B (scene shards; gsorb-slam_amd/sharded.py): compositing of the ranks' layers around the
  * two collectives of the forward and the one of the backward. The reference is single-GPU; north_star: "shard Gaussians across the GPUs,

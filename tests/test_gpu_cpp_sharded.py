@@ -82,10 +82,13 @@ def _schedule(loop, frame, T0, cfg_note, rebalance=None):
     comp = loop.render_composite(T)
     res["render"] = comp[0].cpu().numpy()
     res["map"] = loop.map_frame(rgb, depth, T, MAP_ITERS)
-    hist, best = loop.track(rgb, depth, T0, 1)
+    # (with the feature matches' reprojection term: every rank of a sharded run holds it in full, its gradient enters each rank's rows with 1 / world)
+    obs, Xw, s2, cx, cy = _matches(_poses()[0])
+    m = (obs.to(T.device), Xw.to(T.device), s2.to(T.device), cx, cy)
+    hist, best = loop.track(rgb, depth, T0, 1, *m)
     res["pose_sums"] = loop.last_pose_sums().cpu().numpy()
     res["track1"] = hist
-    hist, best = loop.track(rgb, depth, T0, TRACK_ITERS)
+    hist, best = loop.track(rgb, depth, T0, TRACK_ITERS, *m)
     res["track"], res["pose"] = hist, best.cpu().numpy()
     res["added"] = loop.add_gaussians(rgb * 0.0 + 0.9, depth, T)     # a bright frame nobody explains: the dark-pixel rule adds nothing, the silhouette rule might
     res["size"] = loop.size()
@@ -220,3 +223,52 @@ def test_two_gpus_rccl_drive_the_sharded_cpp_loop():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
     _run("nccl", world=2)
+
+
+def _matches(T, n=60, seed=9):
+    """feature matches: world points in front of the camera of T and their (noisy) pixel observations"""
+    g = torch.Generator().manual_seed(seed)
+    Xc = torch.stack([torch.rand(n, generator=g) * 1.2 - 0.6, torch.rand(n, generator=g) * 0.9 - 0.45, 1.0 + 2.0 * torch.rand(n, generator=g)], 1)
+    Xw = (Xc - T[:3, 3]) @ T[:3, :3]
+    cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
+    obs = torch.stack([FX * Xc[:, 0] / Xc[:, 2] + cx, FY * Xc[:, 1] / Xc[:, 2] + cy], 1) + 0.5 * torch.randn(n, 2, generator=g)
+    obs[::7] += 8.0                                                       # a few outliers: frozen out halfway through (chi-square 5.991)
+    return obs, Xw, torch.full((n,), 1.0), cx, cy
+
+
+@pytest.mark.gpu
+def test_cpp_track_with_feature_matches_follows_the_python_harness():
+    """SlamLoop::Track with the ORB matches' reprojection term (Render.cc:1031-1096; gsr_reproj_loss inside the direct loop, fused pose step and
+    two-launch form; the tensor expressions on the autograd path) against the Python harness's track() with the same matches on the same map:
+    loss curves, the pose, and the term really pulls (without it the curve differs)."""
+    gsr, _C, sharded = _setup()
+    hz = __import__("gsorb_slam_amd.harness", fromlist=["x"])
+    sc, raw = _scene(gsr)
+    frame = _frame(_C, raw)
+    T, T0 = _poses()
+    obs, Xw, s2, cx, cy = _matches(T)
+    FW, iters = 5.0, 12
+    K = torch.tensor([[FX, 0.0, cx], [0.0, FY, cy], [0.0, 0.0, 1.0]], device="cuda")
+    g = hz.GaussianMap(hz.Config(), FX, FY, device="cuda")
+    g.add_points(raw[0], raw[1])
+    with torch.no_grad():
+        g.unnorm_quat.copy_(raw[2].cuda()); g.logit_opacities.copy_(raw[3].cuda()); g.log_scales.copy_(raw[4].cuda())
+    g.cfg.feature_weight_tracking = FW
+    r = hz.SlamRenderer(g, W, H)
+    mt = (torch.cat([obs, torch.ones(len(obs), 1)], 1).reshape(-1, 3, 1).cuda(), torch.cat([Xw, torch.ones(len(Xw), 1)], 1).reshape(-1, 4, 1).cuda(), s2.reshape(-1, 1).cuda())
+    T_ref, h_ref = r.track(hz.Frame(frame[0], frame[1], frame[2]), T0.cuda(), iters=iters, matches=mt, K=K)
+    out = {}
+    for name, cfg in (("fused", dict()), ("two-launch", dict(fused_update=False)), ("autograd", dict(direct=False)), ("no-matches", dict())):
+        loop = _loop(_C, raw, feature_weight_tracking=FW, **cfg)
+        args = () if name == "no-matches" else (obs.cuda(), Xw.cuda(), s2.cuda(), cx, cy)
+        h, best = loop.track(frame[0], frame[1], T0.cuda(), iters, *args)
+        out[name] = (np.array(h), best.cpu().numpy())
+    n = min(len(h_ref), *(len(out[k][0]) for k in ("fused", "two-launch", "autograd")))
+    assert n >= 6
+    scale = np.abs(np.array(h_ref)).max()
+    for k in ("fused", "two-launch", "autograd"):
+        e = np.abs(out[k][0][:n] - np.array(h_ref)[:n]).max() / scale
+        print("  track with matches, C++ %-10s vs Python harness: loss curve %.1e over %d iterations, pose %.1e" % (k, e, n, np.abs(out[k][1] - T_ref.cpu().numpy()).max()))
+        assert e < 5e-3 and np.abs(out[k][1] - T_ref.cpu().numpy()).max() < 1e-3
+    gap = np.abs(out["no-matches"][0][:n] - out["fused"][0][:n]).max() / scale
+    assert gap > 0.05, gap                                                # the term is a real share of the objective

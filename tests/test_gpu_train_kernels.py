@@ -595,3 +595,46 @@ def test_fused_mapping_loss_equals_its_separate_kernels(gsr, hz, shape):
     assert (reg_out.cpu() - reg_ref.cpu()).abs().max() <= 2e-5 * max(float(reg_ref.abs().max()), 1e-12)
     assert (gi - image.grad).abs().max() <= 2e-6 * float(image.grad.abs().max())
     assert (gd - depth.grad).abs().max() <= 2e-6 * float(depth.grad.abs().max())
+
+
+@pytest.mark.parametrize("M", [1, 37, 700])
+def test_reprojection_term_adds_its_pose_sums_and_its_value(gsr, hz, M):
+    """gsr_reproj_loss (the ORB matches' term of the tracking loss, src/Render.cc:1031-1096) against float64 autograd through the reference's
+    expressions: value added to the loss, the twelve sums dL/dR (row-major), dL/dt ADDED to the pose row; inliers recomputed (chi-square 5.991),
+    stored and re-used; the gradient scale of a sharded run."""
+    g = torch.Generator().manual_seed(M)
+    fx, fy, cx, cy, w = 260.0, 258.0, 159.5, 119.5, 0.1
+    T = torch.tensor(__import__("util").pose(0.03, (0.02, -0.01, 0.04)), dtype=torch.float64)
+    Xc = torch.stack([torch.rand(M, generator=g) * 1.2 - 0.6, torch.rand(M, generator=g) * 0.9 - 0.45, 1.0 + 2.0 * torch.rand(M, generator=g)], 1).double()
+    Xw = (Xc - T[:3, 3]) @ T[:3, :3]                                          # Xc = R Xw + t
+    noise = torch.randn(M, 2, generator=g).double() * torch.where(torch.arange(M) % 5 == 0, 6.0, 0.7).unsqueeze(1)   # every fifth match an outlier
+    obs = torch.stack([fx * Xc[:, 0] / Xc[:, 2] + cx, fy * Xc[:, 1] / Xc[:, 2] + cy], 1) + noise
+    s2 = (0.5 + torch.rand(M, generator=g)).double()
+
+    def ref(mask):
+        Tr = T.clone().requires_grad_(True)
+        X = Xw @ Tr[:3, :3].t() + Tr[:3, 3]
+        e = torch.stack([fx * X[:, 0] / X[:, 2] + cx, fy * X[:, 1] / X[:, 2] + cy], 1) - obs
+        werr = s2 * (e * e).sum(1)
+        m = mask if mask is not None else torch.ones(M, dtype=torch.bool)
+        val = werr[m].sum()
+        val.backward()
+        return float(val), torch.cat([Tr.grad[:3, :3].reshape(-1), Tr.grad[:3, 3]]), werr.detach() < 5.991
+    c = lambda t: t.to(torch.float32).cuda().contiguous()
+    Td = c(T.reshape(-1))
+    val_all, grad_all, inl_ref = ref(None)
+    row = torch.full((12,), 3.0, device="cuda"); loss = torch.full((1,), 7.0, device="cuda")
+    gsr.capi.reproj_loss(c(obs), c(Xw), c(s2), Td, fx, fy, cx, cy, w, row, loss, refresh=2)
+    assert abs(float(loss) - 7.0 - w * val_all) <= 2e-5 * (1 + w * val_all)
+    assert ((row.cpu().double() - 3.0) - w * grad_all).abs().max() <= 2e-4 * max(1.0, float((w * grad_all).abs().max()))
+    # recompute the inliers, store them, use them again (with a 1/world gradient scale)
+    inl = torch.ones(M, dtype=torch.uint8, device="cuda")
+    row.zero_(); loss.zero_()
+    gsr.capi.reproj_loss(c(obs), c(Xw), c(s2), Td, fx, fy, cx, cy, w, row, loss, inliers=inl, refresh=1)
+    assert torch.equal(inl.cpu().bool(), inl_ref) and (M < 5 or not bool(inl_ref.all()))
+    val_in, grad_in, _ = ref(inl_ref)
+    assert abs(float(loss) - w * val_in) <= 2e-5 * (1 + w * val_in)
+    row2 = torch.zeros(12, device="cuda"); loss2 = torch.zeros(1, device="cuda")
+    gsr.capi.reproj_loss(c(obs), c(Xw), c(s2), Td, fx, fy, cx, cy, w, row2, loss2, inliers=inl, refresh=0, grad_scale=0.25)
+    assert float(loss2) == float(loss) and (row2 * 4 - row).abs().max() <= 1e-6 * max(1.0, float(row.abs().max()))
+    assert (row.cpu().double() - w * grad_in).abs().max() <= 2e-4 * max(1.0, float((w * grad_in).abs().max()))
