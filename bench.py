@@ -430,62 +430,48 @@ def shard_step(a, gsr, td, rank, world, dev):
 
 
 def shard_render(a, gsr, td, rank, world, dev, weak=False):
-    """The rasterize path WITH its exchange. Strong scaling (default): --splats Gaussians in total, split into depth slabs over the
-    ranks (sharded.shard_by_depth_slabs). Weak scaling (weak=True; the use case BASELINE configs 4-5 describe: a map that grows with the
-    node): --splats Gaussians PER RANK — rank r owns the r-th of `world` equal depth slabs of the view's depth range, the map is
-    world x --splats Gaussians. Per step every rank renders its slab (fused colour + depth / silhouette pass),
-    the layers are composited (all-gather of 2 floats/pixel/rank + one all-reduce of 4 channels), a fixed upstream
-    gradient is taken back through the composite (all-gather of 1 float/pixel/rank) and the rasterizer's backward to the
-    Gaussians and the pose, and the pose gradient is all-reduced (16 floats) — north_star: 'shards Gaussians across the
-    GPUs with an RCCL all-reduce on pose/loss gradients only'. Through the operator boundary (Python op)."""
+    """The rasterize path WITH its exchange, through the C++ loop's sharded render (ORB_SLAM2::SlamLoop::ShardRenderStep, torch_ext/DirectLoop.cpp).
+    Strong scaling (default): --splats Gaussians in total, cut into `world` k-d cells (sharded.KdPartition). Weak scaling (weak=True; the use case
+    BASELINE configs 4-5 describe: a map that grows with the node): --splats Gaussians PER RANK — rank r owns the r-th of `world` equal depth slabs of the
+    view's depth range, the map is world x --splats Gaussians. Per step every rank renders its cell (fused colour + depth / silhouette pass), the layers
+    are composited (all-gather of 2 floats/pixel/rank + one all-reduce of 4 planes), a fixed upstream gradient is taken back through the composite
+    (all-gather of 1 float/pixel/rank) and the rasterizer's backward to the Gaussians and the pose, and the pose rows are all-reduced (24 KB) —
+    north_star: 'shards Gaussians across the GPUs with an RCCL all-reduce on pose/loss gradients only'. The collectives are RCCL calls on the loop's stream."""
     syn = gsr.synthetic
     sharded = __import__("gsorb_slam_amd.sharded", fromlist=["x"])
     sys.path.insert(0, os.path.join(ROOT, "gsorb-slam_amd"))
-    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C
     camd = syn.CAMERAS[a.camera]
     cam = syn.make_camera(**camd)
     W, H = cam.width, cam.height
-    if weak:   # every rank generates only ITS slab: depth range [0.5, 6.0] cut into `world` equal parts, --splats Gaussians each
+    t = lambda x: torch.tensor(x, dtype=torch.float32)
+    if weak:   # every rank generates only ITS slab: depth range [0.5, 6.0] cut into `world` equal parts, --splats Gaussians each; the slabs ARE the front-to-back order
         z0, z1 = 0.5 + 5.5 * rank / world, 0.5 + 5.5 * (rank + 1) / world
         sc = syn.make_scene(a.splats, cam, seed=1234 + rank, scale_mult=a.scale_mult, z_range=(z0, z1))
-        idx = np.arange(a.splats)
+        idx, nodes, how = torch.arange(a.splats), torch.empty(0), "depth slabs"
     else:
         sc = syn.make_scene(a.splats, cam, seed=1234, scale_mult=a.scale_mult)      # the SAME scene on every rank
-        idx = sharded.shard_by_depth_slabs(torch.tensor(sc.means3D[:, 2]), world)[rank].numpy()
+        part = sharded.KdPartition.build(t(sc.means3D), world)
+        idx, nodes, how = torch.nonzero(part.assign(t(sc.means3D)) == rank).squeeze(-1), part.nodes, "k-d cells"
     total = a.splats * world if weak else a.splats
-    s = gsr.capi.Settings.from_camera(cam, device=dev)
-    rs = dgr.GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=s.tanfovx, tanfovy=s.tanfovy, bg=torch.zeros(3, device=dev),
-                                           scale_modifier=1.0, viewmatrix=s.viewmatrix, projmatrix=s.projmatrix, sh_degree=0,
-                                           campos=s.campos, prefiltered=False)
-    rast = dgr.GaussianRasterizer(raster_settings=rs)
-    comp = sharded.LayerCompositor()
-    t = lambda x: torch.as_tensor(x, dtype=torch.float32, device=dev).contiguous()
-    xyz, op, col, sca, rot = (t(x[idx]).requires_grad_(True) for x in (sc.means3D, sc.opacities, sc.colors, sc.scales, sc.rotations))
-    Tcw = torch.eye(4, device=dev, requires_grad=True)
-    g = torch.Generator().manual_seed(7)
-    G = torch.randn((5, H, W), generator=g).to(dev)
-    key = float(sc.means3D[idx, 2].min()) if len(idx) else float("inf")
-
-    def step():
-        mc = gsr.capi.to_camera(Tcw, xyz)
-        img, ds, _, sur = rast.forward_pair(means3D=mc, means2D=torch.zeros_like(mc, requires_grad=True), opacities=op, colors_precomp=col,
-                                            scales=sca, rotations=rot)
-        rgb, depth, sil, _ = comp.composite(img, ds, key, sur=sur)
-        ((rgb * G[0:3]).sum() + (depth * G[3:4]).sum() + (sil * G[4:5]).sum()).backward()
-        comp.all_reduce_pose_grad(Tcw.grad)
-        for x in (xyz, op, col, sca, rot, Tcw):
-            x.grad = None
+    op = t(sc.opacities).reshape(-1, 1)
+    raw = [t(sc.means3D)[idx], t(sc.colors)[idx], t(sc.rotations)[idx], torch.log(op / (1 - op))[idx], torch.log(t(sc.scales))[idx]]
+    loop = _C.SlamLoop(W, H, camd["fx"], camd["fy"], dev)
+    loop.set_map(*raw)
+    loop.set_shard(td.group.WORLD if world > 1 else None, rank, world, nodes)
+    Tcw = torch.eye(4, device=dev)
+    G = torch.randn((5, H, W), generator=torch.Generator().manual_seed(7)).to(dev).contiguous()
 
     def barrier():
         if world > 1:
             td.barrier()
         torch.cuda.synchronize()
     for _ in range(a.warmup + 10):
-        step()
+        loop.shard_render_step(Tcw, G)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        step()
+        loop.shard_render_step(Tcw, G)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -494,13 +480,13 @@ def shard_render(a, gsr, td, rank, world, dev, weak=False):
         dt = float(tt.item())
     ms = dt / max(a.steps, 1) * 1e3
     plane = W * H * 4
-    return {"what": "sharded fwd+bwd rasterize with its exchange (see bench.py:shard_render): fused colour + depth/silhouette pass of the rank's depth slab, "
-                    "layer compositing, backward through both, pose-gradient all-reduce; collectives INSIDE the timed region",
-            "scaling": "weak" if weak else "strong", "total_splats": total, "splats_per_rank": int(len(idx)), "width": W, "height": H, "ms_per_step": ms,
+    return {"what": "sharded fwd+bwd rasterize with its exchange through the C++ loop (SlamLoop::ShardRenderStep): fused colour + depth/silhouette pass of the rank's cell, "
+                    "layer compositing (three HIP kernels), backward through both, pose-row all-reduce; collectives (RCCL on the loop's stream) INSIDE the timed region",
+            "scaling": "weak" if weak else "strong", "partition": how, "total_splats": total, "splats_per_rank": int(idx.numel()), "width": W, "height": H, "ms_per_step": ms,
             "value": total * W * H / (ms * 1e-3), "unit": "splats*pixels/s",
             "backend": (td.get_backend() if world > 1 else "none (single process)"), "ranks": (td.get_world_size() if world > 1 else 1),
-            "collective_bytes_per_rank_per_step": {"all_gather_fwd": 3 * plane * (world - 1) if world > 1 else 0, "all_reduce_fwd": 4 * plane if world > 1 else 0,
-                                                   "all_gather_bwd": plane * (world - 1) if world > 1 else 0, "all_reduce_pose": 64 if world > 1 else 0}}
+            "collective_bytes_per_rank_per_step": {"all_gather_fwd": 2 * plane * (world - 1) if world > 1 else 0, "all_reduce_fwd": 4 * plane if world > 1 else 0,
+                                                   "all_gather_bwd": plane * (world - 1) if world > 1 else 0, "all_reduce_pose": 512 * 12 * 4 if world > 1 else 0}}
 
 
 def main():
@@ -572,10 +558,10 @@ def main():
                                             "what": "every rank renders its OWN --splats scene, no collective in the timed region"}
                 out.update(value=sr["value"], ms_per_step=sr["ms_per_step"], scaling=sr["scaling"])
                 what = (f"{a.splats} Gaussians PER RANK ({sr['total_splats']} in the map: rank r owns the r-th depth slab)" if a.scaling == "weak"
-                        else f"{a.splats} Gaussians in TOTAL split into depth slabs over {world} ranks")
-                out["config"]["workload"] = (what + f", {sr['width']}x{sr['height']}, sharded fwd+bwd rasterize with layer compositing (three HIP kernels, "
-                                             f"gsr_composite_*) and pose-gradient all-reduce inside the timed region; backend {sr['backend']} ({sr['ranks']} ranks)")
-                out["config"]["parallelism"] = f"scene shards (depth slabs) x{world}, {sr['scaling']} scaling, torch.distributed backend {sr['backend']}"
+                        else f"{a.splats} Gaussians in TOTAL cut into k-d cells over {world} ranks")
+                out["config"]["workload"] = (what + f", {sr['width']}x{sr['height']}, sharded fwd+bwd rasterize through the C++ loop (SlamLoop::ShardRenderStep) with layer "
+                                             f"compositing (three HIP kernels, gsr_composite_*) and pose-row all-reduce inside the timed region; backend {sr['backend']} ({sr['ranks']} ranks)")
+                out["config"]["parallelism"] = f"scene shards ({sr['partition']}) x{world}, {sr['scaling']} scaling, RCCL on the loop's stream (bootstrap: torch.distributed {sr['backend']})"
                 out["config"]["splats_total"] = sr["total_splats"]
                 out.pop("step_ms_percentiles", None)
                 out["shard_render_" + sr_other["scaling"]] = sr_other

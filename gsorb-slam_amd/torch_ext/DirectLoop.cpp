@@ -69,6 +69,7 @@ struct SlamLoop::Direct {
     // sharded (SetShard): the composite of all ranks' layers and what its backward needs
     c10::intrusive_ptr<c10d::ProcessGroup> pg;
     int rank = 0, world = 1;
+    torch::Tensor step_pose;                                             // ShardRenderStep: the pose tensor of the previous call
     bool order_stale = true;                                             // the pose changed since gsr_shard_order ran
     bool staged = false;                                                 // the group cannot move device tensors (gloo): through the host
     ncclComm_t comm = nullptr;                                           // backend "nccl": the loop's OWN RCCL communicator — its collectives are enqueued on the loop's
@@ -585,6 +586,42 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> SlamLoop::RenderComposit
     const int64_t HW = (int64_t)H_ * W_;
     const auto plane = [&](int64_t off, int64_t n) { return d.comp.slice(0, off, off + n * HW).reshape({n, H_, W_}); };
     return {plane(0, 3).clone(), plane(5 * HW + 4, 1).clone(), torch::cat({plane(3 * HW, 1), plane(4 * HW + 4, 1)}, 0)};
+}
+
+torch::Tensor SlamLoop::ShardRenderStep(const torch::Tensor& Tcw, const torch::Tensor& G)
+{
+    if (!direct_() || !shard_) throw std::runtime_error("ShardRenderStep needs a sharded direct loop (SetShard)");
+    torch::NoGradGuard ng;
+    c10::DeviceGuard guard(dev_);
+    ensure_direct_(1);
+    Direct& d = *d_;
+    void* const st = stream_();
+    if (!G.is_cuda() || G.scalar_type() != torch::kFloat32 || !G.is_contiguous() || G.numel() != (int64_t)5 * H_ * W_) throw std::runtime_error("ShardRenderStep: G must be a contiguous float32 device tensor [5,H,W]");
+    if (!d.step_pose.defined() || !d.step_pose.is_same(Tcw)) { // (a new pose tensor: copy it and make sure the workspace holds the frame)
+        d.Tcw.copy_(Tcw.to(torch::kFloat32).reshape({4, 4}));
+        shard_preflight_();
+        d.step_pose = Tcw;
+    }
+    if (d.n > 0)
+        chk(gsr_map_prepare((size_t)d.n, f(xyz), f(logit_opacities), f(log_scales), f(unnorm_quat), f(d.Tcw), f(d.mc), f(d.opac), f(d.scales), f(d.rots), 0.f, 0.f, 0.f,
+                            nullptr, nullptr, st), "gsr_map_prepare");
+    direct_forward_();
+    shard_composite_forward_(true, false);
+    // the compositor's backward reads the loss's gradient from d.G: hand it the caller's (the silhouette's upstream gradient rides in plane 4)
+    const torch::Tensor keepG = d.G;
+    d.G = G;
+    const long long* const order = (const long long*)d.order.data_ptr<int64_t>();
+    d.stream = (hipStream_t)st;
+    chk(gsr_composite_backward_local(d.world, d.rank, order, f(d.gathered), 2, f(d.layers), f(d.G), H_, W_, f(d.D), f(d.c_own), st), "gsr_composite_backward_local");
+    d.all_gather(d.c_all, d.c_own);
+    chk(gsr_composite_backward_occlusion(d.world, d.rank, order, f(d.gathered), 2, f(d.c_all), f(d.G) + (size_t)4 * H_ * W_, H_, W_, f(d.D) + (size_t)4 * H_ * W_, st),
+        "gsr_composite_backward_occlusion");
+    d.G = keepG;
+    direct_backward_(false, false, nullptr, nullptr);
+    if (d.n > 0) chk(gsr_pose_grad(f(xyz), f(d.d_mc), (size_t)d.n, f(d.Tcw), f(d.pose_partial), nullptr, st), "gsr_pose_grad");
+    else d.pose_partial.zero_();
+    d.all_reduce(d.pose_partial);
+    return d.pose_partial;
 }
 
 // Sharded: the cell of the k-d partition every point lies in ([n] int64 ranks) — the owner rule of map growth

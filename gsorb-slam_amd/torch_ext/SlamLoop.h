@@ -102,6 +102,11 @@ public:
     void SetShard(c10::intrusive_ptr<c10d::ProcessGroup> group, int rank, int world, const torch::Tensor& kd_nodes);
     // the whole map's render for a pose from every rank's shard: {colour [3,H,W], surface depth [1,H,W], depth / silhouette [2,H,W]} (collective call)
     std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> RenderComposite(const torch::Tensor& Tcw);
+    // The sharded rasterize path forwards and backwards in one call (collective; what bench.py's N > 1 headline times): the own cell's render, the
+    // composite of all ranks' layers, an upstream gradient of the composite G [5,H,W] = d/d(rgb, depth, silhouette) taken back through the compositor and
+    // the rasterizer to this rank's Gaussians (gradient buffers of the workspace) and to the pose — returns the [GSR_POSE_PARTIALS, 12] pose rows summed over the
+    // ranks (their column sums are dL/dR row-major, dL/dt). Launches only: nothing here synchronises with the host.
+    torch::Tensor ShardRenderStep(const torch::Tensor& Tcw, const torch::Tensor& G);
     // Re-balance of a sharded map (sharded.rebalance_loop drives the exchange): every Gaussian of this loop with what travels with it — raw
     // parameters (14 floats: xyz, rgb, quaternion, logit, log-scales), exp_avg (14), exp_avg_sq (14): [n, 42] —, and the surgery that keeps the
     // rows `keep` and appends the rows that arrive from other ranks WITH their moments (Gaussian.cc:218-258 does the same with zeros / a selection)

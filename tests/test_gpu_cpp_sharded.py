@@ -272,3 +272,35 @@ def test_cpp_track_with_feature_matches_follows_the_python_harness():
         assert e < 5e-3 and np.abs(out[k][1] - T_ref.cpu().numpy()).max() < 1e-3
     gap = np.abs(out["no-matches"][0][:n] - out["fused"][0][:n]).max() / scale
     assert gap > 0.05, gap                                                # the term is a real share of the objective
+
+
+@pytest.mark.gpu
+def test_shard_render_step_pose_sums_equal_autograd_through_the_python_operator():
+    """SlamLoop::ShardRenderStep (what bench.py's N > 1 headline times) with one rank and no group: the composite is the render, so the pose sums it returns
+    must be the gradient of sum(G . (rgb, depth, silhouette)) w.r.t. the pose that autograd finds through the Python operator's fused pair."""
+    gsr, _C, sharded = _setup()
+    import diff_gaussian_rasterization as dgr
+    sc, raw = _scene(gsr)
+    T = _poses()[0].cuda()
+    loop = _loop(_C, raw)
+    loop.set_shard(None, 0, 1, torch.empty(0))
+    G = torch.randn((5, H, W), generator=torch.Generator().manual_seed(3)).cuda().contiguous()
+    rows = loop.shard_render_step(T, G).clone()
+    rows2 = loop.shard_render_step(T, G)                                   # (a second call on the same pose: same result up to the atomics' order)
+    sums = rows.sum(0).cpu().double()
+    assert (rows2.sum(0).cpu().double() - sums).abs().max() <= 1e-3 * sums.abs().max()
+    cam = gsr.synthetic.make_camera(W, H, FX, FY)
+    s = gsr.capi.Settings.from_camera(cam, device="cuda")
+    rs = dgr.GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=s.tanfovx, tanfovy=s.tanfovy, bg=torch.zeros(3, device="cuda"), scale_modifier=1.0,
+                                           viewmatrix=s.viewmatrix, projmatrix=s.projmatrix, sh_degree=0, campos=s.campos, prefiltered=False)
+    rast = dgr.GaussianRasterizer(raster_settings=rs)
+    Tp = T.clone().requires_grad_(True)
+    xyz = raw[0].cuda()
+    mc = gsr.capi.to_camera(Tp, xyz)
+    img, ds, _, _ = rast.forward_pair(means3D=mc, means2D=torch.zeros_like(mc, requires_grad=True), opacities=torch.sigmoid(raw[3].cuda()), colors_precomp=raw[1].cuda(),
+                                      scales=torch.exp(raw[4].cuda()), rotations=torch.nn.functional.normalize(raw[2].cuda()))
+    ((img * G[0:3]).sum() + (ds * G[3:5]).sum()).backward()
+    ref = torch.cat([Tp.grad[:3, :3].reshape(-1), Tp.grad[:3, 3]]).cpu().double()
+    e = float((sums - ref).abs().max() / ref.abs().max())
+    print("\n  ShardRenderStep pose sums vs autograd through the Python operator: %.1e" % e)
+    assert e < 2e-3                                                          # (sums of ~1e5 signed terms that cancel: float atomics in the backward)
