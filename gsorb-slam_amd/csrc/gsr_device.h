@@ -30,6 +30,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// This library is written for gfx950 (MI355X) and leans on gfx9 behaviour outside the HIP memory model: hand-overs between workgroups of one launch through
+// write-through (sc1) stores, `s_waitcnt vmcnt(0)` and relaxed agent-scope tickets instead of release / acquire fences (csrc/gsr_train.h: last_arriver;
+// K_bin_colscan), row_bcast DPP reductions, LDS handed out in 1280-byte granules. On another target they would race or fail to assemble — silently. Refuse to build.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "gsorb-slam_amd is written for gfx950 (CDNA4); its in-launch hand-overs and DPP idioms are not portable: build with --offload-arch=gfx950"
+#endif
+
 #define GSR_TILE 16
 #define GSR_TILE_PIX 256
 #define GSR_ALIGN 256
