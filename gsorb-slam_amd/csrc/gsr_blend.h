@@ -394,7 +394,11 @@ __device__ __forceinline__ void blend_bwd_rgb(ImageView im, char* __restrict__ b
         auto gp_load = [&](const int p) -> float4 {
             // (measured and dropped in round 4: pixel-major float4 entries, one ds_read_b128 per pixel instead of three or four ds_read_b32, with
             // byte-sized lists to stay inside ten LDS blocks: plain kernel 221 -> 238 us (8 spills), fused pair 266 -> 266)
+#ifdef GSR_EXP_NOGP // timing experiment (wrong colour sums): the reduce phase without its 48 dL/dpixel reads = 96 of its ~263 LDS cycles
+            return make_float4(pxf, pyf, 1.f, 0.f);
+#else
             return make_float4(GP[0][r * 17 + p], GP[1][r * 17 + p], GP[2][r * 17 + p], 0.f);
+#endif
         };
         auto reduce = [&](const int b0, const int nb) {
             lds_turn();
