@@ -66,6 +66,7 @@ struct SlamLoop::Direct {
     torch::Tensor pose_acc;                                              // [64, 12] the fused pose step's accumulator rows (zero between launches)
     torch::Tensor tickets;                                               // [2 * GSR_TICKET_WORDS] arrival counters of the kernels that finish their own sums (zero between launches)
     int64_t history_len = 0;
+    bool fresh = true; // the workspace was (re)built for a new map size: one pre-flight forward sizes the binning workspace before the first batch of iterations
     // sharded (SetShard): the composite of all ranks' layers and what its backward needs
     c10::intrusive_ptr<c10d::ProcessGroup> pg;
     int rank = 0, world = 1;
@@ -220,6 +221,7 @@ void SlamLoop::ensure_direct_(int64_t history_len)
     }
     if (d.n != n) { // per map size
         d.n = n;
+        d.fresh = true;
         d.geom = torch::empty({(int64_t)gsr_geom_bytes((int)n)}, bo);
         d.mc = torch::empty({n, 3}, fo); d.opac = torch::empty({n}, fo); d.scales = torch::empty({n, 3}, fo); d.rots = torch::empty({n, 4}, fo);
         d.radii = torch::empty({n}, fo.dtype(torch::kInt32));
@@ -404,6 +406,9 @@ std::vector<double> SlamLoop::MapFrame(const LoopFrame& fr, int iters)
     const LoopFrame frame{fr.rgb.to(dev_, torch::kFloat32).contiguous(), fr.depth.to(dev_, torch::kFloat32).contiguous(), fr.Tcw};
     d.Tcw.copy_(fr.Tcw.to(torch::kFloat32).reshape({4, 4}));
     if (shard_) { shard_preflight_(); d.order_stale = true; }
+    else if (d.fresh) shard_preflight_(); // (unsharded too — ADVICE r4: inside a batch nobody looks; an iteration that overflowed is still retaken below,
+                                          // but the iterations behind it ran with Adam step numbers one too high: size the workspace BEFORE the batch instead)
+    d.fresh = false;
     int done = 0;
     while (done < iters) {
         const int batch = iters - done;
@@ -446,7 +451,8 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
     d.pose_moments.zero_();
     d.best.zero_(); d.best.slice(0, 0, 1).fill_(std::numeric_limits<float>::infinity());
     chk(gsr_pose_from_quat(f(d.pose), f(d.pose) + 4, f(d.Tcw), st), "gsr_pose_from_quat");
-    if (shard_) shard_preflight_();
+    if (shard_ || d.fresh) shard_preflight_();
+    d.fresh = false;
     // the map does not move while the pose is tracked: its activations are formed once per call
     if (d.n > 0) chk(gsr_map_prepare((size_t)d.n, nullptr, f(logit_opacities), f(log_scales), f(unnorm_quat), nullptr, nullptr, f(d.opac), f(d.scales), f(d.rots), 0.f, 0.f, 0.f,
                         nullptr, nullptr, st), "gsr_map_prepare");

@@ -217,7 +217,10 @@ std::vector<double> SlamLoop::Track(const LoopFrame& frame, const torch::Tensor&
 
 double SlamLoop::MappingIteration(const LoopFrame& fr)
 {
-    if (direct_()) return MapFrame(fr, 1).at(0);
+    if (direct_()) {
+        const auto l = MapFrame(fr, 1);
+        return l.empty() ? std::numeric_limits<double>::quiet_NaN() : l[0]; // (an empty map renders nothing and has no loss)
+    }
     const auto Tcw = fr.Tcw.to(dev_, torch::kFloat32);
     auto [rimage, rsur, rdepth] = RenderPair(Tcw, false);
     if (cfg_.fused_ops) { // Render.cc:436-471 as: pixel terms (2 launches), SSIM (1 + a sum), regularisers (2), a handful of scalar operations
