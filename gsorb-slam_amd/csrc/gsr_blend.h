@@ -527,7 +527,7 @@ __device__ __forceinline__ void blend_bwd_rgb(ImageView im, char* __restrict__ b
 // COLORS = false: nobody consumes the colour sums (a tracking iteration: the pose is the only parameter, the colours and the depth channel's
 // colour are constants) — the reduce phase then skips its dL/dpixel reads and three or four of its nine or ten sums, the records are six floats.
 // SIL = false (with DUAL): dL_dds holds the depth plane only, the silhouette's upstream gradient is zero (both loops use the silhouette as a
-// detached mask): its accum_rec recursion and its term of dL/dalpha leave the loop.
+// detached mask); with SIL the plane is read once per pixel and folded into the background factor of dL/dalpha (below): no work in the loop.
 template <int Q, bool DUAL, bool COLORS, bool SIL>
 __device__ __forceinline__ void blend_bwd_lean(ImageView im, char* __restrict__ binning, GeomView g, const float* __restrict__ bg, int W, int H,
                                                int grid_x, int ntiles, int tile0, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dds)
@@ -604,13 +604,15 @@ __device__ __forceinline__ void blend_bwd_lean(ImageView im, char* __restrict__ 
                 g2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
     const float g3 = DUAL && inside ? dL_dds[pix] : 0.f, g4 = DUAL && SIL && inside ? dL_dds[HW + pix] : 0.f; // (their background is 0)
     const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
-    const float nTf_bg = -T_final * bg_dot;
+    // The silhouette channel (colour 1 on every splat) needs no recursion of its own: what it accumulates is 1 - T_final, so its share of
+    // dL/dalpha_i, g4 T_i (1 - accum_rec_i) = g4 T_final / (1 - alpha_i), has the background term's form with colour -1 and rides in its factor.
+    const float nTf_bg = -T_final * (bg_dot - g4);
     // colour accumulated behind the current splat (the reference's accum_rec, updated eagerly:
     // last_alpha*last_color + (1-last_alpha)*accum_rec == fma(alpha, c - S, S) one step later). Kept per
     // channel: c - S is formed BEFORE the contraction with the pixel gradient — neighbouring splats have
     // similar colours (depth renders!), and contracting first turns an exact small difference into the
     // difference of two rounded large numbers (measured: 9e-5 instead of 1e-6 on long lists).
-    float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f;
+    float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f;
     constexpr int NC = !COLORS ? 6 : DUAL ? 10 : 9;       // sums per (quad, splat) record
     if (COLORS) {
         G01[lane] = make_float2(g0, g1);
@@ -755,15 +757,10 @@ __device__ __forceinline__ void blend_bwd_lean(ImageView im, char* __restrict__ 
             T = T * ia;
             const float e0 = B.z - S0, e1 = B.w - S1, e2 = Cz.x - S2;
             float eg = fmaf(e2, g2, fmaf(e1, g1, e0 * g0)); // (colour - accum_rec) . dL_dpix
-            if (DUAL) { // the depth and silhouette channels: colours (z, 1)
+            if (DUAL) { // the depth channel: colour z (the silhouette's term sits in nTf_bg)
                 const float e3 = Cz.z - S3;
                 eg = fmaf(e3, g3, eg);
                 S3 = fmaf(alpha, e3, S3);
-                if (SIL) {
-                    const float e4 = 1.0f - S4;
-                    eg = fmaf(e4, g4, eg);
-                    S4 = fmaf(alpha, e4, S4);
-                }
             }
             const float dL_dalpha = fmaf(nTf_bg, ia, eg * T); // - T_final/(1-alpha) * (bg . dL_dpix)
             S0 = fmaf(alpha, e0, S0); S1 = fmaf(alpha, e1, S1); S2 = fmaf(alpha, e2, S2);
