@@ -399,7 +399,7 @@ def shard_step(a, gsr, td, rank, world, dev):
         torch.cuda.synchronize()
 
     def timed(fn):
-        fn(3)
+        fn(max(a.shard_steps, 20))      # warm-up: clocks, and RCCL's first launches (measured: the first 20 iterations after 3 run 8 % slow)
         barrier()
         t0 = time.perf_counter()
         ran = fn(max(a.shard_steps, 1))
@@ -413,6 +413,14 @@ def shard_step(a, gsr, td, rank, world, dev):
 
     map_ms, n = timed(lambda k: len(loop.map_frame(rgb, depth, T, k)))      # SlamLoop::MapFrame: the losses are read back once, like Render::RenderForFrame
     track_ms, ran = timed(lambda k: len(loop.track(rgb, depth, T0, k)[0]))  # (it stops early only if the loss stalls: what ran is what is counted)
+    same = None
+    if world == 1:      # the SAME loop class on the SAME scene without SetShard: what the compositing and its exchange cost at one rank
+        plain = _C.SlamLoop(W, H, camd["fx"], camd["fy"], dev)
+        plain.set_map(*raw)
+        m_ms, _ = timed(lambda k: len(plain.map_frame(rgb, depth, T, k)))
+        t_ms, _ = timed(lambda k: len(plain.track(rgb, depth, T0, k)[0]))
+        same = {"mapping_ms_per_iter": m_ms, "tracking_ms_per_iter": t_ms}
+        del plain
     if own_group:
         td1.destroy_process_group()
     plane = W * H * 4              # DirectLoop.cpp: all-gather (silhouette, surface depth), all-reduce of the 4 premultiplied planes, backward all-gather of 1 plane
@@ -423,6 +431,7 @@ def shard_step(a, gsr, td, rank, world, dev):
             "scaling": "strong", "total_splats": a.splats, "splats_per_rank": int(idx.numel()), "width": W, "height": H,
             "partition": f"k-d cells x{world} (sharded.KdPartition)", "backend": backend, "rccl_ranks": (td.get_world_size() if world > 1 else (1 if own_group else 0)),
             "mapping_ms_per_iter": map_ms, "tracking_ms_per_iter": track_ms, "tracking_iterations_run": ran,
+            "unsharded_same_scene": same, "warmup_iters": max(a.shard_steps, 20),
             "mapping_splats_pixels_per_s": 2 * a.splats * W * H / (map_ms * 1e-3),
             "collectives_per_mapping_iter": {"all_gather_bytes_sent_per_rank": 3 * plane, "all_reduce_bytes": 4 * plane, "all_reduce_floats": 3},
             "collectives_per_tracking_iter": {"all_gather_bytes_sent_per_rank": 3 * plane, "all_reduce_bytes": 4 * plane, "all_reduce_floats": 512 * 12},

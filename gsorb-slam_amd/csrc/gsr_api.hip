@@ -521,20 +521,25 @@ int gsr_dist2(int P, const float* points, float* mean_dists, char* workspace, si
     return GSR_OK;
 }
 
+// (the streaming SSIM kernels address a plane with 32-bit byte offsets)
+static bool ssim_plane_ok(int H, int W) { return H > 0 && W > 0 && (unsigned long long)H * (unsigned long long)W < (1ull << 30); }
+
 size_t gsr_ssim_partials(int C, int H, int W)
 {
     if (C <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)C * ((H + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE) * ((W + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE);
+    const gsr::SsimGrid g = gsr::ssim_grid(C, H, W);
+    return (size_t)C * g.nsx * g.nsy; // one row of sums per wave of the launch
 }
 
 int gsr_ssim_forward(const float* img1, const float* img2, int C, int H, int W, const float* taps11, float* partial,
                      float* dmaps, void* stream)
 {
-    if (!img1 || !img2 || !taps11 || !partial || C <= 0 || C > 65535 || H <= 0 || W <= 0) return GSR_EINVAL;
+    if (!img1 || !img2 || !taps11 || !partial || C <= 0 || C > 65535 || !ssim_plane_ok(H, W)) return GSR_EINVAL;
     gsr::SsimTaps t;
     for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
-    const dim3 grid((W + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, (H + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, C);
-    hipLaunchKernelGGL(gsr::K_ssim_fwd<false>, grid, dim3(GSR_SSIM_TILE * GSR_SSIM_TILE), 0, (hipStream_t)stream, img1, img2, H, W, t, partial, dmaps, gsr::MapLossPlanes{});
+    const gsr::SsimGrid sg = gsr::ssim_grid(C, H, W);
+    hipLaunchKernelGGL(gsr::K_ssim_fwd<false>, dim3((unsigned)gsr_ssim_partials(C, H, W)), dim3(64), 0, (hipStream_t)stream, img1, img2, C, H, W, t, sg, partial, dmaps,
+                       gsr::MapLossPlanes{});
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -542,11 +547,12 @@ int gsr_ssim_forward(const float* img1, const float* img2, int C, int H, int W, 
 int gsr_ssim_backward(const float* img1, const float* img2, const float* dmaps, int C, int H, int W, const float* taps11,
                       const float* dL_dmean, float* dL_dimg1, void* stream)
 {
-    if (!img1 || !img2 || !dmaps || !taps11 || !dL_dmean || !dL_dimg1 || C <= 0 || C > 65535 || H <= 0 || W <= 0) return GSR_EINVAL;
+    if (!img1 || !img2 || !dmaps || !taps11 || !dL_dmean || !dL_dimg1 || C <= 0 || C > 65535 || !ssim_plane_ok(H, W)) return GSR_EINVAL;
     gsr::SsimTaps t;
     for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
-    const dim3 grid((W + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, (H + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, C);
-    hipLaunchKernelGGL(gsr::K_ssim_bwd<false>, grid, dim3(GSR_SSIM_TILE * GSR_SSIM_TILE), 0, (hipStream_t)stream, img1, img2, dmaps, H, W, t, dL_dmean, dL_dimg1, gsr::MapLossGrad{});
+    const gsr::SsimGrid sg = gsr::ssim_grid(C, H, W);
+    hipLaunchKernelGGL(gsr::K_ssim_bwd<false>, dim3((unsigned)gsr_ssim_partials(C, H, W)), dim3(64), 0, (hipStream_t)stream, img1, img2, dmaps, C, H, W, t, sg, dL_dmean,
+                       dL_dimg1, gsr::MapLossGrad{});
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -758,12 +764,13 @@ int gsr_shard_order(int world, const float* kd_nodes, const float* Tcw, long lon
 int gsr_map_loss_forward(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb, const float* frame_depth,
                          int H, int W, const float* taps11, float sil_thr, float* partial6, float* dmaps, void* stream)
 {
-    if (!image || !frame_rgb || !frame_depth || !taps11 || !partial6 || !dmaps || H <= 0 || W <= 0) return GSR_EINVAL;
+    if (!image || !frame_rgb || !frame_depth || !taps11 || !partial6 || !dmaps || !ssim_plane_ok(H, W)) return GSR_EINVAL;
     gsr::SsimTaps t;
     for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
-    const dim3 grid((W + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, (H + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, 3);
+    const gsr::SsimGrid sg = gsr::ssim_grid(3, H, W);
     const gsr::MapLossPlanes ml{depth, sur, sil, frame_depth, sil_thr, partial6};
-    hipLaunchKernelGGL(gsr::K_ssim_fwd<true>, grid, dim3(GSR_SSIM_TILE * GSR_SSIM_TILE), 0, (hipStream_t)stream, image, frame_rgb, H, W, t, (float*)nullptr, dmaps, ml);
+    hipLaunchKernelGGL(gsr::K_ssim_fwd<true>, dim3(2u * (unsigned)gsr_ssim_partials(3, H, W)), dim3(64), 0, (hipStream_t)stream, image, frame_rgb, 3, H, W, t, sg, (float*)nullptr,
+                       dmaps, ml);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -786,12 +793,12 @@ int gsr_map_loss_finish(const float* partial6, const float* reg_partial, size_t 
 int gsr_map_loss_backward(const float* image, const float* depth, const float* frame_rgb, const float* frame_depth, const float* dmaps, int H, int W,
                           const float* taps11, const float* w3, const float* neg_c_ssim, const float* sums, float* dL_dimage, float* dL_ddepth, void* stream)
 {
-    if (!image || !frame_rgb || !frame_depth || !dmaps || !taps11 || !w3 || !neg_c_ssim || !sums || !dL_dimage || H <= 0 || W <= 0) return GSR_EINVAL;
+    if (!image || !frame_rgb || !frame_depth || !dmaps || !taps11 || !w3 || !neg_c_ssim || !sums || !dL_dimage || !ssim_plane_ok(H, W)) return GSR_EINVAL;
     gsr::SsimTaps t;
     for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
-    const dim3 grid((W + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, (H + GSR_SSIM_TILE - 1) / GSR_SSIM_TILE, 3);
+    const gsr::SsimGrid sg = gsr::ssim_grid(3, H, W);
     const gsr::MapLossGrad mg{depth, frame_depth, sums, w3[0] / (3.f * (float)((size_t)H * W)), w3[1], dL_ddepth};
-    hipLaunchKernelGGL(gsr::K_ssim_bwd<true>, grid, dim3(GSR_SSIM_TILE * GSR_SSIM_TILE), 0, (hipStream_t)stream, image, frame_rgb, dmaps, H, W, t, neg_c_ssim,
+    hipLaunchKernelGGL(gsr::K_ssim_bwd<true>, dim3((dL_ddepth ? 2u : 1u) * (unsigned)gsr_ssim_partials(3, H, W)), dim3(64), 0, (hipStream_t)stream, image, frame_rgb, dmaps, 3, H, W, t, sg, neg_c_ssim,
                        dL_dimage, mg);
     GSR_LAUNCHED();
     return GSR_OK;

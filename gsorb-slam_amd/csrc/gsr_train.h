@@ -15,14 +15,36 @@
 
 namespace gsr {
 
-#define GSR_SSIM_TILE 16
 #define GSR_SSIM_R 5 // window radius: 11 taps
-#define GSR_SSIM_HALO (GSR_SSIM_TILE + 2 * GSR_SSIM_R)
+#define GSR_SSIM_COLS (64 - 2 * GSR_SSIM_R) // output columns of a wave's strip: one lane per INPUT column, the five on either side are halo
+#ifndef GSR_SSIM_WAVES
+#define GSR_SSIM_WAVES 1024 // waves a launch aims for: one per SIMD of the chip (256 CUs x 4)
+#endif
 struct SsimTaps {
     float g[2 * GSR_SSIM_R + 1];
 };
+// How the SSIM kernels cut an image (round 5): a wave owns a strip of GSR_SSIM_COLS output columns and a segment of `rows` output rows of one
+// channel and streams down the strip, one image row per step (below). nsx strips x nsy segments x C channels = the launch's single-wave workgroups
+// (= gsr_ssim_partials); the segments are as tall as a launch of ~GSR_SSIM_WAVES waves allows (the ten halo rows of a segment are its overhead),
+// at least 16 rows.
+struct SsimGrid {
+    int nsx, nsy, rows;
+};
+__host__ __device__ inline SsimGrid ssim_grid(int C, int H, int W)
+{
+    SsimGrid g;
+    g.nsx = (W + GSR_SSIM_COLS - 1) / GSR_SSIM_COLS;
+    int want = GSR_SSIM_WAVES / (C * g.nsx);
+    const int most = (H + 15) / 16;
+    want = want > most ? most : want;
+    want = want < 1 ? 1 : want;
+    g.rows = (H + want - 1) / want;
+    g.rows = (g.rows + 2 * GSR_SSIM_R + 2 * GSR_SSIM_R) / (2 * GSR_SSIM_R + 1) * (2 * GSR_SSIM_R + 1) - 2 * GSR_SSIM_R; // rows + 10 steps: whole groups of eleven
+    g.nsy = (H + g.rows - 1) / g.rows;
+    return g;
+}
 // sum over the wave in eight DPP adds (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, row_bcast15 / row_bcast31 across them): the total is in
-// lane 63. (__shfl_xor is six ds_bpermute round trips through the LDS pipe, which is what the SSIM kernels are short of.)
+// lane 63. (__shfl_xor is six ds_bpermute round trips through the LDS pipe.)
 template <int CTRL, int ROWS>
 __device__ __forceinline__ float dpp_add_f(float v)
 {
@@ -34,7 +56,6 @@ __device__ __forceinline__ float wave_sum_lane63(float v)
     v = dpp_add_f<0x142, 0xa>(v); v = dpp_add_f<0x143, 0xc>(v);
     return v;
 }
-
 // "Am I the last workgroup of this launch to arrive?" for kernels that finish their own partial sums (K_track_loss, K_pose_step). Called by ONE
 // thread after the workgroup's write-through stores have drained (s_waitcnt vmcnt(0) in every storing wave + __syncthreads()). One counter word
 // takes ~11 ns per arrival (512-1024 workgroups on one word: 6-11 us, measured), so the arrivals are sharded: the workgroups with the same
@@ -63,145 +84,177 @@ struct MapLossPlanes {
     float* partial6;                         // [6][workgroups]
 };
 // zero-padded "same" cross-correlation, like conv2d(padding = 5): out[y][x] = sum_k sum_l g[k] g[l] in[y + k - 5][x + l - 5]
+//
+// Round 5: a STREAMING separable window. One wave per (channel, strip, segment); lane = input column; per step the wave takes ONE image row
+// (requested eleven steps earlier: a register queue, so the only trips to memory a wave waits for are its first), hands it round through a
+// wave-private LDS row (one 8-byte write, eleven 8-byte reads: the two images interleaved), forms the five horizontal window sums of its column,
+// keeps the last eleven rows of them in registers (the loop is unrolled by eleven: the ring's slots are static) and, from the eleventh row on,
+// the vertical sums of the output row five rows up, the SSIM map and its three derivative maps. No barrier, no tile: the two passes of a 16x16
+// tile kernel (round 4: 32.4 us plain, 39.8 us with the mapping loss riding along at 1200x680x3) ran 26 halo rows and three barriers per 16
+// output rows, 38 workgroups deep per CU; every one of them waited for its own loads. The arithmetic is the old kernels', operation for
+// operation (same taps order, same fused multiply-adds: the maps are bit-identical), two window sums per instruction where they share a tap
+// (v_pk_fma_f32: (mu1, mu2), (E11, E22)).
+__device__ __forceinline__ v2f pk_fma(const v2f gg, const v2f x, const v2f acc) { return __builtin_elementwise_fma(gg, x, acc); }
+// the eleven taps as (g, g) pairs in VECTOR registers: as kernel arguments they cost 33 scalar registers (a pair for the packed instructions, the
+// plain one for the others) and the scalar file spills into vector lanes (v_readlane per use); the wave has vector registers to spare
+struct SsimTapRegs {
+    v2f g[2 * GSR_SSIM_R + 1];
+};
+__device__ __forceinline__ SsimTapRegs tap_regs(const SsimTaps& t, const bool reversed)
+{
+    SsimTapRegs r;
+#pragma unroll
+    for (int k = 0; k <= 2 * GSR_SSIM_R; k++) {
+        float g = t.g[reversed ? 2 * GSR_SSIM_R - k : k];
+        asm volatile("" : "+v"(g));
+        r.g[k].x = g; r.g[k].y = g;
+    }
+    return r;
+}
+// element at byte offset `off` (32 bits, a vector register) from a wave-uniform base: global_load ... v_off, s[base:base+1] — the row's offset
+// is ONE vector add per step for every plane the step touches instead of a 64-bit scalar add per plane
+__device__ __forceinline__ float ld_off(const float* base, const uint32_t off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off); }
+__device__ __forceinline__ void st_off(float* base, const uint32_t off, const float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) = v; }
+
+// MAPLOSS: the launch carries as many more single-wave workgroups as it has SSIM waves; they form the pixel terms (colour L1, masked depth L1,
+// masked surface-depth L1 and their counts), one strided share of the pixels each, and fill rows 1..5 of the six-row partial sums; the SSIM
+// waves fill row 0. (Riding on the SSIM waves themselves, as in round 4's tile kernel, the terms cost a lone wave 9 us of issue slots.)
 template <bool MAPLOSS>
-__global__ void __launch_bounds__(GSR_SSIM_TILE* GSR_SSIM_TILE)
-K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W, SsimTaps taps,
+__global__ void __launch_bounds__(64)
+K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int C, int H, int W, SsimTaps taps, SsimGrid sg,
            float* __restrict__ partial, float* __restrict__ dmaps, MapLossPlanes ml)
 {
-    constexpr int TS = GSR_SSIM_TILE, HS = GSR_SSIM_HALO, R = GSR_SSIM_R;
-    // Both passes slide a register window (round 4): a thread forms FOUR neighbouring outputs from 14 inputs it reads once — 3.1 LDS reads
-    // per output and tap-window instead of 11 (one output per thread and pass: 40 us at 1200x680x3). Where the 32.4 us of today go (variant
-    // builds, scripts/ssim_time.py): without the tile loads 24.8, without the row pass 27.5, without the column pass 29.9, without all three
-    // 12.5 — the skeleton (LDS fill, barriers, the SSIM map and its three derivative maps: 29 MB of stores) is the largest part, the two
-    // passes together cost 7 us: a better convolution cannot halve this kernel.
-    __shared__ float ab[2][HS][HS + 1];        // the two images' tile + halo; dead after the row pass: the column sums vv alias it
-    __shared__ float h[5][HS][TS + 1];
-    __shared__ float wsum[TS * TS / 64];
-    float (*const a)[HS + 1] = ab[0];
-    float (*const b)[HS + 1] = ab[1];
-    float* const vv = &ab[0][0][0];           // [5][TS][TS] (1280 floats of the 1404)
-    static_assert(5 * TS * TS <= 2 * HS * (HS + 1) && TS % 4 == 0, "the column sums fit the dead halo tiles");
-    const int tid = threadIdx.x, tx = tid % TS, ty = tid / TS;
-    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS, c = blockIdx.z;
-    const size_t plane = (size_t)H * W;
-    const float* __restrict__ p1 = img1 + c * plane;
-    const float* __restrict__ p2 = img2 + c * plane;
-    // (MAPLOSS: the depth planes of this thread's pixel are requested first: their latency hides behind the whole SSIM computation)
-    float l_fd = 0.f, l_dep = 0.f, l_sur = 0.f, l_sil = 1.0e30f;
-    // the depth term rides on channel 0's workgroups, the surface-depth term on channel 1's (two and three more loads per thread: on one channel's
-    // workgroups alone the four were 9 us of a 41 us kernel)
-    if (MAPLOSS && c < 2 && x0 + tx < W && y0 + ty < H) {
-        const size_t pix = (size_t)(y0 + ty) * W + (x0 + tx);
-        l_fd = ml.fdepth[pix];
-        if (c == 0 && ml.depth) l_dep = ml.depth[pix];
-        if (c == 1 && ml.sur) l_sur = ml.sur[pix];
-        if (c == 1 && ml.sil) l_sil = ml.sil[pix];
-    }
-    { // tile + halo: every load of the thread is requested before the first LDS store (three trips to memory otherwise)
-        constexpr int NI = (HS * HS + TS * TS - 1) / (TS * TS);
-        float va[NI], vb[NI];
-#pragma unroll
-        for (int j = 0; j < NI; j++) {
-            const int i = tid + j * TS * TS, y = i / HS, x = i - y * HS, gy = y0 + y - R, gx = x0 + x - R;
-            const bool in = i < HS * HS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            va[j] = in ? p1[(size_t)gy * W + gx] : 0.f;
-            vb[j] = in ? p2[(size_t)gy * W + gx] : 0.f;
+    constexpr int R = GSR_SSIM_R, NT = 2 * R + 1;
+    __shared__ v2f row[2][64 + 2 * R + 2]; // (image 1, image 2) of the current row at [lane + R]; the pads stay zero
+    const int lane = threadIdx.x;
+    const int nss = C * sg.nsx * sg.nsy;
+    const size_t plane = (size_t)H * W, N = (size_t)C * plane;
+    if (MAPLOSS && (int)blockIdx.x >= nss) {
+        const size_t first = ((size_t)blockIdx.x - nss) * 64 + lane, stride = ((size_t)gridDim.x - nss) * 64;
+        float l1 = 0.f, l2 = 0.f, l3 = 0.f, l4 = 0.f, l5 = 0.f;
+        const bool has_d = ml.depth != nullptr, has_s = ml.sur != nullptr, has_m = ml.sil != nullptr;
+        const float* const pd = has_d ? ml.depth : ml.fdepth; // (always valid addresses: what comes back is not used)
+        const float* const ps = has_s ? ml.sur : ml.fdepth;
+        const float* const pm = has_m ? ml.sil : ml.fdepth;
+#pragma unroll 2
+        for (size_t p = first; p < plane; p += stride) {
+            const float a0 = img1[p], a1 = img1[plane + p], a2 = img1[2 * plane + p], b0 = img2[p], b1 = img2[plane + p], b2 = img2[2 * plane + p];
+            const float fd = ml.fdepth[p], dp = pd[p], su = ps[p], si = has_m ? pm[p] : 1.0e30f;
+            l1 += (fabsf(a0 - b0) + fabsf(a1 - b1)) + fabsf(a2 - b2);
+            const bool on = fd > 0.f, on2 = on && has_s && si > ml.thr;
+            l2 += on && has_d ? fabsf(dp - fd) : 0.f;
+            l3 += on ? 1.f : 0.f;
+            l4 += on2 ? fabsf(su - fd) : 0.f;
+            l5 += on2 ? 1.f : 0.f;
         }
-#pragma unroll
-        for (int j = 0; j < NI; j++) {
-            const int i = tid + j * TS * TS, y = i / HS, x = i - y * HS;
-            if (i < HS * HS) { a[y][x] = va[j]; b[y][x] = vb[j]; }
+        l1 = wave_sum_lane63(l1); l2 = wave_sum_lane63(l2); l3 = wave_sum_lane63(l3); l4 = wave_sum_lane63(l4); l5 = wave_sum_lane63(l5);
+        if (lane == 63) {
+            float* const o = ml.partial6 + (blockIdx.x - nss);
+            o[(size_t)1 * nss] = l1; o[(size_t)2 * nss] = l2; o[(size_t)3 * nss] = l3; o[(size_t)4 * nss] = l4; o[(size_t)5 * nss] = l5;
         }
-    }
-    __syncthreads();
-    const float own1 = MAPLOSS ? a[ty + R][tx + R] : 0.f, own2 = MAPLOSS ? b[ty + R][tx + R] : 0.f; // (the tiles are overwritten below)
-    // row pass: five window sums per (halo row, column). GSR_SSIM_RO neighbouring columns per thread from one sliding register window
-    // (four: 104 work items, two of the workgroup's four waves; two: 208, all four), the three products formed once per input.
-#ifndef GSR_SSIM_RO
-#define GSR_SSIM_RO 4 // (plain kernel at 1200x680x3: 32.4 us with four, 33.1 with two; 34.7 before the products were hoisted and the loads batched)
-#endif
-    constexpr int RO = GSR_SSIM_RO;
-    for (int i = tid; i < HS * (TS / RO); i += TS * TS) {
-        const int y = i / (TS / RO), xg = (i - y * (TS / RO)) * RO;
-        float pa[2 * R + RO], pb[2 * R + RO], paa[2 * R + RO], pbb[2 * R + RO], pab[2 * R + RO];
-#pragma unroll
-        for (int k = 0; k < 2 * R + RO; k++) { pa[k] = a[y][xg + k]; pb[k] = b[y][xg + k]; }
-#pragma unroll
-        for (int k = 0; k < 2 * R + RO; k++) { paa[k] = pa[k] * pa[k]; pbb[k] = pb[k] * pb[k]; pab[k] = pa[k] * pb[k]; }
-#pragma unroll
-        for (int o = 0; o < RO; o++) {
-            float s1 = 0.f, s2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
-#pragma unroll
-            for (int k = 0; k <= 2 * R; k++) {
-                const float g = taps.g[k];
-                s1 = fmaf(g, pa[o + k], s1); s2 = fmaf(g, pb[o + k], s2);
-                s11 = fmaf(g, paa[o + k], s11); s22 = fmaf(g, pbb[o + k], s22); s12 = fmaf(g, pab[o + k], s12);
-            }
-            h[0][y][xg + o] = s1; h[1][y][xg + o] = s2; h[2][y][xg + o] = s11; h[3][y][xg + o] = s22; h[4][y][xg + o] = s12;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < 5 * TS * (TS / 4); i += TS * TS) { // column pass: (quantity, column, four rows) per thread
-        const int q = i / (TS * (TS / 4)), rem = i - q * (TS * (TS / 4)), cx = rem % TS, yg = (rem / TS) * 4;
-        float cv[2 * R + 4];
-#pragma unroll
-        for (int k = 0; k < 2 * R + 4; k++) cv[k] = h[q][yg + k][cx];
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-            float sv = 0.f;
-#pragma unroll
-            for (int k = 0; k <= 2 * R; k++) sv = fmaf(taps.g[k], cv[o + k], sv);
-            vv[(q * TS + yg + o) * TS + cx] = sv;
-        }
-    }
-    __syncthreads();
-    float v[5];
-#pragma unroll
-    for (int q = 0; q < 5; q++) v[q] = vv[(q * TS + ty) * TS + tx];
-    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-    const float mu1 = v[0], mu2 = v[1], mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-    const float s1 = v[2] - mu1_sq, s2 = v[3] - mu2_sq, s12 = v[4] - mu12;
-    const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cc = mu1_sq + mu2_sq + C1, D = s1 + s2 + C2;
-    const float inv = 1.f / (Cc * D), m = (A * B) * inv;
-    const int gx = x0 + tx, gy = y0 + ty;
-    const bool inside = gx < W && gy < H;
-    if (inside && dmaps) {
-        // d(map)/d(mu1), d(map)/d(E[x^2]), d(map)/d(E[xy]) with s1 = E[x^2] - mu1^2, s12 = E[xy] - mu1 mu2
-        const size_t o = c * plane + (size_t)gy * W + gx, N = (size_t)gridDim.z * plane;
-        dmaps[o] = 2.f * mu2 * (B - A) * inv - 2.f * mu1 * m * (1.f / Cc - 1.f / D);
-        dmaps[N + o] = -m / D;
-        dmaps[2 * N + o] = 2.f * A * inv;
-    }
-    float sum = inside ? m : 0.f;
-    const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (MAPLOSS) {
-        __shared__ float wl[TS * TS / 64][6];
-        float l[6] = {sum, inside ? fabsf(own1 - own2) : 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (c == 0 && inside && l_fd > 0.f) {
-            if (ml.depth) l[2] = fabsf(l_dep - l_fd);
-            l[3] = 1.f;
-        }
-        if (c == 1 && inside && l_fd > 0.f && ml.sur && l_sil > ml.thr) { l[4] = fabsf(l_sur - l_fd); l[5] = 1.f; }
-#pragma unroll
-        for (int q = 0; q < 6; q++) l[q] = wave_sum_lane63(l[q]);
-        if ((tid & 63) == 63) {
-#pragma unroll
-            for (int q = 0; q < 6; q++) wl[tid >> 6][q] = l[q];
-        }
-        __syncthreads();
-        if (tid < 6) ml.partial6[(size_t)tid * ((size_t)gridDim.x * gridDim.y * gridDim.z) + wg] = (wl[0][tid] + wl[1][tid]) + (wl[2][tid] + wl[3][tid]); // six planes
         return;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    if ((tid & 63) == 0) wsum[tid >> 6] = sum;
-    __syncthreads();
-    if (tid == 0) { // one partial per workgroup, summed by the caller: a deterministic total
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < TS * TS / 64; q++) t += wsum[q];
-        partial[wg] = t;
+    // (integer division runs on the vector pipe: without the readfirstlane the quotients, and every address and condition made from them, stay there)
+    const int sx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % sg.nsx)), sy = __builtin_amdgcn_readfirstlane((int)((blockIdx.x / sg.nsx) % sg.nsy)),
+              c = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / (sg.nsx * sg.nsy)));
+    const int gx = sx * GSR_SSIM_COLS - R + lane, y0 = sy * sg.rows;
+    const int nrows = min(sg.rows, H - y0);
+    const bool col_in = gx >= 0 && gx < W, col_out = lane >= R && lane < 64 - R && gx < W;
+    const float* __restrict__ p1 = img1 + c * plane;
+    const float* __restrict__ p2 = img2 + c * plane;
+    {
+        v2f z; z.x = 0.f; z.y = 0.f;
+        row[0][lane] = z; row[1][lane] = z;
+        if (lane < 2 * R + 2) { row[0][64 + lane] = z; row[1][64 + lane] = z; }
+        lds_turn();
     }
+    // The queue holds what the loads return, untouched (a select on a value just requested would wait for it): rows outside the image are
+    // asked for at clamped addresses and zeroed when they are taken out.
+    const uint32_t gxb = 4u * (uint32_t)min(max(gx, 0), W - 1), Wb = 4u * (uint32_t)W;
+    const SsimTapRegs tg = tap_regs(taps, false);
+    float qa[NT], qb[NT];
+    auto request = [&](const int i, const int slot) { // image row y0 - R + i into queue slot `slot`
+        const uint32_t off = gxb + (uint32_t)min(max(y0 - R + i, 0), H - 1) * Wb;
+        qa[slot] = ld_off(p1, off);
+        qb[slot] = ld_off(p2, off);
+    };
+#pragma unroll
+    for (int j = 0; j < NT; j++) request(j, j);
+    // row i goes through LDS one step AHEAD of its arithmetic: the eleven reads of step i + 1 are in flight while step i's sums are formed
+    auto stage = [&](const int i, const int j, v2f (&n)[NT]) {
+        const int gy = y0 - R + i;
+        const bool in = col_in && gy >= 0 && gy < H;
+        v2f ab; ab.x = in ? qa[j] : 0.f; ab.y = in ? qb[j] : 0.f;
+        request(i + NT, j);
+        v2f* const buf = row[i & 1];
+        buf[lane + R] = ab;
+        lds_turn(); // (the wave's LDS queue is in order; the compiler must not lift the neighbours' reads above the write: to it they do not alias)
+#pragma unroll
+        for (int k = 0; k < NT; k++) n[k] = buf[lane + k];
+    };
+    v2f hA[NT], hB[NT]; // the ring: (mu1, mu2) and (E11, E22) row sums of the last eleven rows, E12's in hC
+    float hC[NT];
+    float lsum = 0.f;
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    v2f ncur[NT];
+    stage(0, 0, ncur);
+    // step i: the sums of image row y0 - R + i enter the ring (slot j = i % 11), output row y0 + i - 10 goes out (OUT: from the eleventh step on)
+    auto step = [&](const int i, const int j, auto OUT) {
+        v2f nn[NT];
+        stage(i + 1, (j + 1) % NT, nn);
+        v2f sA, sB; sA.x = 0.f; sA.y = 0.f; sB = sA;
+        float sC = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const v2f g = tg.g[k];
+            const v2f sq = ncur[k] * ncur[k];
+            const float xy = ncur[k].x * ncur[k].y;
+            sA = pk_fma(g, ncur[k], sA); sB = pk_fma(g, sq, sB); sC = fmaf(g.x, xy, sC);
+        }
+        hA[j] = sA; hB[j] = sB; hC[j] = sC;
+#pragma unroll
+        for (int k = 0; k < NT; k++) ncur[k] = nn[k];
+        if (!decltype(OUT)::value) return;
+        // the window's rows are the ring's slots j + 1 ... j + 11 (mod 11), top to bottom
+        v2f vA, vB; vA.x = 0.f; vA.y = 0.f; vB = vA;
+        float vC = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const v2f g = tg.g[k];
+            const int sl = (j + 1 + k) % NT;
+            vA = pk_fma(g, hA[sl], vA); vB = pk_fma(g, hB[sl], vB); vC = fmaf(g.x, hC[sl], vC);
+        }
+        const float mu1 = vA.x, mu2 = vA.y, mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = vB.x - mu1_sq, s2 = vB.y - mu2_sq, s12 = vC - mu12;
+        const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cc = mu1_sq + mu2_sq + C1, D = s1 + s2 + C2;
+        // (hardware reciprocals, 1 ulp: four IEEE divisions were 40 of the step's ~230 vector instructions)
+        const float rC = __builtin_amdgcn_rcpf(Cc), rD = __builtin_amdgcn_rcpf(D), inv = rC * rD, m = (A * B) * inv;
+        const int orow = i - 2 * R;
+        const bool ok = col_out && orow < nrows; // (the last segment of an image runs whole groups of eleven steps too)
+        if (dmaps) {
+            // d(map)/d(mu1), d(map)/d(E[x^2]), d(map)/d(E[xy]) with s1 = E[x^2] - mu1^2, s12 = E[xy] - mu1 mu2
+            float* const o = dmaps + c * plane;
+            const float d0 = 2.f * mu2 * (B - A) * inv - 2.f * mu1 * m * (rC - rD), d1 = -m * rD, d2 = 2.f * A * inv;
+            if (ok) {
+                const uint32_t off = gxb + (uint32_t)(y0 + orow) * Wb;
+                st_off(o, off, d0); st_off(o + N, off, d1); st_off(o + 2 * N, off, d2);
+            }
+        }
+        lsum += ok ? m : 0.f;
+    };
+    // whole groups of eleven steps (the loop's trip count is the only thing that varies): the first fills the ring and puts out one row
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        if (j < NT - 1) step(j, j, std::false_type{});
+        else step(j, j, std::true_type{});
+    }
+    for (int base = NT; base < nrows + 2 * R; base += NT) {
+#pragma unroll
+        for (int j = 0; j < NT; j++) step(base + j, j, std::true_type{});
+    }
+    // one sum per wave, added up by the caller (or K_map_finish): a deterministic total
+    const float t = wave_sum_lane63(lsum);
+    if (lane == 63) (MAPLOSS ? ml.partial6 : partial)[blockIdx.x] = t;
 }
 
 // dL/dimg1 = scale * ( corrT(dmu1) + 2 img1 corrT(dE11) + img2 corrT(dE12) ), corrT = the transposed window:
@@ -215,91 +268,121 @@ struct MapLossGrad {
     float* ddepth;               // [H,W]
 };
 template <bool MAPLOSS>
-__global__ void __launch_bounds__(GSR_SSIM_TILE* GSR_SSIM_TILE)
-K_ssim_bwd(const float* __restrict__ img1, const float* __restrict__ img2, const float* __restrict__ dmaps, int H, int W,
-           SsimTaps taps, const float* __restrict__ dL_dmean, float* __restrict__ dL_dimg1, MapLossGrad mg)
+__global__ void __launch_bounds__(64)
+K_ssim_bwd(const float* __restrict__ img1, const float* __restrict__ img2, const float* __restrict__ dmaps, int C, int H, int W,
+           SsimTaps taps, SsimGrid sg, const float* __restrict__ dL_dmean, float* __restrict__ dL_dimg1, MapLossGrad mg)
 {
-    constexpr int TS = GSR_SSIM_TILE, HS = GSR_SSIM_HALO, R = GSR_SSIM_R;
-    __shared__ float d[3][HS][HS + 1];         // (dead after the row pass: the column sums vv alias it; sliding windows as in K_ssim_fwd)
-    __shared__ float h[3][HS][TS + 1];
-    float* const vv = &d[0][0][0];            // [3][TS][TS]
-    const int tid = threadIdx.x, tx = tid % TS, ty = tid / TS;
-    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS, c = blockIdx.z;
-    const size_t plane = (size_t)H * W, N = (size_t)gridDim.z * plane;
-    float l_fd = 0.f, l_dep = 0.f, l_cnt = 1.f; // (MAPLOSS: requested first, used last)
-    if (MAPLOSS && c == 0 && mg.ddepth && x0 + tx < W && y0 + ty < H) {
-        const size_t pix = (size_t)(y0 + ty) * W + (x0 + tx);
-        l_fd = mg.fdepth[pix];
-        if (mg.depth) l_dep = mg.depth[pix];
-        l_cnt = mg.sums[2];
+    // the forward's streaming scheme on the three derivative maps (transposed window: the taps run backwards); the images' own pixels of the
+    // OUTPUT row travel in the queue with the input row that completes its window. MAPLOSS: the depth plane's gradient is elementwise — the
+    // workgroups past the SSIM waves (the launch has them only when a depth gradient is asked for) write it, a strided share of the pixels each.
+    constexpr int R = GSR_SSIM_R, NT = 2 * R + 1;
+    __shared__ v2f rowA[2][64 + 2 * R + 2];
+    __shared__ float rowC[2][64 + 2 * R + 2];
+    const int lane = threadIdx.x;
+    const int nss = C * sg.nsx * sg.nsy;
+    const size_t plane = (size_t)H * W, N = (size_t)C * plane;
+    if (MAPLOSS && (int)blockIdx.x >= nss) {
+        if (!mg.ddepth) return;
+        const size_t first = ((size_t)blockIdx.x - nss) * 64 + lane, stride = ((size_t)gridDim.x - nss) * 64;
+        const float k = mg.w_depth / fmaxf(mg.sums[2], 1.f);
+        const float* const pd = mg.depth ? mg.depth : mg.fdepth;
+#pragma unroll 4
+        for (size_t p = first; p < plane; p += stride) {
+            const float fd = mg.fdepth[p], dd = mg.depth ? pd[p] - fd : 0.f;
+            mg.ddepth[p] = fd > 0.f ? k * ((float)(dd > 0.f) - (float)(dd < 0.f)) : 0.f;
+        }
+        return;
     }
-    { // tile + halo of the three maps: every load of the thread is requested before the first LDS store
-        constexpr int NI = (HS * HS + TS * TS - 1) / (TS * TS);
-        float vd[NI][3];
-#pragma unroll
-        for (int j = 0; j < NI; j++) {
-            const int i = tid + j * TS * TS, y = i / HS, x = i - y * HS, gy = y0 + y - R, gx = x0 + x - R;
-            const bool in = i < HS * HS && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const size_t o = c * plane + (size_t)(in ? gy : 0) * W + (in ? gx : 0);
-#pragma unroll
-            for (int q = 0; q < 3; q++) vd[j][q] = in ? dmaps[q * N + o] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < NI; j++) {
-            const int i = tid + j * TS * TS, y = i / HS, x = i - y * HS;
-            if (i < HS * HS) {
-#pragma unroll
-                for (int q = 0; q < 3; q++) d[q][y][x] = vd[j][q];
-            }
-        }
+    const int sx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % sg.nsx)), sy = __builtin_amdgcn_readfirstlane((int)((blockIdx.x / sg.nsx) % sg.nsy)),
+              c = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / (sg.nsx * sg.nsy)));
+    const int gx = sx * GSR_SSIM_COLS - R + lane, y0 = sy * sg.rows;
+    const int nrows = min(sg.rows, H - y0);
+    const bool col_in = gx >= 0 && gx < W, col_out = lane >= R && lane < 64 - R && gx < W;
+    {
+        v2f z; z.x = 0.f; z.y = 0.f;
+        rowA[0][lane] = z; rowA[1][lane] = z; rowC[0][lane] = 0.f; rowC[1][lane] = 0.f;
+        if (lane < 2 * R + 2) { rowA[0][64 + lane] = z; rowA[1][64 + lane] = z; rowC[0][64 + lane] = 0.f; rowC[1][64 + lane] = 0.f; }
+        lds_turn();
     }
-    __syncthreads();
-    for (int i = tid; i < 3 * HS * (TS / 4); i += TS * TS) { // row pass: (map, halo row, four columns) per thread
-        const int q = i / (HS * (TS / 4)), rem = i - q * (HS * (TS / 4)), y = rem / (TS / 4), xg = (rem - y * (TS / 4)) * 4;
-        float dv[2 * R + 4];
+    const float scale = dL_dmean[0] / (float)N;
+    // (the queue as in the forward: raw loads from clamped addresses, zeroed when they are taken out)
+    const uint32_t gxb = 4u * (uint32_t)min(max(gx, 0), W - 1), Wb = 4u * (uint32_t)W;
+    const SsimTapRegs tg = tap_regs(taps, true); // (transposed window: tap k of the loops below is g[10 - k])
+    const float* __restrict__ d0 = dmaps + c * plane;
+    const float* __restrict__ pi1 = img1 + c * plane;
+    const float* __restrict__ pi2 = img2 + c * plane;
+    float q0[NT], q1[NT], q2[NT], qi1[NT], qi2[NT];
+    auto request = [&](const int i, const int slot) {
+        const uint32_t off = gxb + (uint32_t)min(max(y0 - R + i, 0), H - 1) * Wb;
+        q0[slot] = ld_off(d0, off);
+        q1[slot] = ld_off(d0 + N, off);
+        q2[slot] = ld_off(d0 + 2 * N, off);
+        const uint32_t oo = gxb + (uint32_t)min(max(y0 + i - 2 * R, 0), H - 1) * Wb; // the output pixel of step i: row y0 + i - 10
+        qi1[slot] = ld_off(pi1, oo);
+        qi2[slot] = ld_off(pi2, oo);
+    };
 #pragma unroll
-        for (int k = 0; k < 2 * R + 4; k++) dv[k] = d[q][y][xg + k];
+    for (int j = 0; j < NT; j++) request(j, j);
+    // (row i goes through LDS one step ahead of its arithmetic, as in the forward; the output pixel's own values are taken out with it)
+    auto stage = [&](const int i, const int j, v2f (&nA)[NT], float (&nC)[NT], float& i1, float& i2) {
+        const int gy = y0 - R + i;
+        const bool in = col_in && gy >= 0 && gy < H;
+        v2f d01; d01.x = in ? q0[j] : 0.f; d01.y = in ? q1[j] : 0.f;
+        const float d2 = in ? q2[j] : 0.f;
+        i1 = qi1[j]; i2 = qi2[j];
+        request(i + NT, j);
+        v2f* const bA = rowA[i & 1];
+        float* const bC = rowC[i & 1];
+        bA[lane + R] = d01;
+        bC[lane + R] = d2;
+        lds_turn();
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
-            float sv = 0.f;
+        for (int k = 0; k < NT; k++) { nA[k] = bA[lane + k]; nC[k] = bC[lane + k]; }
+    };
+    v2f hA[NT];
+    float hC[NT];
+    v2f cA[NT];
+    float cC[NT], ci1, ci2;
+    stage(0, 0, cA, cC, ci1, ci2);
+    auto step = [&](const int i, const int j, auto OUT) {
+        v2f nA[NT];
+        float nC[NT], ni1, ni2;
+        stage(i + 1, (j + 1) % NT, nA, nC, ni1, ni2);
+        v2f sA; sA.x = 0.f; sA.y = 0.f;
+        float sC = 0.f;
 #pragma unroll
-            for (int k = 0; k <= 2 * R; k++) sv = fmaf(taps.g[2 * R - k], dv[o + k], sv); // transposed: tap k meets d[x - k + 5] = halo column x + (10 - k)
-            h[q][y][xg + o] = sv;
+        for (int k = 0; k < NT; k++) { // transposed: tap k meets d[x - k + 5] = column lane + (10 - k) of the padded row
+            const v2f g = tg.g[k];
+            sA = pk_fma(g, cA[k], sA); sC = fmaf(g.x, cC[k], sC);
         }
+        hA[j] = sA; hC[j] = sC;
+        const float i1 = ci1, i2 = ci2;
+#pragma unroll
+        for (int k = 0; k < NT; k++) { cA[k] = nA[k]; cC[k] = nC[k]; }
+        ci1 = ni1; ci2 = ni2;
+        if (!decltype(OUT)::value) return;
+        v2f vA; vA.x = 0.f; vA.y = 0.f;
+        float vC = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const v2f g = tg.g[k];
+            const int sl = (j + 1 + k) % NT;
+            vA = pk_fma(g, hA[sl], vA); vC = fmaf(g.x, hC[sl], vC);
+        }
+        const int orow = i - 2 * R;
+        const bool ok = col_out && orow < nrows;
+        float gval = scale * (vA.x + 2.f * i1 * vA.y + i2 * vC);
+        if (MAPLOSS) gval += mg.ci * ((float)(i1 - i2 > 0.f) - (float)(i1 - i2 < 0.f));
+        if (ok) st_off(dL_dimg1 + c * plane, gxb + (uint32_t)(y0 + orow) * Wb, gval);
+    };
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        if (j < NT - 1) step(j, j, std::false_type{});
+        else step(j, j, std::true_type{});
     }
-    __syncthreads();
-    for (int i = tid; i < 3 * TS * (TS / 4); i += TS * TS) { // column pass: (map, column, four rows) per thread
-        const int q = i / (TS * (TS / 4)), rem = i - q * (TS * (TS / 4)), cx = rem % TS, yg = (rem / TS) * 4;
-        float cv[2 * R + 4];
+    for (int base = NT; base < nrows + 2 * R; base += NT) {
 #pragma unroll
-        for (int k = 0; k < 2 * R + 4; k++) cv[k] = h[q][yg + k][cx];
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-            float sv = 0.f;
-#pragma unroll
-            for (int k = 0; k <= 2 * R; k++) sv = fmaf(taps.g[2 * R - k], cv[o + k], sv);
-            vv[(q * TS + yg + o) * TS + cx] = sv;
-        }
-    }
-    __syncthreads();
-    float v[3];
-#pragma unroll
-    for (int q = 0; q < 3; q++) v[q] = vv[(q * TS + ty) * TS + tx];
-    const int gx = x0 + tx, gy = y0 + ty;
-    if (gx < W && gy < H) {
-        const size_t o = c * plane + (size_t)gy * W + gx;
-        const float scale = dL_dmean[0] / (float)N;
-        const float i1 = img1[o], i2 = img2[o];
-        float gval = scale * (v[0] + 2.f * i1 * v[1] + i2 * v[2]);
-        if (MAPLOSS) {
-            gval += mg.ci * ((float)(i1 - i2 > 0.f) - (float)(i1 - i2 < 0.f));
-            if (c == 0 && mg.ddepth) {
-                const size_t pix = (size_t)gy * W + gx;
-                const float dd = mg.depth ? l_dep - l_fd : 0.f;
-                mg.ddepth[pix] = l_fd > 0.f ? (mg.w_depth / fmaxf(l_cnt, 1.f)) * ((float)(dd > 0.f) - (float)(dd < 0.f)) : 0.f;
-            }
-        }
-        dL_dimg1[o] = gval;
+        for (int j = 0; j < NT; j++) step(base + j, j, std::true_type{});
     }
 }
 

@@ -15,12 +15,18 @@ partial=torch.empty((int(L.gsr_ssim_partials(Cc,H,W)),),device='cuda'); dmaps=to
 p=capi._p; st=capi._stream
 def fwd(): capi._check(L.gsr_ssim_forward(p(a),p(b),Cc,H,W,tp,p(partial),p(dmaps),st()))
 def bwd(): capi._check(L.gsr_ssim_backward(p(a),p(b),p(dmaps),Cc,H,W,tp,p(g1),p(out),st()))
-for _ in range(300): fwd(); bwd()
+# the mapping loss's variants (the pixel terms riding on the SSIM passes): gsr_map_loss_forward / _backward
+dep=torch.rand(H,W,device='cuda')*3+0.5; sur=dep.clone(); sil=torch.rand(H,W,device='cuda'); fd=dep+0.05*torch.randn_like(dep); fd[::7]=0
+np6=int(L.gsr_ssim_partials(3,H,W)); partial6=torch.empty((np6*6,),device='cuda'); dm=torch.empty(3,3,H,W,device='cuda')
+w3=(C.c_float*3)(0.8,0.7,0.35); sums=torch.ones(8,device='cuda')*1000; neg=torch.tensor([-0.2],device='cuda'); gi=torch.empty_like(a); gd=torch.empty_like(dep)
+def mfwd(): capi._check(L.gsr_map_loss_forward(p(a),p(dep),p(sur),p(sil),p(b),p(fd),H,W,tp,0.99,p(partial6),p(dm),st()))
+def mbwd(): capi._check(L.gsr_map_loss_backward(p(a),p(dep),p(b),p(fd),p(dm),H,W,tp,w3,p(neg),p(sums),p(gi),p(gd),st()))
+for _ in range(300): fwd(); bwd(); mfwd(); mbwd()
 torch.cuda.synchronize()
 res={}
-for name,fn in (("fwd",fwd),("bwd",bwd)):
+for name,fn in (("fwd",fwd),("bwd",bwd),("mfwd",mfwd),("mbwd",mbwd)):
     e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(200): fn()
     e1.record(); torch.cuda.synchronize(); res[name]=e0.elapsed_time(e1)/200*1e3
-print(os.environ.get('GSR_LIB_OVERRIDE','default'), "ssim fwd %.1f us  bwd %.1f us   (sum %.6f)"%(res['fwd'],res['bwd'],float(partial.sum())/(Cc*H*W)))
+print(os.environ.get('GSR_LIB_OVERRIDE','default'), "ssim fwd %.1f us  bwd %.1f us   map-loss fwd %.1f us  bwd %.1f us   (sum %.6f)"%(res['fwd'],res['bwd'],res['mfwd'],res['mbwd'],float(partial.sum())/(Cc*H*W)))
