@@ -225,8 +225,8 @@ int gsr_dist2(int P, const float* points /* [P,3] */, float* mean_dists /* [P] *
  * SSIM (reference ORB_SLAM2::ssim, src/Utils.cc:77-100: five depthwise 11x11 convolutions + elementwise passes through
  * libtorch, and their autograd): mean over [C,H,W] of the SSIM map of img1 vs img2 with the 11-tap separable window
  * `taps11` (host pointer; zero padding like conv2d(padding=5)) and its gradient w.r.t. img1.
- *   gsr_ssim_forward  writes one partial sum of the map per workgroup (gsr_ssim_partials of them; the caller adds them
- *                     up and divides by C*H*W) and, if dmaps != NULL, the three derivative maps [3,C,H,W] the backward needs
+ *   gsr_ssim_forward  writes one partial sum of the map per wave of its launch (gsr_ssim_partials of them; the caller adds them
+ *                     up and divides by C*H*W; H*W < 2^30) and, if dmaps != NULL, the three derivative maps [3,C,H,W] the backward needs
  *   gsr_ssim_backward dL_dimg1 [C,H,W] = (*dL_dmean / (C*H*W)) * d(sum of the map)/d(img1); dL_dmean is a DEVICE scalar
  * Adam (reference torch::optim::Adam as src/Gaussian.cc:144-175 configures it: no weight decay, no amsgrad): one
  * in-place step of one parameter tensor, `step` = the 1-based step count of that tensor; the hyper-parameters are doubles,

@@ -29,4 +29,23 @@ for name,fn in (("fwd",fwd),("bwd",bwd),("mfwd",mfwd),("mbwd",mbwd)):
     e0.record()
     for _ in range(200): fn()
     e1.record(); torch.cuda.synchronize(); res[name]=e0.elapsed_time(e1)/200*1e3
+e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(200): fwd(); bwd(); mfwd(); mbwd()
+e1.record(); torch.cuda.synchronize()
+print("interleaved (four different kernels in turn: cold instruction caches): %.1f us per round of four, sum of the four alone %.1f"%(e0.elapsed_time(e1)/200*1e3, sum(res.values())))
 print(os.environ.get('GSR_LIB_OVERRIDE','default'), "ssim fwd %.1f us  bwd %.1f us   map-loss fwd %.1f us  bwd %.1f us   (sum %.6f)"%(res['fwd'],res['bwd'],res['mfwd'],res['mbwd'],float(partial.sum())/(Cc*H*W)))
+# does it matter that the inputs were just written by another kernel (as in the loop: the render is the blend kernel's output)?
+for label, pre in (("inputs rewritten before every launch", lambda: (a.mul_(1.0), dep.mul_(1.0), sur.mul_(1.0))), ("inputs untouched", lambda: None)):
+    tot = 0.0
+    for _ in range(100):
+        pre(); e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+        e0.record(); mfwd(); e1.record(); torch.cuda.synchronize(); tot += e0.elapsed_time(e1)
+    print("map-loss fwd, %s: %.1f us (events around single launches)" % (label, tot / 100 * 1e3))
+for name, fn in (("plain fwd", fwd), ("plain bwd", bwd), ("map-loss bwd", mbwd)):
+    for label, pre in (("rewritten", lambda: (a.mul_(1.0), dm.mul_(1.0), dmaps.mul_(1.0))), ("untouched", lambda: None)):
+        tot = 0.0
+        for _ in range(100):
+            pre(); e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize(); tot += e0.elapsed_time(e1)
+        print("%s, inputs %s: %.1f us" % (name, label, tot / 100 * 1e3))
