@@ -10,7 +10,7 @@
 //   tracking: gsr_to_camera -> gsr_forward_ws -> gsr_pixel_loss -> gsr_pixel_loss_backward_add -> gsr_backward ->
 //             gsr_pose_grad -> gsr_pose_update                                                                          (13 launches)
 // with no allocation, no gradient tensor of a raw parameter, and no host synchronisation except where the reference has one
-// (the tracking loop reads its loss every iteration, Render.cc:1107; the mapping loop of RenderForFrame never does: MapFrame
+// (the tracking loop reads its loss every iteration, Render.cc:1107 — posted by the pose kernel into host-mapped memory the loop spins on; the mapping loop of RenderForFrame never does: MapFrame
 // reads all losses back once, at the end). Reference: src/Render.cc:420-483, :1054-1126; src/Gaussian.cc:97-175.
 //
 // SHARDED (SetShard; multi-GPU scheme B): every rank holds a shard of the map — one cell of a k-d partition — with its Adam
@@ -30,6 +30,9 @@
 #include <rccl/rccl.h> // (types and prototypes only: the library is opened at run time, below)
 #include <dlfcn.h>
 
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -66,6 +69,12 @@ struct SlamLoop::Direct {
     torch::Tensor pose_acc;                                              // [64, 12] the fused pose step's accumulator rows (zero between launches)
     torch::Tensor tickets;                                               // [2 * GSR_TICKET_WORDS] arrival counters of the kernels that finish their own sums (zero between launches)
     int64_t history_len = 0;
+    // The tracking loop looks at every loss (Render.cc:1107). Read back with a copy and a stream synchronisation that look costs ~20 us per
+    // iteration (a 4 us copy kernel, the interrupt that wakes the host, the next launch's latency: the GPU idles through all three); the loop's
+    // losses are instead POSTED by the pose kernel into host memory the device can write (fine-grained, mapped) and the host spins on the slot.
+    float* posted = nullptr;        // host address [posted_len]
+    float* posted_dev = nullptr;    // the device's address of the same words
+    int64_t posted_len = 0;
     bool fresh = true; // the workspace was (re)built for a new map size: one pre-flight forward sizes the binning workspace before the first batch of iterations
     // sharded (SetShard): the composite of all ranks' layers and what its backward needs
     c10::intrusive_ptr<c10d::ProcessGroup> pg;
@@ -121,7 +130,33 @@ void nccl_chk(ncclResult_t r, const char* what)
 SlamLoop::Direct::~Direct()
 {
     if (comm) (void)Rccl::get().CommDestroy(comm);
+    if (posted) (void)hipHostFree(posted);
 }
+
+namespace {
+constexpr uint32_t kNotPosted = 0xFFFFFFFFu; // (a NaN no kernel produces: the pose kernel's own NaN is the canonical one)
+// the loss the pose kernel of this iteration posts: spin on the word; every few thousand looks ask the stream whether it has run dry
+// (a kernel that died never posts) and give up after ten seconds
+float wait_posted(const float* slot, hipStream_t st)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 1;; spins++) {
+        uint32_t v;
+        v = __atomic_load_n(reinterpret_cast<const uint32_t*>(slot), __ATOMIC_ACQUIRE);
+        if (v != kNotPosted) { float x; std::memcpy(&x, &v, 4); return x; }
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFu) == 0) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q != hipErrorNotReady) { // drained (or failed): one last look
+                v = __atomic_load_n(reinterpret_cast<const uint32_t*>(slot), __ATOMIC_ACQUIRE);
+                if (v != kNotPosted) { float x; std::memcpy(&x, &v, 4); return x; }
+                throw std::runtime_error(std::string("tracking loop: the pose kernel never posted its loss (") + hipGetErrorString(q) + ")");
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) throw std::runtime_error("tracking loop: no loss posted within 10 s");
+        }
+    }
+}
+} // namespace
 
 void SlamLoop::Direct::all_gather(torch::Tensor out, const torch::Tensor& in)
 {
@@ -233,6 +268,15 @@ void SlamLoop::ensure_direct_(int64_t history_len)
         grow_binning_(cfg_.binning_capacity > 0 ? (size_t)cfg_.binning_capacity : 4 * (size_t)n + 65536); // grows at the first synchronised look at an overflow
     }
     if (d.history_len < history_len) { d.history = torch::empty({history_len}, fo); d.history_len = history_len; }
+    if (d.posted_len < history_len) {
+        if (d.posted) { (void)hipHostFree(d.posted); d.posted = nullptr; }
+        void* dp = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&d.posted), (size_t)history_len * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer(&dp, d.posted, 0) != hipSuccess)
+            throw std::runtime_error("direct loop: no host-mapped memory for the posted losses");
+        d.posted_dev = static_cast<float*>(dp);
+        d.posted_len = history_len;
+    }
     if (shard_ && !d.gathered.defined()) {
         // comp: the four planes the all-reduce sums, the three regulariser sums right behind them (ONE all-reduce carries both), then the
         // composite's silhouette and surface depth
@@ -492,8 +536,9 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
         chk(gsr_track_loss(img, dep, sur, sil, f(frame.rgb), f(frame.depth), H_, W_, 0.99f, w3, f(d.loss_partial), f(d.sums), f(d.g_image), f(d.g_ds),
                            reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()), st), "gsr_track_loss");
         gsr_pose_update_args u{};
-        u.quat_trans = f(d.pose); u.moments = f(d.pose_moments); u.best = f(d.best); u.history = f(d.history) + it; u.Tcw = f(d.Tcw);
+        u.quat_trans = f(d.pose); u.moments = f(d.pose_moments); u.best = f(d.best); u.history = d.posted_dev + it; u.Tcw = f(d.Tcw);
         u.partial = f(d.pose_partial); u.loss = f(d.sums) + 5; u.geom = b(d.geom);
+        __atomic_store_n(reinterpret_cast<uint32_t*>(d.posted + it), kNotPosted, __ATOMIC_RELEASE);
         u.lr = cfg_.lr_cam_quat; u.beta1 = 0.9; u.beta2 = 0.999; u.eps = 1e-15; u.step = ++step;
         uint32_t* const tickets = reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()) + GSR_TICKET_WORDS;
         if (shard_) { // every rank holds the pose sums of its shard: the rows are summed over the ranks before the (replicated) pose step
@@ -518,7 +563,7 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
             } else
                 chk(gsr_pose_step(f(xyz), f(d.d_mc), (size_t)d.n, &u, tickets, st), "gsr_pose_step"); // the pose sums and the step in one launch
         }
-        const double lv = d.history.slice(0, it, it + 1).item<float>(); // Render.cc:1107: the loop looks at every loss
+        const double lv = wait_posted(d.posted + it, (hipStream_t)st); // Render.cc:1107: the loop looks at every loss
         if (shard_) {
             if (std::isnan(lv) && shard_any_(direct_overflowed_()))
                 throw std::runtime_error("sharded loop: a rank's binning workspace overflowed while tracking; raise LoopConfig::binning_capacity");
