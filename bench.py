@@ -388,6 +388,7 @@ def shard_step(a, gsr, td, rank, world, dev):
     loop = _C.SlamLoop(W, H, camd["fx"], camd["fy"], dev)
     loop.set_map(*[x[idx] for x in raw])
     loop.set_shard(group, rank, world, part.nodes)
+    transport = loop.shard_transport()   # "rccl": the loop's own communicator on its stream; "c10d": the group's collectives (fallback); "local": no group
     T = torch.eye(4, device=dev)
     rgb, sur, _ = loop.render_composite(T)
     rgb, depth = (rgb * 0.9 + 0.05).contiguous(), sur[0].contiguous()
@@ -431,7 +432,7 @@ def shard_step(a, gsr, td, rank, world, dev):
             "scaling": "strong", "total_splats": a.splats, "splats_per_rank": int(idx.numel()), "width": W, "height": H,
             "partition": f"k-d cells x{world} (sharded.KdPartition)", "backend": backend, "rccl_ranks": (td.get_world_size() if world > 1 else (1 if own_group else 0)),
             "mapping_ms_per_iter": map_ms, "tracking_ms_per_iter": track_ms, "tracking_iterations_run": ran,
-            "unsharded_same_scene": same, "warmup_iters": max(a.shard_steps, 20),
+            "unsharded_same_scene": same, "warmup_iters": max(a.shard_steps, 20), "transport": transport,
             "mapping_splats_pixels_per_s": 2 * a.splats * W * H / (map_ms * 1e-3),
             "collectives_per_mapping_iter": {"all_gather_bytes_sent_per_rank": 3 * plane, "all_reduce_bytes": 4 * plane, "all_reduce_floats": 3},
             "collectives_per_tracking_iter": {"all_gather_bytes_sent_per_rank": 3 * plane, "all_reduce_bytes": 4 * plane, "all_reduce_floats": 512 * 12},
@@ -494,6 +495,7 @@ def shard_render(a, gsr, td, rank, world, dev, weak=False):
             "scaling": "weak" if weak else "strong", "partition": how, "total_splats": total, "splats_per_rank": int(idx.numel()), "width": W, "height": H, "ms_per_step": ms,
             "value": total * W * H / (ms * 1e-3), "unit": "splats*pixels/s",
             "backend": (td.get_backend() if world > 1 else "none (single process)"), "ranks": (td.get_world_size() if world > 1 else 1),
+            "transport": loop.shard_transport(),
             "collective_bytes_per_rank_per_step": {"all_gather_fwd": 2 * plane * (world - 1) if world > 1 else 0, "all_reduce_fwd": 4 * plane if world > 1 else 0,
                                                    "all_gather_bwd": plane * (world - 1) if world > 1 else 0, "all_reduce_pose": 512 * 12 * 4 if world > 1 else 0}}
 

@@ -33,6 +33,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -209,21 +210,50 @@ void SlamLoop::SetShard(c10::intrusive_ptr<c10d::ProcessGroup> pg, int rank, int
     if (d.comm) { (void)Rccl::get().CommDestroy(d.comm); d.comm = nullptr; }
     if (pg && !d.staged) { // the communicator's id travels through the group (a device tensor: the group's backend is RCCL too)
         c10::DeviceGuard guard(dev_);
-        ncclUniqueId id;
-        if (rank == 0) nccl_chk(Rccl::get().GetUniqueId(&id), "ncclGetUniqueId");
-        auto bytes = torch::empty({(int64_t)sizeof(id)}, torch::kUInt8);
-        std::memcpy(bytes.data_ptr(), &id, sizeof(id));
-        auto on_dev = bytes.to(dev_);
-        std::vector<torch::Tensor> v{on_dev};
-        pg->broadcast(v)->wait();
-        bytes = on_dev.to(torch::kCPU);
-        std::memcpy(&id, bytes.data_ptr(), sizeof(id));
-        nccl_chk(Rccl::get().CommInitRank(&d.comm, world, id, rank), "ncclCommInitRank");
+        // Every rank must end up on the SAME transport: a rank whose own communicator failed says so in a second broadcast-free exchange (an
+        // all-reduce of one flag through the group) and all of them fall back to the group's own collectives (c10d's RCCL communicator: the same
+        // wire, issued through libtorch on this stream — slower to launch, never wrong).
+        int ok = 1;
+        std::string why;
+        try {
+            ncclUniqueId id;
+            std::memset(&id, 0, sizeof(id));
+            if (rank == 0) nccl_chk(Rccl::get().GetUniqueId(&id), "ncclGetUniqueId");
+            auto bytes = torch::empty({(int64_t)sizeof(id)}, torch::kUInt8);
+            std::memcpy(bytes.data_ptr(), &id, sizeof(id));
+            auto on_dev = bytes.to(dev_);
+            std::vector<torch::Tensor> v{on_dev};
+            pg->broadcast(v)->wait();
+            bytes = on_dev.to(torch::kCPU);
+            std::memcpy(&id, bytes.data_ptr(), sizeof(id));
+            nccl_chk(Rccl::get().CommInitRank(&d.comm, world, id, rank), "ncclCommInitRank");
+        } catch (const std::exception& e) {
+            ok = 0; why = e.what();
+            d.comm = nullptr;
+        }
+        auto flag = torch::full({1}, (float)ok, torch::TensorOptions().device(dev_).dtype(torch::kFloat32));
+        std::vector<torch::Tensor> fv{flag};
+        c10d::AllreduceOptions opts;
+        opts.reduceOp = c10d::ReduceOp::MIN;
+        pg->allreduce(fv, opts)->wait();
+        if (flag.item<float>() < 0.5f) {
+            if (d.comm) { (void)Rccl::get().CommDestroy(d.comm); d.comm = nullptr; }
+            if (!ok) fprintf(stderr, "[gsr] SetShard: own RCCL communicator unavailable on rank %d (%s): the loop's collectives go through the process group\n", rank, why.c_str());
+        }
     }
     d.kd_nodes = (kd_nodes.defined() && kd_nodes.numel() > 0) ? kd_nodes.to(dev_, torch::kFloat32).contiguous() : torch::Tensor();
     d.order = torch::arange(world, torch::TensorOptions().device(dev_).dtype(torch::kInt64)); // (no partition given: the ranks ARE the order, e.g. depth slabs)
     shard_ = true;
     d.gathered = torch::Tensor(); // (re-sized by ensure_direct_)
+}
+
+// which way the sharded loop's collectives travel: "rccl" (the loop's own communicator, launched on the loop's stream), "c10d" (the process group's
+// collectives), "staged" (a host-side backend: device -> host -> group -> device), "local" (one rank, no group), "" (not sharded)
+std::string SlamLoop::ShardTransport() const
+{
+    if (!shard_ || !d_) return "";
+    if (!d_->pg) return "local";
+    return d_->comm ? "rccl" : d_->staged ? "staged" : "c10d";
 }
 
 SlamLoop::~SlamLoop() = default;

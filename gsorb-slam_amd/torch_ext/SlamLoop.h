@@ -115,6 +115,7 @@ public:
     // (inspection) the twelve pose sums dL/dR (row-major), dL/dt of the last tracking iteration that went through gsr_pose_grad's rows — the
     // sharded loop (summed over the ranks) and the unsharded one with LoopConfig::fused_update = false
     torch::Tensor LastPoseSums() const;
+    std::string ShardTransport() const;
 
     // both renders of an iteration: {colour [3,H,W], surface (median) depth [1,H,W], depth/silhouette [2,H,W]}
     std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> RenderPair(const torch::Tensor& Tcw, bool tracking);

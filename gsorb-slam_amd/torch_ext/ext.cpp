@@ -109,6 +109,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         .def("export_rows", &ORB_SLAM2::SlamLoop::ExportRows)
         .def("replace_rows", &ORB_SLAM2::SlamLoop::ReplaceRows)
         .def("last_pose_sums", &ORB_SLAM2::SlamLoop::LastPoseSums)
+        .def("shard_transport", &ORB_SLAM2::SlamLoop::ShardTransport)
         .def("size", &ORB_SLAM2::SlamLoop::size)
         .def("params", [](ORB_SLAM2::SlamLoop& l) { return std::vector<torch::Tensor>{l.xyz, l.rgb, l.unnorm_quat, l.logit_opacities, l.log_scales}; });
 

@@ -118,6 +118,7 @@ def _worker(rank, world, port, backend, q):
         frame = _frame(_C, raw, dev)
         loop = _loop(_C, [x[idx] for x in raw], dev, fused_update=True)
         loop.set_shard(dist.group.WORLD, rank, world, part.nodes)
+        assert loop.shard_transport() == ("rccl" if backend == "nccl" else "staged"), loop.shard_transport()   # (never the silent fallback)
         _RANK[id(loop)] = rank
         res = _schedule(loop, frame, _poses()[1].cuda(dev), "sharded %s world %d" % (backend, world),
                         rebalance=(lambda l: sharded.rebalance_loop(l, rank, world, dist.group.WORLD, tolerance=1.02)) if world > 1 else None)
