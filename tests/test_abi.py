@@ -42,6 +42,21 @@ def test_workspace_sizes_are_sane(gsr):
     assert L.gsr_error_string(-1).decode() == "invalid argument"
 
 
+def test_ssim_partials_follow_the_streaming_kernels_grid(gsr):
+    """gsr_ssim_partials = the waves of an SSIM launch (csrc/gsr_train.h: ssim_grid): strips of 54 output columns, segments of 11 m - 10 rows,
+    about one wave per SIMD (1024) where the image is large enough, segments of at least 16 rows where it is not. Host arithmetic: no GPU."""
+    L = gsr.lib()
+    for C_, H, W in [(3, 680, 1200), (3, 480, 640), (1, 17, 23), (3, 1, 1), (3, 2160, 3840), (4, 64, 5000)]:
+        nsx = -(-W // 54)
+        want = max(1, min(1024 // (C_ * nsx), -(-H // 16)))
+        rows = -(-H // want)
+        rows = (rows + 20) // 11 * 11 - 10
+        assert (rows + 10) % 11 == 0 and rows >= 1
+        assert int(L.gsr_ssim_partials(C_, H, W)) == C_ * nsx * (-(-H // rows)), (C_, H, W)
+    assert int(L.gsr_ssim_partials(3, 680, 1200)) == 897
+    assert int(L.gsr_ssim_partials(0, 5, 5)) == 0
+
+
 def test_struct_layout_matches_header(gsr):
     # field order of the ctypes mirrors must follow include/gsr.h
     src = open(os.path.join(ROOT, "include", "gsr.h")).read()
