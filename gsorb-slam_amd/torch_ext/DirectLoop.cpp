@@ -145,7 +145,9 @@ float wait_posted(const float* slot, hipStream_t st)
         uint32_t v;
         v = __atomic_load_n(reinterpret_cast<const uint32_t*>(slot), __ATOMIC_ACQUIRE);
         if (v != kNotPosted) { float x; std::memcpy(&x, &v, 4); return x; }
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#endif
         if ((spins & 0xFFFu) == 0) {
             const hipError_t q = hipStreamQuery(st);
             if (q != hipErrorNotReady) { // drained (or failed): one last look
