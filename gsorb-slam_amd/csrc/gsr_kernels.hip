@@ -248,6 +248,10 @@ __device__ __forceinline__ uint32_t lds_take(uint32_t* p)
     return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // Count pass: histogram of the window's tiles in LDS -> the range's row of the count matrix (its columns of the window).
+// (Round 5, measured and dropped: the column scan and the tile scan INSIDE this launch, handed over by "who arrived last" tickets three levels deep —
+// per (window, group of 16 ranges), per window, per frame; nobody waits for anybody, the crossing data written through and read at agent scope:
+// 33.6 us for the one launch against 11.3 + 9.4 for count + K_bin_colscan. A device-scope ticket and the agent-scope reads behind it cost ~2 us of
+// latency each on this chip and three levels put nine of them in a row: a launch boundary is cheaper.)
 // (Measured and dropped: K_preprocess and this pass in one launch, 1024-thread workgroups projecting four splats per
 // thread and counting as they go — 38 us against 28.5 + 7.5 us for the two launches. Round 5, on the bucketed records: one workgroup per
 // splat range that takes the eight windows' pieces one after the other, the whole matrix row in LDS — 16.1 / 20.6 us at 1024 / 512 threads
