@@ -1274,7 +1274,7 @@ __device__ void pose_update_body(const PoseUpdate& u, const int nrows, const flo
     }
     if (lane != 0) return;
     float q[4] = {pq[0], pq[1], pq[2], pq[3]}, t[3] = {pq[4], pq[5], pq[6]};
-    const float lv = skip ? __builtin_nanf("") : loss_in;
+    const float lv = (skip || loss_in != loss_in) ? __builtin_nanf("") : loss_in; // (one NaN pattern only: the loop that spins on the slot keeps another one for "not posted yet")
     __hip_atomic_store(u.history, lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (the slot may be host memory the loop spins on: DirectLoop.cpp)
     if (lv == lv && lv < best0) {
         u.best[0] = lv;
