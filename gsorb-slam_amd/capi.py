@@ -44,7 +44,7 @@ class ForwardArgs(C.Structure):
                 ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int),
                 ("out_color", C.c_void_p), ("out_depth", C.c_void_p), ("radii", C.c_void_p),
                 ("profile_events", C.POINTER(C.c_void_p)), ("band_y0", C.c_int), ("band_y1", C.c_int),
-                ("out_ds", C.c_void_p)]
+                ("out_ds", C.c_void_p), ("pre_Tcw", C.c_void_p), ("means_cam_out", C.c_void_p)]
 
 
 class BackwardArgs(C.Structure):
@@ -342,13 +342,17 @@ class Workspace:
 
 
 def forward_ws(s: Settings, ws: Workspace, means3D, opacities, colors=None, shs=None, scales=None,
-               rotations=None, cov3D_precomp=None, events=None, dual: bool = False) -> ForwardState:
+               rotations=None, cov3D_precomp=None, events=None, dual: bool = False, pre_Tcw=None, means_cam_out=None) -> ForwardState:
+    """pre_Tcw [4,4] (device, world -> camera) + means_cam_out [P,3]: `means3D` are WORLD means, the projection kernel moves them into the camera
+    frame itself and leaves them in means_cam_out (gsr_forward_args.pre_Tcw)."""
     L = lib()
     dev, ins = (s.viewmatrix.device, means3D) if isinstance(means3D, dict) else \
         _prep(s, means3D, opacities, colors, shs, scales, rotations, cov3D_precomp)
     a, P, M = _fwd_args(s, ins["means3D"], ins["opacities"], ins["colors"], ins["shs"], ins["scales"],
                         ins["rotations"], ins["cov3D"], ws.color, ws.depth, ws.radii, events, (0, 0), ws.ds if dual else None)
     assert P == ws.P and s.image_width == ws.W and s.image_height == ws.H
+    if pre_Tcw is not None:
+        a.pre_Tcw, a.means_cam_out = _p(pre_Tcw), _p(means_cam_out)
     _check(L.gsr_forward_ws(C.byref(a), _p(ws.geom), _p(ws.binning), ws.binning_bytes, _p(ws.image), _stream()))
     return ForwardState(s, P, M, -1, ins, ws.color, ws.depth, ws.radii[:P], ws.geom, ws.binning, ws.image,
                         ws_binning_bytes=ws.binning_bytes, ds=ws.ds if dual else None)

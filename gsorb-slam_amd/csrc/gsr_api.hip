@@ -61,6 +61,7 @@ int check_forward(const gsr_forward_args* a)
     if (has_sh && (a->M <= 0 || a->D < 0 || a->D > 3 || (a->D + 1) * (a->D + 1) > a->M || !a->cam_pos)) return GSR_EINVAL;
     const bool has_sr = a->scales != nullptr && a->rotations != nullptr, has_cov = a->cov3D_precomp != nullptr;
     if (has_sr == has_cov) return GSR_EINVAL; // exactly one (:313-316)
+    if (a->pre_Tcw && !a->means_cam_out) return GSR_EINVAL; // (the camera-frame means must go somewhere: the backward takes them)
     return GSR_OK;
 }
 
@@ -72,6 +73,7 @@ gsr::SplatInputs splat_inputs(const float* means3D, const float* scales, const f
     in.means3D = means3D; in.scales = scales; in.rotations = rotations; in.opacities = opacities;
     in.shs = shs; in.cov3D_precomp = cov3D; in.colors_precomp = colors;
     in.view = view; in.proj = proj; in.campos = campos;
+    in.pre_Tcw = nullptr; in.means_cam_out = nullptr;
     return in;
 }
 
@@ -137,9 +139,10 @@ int forward_head(const gsr_forward_args* a, char* geom, char* image, hipStream_t
     const int T = f.grid_x * f.grid_y;
     geom_layout(geom, P, gv);
     image_layout(image, W, H, iv);
-    const gsr::SplatInputs in = splat_inputs(a->means3D, a->scales, a->rotations, a->opacities, a->shs,
-                                             a->cov3D_precomp, a->colors_precomp, a->viewmatrix,
-                                             a->projmatrix, a->cam_pos);
+    gsr::SplatInputs in = splat_inputs(a->means3D, a->scales, a->rotations, a->opacities, a->shs,
+                                       a->cov3D_precomp, a->colors_precomp, a->viewmatrix,
+                                       a->projmatrix, a->cam_pos);
+    in.pre_Tcw = a->pre_Tcw; in.means_cam_out = a->means_cam_out;
     const StageTimer tm{a->profile_events, st};
     tm.begin(GSR_FWD_PREPROCESS);
     hipLaunchKernelGGL(gsr::K_preprocess, dim3((P + GSR_PRE_THREADS - 1) / GSR_PRE_THREADS), dim3(GSR_PRE_THREADS), 0, st, f, in, a->radii, *gv);

@@ -45,6 +45,8 @@ struct SplatInputs {
     const float* view;
     const float* proj;
     const float* campos;
+    const float* pre_Tcw;   // (NULL, or: means3D are world means, moved into the camera frame here — gsr_forward_args.pre_Tcw)
+    float* means_cam_out;
 };
 
 __device__ __forceinline__ void load_cov3d(const SplatInputs& in, const FrameParams& f, int idx, float cov[6])
@@ -91,7 +93,19 @@ __device__ __forceinline__ uint4 preprocess_splat(const int idx, const FramePara
     float vm[16], pm[16]; // the two matrices: scalar loads, requested with the rest
 #pragma unroll
     for (int k = 0; k < 16; k++) { vm[k] = in.view[k]; pm[k] = in.proj[k]; }
+    float T[12] = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+    if (in.pre_Tcw) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) T[k] = in.pre_Tcw[k];
+    }
     pin(p.x); pin(p.y); pin(p.z); pin(opac); pin(cp.x); pin(cp.y); pin(cp.z);
+    if (in.pre_Tcw) { // mc = X R^T + t with K_to_camera's arithmetic (gsr_train.h): the mean the rest of the pipeline sees, and the backward's
+        const float x = p.x, y = p.y, z = p.z;
+        p.x = fmaf(T[2], z, fmaf(T[1], y, T[0] * x)) + T[3];
+        p.y = fmaf(T[6], z, fmaf(T[5], y, T[4] * x)) + T[7];
+        p.z = fmaf(T[10], z, fmaf(T[9], y, T[8] * x)) + T[11];
+        in.means_cam_out[3 * (size_t)idx] = p.x; in.means_cam_out[3 * (size_t)idx + 1] = p.y; in.means_cam_out[3 * (size_t)idx + 2] = p.z;
+    }
     if (in.cov3D_precomp) {
 #pragma unroll
         for (int k = 0; k < 6; k++) pin(cov[k]);

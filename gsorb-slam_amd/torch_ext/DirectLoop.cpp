@@ -7,7 +7,7 @@
 // parameters, the Adam moments, one workspace that lives as long as the map's size), and an iteration is
 //   mapping : gsr_map_prepare -> gsr_forward_ws (fused pair) -> gsr_map_loss_forward -> gsr_map_loss_finish -> gsr_map_loss_backward ->
 //             gsr_backward [with gsr_map_update fused into its per-splat stage]                                           (13 launches)
-//   tracking: gsr_to_camera -> gsr_forward_ws -> gsr_pixel_loss -> gsr_pixel_loss_backward_add -> gsr_backward ->
+//   tracking: gsr_forward_ws [the camera transform inside its projection kernel: pre_Tcw] -> gsr_track_loss -> gsr_backward ->
 //             gsr_pose_grad -> gsr_pose_update                                                                          (13 launches)
 // with no allocation, no gradient tensor of a raw parameter, and no host synchronisation except where the reference has one
 // (the tracking loop reads its loss every iteration, Render.cc:1107 — posted by the pose kernel into host-mapped memory the loop spins on; the mapping loop of RenderForFrame never does: MapFrame
@@ -360,7 +360,7 @@ void SlamLoop::grow_binning_(size_t capacity)
 }
 
 // the fused colour + depth / silhouette pass on the workspace (sync-free), and its backward
-void SlamLoop::direct_forward_()
+void SlamLoop::direct_forward_(bool from_world)
 {
     Direct& d = *d_;
     if (d.n == 0) { d.layers.zero_(); return; } // (an empty shard still takes part in the exchange: its layer is nothing)
@@ -368,7 +368,10 @@ void SlamLoop::direct_forward_()
     gsr_forward_args a{};
     a.P = (int)d.n; a.D = 0; a.M = 0;
     a.background = f(d.bg); a.width = W_; a.height = H_;
-    a.means3D = f(d.mc); a.colors_precomp = f(rgb); a.opacities = f(d.opac); a.scales = f(d.scales); a.scale_modifier = s.scale_modifier;
+    // from_world (a tracking iteration): the projection kernel moves the world means into the camera frame of the pose on the device itself and leaves them in
+    // d.mc for the backward (gsr_forward_args.pre_Tcw) — gsr_to_camera's launch less per iteration
+    a.means3D = from_world ? f(xyz) : f(d.mc); a.pre_Tcw = from_world ? f(d.Tcw) : nullptr; a.means_cam_out = from_world ? f(d.mc) : nullptr;
+    a.colors_precomp = f(rgb); a.opacities = f(d.opac); a.scales = f(d.scales); a.scale_modifier = s.scale_modifier;
     a.rotations = f(d.rots); a.viewmatrix = f(d.view); a.projmatrix = f(d.proj); a.cam_pos = f(d.campos);
     a.tan_fovx = s.tanfovx; a.tan_fovy = s.tanfovy; a.prefiltered = 0;
     a.out_color = f(d.out_color); a.out_depth = f(d.out_sur); a.radii = d.radii.data_ptr<int>(); a.out_ds = f(d.out_ds);
@@ -561,8 +564,7 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
     double last_loss = 0.0;
     int step = 0;
     for (int it = 0; it < iters; it++) {
-        if (d.n > 0) chk(gsr_to_camera(f(xyz), (size_t)d.n, f(d.Tcw), f(d.mc), st), "gsr_to_camera");
-        direct_forward_();
+        direct_forward_(true); // (the camera transform of Render.cc:750-752 rides in the projection kernel)
         if (shard_) shard_composite_forward_(true, false);
         // Render.cc:1088-1105: the masked L1 sums and their gradient planes, one pass over the render
         chk(gsr_track_loss(img, dep, sur, sil, f(frame.rgb), f(frame.depth), H_, W_, 0.99f, w3, f(d.loss_partial), f(d.sums), f(d.g_image), f(d.g_ds),

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 7 /* 7: gsr_composite_* take the plane count of the gathered buffer, gsr_shard_order and gsr_reproj_loss added; 6: gsr_track_loss, gsr_pose_step, gsr_backward_args.fused_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
+#define GSR_ABI_VERSION 8 /* 8: gsr_forward_args.pre_Tcw / means_cam_out appended (the camera transform inside the projection kernel); 7: gsr_composite_* take the plane count of the gathered buffer, gsr_shard_order and gsr_reproj_loss added; 6: gsr_track_loss, gsr_pose_step, gsr_backward_args.fused_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
                            * 5: gsr_map_prepare / gsr_map_update / gsr_map_loss_total / gsr_pose_update / gsr_pixel_loss_backward_add / gsr_composite_* added, GSR_LOSS_PARTIALS 256 -> 1024 */
 
 #define GSR_OK 0
@@ -80,6 +80,13 @@ typedef struct gsr_forward_args {
      * splat's view-space depth, what preprocess computes anyway), out_ds[1] = sum alpha_i T_i; background 0. One
      * preprocess / binning / sort / gather / exp / alpha / T per pair instead of two. */
     float* out_ds;
+    /* The tracking loop's camera transform inside the projection kernel (new capability; NULL = means3D is used as it is). GSORB-SLAM moves the
+     * means into the camera frame before every render of a tracked pose — mc = X R^T + t through bmm, src/Render.cc:750-752 — and rasterizes with
+     * an identity view. With pre_Tcw (DEVICE pointer, row-major 4x4, world -> camera) means3D holds the WORLD means, the kernel forms mc with
+     * gsr_to_camera's arithmetic, uses it as the splat's mean and stores it to means_cam_out [P,3] (what gsr_backward_args.means3D then takes):
+     * gsr_to_camera's launch and its 24 bytes per splat of traffic less per iteration. */
+    const float* pre_Tcw;
+    float* means_cam_out;
 } gsr_forward_args;
 
 /* forward stages, in launch order */

@@ -638,3 +638,35 @@ def test_reprojection_term_adds_its_pose_sums_and_its_value(gsr, hz, M):
     gsr.capi.reproj_loss(c(obs), c(Xw), c(s2), Td, fx, fy, cx, cy, w, row2, loss2, inliers=inl, refresh=0, grad_scale=0.25)
     assert float(loss2) == float(loss) and (row2 * 4 - row).abs().max() <= 1e-6 * max(1.0, float(row.abs().max()))
     assert (row.cpu().double() - w * grad_in).abs().max() <= 2e-4 * max(1.0, float((w * grad_in).abs().max()))
+
+
+def test_camera_transform_inside_the_projection_kernel_is_gsr_to_camera_bit_for_bit(gsr, syn):
+    """gsr_forward_args.pre_Tcw: world means + the pose on the device -> the same render, the same radii / tile lists and the same camera-frame means
+    as gsr_to_camera followed by the plain forward (what a tracking iteration did before: src/Render.cc:750-752 + the render)."""
+    import util
+    cam = syn.make_camera(**syn.TUM1)
+    sc = syn.make_scene(20000, cam, seed=11, scale_mult=2.0, frac_behind=0.1, frac_offscreen=0.2)
+    s = gsr.capi.Settings.from_camera(cam)
+    dev = s.viewmatrix.device
+    t = lambda x: torch.as_tensor(x, dtype=torch.float32, device=dev).contiguous()
+    T = t(util.pose(0.05, (0.02, -0.03, 0.04)))
+    Xc = t(sc.means3D)
+    Xw = ((Xc - T[:3, 3]) @ T[:3, :3]).contiguous()                      # Xc ~ R Xw + t
+    mc = torch.empty_like(Xw)
+    gsr.capi._check(gsr.lib().gsr_to_camera(gsr.capi._p(Xw), Xw.shape[0], gsr.capi._p(T), gsr.capi._p(mc), gsr.capi._stream()))
+    ws = gsr.capi.Workspace(Xw.shape[0], cam.width, cam.height, max_rendered=4_000_000, device=dev)
+    kw = dict(colors=t(sc.colors), scales=t(sc.scales), rotations=t(sc.rotations))
+    a = gsr.forward_ws(s, ws, mc, t(sc.opacities), dual=True, **kw)
+    ref = [x.clone() for x in (a.color, a.depth, a.radii, a.ds)]
+    da = gsr.debug_export(a)
+    out = torch.zeros_like(Xw)
+    b = gsr.forward_ws(s, ws, Xw, t(sc.opacities), dual=True, pre_Tcw=T, means_cam_out=out, **kw)
+    db = gsr.debug_export(b)
+    assert torch.equal(out, mc)
+    for x, y in zip(ref, (b.color, b.depth, b.radii, b.ds)):
+        assert torch.equal(x, y)
+    import numpy as np
+    np.testing.assert_array_equal(da["ranges"], db["ranges"]); np.testing.assert_array_equal(da["point_list"], db["point_list"])
+    # rejected before any launch: a transform without a place for the camera-frame means
+    with pytest.raises(Exception):
+        gsr.forward_ws(s, ws, Xw, t(sc.opacities), dual=True, pre_Tcw=T, means_cam_out=None, **kw)
