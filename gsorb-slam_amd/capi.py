@@ -44,7 +44,11 @@ class ForwardArgs(C.Structure):
                 ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int),
                 ("out_color", C.c_void_p), ("out_depth", C.c_void_p), ("radii", C.c_void_p),
                 ("profile_events", C.POINTER(C.c_void_p)), ("band_y0", C.c_int), ("band_y1", C.c_int),
-                ("out_ds", C.c_void_p), ("pre_Tcw", C.c_void_p), ("means_cam_out", C.c_void_p)]
+                ("out_ds", C.c_void_p), ("pre_Tcw", C.c_void_p), ("means_cam_out", C.c_void_p), ("raw", C.c_void_p)]
+
+
+class RawOutputs(C.Structure):
+    _fields_ = [("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("reg_limit", C.c_float), ("reg_partial", C.c_void_p)]
 
 
 class BackwardArgs(C.Structure):
@@ -342,7 +346,7 @@ class Workspace:
 
 
 def forward_ws(s: Settings, ws: Workspace, means3D, opacities, colors=None, shs=None, scales=None,
-               rotations=None, cov3D_precomp=None, events=None, dual: bool = False, pre_Tcw=None, means_cam_out=None) -> ForwardState:
+               rotations=None, cov3D_precomp=None, events=None, dual: bool = False, pre_Tcw=None, means_cam_out=None, raw=None) -> ForwardState:
     """pre_Tcw [4,4] (device, world -> camera) + means_cam_out [P,3]: `means3D` are WORLD means, the projection kernel moves them into the camera
     frame itself and leaves them in means_cam_out (gsr_forward_args.pre_Tcw)."""
     L = lib()
@@ -353,6 +357,9 @@ def forward_ws(s: Settings, ws: Workspace, means3D, opacities, colors=None, shs=
     assert P == ws.P and s.image_width == ws.W and s.image_height == ws.H
     if pre_Tcw is not None:
         a.pre_Tcw, a.means_cam_out = _p(pre_Tcw), _p(means_cam_out)
+    if raw is not None:   # (opacities_out, scales_out, rotations_out, reg_limit, reg_partial or None): the three inputs are RAW parameters
+        ro = RawOutputs(_p(raw[0]), _p(raw[1]), _p(raw[2]), float(raw[3]), _p(raw[4]))
+        a.raw = C.cast(C.pointer(ro), C.c_void_p)
     _check(L.gsr_forward_ws(C.byref(a), _p(ws.geom), _p(ws.binning), ws.binning_bytes, _p(ws.image), _stream()))
     return ForwardState(s, P, M, -1, ins, ws.color, ws.depth, ws.radii[:P], ws.geom, ws.binning, ws.image,
                         ws_binning_bytes=ws.binning_bytes, ds=ws.ds if dual else None)

@@ -62,6 +62,7 @@ int check_forward(const gsr_forward_args* a)
     const bool has_sr = a->scales != nullptr && a->rotations != nullptr, has_cov = a->cov3D_precomp != nullptr;
     if (has_sr == has_cov) return GSR_EINVAL; // exactly one (:313-316)
     if (a->pre_Tcw && !a->means_cam_out) return GSR_EINVAL; // (the camera-frame means must go somewhere: the backward takes them)
+    if (a->raw && (!has_sr || !a->raw->opacities || !a->raw->scales || !a->raw->rotations)) return GSR_EINVAL;
     return GSR_OK;
 }
 
@@ -74,6 +75,7 @@ gsr::SplatInputs splat_inputs(const float* means3D, const float* scales, const f
     in.shs = shs; in.cov3D_precomp = cov3D; in.colors_precomp = colors;
     in.view = view; in.proj = proj; in.campos = campos;
     in.pre_Tcw = nullptr; in.means_cam_out = nullptr;
+    in.opac_out = in.scales_out = in.rots_out = nullptr; in.reg_limit = 0.f; in.reg_partial = nullptr;
     return in;
 }
 
@@ -145,7 +147,11 @@ int forward_head(const gsr_forward_args* a, char* geom, char* image, hipStream_t
     in.pre_Tcw = a->pre_Tcw; in.means_cam_out = a->means_cam_out;
     const StageTimer tm{a->profile_events, st};
     tm.begin(GSR_FWD_PREPROCESS);
-    hipLaunchKernelGGL(gsr::K_preprocess, dim3((P + GSR_PRE_THREADS - 1) / GSR_PRE_THREADS), dim3(GSR_PRE_THREADS), 0, st, f, in, a->radii, *gv);
+    if (a->raw) {
+        in.opac_out = a->raw->opacities; in.scales_out = a->raw->scales; in.rots_out = a->raw->rotations; in.reg_limit = a->raw->reg_limit; in.reg_partial = a->raw->reg_partial;
+        hipLaunchKernelGGL(gsr::K_preprocess<true>, dim3((P + GSR_PRE_THREADS - 1) / GSR_PRE_THREADS), dim3(GSR_PRE_THREADS), 0, st, f, in, a->radii, *gv);
+    } else
+        hipLaunchKernelGGL(gsr::K_preprocess<false>, dim3((P + GSR_PRE_THREADS - 1) / GSR_PRE_THREADS), dim3(GSR_PRE_THREADS), 0, st, f, in, a->radii, *gv);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_PREPROCESS);
     tm.begin(GSR_FWD_SCAN);

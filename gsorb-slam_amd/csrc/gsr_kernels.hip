@@ -47,6 +47,11 @@ struct SplatInputs {
     const float* campos;
     const float* pre_Tcw;   // (NULL, or: means3D are world means, moved into the camera frame here — gsr_forward_args.pre_Tcw)
     float* means_cam_out;
+    // RAW (gsr_forward_args.raw; K_preprocess<true>): opacities / scales / rotations above hold the RAW parameters (logits, log-scales, un-normalised
+    // quaternions); the kernel applies gsr_map_prepare's activations, stores what the backward takes and writes the scale regularisers' partial sums
+    float *opac_out, *scales_out, *rots_out;
+    float reg_limit;
+    float* reg_partial;
 };
 
 __device__ __forceinline__ void load_cov3d(const SplatInputs& in, const FrameParams& f, int idx, float cov[6])
@@ -74,7 +79,8 @@ __device__ __forceinline__ void load_cov3d(const SplatInputs& in, const FramePar
 // VGPRs for seven / eight waves per SIMD instead of six (it spills 44 / 72 bytes): 41.9 / 82 us.
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 // one splat: everything but its bin record, which is returned ({tiles of the band-clipped rectangle, depth bits, x0 | y0 << 16, x1 | y1 << 16})
-__device__ __forceinline__ uint4 preprocess_splat(const int idx, const FrameParams& f, const SplatInputs& in, int* __restrict__ radii_out, const GeomView& g)
+template <bool RAW>
+__device__ __forceinline__ uint4 preprocess_splat(const int idx, const FrameParams& f, const SplatInputs& in, int* __restrict__ radii_out, const GeomView& g, float (&reg)[3])
 {
     float3 p = make_float3(in.means3D[3 * (size_t)idx], in.means3D[3 * (size_t)idx + 1], in.means3D[3 * (size_t)idx + 2]);
     float cov[6];
@@ -111,6 +117,18 @@ __device__ __forceinline__ uint4 preprocess_splat(const int idx, const FramePara
         for (int k = 0; k < 6; k++) pin(cov[k]);
     } else {
         pin(sc.x); pin(sc.y); pin(sc.z); pin(q.x); pin(q.y); pin(q.z); pin(q.w);
+        if (RAW) { // K_map_prepare's activations, operation for operation (gsr_train.h): sigmoid, exp, torch's normalize; the regularisers' three sums
+            opac = 1.f / (1.f + expf(-opac));
+            sc = make_float3(expf(sc.x), expf(sc.y), expf(sc.z));
+            const float inv = 1.f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+            q = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+            in.opac_out[idx] = opac;
+            in.scales_out[3 * (size_t)idx] = sc.x; in.scales_out[3 * (size_t)idx + 1] = sc.y; in.scales_out[3 * (size_t)idx + 2] = sc.z;
+            reinterpret_cast<float4*>(in.rots_out)[idx] = q;
+            const float wgt = (float)(sc.x > in.reg_limit) + (float)(sc.y > in.reg_limit) + (float)(sc.z > in.reg_limit);
+            const float mx = fmaxf(sc.x, fmaxf(sc.y, sc.z)), mn = fminf(sc.x, fminf(sc.y, sc.z));
+            reg[0] = wgt; reg[1] = wgt * (mx - in.reg_limit); reg[2] = wgt * (mx - mn);
+        }
         cov3d_from_scale_rot(sc, f.scale_modifier, q, cov);
     }
     Projected pr;
@@ -147,7 +165,8 @@ __device__ __forceinline__ uint4 preprocess_splat(const int idx, const FramePara
 // The bin records leave BUCKETED by tile window (round 5): the workgroup's records of window w go, densely, to the piece (workgroup, w) of the
 // pool, a splat whose rectangle crosses a window boundary to both pieces; the binning passes of window w then read what concerns them and
 // nothing else (gsr_device.h). A returning LDS atomic hands out the slot, one barrier before the eight counts are stored: no global atomic.
-__global__ void __launch_bounds__(GSR_PRE_THREADS)
+template <bool RAW>
+__global__ void __launch_bounds__(GSR_PRE_THREADS) __attribute__((amdgpu_waves_per_eu(RAW ? 5 : 6, 8))) // (six waves per SIMD: 80 registers — what the kernel had before it became a template; the variant with the activations takes 90)
 K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomView g)
 {
     __shared__ uint32_t s_cnt[GSR_BIN_NWIN];
@@ -155,7 +174,8 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
     if (threadIdx.x < GSR_BIN_NWIN) s_cnt[threadIdx.x] = 0u;
     if (idx == 0) g.hdr->ticket = 0u; // (K_bin_colscan's arrival counter: a launch boundary lies between this store and its first use)
     __syncthreads();
-    const uint4 br = idx < f.P ? preprocess_splat(idx, f, in, radii_out, g) : make_uint4(0u, 0u, 0u, 0u);
+    float reg[3] = {0.f, 0.f, 0.f};
+    const uint4 br = idx < f.P ? preprocess_splat<RAW>(idx, f, in, radii_out, g, reg) : make_uint4(0u, 0u, 0u, 0u);
     if (br.x != 0u) {
         const int T = f.grid_x * f.grid_y;
         const int x0 = (int)(br.z & 0xFFFFu), y0 = (int)(br.z >> 16), x1 = (int)(br.w & 0xFFFFu), y1 = (int)(br.w >> 16);
@@ -169,8 +189,22 @@ K_preprocess(FrameParams f, SplatInputs in, int* __restrict__ radii_out, GeomVie
             g.pool[((size_t)blockIdx.x * GSR_BIN_NWIN + w) * GSR_BIN_PIECE + slot] = rec;
         }
     }
+    __shared__ float s_reg[GSR_PRE_THREADS / 64][3];
+    if (RAW && in.reg_partial) { // K_map_prepare's row of three sums per 256 Gaussians (same order of additions: a butterfly per wave, the four waves pairwise)
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) reg[q] += __shfl_xor(reg[q], off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) s_reg[threadIdx.x >> 6][q] = reg[q];
+        }
+    }
     __syncthreads();
     if (threadIdx.x < GSR_BIN_NWIN) g.pcnt[(size_t)blockIdx.x * GSR_BIN_NWIN + threadIdx.x] = (uint16_t)s_cnt[threadIdx.x];
+    if (RAW && in.reg_partial && threadIdx.x < 3)
+        in.reg_partial[(size_t)blockIdx.x * 3 + threadIdx.x] = (s_reg[0][threadIdx.x] + s_reg[1][threadIdx.x]) + (s_reg[2][threadIdx.x] + s_reg[3][threadIdx.x]);
 }
 
 __global__ void __launch_bounds__(256)

@@ -5,7 +5,7 @@
 // Adam launches, allocations of every intermediate — 1.08-1.30 ms per iteration of which the rasterizer pair is 0.55
 // (profiles/r04_loop.md). Here nothing inside an iteration goes through a tensor library: libtorch owns the memory (the
 // parameters, the Adam moments, one workspace that lives as long as the map's size), and an iteration is
-//   mapping : gsr_map_prepare -> gsr_forward_ws (fused pair) -> gsr_map_loss_forward -> gsr_map_loss_finish -> gsr_map_loss_backward ->
+//   mapping : gsr_forward_ws (fused pair; camera transform, activations and the regularisers' partial sums inside its projection kernel: pre_Tcw, raw) -> gsr_map_loss_forward -> gsr_map_loss_finish -> gsr_map_loss_backward ->
 //             gsr_backward [with gsr_map_update fused into its per-splat stage]                                           (13 launches)
 //   tracking: gsr_forward_ws [the camera transform inside its projection kernel: pre_Tcw] -> gsr_track_loss -> gsr_backward ->
 //             gsr_pose_grad -> gsr_pose_update                                                                          (13 launches)
@@ -360,7 +360,7 @@ void SlamLoop::grow_binning_(size_t capacity)
 }
 
 // the fused colour + depth / silhouette pass on the workspace (sync-free), and its backward
-void SlamLoop::direct_forward_(bool from_world)
+void SlamLoop::direct_forward_(bool from_world, bool raw, float reg_limit)
 {
     Direct& d = *d_;
     if (d.n == 0) { d.layers.zero_(); return; } // (an empty shard still takes part in the exchange: its layer is nothing)
@@ -371,8 +371,11 @@ void SlamLoop::direct_forward_(bool from_world)
     // from_world (a tracking iteration): the projection kernel moves the world means into the camera frame of the pose on the device itself and leaves them in
     // d.mc for the backward (gsr_forward_args.pre_Tcw) — gsr_to_camera's launch less per iteration
     a.means3D = from_world ? f(xyz) : f(d.mc); a.pre_Tcw = from_world ? f(d.Tcw) : nullptr; a.means_cam_out = from_world ? f(d.mc) : nullptr;
-    a.colors_precomp = f(rgb); a.opacities = f(d.opac); a.scales = f(d.scales); a.scale_modifier = s.scale_modifier;
-    a.rotations = f(d.rots); a.viewmatrix = f(d.view); a.projmatrix = f(d.proj); a.cam_pos = f(d.campos);
+    // raw (a mapping iteration of the unsharded loop): the projection kernel also applies the activations (gsr_map_prepare's: sigmoid, exp, normalize), leaves them in
+    // d.opac / d.scales / d.rots for the backward and writes the scale regularisers' partial sums (gsr_forward_args.raw) — gsr_map_prepare's launch less per iteration
+    gsr_raw_outputs ro{f(d.opac), f(d.scales), f(d.rots), reg_limit, f(d.reg_partial)};
+    a.colors_precomp = f(rgb); a.opacities = raw ? f(logit_opacities) : f(d.opac); a.scales = raw ? f(log_scales) : f(d.scales); a.scale_modifier = s.scale_modifier;
+    a.rotations = raw ? f(unnorm_quat) : f(d.rots); a.raw = raw ? &ro : nullptr; a.viewmatrix = f(d.view); a.projmatrix = f(d.proj); a.cam_pos = f(d.campos);
     a.tan_fovx = s.tanfovx; a.tan_fovy = s.tanfovy; a.prefiltered = 0;
     a.out_color = f(d.out_color); a.out_depth = f(d.out_sur); a.radii = d.radii.data_ptr<int>(); a.out_ds = f(d.out_ds);
     chk(gsr_forward_ws(&a, b(d.geom), b(d.binning), d.binning_bytes, b(d.image), stream_()), "gsr_forward_ws");
@@ -422,10 +425,14 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
     const size_t n = (size_t)d.n;
     const float limit = (float)(0.1 * cfg_.scene_radius), wl = (float)cfg_.reg_long_weight, wsc = (float)cfg_.reg_scalar_weight;
     if (shard_ && !cfg_.fused_loss) throw std::runtime_error("the sharded loop needs LoopConfig::fused_loss");
+    // (the unsharded loop with the fused loss: camera transform, activations and the regularisers' partial sums ride in the projection kernel; the other
+    // configurations finish the regularisers' sums right here, in gsr_map_prepare's second launch)
+    const bool in_projection = cfg_.fused_loss && !shard_ && n > 0;
     if (n == 0) d.reg_tot.zero_();
-    else chk(gsr_map_prepare(n, f(xyz), f(logit_opacities), f(log_scales), f(unnorm_quat), f(d.Tcw), f(d.mc), f(d.opac), f(d.scales), f(d.rots), limit, wl, wsc,
-                        f(d.reg_partial), shard_ ? f(d.reg_tot) : cfg_.fused_loss ? nullptr : f(d.reg_out), st), "gsr_map_prepare");
-    direct_forward_();
+    else if (!in_projection)
+        chk(gsr_map_prepare(n, f(xyz), f(logit_opacities), f(log_scales), f(unnorm_quat), f(d.Tcw), f(d.mc), f(d.opac), f(d.scales), f(d.rots), limit, wl, wsc,
+                            f(d.reg_partial), shard_ ? f(d.reg_tot) : cfg_.fused_loss ? nullptr : f(d.reg_out), st), "gsr_map_prepare");
+    direct_forward_(in_projection, in_projection, limit);
     if (shard_) { shard_composite_forward_(d.order_stale, true); d.order_stale = false; }
     // Render.cc:436-471: lam * L1 + (1 - lam) * (1 - SSIM), masked depth L1, masked surface-depth L1 (no gradient), the regularisers
     const float w3[3] = {(float)(cfg_.im_weight_mapping * cfg_.lam), (float)cfg_.depth_weight_mapping, (float)cfg_.sur_depth_weight_mapping};

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 8 /* 8: gsr_forward_args.pre_Tcw / means_cam_out appended (the camera transform inside the projection kernel); 7: gsr_composite_* take the plane count of the gathered buffer, gsr_shard_order and gsr_reproj_loss added; 6: gsr_track_loss, gsr_pose_step, gsr_backward_args.fused_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
+#define GSR_ABI_VERSION 8 /* 8: gsr_forward_args.pre_Tcw / means_cam_out / raw appended (the camera transform and the map's activations inside the projection kernel); 7: gsr_composite_* take the plane count of the gathered buffer, gsr_shard_order and gsr_reproj_loss added; 6: gsr_track_loss, gsr_pose_step, gsr_backward_args.fused_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
                            * 5: gsr_map_prepare / gsr_map_update / gsr_map_loss_total / gsr_pose_update / gsr_pixel_loss_backward_add / gsr_composite_* added, GSR_LOSS_PARTIALS 256 -> 1024 */
 
 #define GSR_OK 0
@@ -39,6 +39,15 @@ extern "C" {
  * device buffer of at least `bytes` bytes, 256-byte aligned, valid until the
  * matching gsr_backward has run. Contents need not be zeroed. */
 typedef char* (*gsr_alloc_fn)(void* user, size_t bytes);
+
+/* Where the projection kernel leaves the map's activations when it forms them itself (gsr_forward_args.raw, below). */
+typedef struct gsr_raw_outputs {
+    float* opacities;   /* [P]   sigmoid(logit) */
+    float* scales;      /* [P,3] exp(log-scale) */
+    float* rotations;   /* [P,4] q / max(|q|, 1e-12) */
+    float reg_limit;    /* the regularisers' scale limit (gsr_map_prepare's `limit`) */
+    float* reg_partial; /* NULL: no regularisers */
+} gsr_raw_outputs;
 
 /* Arguments of Rasterizer::forward (rasterizer.h:34-58), same meaning and order. */
 typedef struct gsr_forward_args {
@@ -87,6 +96,12 @@ typedef struct gsr_forward_args {
      * gsr_to_camera's launch and its 24 bytes per splat of traffic less per iteration. */
     const float* pre_Tcw;
     float* means_cam_out;
+    /* The mapping loop's activations inside the projection kernel (new capability; NULL = opacities / scales / rotations are what the reference's
+     * rasterizer takes). With `raw` (a HOST struct) those three hold the RAW parameters of Gaussian::GaussianOptimizer — logit opacities, log-scales,
+     * un-normalised quaternions — and the kernel applies gsr_map_prepare's activations itself (sigmoid, exp, torch's normalize: the same operations),
+     * stores the activated values where gsr_backward will read them, and — reg_partial != NULL — writes gsr_map_prepare's rows of the scale
+     * regularisers' three sums ([3 * ceil(P / 256)], the layout gsr_map_loss_finish takes). Needs scales + rotations (not cov3D_precomp). */
+    const struct gsr_raw_outputs* raw;
 } gsr_forward_args;
 
 /* forward stages, in launch order */

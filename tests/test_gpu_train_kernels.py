@@ -670,3 +670,41 @@ def test_camera_transform_inside_the_projection_kernel_is_gsr_to_camera_bit_for_
     # rejected before any launch: a transform without a place for the camera-frame means
     with pytest.raises(Exception):
         gsr.forward_ws(s, ws, Xw, t(sc.opacities), dual=True, pre_Tcw=T, means_cam_out=None, **kw)
+
+
+def test_activations_inside_the_projection_kernel_are_gsr_map_prepare_bit_for_bit(gsr, syn):
+    """gsr_forward_args.raw (+ pre_Tcw): raw parameters in -> the render, the radii / tile lists, the activated tensors the backward takes and the scale
+    regularisers' partial sums that gsr_map_prepare followed by the plain forward produce (what a mapping iteration did before)."""
+    import util
+    cam = syn.make_camera(**syn.TUM1)
+    sc = syn.make_scene(30000, cam, seed=12, scale_mult=3.0, frac_behind=0.1, frac_offscreen=0.2)
+    s = gsr.capi.Settings.from_camera(cam)
+    dev = s.viewmatrix.device
+    t = lambda x: torch.as_tensor(x, dtype=torch.float32, device=dev).contiguous()
+    n = sc.means3D.shape[0]
+    T = t(util.pose(0.04, (0.01, 0.02, -0.03)))
+    Xw = ((t(sc.means3D) - T[:3, 3]) @ T[:3, :3]).contiguous()
+    op = t(sc.opacities).reshape(-1)
+    logit = torch.log(op / (1 - op)).contiguous(); quat = (t(sc.rotations) * 1.7).contiguous()
+    ls = torch.log(t(sc.scales).abs().clamp_min(1e-6)).contiguous()      # (the scene's splats behind the camera carry negative scales)
+    p = gsr.capi._p
+    L = gsr.lib()
+    mc = torch.empty((n, 3), device=dev); o1 = torch.empty((n,), device=dev); s1 = torch.empty((n, 3), device=dev); r1 = torch.empty((n, 4), device=dev)
+    rows = (n + 255) // 256
+    reg1 = torch.empty((3 * rows,), device=dev)
+    limit = float(torch.quantile(torch.exp(ls).reshape(-1), 0.8))      # some scales beyond the limit
+    gsr.capi._check(L.gsr_map_prepare(n, p(Xw), p(logit), p(ls), p(quat), p(T), p(mc), p(o1), p(s1), p(r1), limit, 5.0, 10.0, p(reg1), None, None))
+    ws = gsr.capi.Workspace(n, cam.width, cam.height, max_rendered=6_000_000, device=dev)
+    a = gsr.forward_ws(s, ws, mc, o1.reshape(-1, 1), colors=t(sc.colors), scales=s1, rotations=r1, dual=True)
+    ref = [x.clone() for x in (a.color, a.depth, a.radii, a.ds)]
+    da = gsr.debug_export(a)
+    mc2 = torch.zeros_like(mc); o2 = torch.zeros_like(o1); s2 = torch.zeros_like(s1); r2 = torch.zeros_like(r1); reg2 = torch.zeros_like(reg1)
+    b = gsr.forward_ws(s, ws, Xw, logit.reshape(-1, 1), colors=t(sc.colors), scales=ls, rotations=quat, dual=True, pre_Tcw=T, means_cam_out=mc2,
+                       raw=(o2, s2, r2, limit, reg2))
+    db = gsr.debug_export(b)
+    for x, y in ((mc, mc2), (o1, o2), (s1, s2), (r1, r2), (reg1, reg2)):
+        assert torch.equal(x, y)
+    assert float(reg1.reshape(-1, 3)[:, 0].sum()) > 0                   # (the regularisers are not vacuous here)
+    for x, y in zip(ref, (b.color, b.depth, b.radii, b.ds)):
+        assert torch.equal(x, y)
+    np.testing.assert_array_equal(da["ranges"], db["ranges"]); np.testing.assert_array_equal(da["point_list"], db["point_list"])
