@@ -690,11 +690,14 @@ int gsr_map_prepare(size_t n, const float* xyz, const float* logit, const float*
                     float* means_cam, float* opacities, float* scales, float* rotations, float reg_limit, float w_long, float w_scalar,
                     float* reg_partial, float* reg_out, void* stream)
 {
-    if ((means_cam && (!xyz || !Tcw)) || (opacities && !logit) || ((scales || reg_partial) && !log_scales) || (rotations && !unnorm_quat) ||
+    // (log_scales == NULL with reg_partial and reg_out: the partial sums are already there — the projection kernel wrote them, gsr_forward_args.raw — and only
+    // their finish is wanted)
+    const bool finish_only = !log_scales && reg_partial && reg_out && !means_cam && !opacities && !scales && !rotations;
+    if ((means_cam && (!xyz || !Tcw)) || (opacities && !logit) || ((scales || reg_partial) && !log_scales && !finish_only) || (rotations && !unnorm_quat) ||
         (reg_out && !reg_partial) || (n + 255) / 256 > 0x7FFFFFFFu)
         return GSR_EINVAL;
     const unsigned rows = (unsigned)((n + 255) / 256);
-    if (n > 0)
+    if (n > 0 && !finish_only)
         hipLaunchKernelGGL(gsr::K_map_prepare, dim3(rows), dim3(256), 0, (hipStream_t)stream, n, xyz, logit, log_scales, unnorm_quat, Tcw, means_cam,
                            opacities, scales, rotations, reg_limit, reg_partial);
     GSR_LAUNCHED();

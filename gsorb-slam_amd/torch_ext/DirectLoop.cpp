@@ -427,12 +427,15 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
     if (shard_ && !cfg_.fused_loss) throw std::runtime_error("the sharded loop needs LoopConfig::fused_loss");
     // (the unsharded loop with the fused loss: camera transform, activations and the regularisers' partial sums ride in the projection kernel; the other
     // configurations finish the regularisers' sums right here, in gsr_map_prepare's second launch)
-    const bool in_projection = cfg_.fused_loss && !shard_ && n > 0;
+    const bool in_projection = cfg_.fused_loss && n > 0;
     if (n == 0) d.reg_tot.zero_();
     else if (!in_projection)
         chk(gsr_map_prepare(n, f(xyz), f(logit_opacities), f(log_scales), f(unnorm_quat), f(d.Tcw), f(d.mc), f(d.opac), f(d.scales), f(d.rots), limit, wl, wsc,
                             f(d.reg_partial), shard_ ? f(d.reg_tot) : cfg_.fused_loss ? nullptr : f(d.reg_out), st), "gsr_map_prepare");
     direct_forward_(in_projection, in_projection, limit);
+    // (sharded: the cell's three regulariser sums go into the all-reduce behind the composite's planes — the finish of the rows the projection kernel wrote)
+    if (in_projection && shard_)
+        chk(gsr_map_prepare(n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, limit, wl, wsc, f(d.reg_partial), f(d.reg_tot), st), "gsr_map_prepare (finish)");
     if (shard_) { shard_composite_forward_(d.order_stale, true); d.order_stale = false; }
     // Render.cc:436-471: lam * L1 + (1 - lam) * (1 - SSIM), masked depth L1, masked surface-depth L1 (no gradient), the regularisers
     const float w3[3] = {(float)(cfg_.im_weight_mapping * cfg_.lam), (float)cfg_.depth_weight_mapping, (float)cfg_.sur_depth_weight_mapping};

@@ -329,6 +329,7 @@ int gsr_pixel_loss_backward_add(const float* image, const float* depth, const fl
  *                    scales [n,3] = exp(log_scales), rotations [n,4] = q / max(|q|, 1e-12); any output may be NULL. With
  *                    reg_partial (scratch of 3 * ((n + 255) / 256) floats; reg_out = NULL: the rows only, for gsr_map_loss_finish) and reg_out [4] it also evaluates the two scale
  *                    regularisers (gsr_scale_reg's out: {sum w, reg_scalar, sum w (max - min), w_long * reg_long + w_scalar * reg_scalar}).
+ *                    log_scales = NULL with reg_partial and reg_out and no other output: only the finish of rows that are already there (gsr_forward_args.raw wrote them).
  *   gsr_map_update   from the rasterizer's gradients (gsr_backward on camera-frame means with an identity view matrix: dL_dmean3D is
  *                    dL/dmeans_cam) to an Adam step of the five raw tensors, in place: dL/dxyz = dmc R; dL/dlogit = dopac * o (1 - o);
  *                    dL/dlog_scales = dscale * scale + the regularisers' gradient (reg_out != NULL); dL/dq through the normalisation;
