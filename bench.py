@@ -403,18 +403,24 @@ def shard_step(a, gsr, td, rank, world, dev):
             td.barrier()
         torch.cuda.synchronize()
 
+    batches = []
+
     def timed(fn):
         fn(max(a.shard_steps, 20))      # warm-up: clocks, and RCCL's first launches (measured: the first 20 iterations after 3 run 8 % slow)
-        barrier()
-        t0 = time.perf_counter()
-        ran = fn(max(a.shard_steps, 1))
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            td.all_reduce(tt, op=td.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt / max(ran, 1) * 1e3, ran
+        per = []
+        for _ in range(3):              # three timed batches, the MEDIAN is reported (a batch now and then runs 10-15 % slow behind a one-rank RCCL group: all three are in `batches_ms`)
+            barrier()
+            t0 = time.perf_counter()
+            ran = fn(max(a.shard_steps, 1))
+            barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+                td.all_reduce(tt, op=td.ReduceOp.MAX)
+                dt = float(tt.item())
+            per.append(dt / max(ran, 1) * 1e3)
+        batches.append([round(x, 4) for x in per])
+        return sorted(per)[1], ran
 
     map_ms, n = timed(lambda k: len(loop.map_frame(rgb, depth, T, k)))      # SlamLoop::MapFrame: the losses are read back once, like Render::RenderForFrame
     track_ms, ran = timed(lambda k: len(loop.track(rgb, depth, T0, k)[0]))  # (it stops early only if the loss stalls: what ran is what is counted)
@@ -436,7 +442,7 @@ def shard_step(a, gsr, td, rank, world, dev):
             "scaling": "strong", "total_splats": a.splats, "splats_per_rank": int(idx.numel()), "width": W, "height": H,
             "partition": f"k-d cells x{world} (sharded.KdPartition)", "backend": backend, "rccl_ranks": (td.get_world_size() if world > 1 else (1 if own_group else 0)),
             "mapping_ms_per_iter": map_ms, "tracking_ms_per_iter": track_ms, "tracking_iterations_run": ran,
-            "unsharded_same_scene": same, "warmup_iters": max(a.shard_steps, 20), "transport": transport,
+            "unsharded_same_scene": same, "warmup_iters": max(a.shard_steps, 20), "transport": transport, "batches_ms": batches,
             "mapping_splats_pixels_per_s": 2 * a.splats * W * H / (map_ms * 1e-3),
             "collectives_per_mapping_iter": {"all_gather_bytes_sent_per_rank": 3 * plane, "all_reduce_bytes": 4 * plane, "all_reduce_floats": 3},
             "collectives_per_tracking_iter": {"all_gather_bytes_sent_per_rank": 3 * plane, "all_reduce_bytes": 4 * plane, "all_reduce_floats": 512 * 12},
