@@ -20,7 +20,7 @@ EXPORTS = ["gsr_forward", "gsr_forward_ws", "gsr_ws_status", "gsr_backward", "gs
            "gsr_debug_export", "gsr_acc_view", "gsr_knn_bytes", "gsr_dist2", "gsr_ssim_partials", "gsr_ssim_forward", "gsr_ssim_backward",
            "gsr_adam_step", "gsr_pose_grad", "gsr_to_camera", "gsr_pose_from_quat", "gsr_pose_from_quat_backward",
            "gsr_pixel_loss", "gsr_pixel_loss_backward", "gsr_pixel_loss_backward_add", "gsr_track_loss", "gsr_scale_reg", "gsr_scale_reg_backward",
-           "gsr_map_prepare", "gsr_map_update", "gsr_map_loss_total", "gsr_map_loss_forward", "gsr_map_loss_finish", "gsr_map_loss_backward", "gsr_pose_update", "gsr_pose_step", "gsr_composite_forward", "gsr_composite_backward_local",
+           "gsr_map_prepare", "gsr_map_update", "gsr_map_loss_total", "gsr_map_loss_forward", "gsr_map_loss_finish", "gsr_map_loss_backward", "gsr_pose_update", "gsr_pose_step", "gsr_pose_finish", "gsr_composite_forward", "gsr_composite_backward_local",
            "gsr_composite_backward_occlusion", "gsr_shard_order", "gsr_reproj_loss", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
 
 
@@ -85,7 +85,7 @@ class MapUpdateArgs(C.Structure):
 
 
 class PoseStepArgs(C.Structure):
-    _fields_ = [("means_world", C.c_void_p), ("update", C.c_void_p)]
+    _fields_ = [("means_world", C.c_void_p), ("update", C.c_void_p), ("sums_only", C.c_int)]
 
 
 class PoseUpdateArgs(C.Structure):
@@ -161,6 +161,8 @@ def lib():
     L.gsr_scale_reg_backward.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.gsr_pixel_loss_backward_add.restype = C.c_int
     L.gsr_pixel_loss_backward_add.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float)] + [C.c_void_p] * 6
+    L.gsr_pose_finish.restype = C.c_int
+    L.gsr_pose_finish.argtypes = [C.POINTER(PoseUpdateArgs), C.c_void_p, C.c_void_p, C.c_void_p]
     L.gsr_pose_step.restype = C.c_int
     L.gsr_pose_step.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(PoseUpdateArgs), C.c_void_p, C.c_void_p]
     L.gsr_track_loss.restype = C.c_int

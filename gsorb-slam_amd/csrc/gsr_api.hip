@@ -383,8 +383,8 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
         if (rc != GSR_OK) return rc;
     }
     if (a->P == 0) { // src/Rasterizer.cu:263. An empty map still owes the tracking loop its bookkeeping: loss history, best pose, the next Tcw
-        if (a->fused_pose_step && ((a->stages ? a->stages : GSR_STAGE_SPLAT) & GSR_STAGE_SPLAT)) {
-            hipLaunchKernelGGL(gsr::K_pose_finish, dim3(1), dim3(64), 0, st, pu, const_cast<float*>(a->fused_pose_step->update->partial));
+        if (a->fused_pose_step && !a->fused_pose_step->sums_only && ((a->stages ? a->stages : GSR_STAGE_SPLAT) & GSR_STAGE_SPLAT)) {
+            hipLaunchKernelGGL(gsr::K_pose_finish, dim3(1), dim3(64), 0, st, pu, const_cast<float*>(a->fused_pose_step->update->partial), (float*)nullptr);
             GSR_LAUNCHED();
         }
         return GSR_OK;
@@ -449,7 +449,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
             k.X = ps->means_world; k.acc = const_cast<float*>(ps->update->partial);
             if (stages & GSR_STAGE_REZERO) hipLaunchKernelGGL((gsr::K_splat_bwd_pose<true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, k);
             else hipLaunchKernelGGL((gsr::K_splat_bwd_pose<false>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, k);
-            hipLaunchKernelGGL(gsr::K_pose_finish, dim3(1), dim3(64), 0, st, u, k.acc);
+            if (!ps->sums_only) hipLaunchKernelGGL(gsr::K_pose_finish, dim3(1), dim3(64), 0, st, u, k.acc, (float*)nullptr);
         } else if (stages & GSR_STAGE_REZERO) hipLaunchKernelGGL((gsr::K_splat_bwd<true, false>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
         else hipLaunchKernelGGL((gsr::K_splat_bwd<false, false>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
         GSR_LAUNCHED();
@@ -837,6 +837,17 @@ int gsr_pose_update(const gsr_pose_update_args* a, void* stream)
     const int rc = make_pose_update(a, &u);
     if (rc != GSR_OK) return rc;
     hipLaunchKernelGGL(gsr::K_pose_update, dim3(1), dim3(64), 0, (hipStream_t)stream, u);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_pose_finish(const gsr_pose_update_args* a, float* acc_rows, float* sums_out, void* stream)
+{
+    if (!acc_rows) return GSR_EINVAL;
+    gsr::PoseUpdate u;
+    const int rc = make_pose_update(a, &u);
+    if (rc != GSR_OK) return rc;
+    hipLaunchKernelGGL(gsr::K_pose_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, u, acc_rows, sums_out);
     GSR_LAUNCHED();
     return GSR_OK;
 }

@@ -1532,7 +1532,7 @@ K_splat_bwd_pose(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, PoseSt
 }
 // adds the accumulator rows up, takes the pose step, leaves the rows zero for the next backward
 __global__ void __launch_bounds__(64)
-K_pose_finish(PoseUpdate u, float* acc)
+K_pose_finish(PoseUpdate u, float* acc, float* sums_out)
 {
     static_assert(GSR_POSE_ACC_ROWS == 64, "one accumulator row per lane");
     float r[12];
@@ -1543,6 +1543,7 @@ K_pose_finish(PoseUpdate u, float* acc)
     float tot[12];
 #pragma unroll
     for (int q = 0; q < 12; q++) tot[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r[q]), 63));
+    if (sums_out && threadIdx.x < 12) sums_out[threadIdx.x] = tot[threadIdx.x];
     pose_update_body<false>(u, 0, tot);
 }
 

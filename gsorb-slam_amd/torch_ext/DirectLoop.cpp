@@ -20,8 +20,8 @@
 //   gsr_shard_order (the cells front to back for this pose) -> gsr_forward_ws (own shard) -> ALL-GATHER (silhouette, surface depth: 2 planes) ->
 //   gsr_composite_forward -> ALL-REDUCE (the four premultiplied planes) -> the loss kernels on the composite [mapping: ALL-REDUCE of the three
 //   regulariser sums before gsr_map_loss_finish] -> gsr_composite_backward_local -> ALL-GATHER (g . L: 1 plane) -> gsr_composite_backward_occlusion
-//   -> gsr_backward on the layer's gradient [mapping: with the Adam step fused; tracking: gsr_pose_grad -> ALL-REDUCE of the pose rows (24 KB)
-//   -> gsr_pose_update]. No per-splat data crosses ranks: north_star's "all-reduce on pose / loss gradients only".
+//   -> gsr_backward on the layer's gradient [mapping: with the Adam step fused; tracking: its per-splat stage adds the cell's pose sums to 64 accumulator rows
+//   -> ALL-REDUCE of the rows (3 KB) -> gsr_pose_finish]. No per-splat data crosses ranks: north_star's "all-reduce on pose / loss gradients only".
 #include "SlamLoop.h"
 
 #include <c10/core/DeviceGuard.h>
@@ -80,6 +80,7 @@ struct SlamLoop::Direct {
     // sharded (SetShard): the composite of all ranks' layers and what its backward needs
     c10::intrusive_ptr<c10d::ProcessGroup> pg;
     int rank = 0, world = 1;
+    torch::Tensor last_sums;                                             // [12] the pose sums of the sharded loop's last tracking step
     torch::Tensor step_pose;                                             // ShardRenderStep: the pose tensor of the previous call
     bool order_stale = true;                                             // the pose changed since gsr_shard_order ran
     bool staged = false;                                                 // the group cannot move device tensors (gloo): through the host
@@ -284,7 +285,7 @@ void SlamLoop::ensure_direct_(int64_t history_len)
         d.proj = rasterizer_.raster_settings_.projmatrix.to(dev_, torch::kFloat32).contiguous();
         d.pose = torch::zeros({7}, fo); d.pose_moments = torch::zeros({14}, fo); d.best = torch::zeros({8}, fo);
         d.tickets = torch::zeros({2 * GSR_TICKET_WORDS}, fo.dtype(torch::kInt32));
-        d.pose_acc = torch::zeros({64, 12}, fo);
+        d.pose_acc = torch::zeros({64, 12}, fo); d.last_sums = torch::zeros({12}, fo);
     }
     if (d.n != n) { // per map size
         d.n = n;
@@ -585,7 +586,15 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
         __atomic_store_n(reinterpret_cast<uint32_t*>(d.posted + it), kNotPosted, __ATOMIC_RELEASE);
         u.lr = cfg_.lr_cam_quat; u.beta1 = 0.9; u.beta2 = 0.999; u.eps = 1e-15; u.step = ++step;
         uint32_t* const tickets = reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()) + GSR_TICKET_WORDS;
-        if (shard_) { // every rank holds the pose sums of its shard: the rows are summed over the ranks before the (replicated) pose step
+        if (shard_ && cfg_.fused_update) { // the shard's pose sums come out of the backward's per-splat stage (accumulator rows), are summed over the ranks, and a one-wave kernel takes the (replicated) step
+            shard_composite_backward_();
+            u.partial = f(d.pose_acc);
+            reproj(it, f(d.pose_acc)); // (the rows are zero here; the term enters every rank's row with weight 1 / world)
+            gsr_pose_step_args ps{f(xyz), &u, 1};
+            direct_backward_(true, true, nullptr, &ps);
+            d_->all_reduce(d.pose_acc);
+            chk(gsr_pose_finish(&u, f(d.pose_acc), f(d.last_sums), st), "gsr_pose_finish");
+        } else if (shard_) { // every rank holds the pose sums of its shard: the rows are summed over the ranks before the (replicated) pose step
             shard_composite_backward_();
             direct_backward_(true, true, nullptr, nullptr);
             if (d.n > 0) chk(gsr_pose_grad(f(xyz), f(d.d_mc), (size_t)d.n, f(d.Tcw), f(d.pose_partial), nullptr, st), "gsr_pose_grad");
@@ -596,7 +605,7 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
         } else if (cfg_.fused_update) { // the backward's per-splat stage forms the pose sums (into accumulator rows that are zero between launches), a one-wave kernel takes the step: no dL/dmeans tensor
             u.partial = f(d.pose_acc);
             reproj(it, f(d.pose_acc)); // (the accumulator rows are zero here: the per-splat stage adds to them, the one-wave kernel behind it sums them)
-            const gsr_pose_step_args ps{f(xyz), &u};
+            const gsr_pose_step_args ps{f(xyz), &u, 0};
             direct_backward_(true, true, nullptr, &ps); // the [z, 1, 0] colours are detached while tracking (Render.cc:949-981)
         } else {
             direct_backward_(true, true, nullptr, nullptr);
@@ -628,6 +637,7 @@ int SlamLoop::shard_rank_() const { return d_ ? d_->rank : 0; }
 torch::Tensor SlamLoop::LastPoseSums() const
 {
     if (!d_ || !d_->pose_partial.defined()) throw std::runtime_error("LastPoseSums: no tracking iteration yet");
+    if (shard_ && cfg_.fused_update) return d_->last_sums.clone(); // (the sharded loop's step kernel leaves the twelve sums it used there)
     return d_->pose_partial.sum(0);
 }
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 8 /* 8: gsr_forward_args.pre_Tcw / means_cam_out / raw appended (the camera transform and the map's activations inside the projection kernel); 7: gsr_composite_* take the plane count of the gathered buffer, gsr_shard_order and gsr_reproj_loss added; 6: gsr_track_loss, gsr_pose_step, gsr_backward_args.fused_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
+#define GSR_ABI_VERSION 8 /* 8: gsr_forward_args.pre_Tcw / means_cam_out / raw appended (the camera transform and the map's activations inside the projection kernel), gsr_pose_step_args.sums_only and gsr_pose_finish added; 7: gsr_composite_* take the plane count of the gathered buffer, gsr_shard_order and gsr_reproj_loss added; 6: gsr_track_loss, gsr_pose_step, gsr_backward_args.fused_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
                            * 5: gsr_map_prepare / gsr_map_update / gsr_map_loss_total / gsr_pose_update / gsr_pixel_loss_backward_add / gsr_composite_* added, GSR_LOSS_PARTIALS 256 -> 1024 */
 
 #define GSR_OK 0
@@ -401,7 +401,12 @@ typedef struct gsr_pose_step_args {
     const float* means_world;                  /* [P,3] the world-frame means (the rasterizer's means3D are their camera-frame images) */
     const struct gsr_pose_update_args* update; /* as for gsr_pose_update; update->partial: 64 * 12 floats that are ZERO between calls (zero them once:
                                                 * the workgroups of the per-splat stage add their sums there, the step leaves them zero) */
+    int sums_only;                             /* 1: the backward only ADDS the pose sums to update->partial's rows and takes no step (a sharded run sums the
+                                                * ranks' rows first: all-reduce them, then gsr_pose_finish) */
 } gsr_pose_step_args;
+/* The step behind a backward with fused_pose_step.sums_only: adds the 64 accumulator rows up, takes gsr_pose_update's step with the total and leaves
+ * the rows zero; sums_out (NULL or 12 DEVICE floats): the twelve pose sums the step used (dL/dR row-major, dL/dt). One single-wave launch. */
+int gsr_pose_finish(const struct gsr_pose_update_args* args, float* acc_rows, float* sums_out, void* stream);
 int gsr_pose_step(const float* means3D, const float* dL_dmeans_cam, size_t n, const gsr_pose_update_args* args, uint32_t* ticket, void* stream);
 /* The feature reprojection term of the tracking loss, weight * Lrpj (src/Render.cc:1031-1096, _featureWeightTracking; Examples/RGB-D/replica.yaml: 0.1):
  * Lrpj = sum over the inlier matches of inv_sigma2 * |K (Xc / Xc.z) - obs|^2, Xc = R Xw + t under the DEVICE pose Tcw (the reference freezes its
