@@ -443,8 +443,10 @@ def test_backward_with_the_pose_step_inside_equals_backward_plus_pose_step(gsr, 
     mk = lambda: dict(pose=torch.cat([q0, t0]).cuda(), mom=torch.zeros(14, device="cuda"), best=torch.tensor([float("inf")] + [0.0] * 7, device="cuda"),
                       hist=torch.zeros(4, device="cuda"), Tcw=torch.eye(4, device="cuda").reshape(16).clone(),
                       part=torch.full((512, 12), 9.0, device="cuda"))
-    A, B = mk(), mk()
+    A, B, D = mk(), mk(), mk()
     B["part"].zero_()                                                          # (the fused step's accumulator rows: zero between calls)
+    D["part"].zero_()                                                          # (third leg: the sums alone out of the backward, the step by gsr_pose_finish — a sharded run's form)
+    sums = torch.zeros(12, device="cuda")
     tickets = torch.zeros(144, dtype=torch.int32, device="cuda")
     for it, lv in enumerate([3.0, float("nan"), 2.5]):
         g = torch.Generator().manual_seed(it)
@@ -455,7 +457,7 @@ def test_backward_with_the_pose_step_inside_equals_backward_plus_pose_step(gsr, 
         a = gsr.capi.PoseUpdateArgs(p(A["pose"]), p(A["mom"]), p(A["best"]), p(A["hist"][it:]), p(A["Tcw"]), p(A["part"]), p(loss), None, 4e-4, 0.9, 0.999, 1e-15, it + 1)
         gsr.capi._check(gsr.lib().gsr_pose_step(p(X), p(gr.dL_dmeans3D), sc.P, C.byref(a), p(tickets), gsr.capi._stream()))
         b = gsr.capi.PoseUpdateArgs(p(B["pose"]), p(B["mom"]), p(B["best"]), p(B["hist"][it:]), p(B["Tcw"]), p(B["part"]), p(loss), None, 4e-4, 0.9, 0.999, 1e-15, it + 1)
-        ps = gsr.capi.PoseStepArgs(p(X), C.cast(C.pointer(b), C.c_void_p))
+        ps = gsr.capi.PoseStepArgs(p(X), C.cast(C.pointer(b), C.c_void_p), 0)
         st2 = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
         gr2 = gsr.backward(st2, dpix, fused_pose_step=ps)
         torch.cuda.synchronize()
@@ -463,7 +465,21 @@ def test_backward_with_the_pose_step_inside_equals_backward_plus_pose_step(gsr, 
         assert (gr2.dL_dmeans3D - gr.dL_dmeans3D).abs().max() <= 1e-5 * gr.dL_dmeans3D.abs().max()      # (still written when given; atomics' order only)
         for k in ("pose", "mom", "Tcw", "best"):
             assert (A[k] - B[k]).abs().max() <= 1e-5 * max(1e-6, float(A[k].abs().max())), (it, k)
+        d = gsr.capi.PoseUpdateArgs(p(D["pose"]), p(D["mom"]), p(D["best"]), p(D["hist"][it:]), p(D["Tcw"]), p(D["part"]), p(loss), None, 4e-4, 0.9, 0.999, 1e-15, it + 1)
+        pd = gsr.capi.PoseStepArgs(p(X), C.cast(C.pointer(d), C.c_void_p), 1)
+        pose_before = D["pose"].clone()
+        st3 = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+        gsr.backward(st3, dpix, fused_pose_step=pd)
+        torch.cuda.synchronize()
+        assert torch.equal(D["pose"], pose_before) and float(D["part"][:64].abs().sum()) > 0.0        # (no step yet: the rows hold the sums)
+        rows = D["part"][:64].sum(0)
+        gsr.capi._check(gsr.lib().gsr_pose_finish(C.byref(d), p(D["part"]), p(sums), gsr.capi._stream()))
+        torch.cuda.synchronize()
+        assert float(D["part"][:64].abs().sum()) == 0.0 and (sums - rows).abs().max() <= 1e-5 * max(1e-6, float(rows.abs().max()))
+        for k in ("pose", "mom", "Tcw", "best"):
+            assert (A[k] - D[k]).abs().max() <= 1e-5 * max(1e-6, float(A[k].abs().max())), (it, k, "sums_only + gsr_pose_finish")
     assert torch.equal(A["hist"].isnan(), B["hist"].isnan()) and torch.equal(A["hist"].nan_to_num(0.0), B["hist"].nan_to_num(0.0))
+    assert torch.equal(A["hist"].isnan(), D["hist"].isnan()) and torch.equal(A["hist"].nan_to_num(0.0), D["hist"].nan_to_num(0.0))
 
 
 def _fused_update_setup(gsr, syn, n=20_000):
