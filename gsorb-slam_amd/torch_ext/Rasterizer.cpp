@@ -144,17 +144,22 @@ RasterizeGaussiansBackwardStaged(const torch::Tensor& background, const torch::T
                                           geomBuffer, R, binningBuffer, imageBuffer, stages, false);
 }
 
+namespace {
+// `full`: the reference's return values exactly (src/Rasterizer.cu:253-293) — dL_dcov3D [P,6] is computed on the scales + rotations path too
+// (there it is the intermediate computeCov2DCUDA hands to computeCov3D's backward, backward.cu:144-274 -> :278-341). false: the lean form the
+// autograd nodes use — with scales + rotations nothing consumes dL_dcov3D (the node hands it to the absent cov3Ds_precomp input), so it is
+// neither allocated nor stored: [0,6].
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
            torch::Tensor>
-RasterizeGaussiansPairBackward(const torch::Tensor& background, const torch::Tensor& means3D,
-                               const torch::Tensor& radii, const torch::Tensor& colors, const torch::Tensor& scales,
-                               const torch::Tensor& rotations, const float scale_modifier,
-                               const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
-                               const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
-                               const torch::Tensor& dL_dout_color, const torch::Tensor& dL_dout_ds, const torch::Tensor& sh,
-                               const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
-                               const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const int stages,
-                               const bool detach_depth_color)
+backward_impl(const torch::Tensor& background, const torch::Tensor& means3D,
+              const torch::Tensor& radii, const torch::Tensor& colors, const torch::Tensor& scales,
+              const torch::Tensor& rotations, const float scale_modifier,
+              const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+              const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+              const torch::Tensor& dL_dout_color, const torch::Tensor& dL_dout_ds, const torch::Tensor& sh,
+              const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
+              const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const int stages,
+              const bool detach_depth_color, const bool full)
 {
     const int P = (int)means3D.size(0);
     const int H = (int)dL_dout_color.size(1), W = (int)dL_dout_color.size(2);
@@ -176,9 +181,7 @@ RasterizeGaussiansPairBackward(const torch::Tensor& background, const torch::Ten
     // except for the tensors the chosen parameterisation leaves untouched
     torch::Tensor dL_dmeans3D = torch::empty({P, 3}, fopt), dL_dmeans2D = torch::empty({P, 3}, fopt),
                   dL_dcolors = torch::empty({P, kChannels}, fopt), dL_dopacity = torch::empty({P, 1}, fopt),
-                  // dL_dcov3D is an intermediate of the scale / rotation path: with scales + rotations nothing consumes it
-                  // (the reference's autograd node hands it to the absent cov3Ds_precomp input), so it is not computed then
-                  dL_dcov3D = has_sr ? torch::empty({0, 6}, fopt) : torch::empty({P, 6}, fopt), dL_dsh = torch::empty({P, M, 3}, fopt),
+                  dL_dcov3D = (has_sr && !full) ? torch::empty({0, 6}, fopt) : torch::empty({P, 6}, fopt), dL_dsh = torch::empty({P, M, 3}, fopt),
                   dL_dscales = has_sr ? torch::empty({P, 3}, fopt) : torch::zeros({P, 3}, fopt),
                   dL_drotations = has_sr ? torch::empty({P, 4}, fopt) : torch::zeros({P, 4}, fopt);
     if (P != 0) {
@@ -197,7 +200,7 @@ RasterizeGaussiansPairBackward(const torch::Tensor& background, const torch::Ten
         a.dL_dpix = fptr(gin);
         a.dL_dmean2D = dL_dmeans2D.data_ptr<float>(); a.dL_dconic = nullptr;
         a.dL_dopacity = dL_dopacity.data_ptr<float>(); a.dL_dcolor = dL_dcolors.data_ptr<float>();
-        a.dL_dmean3D = dL_dmeans3D.data_ptr<float>(); a.dL_dcov3D = has_sr ? nullptr : dL_dcov3D.data_ptr<float>();
+        a.dL_dmean3D = dL_dmeans3D.data_ptr<float>(); a.dL_dcov3D = dL_dcov3D.numel() ? dL_dcov3D.data_ptr<float>() : nullptr;
         a.dL_dsh = M ? dL_dsh.data_ptr<float>() : nullptr;
         a.dL_dscale = has_sr ? dL_dscales.data_ptr<float>() : nullptr;
         a.dL_drot = has_sr ? dL_drotations.data_ptr<float>() : nullptr;
@@ -211,9 +214,28 @@ RasterizeGaussiansPairBackward(const torch::Tensor& background, const torch::Ten
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
                            dL_drotations);
 }
+} // namespace
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor>
+RasterizeGaussiansPairBackward(const torch::Tensor& background, const torch::Tensor& means3D,
+                               const torch::Tensor& radii, const torch::Tensor& colors, const torch::Tensor& scales,
+                               const torch::Tensor& rotations, const float scale_modifier,
+                               const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+                               const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                               const torch::Tensor& dL_dout_color, const torch::Tensor& dL_dout_ds, const torch::Tensor& sh,
+                               const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
+                               const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const int stages,
+                               const bool detach_depth_color)
+{
+    return backward_impl(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+                         tan_fovx, tan_fovy, dL_dout_color, dL_dout_ds, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
+                         stages, detach_depth_color, /*full=*/false);
+}
 
 // The reference's stateless entry point: any number of calls per forward (stages 0 = blend + per-splat +
-// re-zero of the accumulators).
+// re-zero of the accumulators), and the reference's return values: dL_dcov3D is [P,6] and filled whichever
+// parameterisation the caller uses (src/Rasterizer.cu:253-261,265-293).
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
            torch::Tensor>
 RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Tensor& means3D,
@@ -225,9 +247,9 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
                                const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer)
 {
-    return RasterizeGaussiansBackwardStaged(background, means3D, radii, colors, scales, rotations, scale_modifier,
-                                            cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh,
-                                            degree, campos, geomBuffer, R, binningBuffer, imageBuffer, 0);
+    return backward_impl(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+                         tan_fovx, tan_fovy, dL_dout_color, torch::Tensor(), sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
+                         0, false, /*full=*/true);
 }
 
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix)

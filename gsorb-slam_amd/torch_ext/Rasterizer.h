@@ -30,7 +30,8 @@ RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& mea
                        const float tan_fovy, const int image_height, const int image_width, const torch::Tensor& sh,
                        const int degree, const torch::Tensor& campos, const bool prefiltered, const int device_num);
 
-// include/Rasterizer.cuh:50-71 (20 parameters -> 8 gradient tensors)
+// include/Rasterizer.cuh:50-71 (20 parameters -> 8 gradient tensors, the reference's shapes: dL_dcov3D is [P,6] and filled
+// whichever parameterisation is used, src/Rasterizer.cu:253-261,265-293); stateless: any number of calls per forward
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
            torch::Tensor>
 RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Tensor& means3D,
@@ -43,7 +44,9 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                                const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer);
 
 // RasterizeGaussiansBackwardCUDA with an explicit stage mask (gsr_backward_args.stages, include/gsr.h): lets a
-// caller that runs one backward per forward skip the re-zero of the per-splat accumulators.
+// caller that runs one backward per forward skip the re-zero of the per-splat accumulators. This is the opt-in LEAN form the
+// autograd nodes use: with scales + rotations nothing consumes dL_dcov3D (the node would hand it to the absent cov3Ds_precomp
+// input), so it is returned as [0,6] and never stored (40 B per Gaussian of traffic less).
 std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
            torch::Tensor>
 RasterizeGaussiansBackwardStaged(const torch::Tensor& background, const torch::Tensor& means3D,

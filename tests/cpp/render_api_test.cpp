@@ -89,6 +89,22 @@ int main(int argc, char** argv)
     write_t(out, xyz.grad()); write_t(out, rgb.grad()); write_t(out, unnorm_quat.grad());
     write_t(out, logit_opac.grad()); write_t(out, log_scales.grad()); write_t(out, Tcw.grad());
     write_t(out, mean2D.grad()); write_t(out, vis.to(torch::kInt32));
+    if (direct) {
+        // the reference-named FREE functions (include/Rasterizer.cuh:24-71, src/Rasterizer.cu:136-305), called the way _RasterizeGaussians calls
+        // them: the backward returns the reference's eight tensors, dL_dcov3D [P,6] filled on the scales + rotations path too
+        torch::NoGradGuard ng;
+        const torch::Tensor none;
+        auto fw = RasterizeGaussiansCUDA(s.bg, mean3D.detach(), rgb.detach(), opacities.detach(), scales.detach(), norm_qua.detach(), 1.0f, none,
+                                         s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, (int)H, (int)W, none, 0, s.camera_center, false, 0);
+        auto bw = RasterizeGaussiansBackwardCUDA(s.bg, mean3D.detach(), std::get<2>(fw), rgb.detach(), scales.detach(), norm_qua.detach(), 1.0f, none,
+                                                 s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, G, none, 0, s.camera_center, std::get<3>(fw),
+                                                 std::get<0>(fw), std::get<4>(fw), std::get<5>(fw));
+        const auto& dcov = std::get<4>(bw);
+        int32_t shape[2] = {(int32_t)dcov.size(0), (int32_t)dcov.size(1)};
+        out.write(reinterpret_cast<const char*>(shape), sizeof(shape));
+        write_t(out, dcov);
+        write_t(out, std::get<6>(bw)); // dL_dscales of the same call
+    }
     std::printf("ok P=%ld loss=%f\n", (long)P, loss.item<float>());
     return 0;
 }

@@ -134,7 +134,13 @@ def test_operator_boundary_alone_holds_1e4_and_exact_radii(syn):
     assert np.abs(image - f.color)[:, ok].max() <= 1e-4
     assert np.array_equal(depth[md >= 1e-5], f.depth[0][md >= 1e-5])
     np.testing.assert_array_equal(vis.astype(bool), oracle.mark_visible(sc.means3D, cam))
+    # ORB_SLAM2::RasterizeGaussiansBackwardCUDA, the reference-named free function: dL_dcov3D [P,6] as the reference returns it
+    # (src/Rasterizer.cu:253-261,265-293), on the scales + rotations path
+    shape = take(2, np.int32)
+    assert list(shape) == [P, 6]
+    g_cov = take(P * 6).reshape(P, 6); g_s_free = take(P * 3).reshape(P, 3)
     for name, got, ref in (("means3D", g_xyz, b.dL_dmeans3D), ("colors", g_rgb, b.dL_dcolors), ("rotations", g_q, b.dL_drotations),
-                           ("opacity", g_o, b.dL_dopacity), ("scales", g_s, b.dL_dscales), ("means2D", g_m2d, b.dL_dmeans2D)):
+                           ("opacity", g_o, b.dL_dopacity), ("scales", g_s, b.dL_dscales), ("means2D", g_m2d, b.dL_dmeans2D),
+                           ("cov3D (free function)", g_cov, b.dL_dcov3D), ("scales (free function)", g_s_free, b.dL_dscales)):
         assert rel_err(got, ref) <= 1e-4, (name, rel_err(got, ref))
         assert mixed_err(got, ref) <= 1.0, (name, mixed_err(got, ref))

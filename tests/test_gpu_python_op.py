@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import oracle
-from util import pose, rel_err
+from util import mixed_err, pose, rel_err
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -123,6 +123,50 @@ def test_backward_twice_with_retain_graph(syn):
     for a, b, c in zip(g1, g2, g3):
         scale = float(a.abs().max()) + 1e-30
         assert float((a - b).abs().max()) / scale < 1e-5 and float((a - c).abs().max()) / scale < 1e-5
+
+
+def test_reference_named_backward_returns_what_the_reference_returns(syn):
+    """_C.rasterize_gaussians_backward / ORB_SLAM2::RasterizeGaussiansBackwardCUDA (the reference-named free functions,
+    DGR/rasterize_points.cu:117-199, src/Rasterizer.cu:217-305) return the reference's eight tensors with the reference's
+    shapes — dL_dcov3D is [P,6] and FILLED on the scales + rotations path too (there it is computeCov2DCUDA's output,
+    backward.cu:144-274) — and may be called any number of times per forward. The lean form ([0,6]: nothing consumes it)
+    is what the autograd nodes opt into through rasterize_gaussians_backward_staged."""
+    import diff_gaussian_rasterization as dgr
+    cam = syn.make_camera(320, 240, 260.0, 258.0, bg=(0.1, 0.0, 0.2), Tcw=pose())
+    sc = syn.make_scene(6000, cam, seed=21, scale_mult=2.0)
+    o, f = oracle.forward_scene(sc)
+    mc, _ = o.margins(f)
+    g_in = sc.dL_dpix * (mc >= 1e-5)[None]
+    b = o.backward(g_in)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    e = torch.empty(0, device="cuda")
+    bg, m3, col, op, scl, rot = t(cam.bg), t(sc.means3D), t(sc.colors), t(sc.opacities), t(sc.scales), t(sc.rotations)
+    vm, pm, cp = t(cam.viewmatrix), t(cam.projmatrix), t(cam.campos)
+    R, color, radii, geom, binning, img, depth = dgr._C.rasterize_gaussians(
+        bg, m3, col, op, scl, rot, 1.0, e, vm, pm, cam.tanfovx, cam.tanfovy, cam.height, cam.width, e, 0, cp, False)
+    assert R == f.num_rendered
+    args = (bg, m3, radii, col, scl, rot, 1.0, e, vm, pm, cam.tanfovx, cam.tanfovy, t(g_in), e, 0, cp, geom, R, binning, img)
+    for _ in range(2):      # stateless: a second call on the same forward gives the same tensors
+        d2, dcol, dop, d3, dcov, dsh, dscl, drot = dgr._C.rasterize_gaussians_backward(*args)
+        assert tuple(dcov.shape) == (sc.P, 6) and tuple(d2.shape) == (sc.P, 3) and tuple(dop.shape) == (sc.P, 1)
+        assert tuple(dsh.shape) == (sc.P, 0, 3) and tuple(dscl.shape) == (sc.P, 3) and tuple(drot.shape) == (sc.P, 4)
+        assert rel_err(dcov.cpu().numpy(), b.dL_dcov3D) <= 1e-4
+        assert mixed_err(dcov.cpu().numpy(), b.dL_dcov3D) <= 1.0
+        for a, r in ((d2, b.dL_dmeans2D), (dcol, b.dL_dcolors), (dop, b.dL_dopacity), (d3, b.dL_dmeans3D),
+                     (dscl, b.dL_dscales), (drot, b.dL_drotations)):
+            assert rel_err(a.cpu().numpy().reshape(r.shape), r) <= 1e-4
+    # the opt-in lean form: same gradients, no dL_dcov3D on this parameterisation
+    lean = dgr._C.rasterize_gaussians_backward_staged(*args, 0)
+    assert tuple(lean[4].shape) == (0, 6)
+    assert rel_err(lean[6].cpu().numpy(), b.dL_dscales) <= 1e-4
+    # cov3D_precomp path: [P,6] in both forms
+    cov = t(f.stages["cov3D"].reshape(-1, 6))
+    R2, _, radii2, geom2, binning2, img2, _ = dgr._C.rasterize_gaussians(
+        bg, m3, col, op, e, e, 1.0, cov, vm, pm, cam.tanfovx, cam.tanfovy, cam.height, cam.width, e, 0, cp, False)
+    out = dgr._C.rasterize_gaussians_backward(bg, m3, radii2, col, e, e, 1.0, cov, vm, pm, cam.tanfovx, cam.tanfovy, t(g_in), e, 0, cp,
+                                              geom2, R2, binning2, img2)
+    assert R2 == R and tuple(out[4].shape) == (sc.P, 6)
+    assert rel_err(out[4].cpu().numpy(), b.dL_dcov3D) <= 1e-4
 
 
 @pytest.mark.parametrize("detach", [False, True])
