@@ -85,14 +85,14 @@ class MapUpdateArgs(C.Structure):
 
 
 class PoseStepArgs(C.Structure):
-    _fields_ = [("means_world", C.c_void_p), ("update", C.c_void_p), ("sums_only", C.c_int)]
+    _fields_ = [("means_world", C.c_void_p), ("update", C.c_void_p), ("sums_only", C.c_int), ("overflow_out", C.c_void_p)]
 
 
 class PoseUpdateArgs(C.Structure):
     """gsr_pose_update_args (include/gsr.h)"""
     _fields_ = [("quat_trans", C.c_void_p), ("moments", C.c_void_p), ("best", C.c_void_p), ("history", C.c_void_p), ("Tcw", C.c_void_p),
                 ("partial", C.c_void_p), ("loss", C.c_void_p), ("geom", C.c_void_p), ("lr", C.c_double), ("beta1", C.c_double),
-                ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int)]
+                ("beta2", C.c_double), ("eps", C.c_double), ("step", C.c_int), ("skip", C.c_void_p)]
 
 
 def lib():

@@ -446,7 +446,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
             static_assert(GSR_POSE_ACC_ROWS * 12 <= GSR_POSE_PARTIALS * 12, "gsr_pose_grad's scratch holds the accumulator rows");
             const gsr::PoseUpdate& u = pu;
             gsr::PoseStep k;
-            k.X = ps->means_world; k.acc = const_cast<float*>(ps->update->partial);
+            k.X = ps->means_world; k.acc = const_cast<float*>(ps->update->partial); k.overflow_out = ps->sums_only ? ps->overflow_out : nullptr;
             if (stages & GSR_STAGE_REZERO) hipLaunchKernelGGL((gsr::K_splat_bwd_pose<true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, k);
             else hipLaunchKernelGGL((gsr::K_splat_bwd_pose<false>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, k);
             if (!ps->sums_only) hipLaunchKernelGGL(gsr::K_pose_finish, dim3(1), dim3(64), 0, st, u, k.acc, (float*)nullptr);
@@ -822,7 +822,7 @@ int make_pose_update(const gsr_pose_update_args* a, gsr::PoseUpdate* out)
     if (!a || !a->quat_trans || !a->moments || !a->best || !a->history || !a->Tcw || !a->partial || !a->loss || a->step < 1) return GSR_EINVAL;
     gsr::PoseUpdate u;
     u.quat_trans = a->quat_trans; u.moments = a->moments; u.best = a->best; u.history = a->history; u.Tcw = a->Tcw;
-    u.partial = a->partial; u.loss = a->loss; u.overflow = overflow_flag(a->geom);
+    u.partial = a->partial; u.loss = a->loss; u.overflow = overflow_flag(a->geom); u.skip = a->skip;
     const double bc1 = 1.0 - std::pow(a->beta1, (double)a->step), bc2 = 1.0 - std::pow(a->beta2, (double)a->step);
     u.w1 = (float)(1.0 - a->beta1); u.b2 = (float)a->beta2; u.w2 = (float)(1.0 - a->beta2); u.eps = (float)a->eps;
     u.step_size = (float)(a->lr / bc1); u.sqrt_bias2 = (float)std::sqrt(bc2);

@@ -1506,6 +1506,7 @@ K_splat_bwd(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, MapUpdate m
 struct PoseStep {
     const float* X;      // [P,3] world-frame means
     float* acc;          // [GSR_POSE_ACC_ROWS][12], zero between launches
+    float* overflow_out; // nullptr, or where this forward's overflow flag goes as a float (the sharded loop all-reduces it with the rows)
 };
 template <bool REZERO>
 __global__ void __launch_bounds__(256)
@@ -1529,6 +1530,8 @@ K_splat_bwd_pose(FrameParams f, SplatInputs in, GeomView g, SplatGrads o, PoseSt
         const float row = (ws[0][threadIdx.x] + ws[1][threadIdx.x]) + (ws[2][threadIdx.x] + ws[3][threadIdx.x]);
         if (row != 0.f) unsafeAtomicAdd(ps.acc + (size_t)(blockIdx.x % GSR_POSE_ACC_ROWS) * 12 + threadIdx.x, row);
     }
+    // (a store at the top would turn the body's uniform matrix loads into per-lane loads: DESIGN.md section 4, "Dependent trips")
+    if (ps.overflow_out && blockIdx.x == 0 && threadIdx.x == 64) *ps.overflow_out = g.hdr->overflow ? 1.f : 0.f;
 }
 // adds the accumulator rows up, takes the pose step, leaves the rows zero for the next backward
 __global__ void __launch_bounds__(64)
@@ -1545,6 +1548,7 @@ K_pose_finish(PoseUpdate u, float* acc, float* sums_out)
     for (int q = 0; q < 12; q++) tot[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r[q]), 63));
     if (sums_out && threadIdx.x < 12) sums_out[threadIdx.x] = tot[threadIdx.x];
     pose_update_body<false>(u, 0, tot);
+    if (u.skip && threadIdx.x == 0) *u.skip = 0.f; // (read above by the same lane; zero between iterations like the rows)
 }
 
 // ===================================================================================

@@ -1244,6 +1244,7 @@ struct PoseUpdate {
     const float* partial; // [GSR_POSE_BLOCKS][12] K_pose_grad's rows
     const float* loss;    // the iteration's loss (K_loss_finish: sums + 5)
     const uint32_t* overflow;
+    float* skip;          // one float (nullptr: none): non-zero = some rank's forward overflowed (the sharded loop's all-reduced flag)
     float w1, b2, w2, eps, step_size, sqrt_bias2;
 };
 // presum: the twelve sums already added up (K_splat_bwd_pose's last workgroup), or nullptr: this wave adds the nrows rows of u.partial
@@ -1257,7 +1258,7 @@ __device__ void pose_update_body(const PoseUpdate& u, const int nrows, const flo
 #pragma unroll
     for (int k = 0; k < 7; k++) { pq[k] = u.quat_trans[k]; mm[k] = u.moments[k]; vv[k] = u.moments[7 + k]; }
     const float best0 = u.best[0], loss_in = u.loss[0];
-    const bool skip = u.overflow && *u.overflow;
+    const bool skip = (u.overflow && *u.overflow) || (u.skip && *u.skip != 0.f);
     float a[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int b = lane; b < nrows; b += 64) {
 #pragma unroll

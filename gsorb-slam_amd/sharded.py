@@ -287,18 +287,27 @@ class KdPartition:
         return float(self.order(Tcw).index(rank))
 
 
+def _exchange_device(group=None) -> torch.device:
+    """Where a group's collectives take their tensors: an RCCL ("nccl") group moves device memory only (a CPU tensor raises "No backend type
+    associated with device type cpu": ADVICE r5), every other backend used here (gloo) host memory."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def _gather_rows(rows: torch.Tensor, world: int, group=None):
-    """all-gather of row blocks of different lengths: returns the list of every rank's rows"""
-    n = torch.tensor([rows.shape[0]], dtype=torch.int64)
+    """all-gather of row blocks of different lengths: returns the list of every rank's rows (on the host)"""
+    dev = _exchange_device(group)
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
     counts = [int(c) for c in counts]
     mx = max(max(counts), 1)
-    pad = torch.zeros((mx,) + tuple(rows.shape[1:]), dtype=rows.dtype)
-    pad[:rows.shape[0]] = rows.detach().cpu()
+    pad = torch.zeros((mx,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=dev)
+    pad[:rows.shape[0]] = rows.detach().to(dev)
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
-    return [p[:c] for p, c in zip(parts, counts)]
+    return [p[:c].cpu() for p, c in zip(parts, counts)]
 
 
 def rebalance_rows(xyz: torch.Tensor, payload: torch.Tensor, rank: int, world: int, group=None, tolerance: float = 1.25):

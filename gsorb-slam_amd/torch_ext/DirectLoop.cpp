@@ -67,7 +67,9 @@ struct SlamLoop::Direct {
     torch::Tensor d_mc, d_m2d, d_col, d_opac, d_scale, d_rot;            // the rasterizer's gradients
     torch::Tensor loss_partial, sums, reg_partial, reg_out, neg_c, Tcw, bg, view, proj, campos, history;
     torch::Tensor pose, pose_moments, best, pose_partial;                // tracking: [7], [14], [8], [GSR_POSE_PARTIALS, 12]
-    torch::Tensor pose_acc;                                              // [64, 12] the fused pose step's accumulator rows (zero between launches)
+    torch::Tensor pose_acc;                                              // [64 * 12 + 4] the fused pose step's accumulator rows (zero between launches); word 768: the sharded loop's
+                                                                         // overflow flag, which travels in the rows' all-reduce (every rank skips, or none)
+    torch::Tensor pose_partial_buf;                                      // [GSR_POSE_PARTIALS * 12 + 4] pose_partial's storage with the same flag word behind it
     torch::Tensor tickets;                                               // [2 * GSR_TICKET_WORDS] arrival counters of the kernels that finish their own sums (zero between launches)
     int64_t history_len = 0;
     // The tracking loop looks at every loss (Render.cc:1107). Read back with a copy and a stream synchronisation that look costs ~20 us per
@@ -81,7 +83,6 @@ struct SlamLoop::Direct {
     c10::intrusive_ptr<c10d::ProcessGroup> pg;
     int rank = 0, world = 1;
     torch::Tensor last_sums;                                             // [12] the pose sums of the sharded loop's last tracking step
-    torch::Tensor step_pose;                                             // ShardRenderStep: the pose tensor of the previous call
     bool order_stale = true;                                             // the pose changed since gsr_shard_order ran
     bool staged = false;                                                 // the group cannot move device tensors (gloo): through the host
     ncclComm_t comm = nullptr;                                           // backend "nccl": the loop's OWN RCCL communicator — its collectives are enqueued on the loop's
@@ -211,6 +212,7 @@ void SlamLoop::SetShard(c10::intrusive_ptr<c10d::ProcessGroup> pg, int rank, int
     d.pg = pg; d.rank = rank; d.world = world;
     d.staged = pg && pg->getBackendName() != "nccl";
     if (d.comm) { (void)Rccl::get().CommDestroy(d.comm); d.comm = nullptr; }
+    d.fresh = true; // (the first ShardRenderStep / batch on this partition sizes the workspace)
     if (pg && !d.staged) { // the communicator's id travels through the group (a device tensor: the group's backend is RCCL too)
         c10::DeviceGuard guard(dev_);
         // Every rank must end up on the SAME transport: a rank whose own communicator failed says so in a second broadcast-free exchange (an
@@ -218,21 +220,35 @@ void SlamLoop::SetShard(c10::intrusive_ptr<c10d::ProcessGroup> pg, int rank, int
         // wire, issued through libtorch on this stream — slower to launch, never wrong).
         int ok = 1;
         std::string why;
+        //  the sequence of group collectives is the same on every path: a rank that fails BEFORE the broadcast (librccl not loadable,
+        // ncclGetUniqueId) still takes part in it — with a zeroed id — and says so in the flag all-reduce behind it
+        ncclUniqueId id;
+        std::memset(&id, 0, sizeof(id));
         try {
-            ncclUniqueId id;
-            std::memset(&id, 0, sizeof(id));
+            (void)Rccl::get();
             if (rank == 0) nccl_chk(Rccl::get().GetUniqueId(&id), "ncclGetUniqueId");
-            auto bytes = torch::empty({(int64_t)sizeof(id)}, torch::kUInt8);
+        } catch (const std::exception& e) {
+            ok = 0; why = e.what();
+            std::memset(&id, 0, sizeof(id));
+        }
+        {
+            auto bytes = torch::empty({(int64_t)sizeof(id) + 1}, torch::kUInt8); // (the id and rank 0's "I have one" byte)
             std::memcpy(bytes.data_ptr(), &id, sizeof(id));
+            bytes.data_ptr<uint8_t>()[sizeof(id)] = (uint8_t)ok;
             auto on_dev = bytes.to(dev_);
             std::vector<torch::Tensor> v{on_dev};
             pg->broadcast(v)->wait();
             bytes = on_dev.to(torch::kCPU);
             std::memcpy(&id, bytes.data_ptr(), sizeof(id));
-            nccl_chk(Rccl::get().CommInitRank(&d.comm, world, id, rank), "ncclCommInitRank");
-        } catch (const std::exception& e) {
-            ok = 0; why = e.what();
-            d.comm = nullptr;
+            if (!bytes.data_ptr<uint8_t>()[sizeof(id)] && ok) { ok = 0; why = "rank 0 has no RCCL id"; }
+        }
+        if (ok) {
+            try {
+                nccl_chk(Rccl::get().CommInitRank(&d.comm, world, id, rank), "ncclCommInitRank");
+            } catch (const std::exception& e) {
+                ok = 0; why = e.what();
+                d.comm = nullptr;
+            }
         }
         auto flag = torch::full({1}, (float)ok, torch::TensorOptions().device(dev_).dtype(torch::kFloat32));
         std::vector<torch::Tensor> fv{flag};
@@ -285,18 +301,22 @@ void SlamLoop::ensure_direct_(int64_t history_len)
         d.proj = rasterizer_.raster_settings_.projmatrix.to(dev_, torch::kFloat32).contiguous();
         d.pose = torch::zeros({7}, fo); d.pose_moments = torch::zeros({14}, fo); d.best = torch::zeros({8}, fo);
         d.tickets = torch::zeros({2 * GSR_TICKET_WORDS}, fo.dtype(torch::kInt32));
-        d.pose_acc = torch::zeros({64, 12}, fo); d.last_sums = torch::zeros({12}, fo);
+        d.pose_acc = torch::zeros({64 * 12 + 4}, fo); d.last_sums = torch::zeros({12}, fo);
     }
     if (d.n != n) { // per map size
         d.n = n;
         d.fresh = true;
         d.geom = torch::empty({(int64_t)gsr_geom_bytes((int)n)}, bo);
+        //  the header {num_rendered, overflow, ...} is written by the forward's kernels — an EMPTY shard never launches one, and the loss / pose
+        // kernels still read the overflow flag through it: it starts out as "nothing rendered, nothing overflowed"
+        d.geom.slice(0, 0, std::min<int64_t>(256, d.geom.numel())).zero_();
         d.mc = torch::empty({n, 3}, fo); d.opac = torch::empty({n}, fo); d.scales = torch::empty({n, 3}, fo); d.rots = torch::empty({n, 4}, fo);
         d.radii = torch::empty({n}, fo.dtype(torch::kInt32));
         d.d_mc = torch::empty({n, 3}, fo); d.d_m2d = torch::empty({n, 3}, fo); d.d_col = torch::empty({n, 3}, fo); d.d_opac = torch::empty({n}, fo);
         d.d_scale = torch::empty({n, 3}, fo); d.d_rot = torch::empty({n, 4}, fo);
         d.reg_partial = torch::empty({3 * ((n + 255) / 256) + 3}, fo);
-        d.pose_partial = torch::empty({GSR_POSE_PARTIALS, 12}, fo);
+        d.pose_partial_buf = torch::zeros({GSR_POSE_PARTIALS * 12 + 4}, fo);
+        d.pose_partial = d.pose_partial_buf.slice(0, 0, GSR_POSE_PARTIALS * 12).view({GSR_POSE_PARTIALS, 12});
         d.binning = torch::Tensor(); d.binning_bytes = 0;
         grow_binning_(cfg_.binning_capacity > 0 ? (size_t)cfg_.binning_capacity : 4 * (size_t)n + 65536); // grows at the first synchronised look at an overflow
     }
@@ -414,6 +434,7 @@ void SlamLoop::direct_backward_(bool detach_depth_colour, bool means_only, const
 bool SlamLoop::direct_overflowed_()
 {
     int R = 0, ov = 0;
+    if (d_->n == 0) return false; // (an empty shard renders nothing: nothing to overflow)
     chk(gsr_ws_status(b(d_->geom), stream_(), &R, &ov), "gsr_ws_status");
     if (ov) grow_binning_((size_t)R + (size_t)R / 2 + 65536);
     return ov != 0;
@@ -589,8 +610,11 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
         if (shard_ && cfg_.fused_update) { // the shard's pose sums come out of the backward's per-splat stage (accumulator rows), are summed over the ranks, and a one-wave kernel takes the (replicated) step
             shard_composite_backward_();
             u.partial = f(d.pose_acc);
+            //  whether this iteration counts is decided by ALL ranks: the per-splat stage leaves the rank's overflow flag behind the rows, the
+            // all-reduce sums it with them, and every rank's step kernel skips + posts NaN on the total — so every rank then enters shard_any_ below
+            u.skip = f(d.pose_acc) + 64 * 12;
             reproj(it, f(d.pose_acc)); // (the rows are zero here; the term enters every rank's row with weight 1 / world)
-            gsr_pose_step_args ps{f(xyz), &u, 1};
+            gsr_pose_step_args ps{f(xyz), &u, 1, u.skip};
             direct_backward_(true, true, nullptr, &ps);
             d_->all_reduce(d.pose_acc);
             chk(gsr_pose_finish(&u, f(d.pose_acc), f(d.last_sums), st), "gsr_pose_finish");
@@ -600,12 +624,17 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
             if (d.n > 0) chk(gsr_pose_grad(f(xyz), f(d.d_mc), (size_t)d.n, f(d.Tcw), f(d.pose_partial), nullptr, st), "gsr_pose_grad");
             else d.pose_partial.zero_();
             reproj(it, f(d.pose_partial));
-            d_->all_reduce(d.pose_partial);
+            { // the rank's overflow flag (word 1 of the geometry header) behind the rows: summed over the ranks with them, read back as the step's skip flag
+                auto flag = d.pose_partial_buf.slice(0, GSR_POSE_PARTIALS * 12, GSR_POSE_PARTIALS * 12 + 1);
+                if (d.n > 0) flag.copy_(d.geom.slice(0, 0, 8).view(torch::kInt32).slice(0, 1, 2)); else flag.zero_();
+                u.skip = f(flag);
+            }
+            d_->all_reduce(d.pose_partial_buf);
             chk(gsr_pose_update(&u, st), "gsr_pose_update");
         } else if (cfg_.fused_update) { // the backward's per-splat stage forms the pose sums (into accumulator rows that are zero between launches), a one-wave kernel takes the step: no dL/dmeans tensor
             u.partial = f(d.pose_acc);
             reproj(it, f(d.pose_acc)); // (the accumulator rows are zero here: the per-splat stage adds to them, the one-wave kernel behind it sums them)
-            const gsr_pose_step_args ps{f(xyz), &u, 0};
+            const gsr_pose_step_args ps{f(xyz), &u, 0, nullptr};
             direct_backward_(true, true, nullptr, &ps); // the [z, 1, 0] colours are detached while tracking (Render.cc:949-981)
         } else {
             direct_backward_(true, true, nullptr, nullptr);
@@ -693,7 +722,7 @@ std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> SlamLoop::RenderComposit
     return {plane(0, 3).clone(), plane(5 * HW + 4, 1).clone(), torch::cat({plane(3 * HW, 1), plane(4 * HW + 4, 1)}, 0)};
 }
 
-torch::Tensor SlamLoop::ShardRenderStep(const torch::Tensor& Tcw, const torch::Tensor& G)
+torch::Tensor SlamLoop::ShardRenderStep(const torch::Tensor& Tcw, const torch::Tensor& G, int preflight)
 {
     if (!direct_() || !shard_) throw std::runtime_error("ShardRenderStep needs a sharded direct loop (SetShard)");
     torch::NoGradGuard ng;
@@ -702,11 +731,11 @@ torch::Tensor SlamLoop::ShardRenderStep(const torch::Tensor& Tcw, const torch::T
     Direct& d = *d_;
     void* const st = stream_();
     if (!G.is_cuda() || G.scalar_type() != torch::kFloat32 || !G.is_contiguous() || G.numel() != (int64_t)5 * H_ * W_) throw std::runtime_error("ShardRenderStep: G must be a contiguous float32 device tensor [5,H,W]");
-    if (!d.step_pose.defined() || !d.step_pose.is_same(Tcw)) { // (a new pose tensor: copy it and make sure the workspace holds the frame)
-        d.Tcw.copy_(Tcw.to(torch::kFloat32).reshape({4, 4}));
-        shard_preflight_();
-        d.step_pose = Tcw;
-    }
+    //  the pose is copied on EVERY call (64 bytes, no synchronisation: a caller may update its tensor in place), and the pre-flight — it contains
+    // a collective — follows a condition every rank evaluates alike: the caller's argument, or the first call on a (re)built workspace
+    d.Tcw.copy_(Tcw.to(torch::kFloat32).reshape({4, 4}));
+    if (preflight > 0 || (preflight < 0 && d.fresh)) shard_preflight_();
+    d.fresh = false;
     if (d.n > 0)
         chk(gsr_map_prepare((size_t)d.n, f(xyz), f(logit_opacities), f(log_scales), f(unnorm_quat), f(d.Tcw), f(d.mc), f(d.opac), f(d.scales), f(d.rots), 0.f, 0.f, 0.f,
                             nullptr, nullptr, st), "gsr_map_prepare");

@@ -106,7 +106,9 @@ public:
     // composite of all ranks' layers, an upstream gradient of the composite G [5,H,W] = d/d(rgb, depth, silhouette) taken back through the compositor and
     // the rasterizer to this rank's Gaussians (gradient buffers of the workspace) and to the pose — returns the [GSR_POSE_PARTIALS, 12] pose rows summed over the
     // ranks (their column sums are dL/dR row-major, dL/dt). Launches only: nothing here synchronises with the host.
-    torch::Tensor ShardRenderStep(const torch::Tensor& Tcw, const torch::Tensor& G);
+    // preflight: 1 = size every rank's binning workspace for this pose first (one forward + a collective), 0 = never, -1 = on the first call after SetShard or a
+    // change of the map's size. Every rank must pass the same value (the pre-flight contains a collective).
+    torch::Tensor ShardRenderStep(const torch::Tensor& Tcw, const torch::Tensor& G, int preflight = -1);
     // Re-balance of a sharded map (sharded.rebalance_loop drives the exchange): every Gaussian of this loop with what travels with it — raw
     // parameters (14 floats: xyz, rgb, quaternion, logit, log-scales), exp_avg (14), exp_avg_sq (14): [n, 42] —, and the surgery that keeps the
     // rows `keep` and appends the rows that arrive from other ranks WITH their moments (Gaussian.cc:218-258 does the same with zeros / a selection)

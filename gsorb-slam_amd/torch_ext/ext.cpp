@@ -105,7 +105,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
              }, py::call_guard<py::gil_scoped_release>())
         .def("prune_low_opacity", &ORB_SLAM2::SlamLoop::PruneLowOpacity, py::call_guard<py::gil_scoped_release>())
         .def("render_composite", &ORB_SLAM2::SlamLoop::RenderComposite, py::call_guard<py::gil_scoped_release>())
-        .def("shard_render_step", &ORB_SLAM2::SlamLoop::ShardRenderStep, py::call_guard<py::gil_scoped_release>())
+        .def("shard_render_step", &ORB_SLAM2::SlamLoop::ShardRenderStep, py::arg("Tcw"), py::arg("G"), py::arg("preflight") = -1, py::call_guard<py::gil_scoped_release>())
         .def("export_rows", &ORB_SLAM2::SlamLoop::ExportRows)
         .def("replace_rows", &ORB_SLAM2::SlamLoop::ReplaceRows)
         .def("last_pose_sums", &ORB_SLAM2::SlamLoop::LastPoseSums)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 8 /* 8: gsr_forward_args.pre_Tcw / means_cam_out / raw appended (the camera transform and the map's activations inside the projection kernel), gsr_pose_step_args.sums_only and gsr_pose_finish added; 7: gsr_composite_* take the plane count of the gathered buffer, gsr_shard_order and gsr_reproj_loss added; 6: gsr_track_loss, gsr_pose_step, gsr_backward_args.fused_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
+#define GSR_ABI_VERSION 9 /* 9: gsr_pose_update_args.skip and gsr_pose_step_args.overflow_out appended (the sharded loop's overflow decision rides in its pose all-reduce); 8: gsr_forward_args.pre_Tcw / means_cam_out / raw appended (the camera transform and the map's activations inside the projection kernel), gsr_pose_step_args.sums_only and gsr_pose_finish added; 7: gsr_composite_* take the plane count of the gathered buffer, gsr_shard_order and gsr_reproj_loss added; 6: gsr_track_loss, gsr_pose_step, gsr_backward_args.fused_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
                            * 5: gsr_map_prepare / gsr_map_update / gsr_map_loss_total / gsr_pose_update / gsr_pixel_loss_backward_add / gsr_composite_* added, GSR_LOSS_PARTIALS 256 -> 1024 */
 
 #define GSR_OK 0
@@ -391,6 +391,9 @@ typedef struct gsr_pose_update_args {
     const char* geom;     /* NULL: no overflow predicate */
     double lr, beta1, beta2, eps;
     int step;
+    float* skip;          /* NULL: none. One DEVICE float: a non-zero value makes the step behave as after an overflowed forward (NaN recorded, no step).
+                           * A sharded loop all-reduces the ranks' overflow flags into it (gsr_pose_step_args.overflow_out), so that every rank takes
+                           * the same decision; gsr_pose_finish leaves it zero. (ABI 9) */
 } gsr_pose_update_args;
 int gsr_pose_update(const gsr_pose_update_args* args, void* stream);
 /* gsr_pose_grad (the twelve pose sums of dL/dmeans_cam against the world-frame means) and gsr_pose_update in ONE launch: the workgroup of the sums
@@ -403,6 +406,8 @@ typedef struct gsr_pose_step_args {
                                                 * the workgroups of the per-splat stage add their sums there, the step leaves them zero) */
     int sums_only;                             /* 1: the backward only ADDS the pose sums to update->partial's rows and takes no step (a sharded run sums the
                                                 * ranks' rows first: all-reduce them, then gsr_pose_finish) */
+    float* overflow_out;                       /* NULL, or one DEVICE float that receives this rank's overflow flag of the forward (0 / 1): placed behind the
+                                                * rows, it travels in their all-reduce and comes back as gsr_pose_update_args.skip (ABI 9) */
 } gsr_pose_step_args;
 /* The step behind a backward with fused_pose_step.sums_only: adds the 64 accumulator rows up, takes gsr_pose_update's step with the total and leaves
  * the rows zero; sums_out (NULL or 12 DEVICE floats): the twelve pose sums the step used (dL/dR row-major, dL/dt). One single-wave launch. */

@@ -226,6 +226,87 @@ def test_two_gpus_rccl_drive_the_sharded_cpp_loop():
     _run("nccl", world=2)
 
 
+def _empty_cell_worker(rank, world, port, q):
+    """rank 1 owns a cell that holds no Gaussian at all (a split plane outside the scene): its SlamLoop has n = 0 and never launches a rasterizer kernel"""
+    gsr, _C, sharded = _setup()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc, raw = _scene(gsr)
+        nodes = torch.tensor([[0.0, 1.0e3, -1.0, -2.0]])                   # x < 1000 -> leaf (rank) 0, else rank 1: everything is rank 0's
+        mine = [x if rank == 0 else x[:0] for x in raw]
+        frame = _frame(_C, raw, 0)
+        # (recycled allocator memory under the empty rank's workspace: what an uninitialised header would be read from)
+        junk = torch.full((1 << 22,), 0x7F7F7F7F, dtype=torch.int32, device="cuda"); del junk
+        loop = _loop(_C, mine, 0, fused_update=True)
+        loop.set_shard(dist.group.WORLD, rank, world, nodes)
+        rgb, depth, T = frame
+        res = {"size": loop.size()}
+        res["render"] = loop.render_composite(T)[0].cpu().numpy()
+        res["map"] = loop.map_frame(rgb, depth, T, 6)
+        hist, best = loop.track(rgb, depth, _poses()[1].cuda(), 6)
+        res["track"], res["pose"] = hist, best.cpu().numpy()
+        rows = loop.shard_render_step(T, torch.ones((5, H, W), device="cuda"))
+        res["rows"] = rows.sum(0).cpu().numpy()
+        torch.cuda.synchronize()
+        q.put((rank, res))
+    except Exception:
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_an_empty_cell_takes_part_in_the_sharded_loop():
+    """a rank whose cell is empty (d.n == 0) launches no rasterizer kernel, so nothing ever writes its geometry header — the loss / pose kernels and
+    the overflow bookkeeping must not read an uninitialised overflow flag there (a spurious skip on one rank desynchronises the replicated pose and the
+    collectives). World 2 over gloo on one GPU, every Gaussian in rank 0's cell: both ranks must reproduce the UNSHARDED loop (one layer: the composite is the render)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_empty_cell_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    got, t0 = {}, time.time()
+    while len(got) < 2:
+        try:
+            r, res = q.get(timeout=2)
+            assert "error" not in res, "rank %d failed:\n%s" % (r, res.get("error"))
+            got[r] = res
+        except queue.Empty:
+            if [p.exitcode for p in procs if p.exitcode not in (None, 0)] or time.time() - t0 > 300:
+                for p in procs:
+                    p.kill()
+                raise AssertionError("ranks died or hung: exit codes %s" % [p.exitcode for p in procs])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    gsr, _C, sharded = _setup()
+    sc, raw = _scene(gsr)
+    frame = _frame(_C, raw)
+    ref = _loop(_C, raw, fused_update=True)
+    ref_render = ref.render_composite(frame[2])[0].cpu().numpy()
+    ref_map = ref.map_frame(frame[0], frame[1], frame[2], 6)
+    ref_track, ref_pose = ref.track(frame[0], frame[1], _poses()[1].cuda(), 6)
+    assert got[0]["size"] == P and got[1]["size"] == 0
+    for r in (0, 1):
+        assert np.all(np.isfinite(got[r]["map"])) and np.all(np.isfinite(got[r]["track"])), (r, got[r]["map"], got[r]["track"])
+        assert _psnr(got[r]["render"], ref_render) >= 90.0
+        np.testing.assert_allclose(got[r]["map"], ref_map, rtol=2e-4)
+        n = min(len(got[r]["track"]), len(ref_track))
+        assert n >= 3
+        np.testing.assert_allclose(got[r]["track"][:n], ref_track[:n], rtol=2e-3)
+        assert np.abs(got[r]["pose"] - ref_pose.cpu().numpy()).max() < 1e-4
+    np.testing.assert_allclose(got[1]["map"], got[0]["map"], rtol=1e-6)
+    np.testing.assert_allclose(got[1]["track"], got[0]["track"], rtol=1e-6)
+    np.testing.assert_allclose(got[1]["rows"], got[0]["rows"], rtol=1e-6)       # (the all-reduced pose rows: the empty rank added zeros)
+
+
 def _matches(T, n=60, seed=9):
     """feature matches: world points in front of the camera of T and their (noisy) pixel observations"""
     g = torch.Generator().manual_seed(seed)
