@@ -17,8 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def build(force: bool = False) -> None:
-    """Compile both oracle libraries with the committed Makefile."""
-    libs = [os.path.join(_HERE, n) for n in ("libgsr_oracle.so", "libgsr_oracle_omp.so")]
+    """Compile the oracle libraries with the committed Makefile."""
+    libs = [os.path.join(_HERE, n) for n in ("libgsr_oracle.so", "libgsr_oracle_omp.so", "libgsr_oracle_fma.so")]
     src = [os.path.join(_HERE, n) for n in ("gsr_oracle.c", "gsr_oracle.h", "Makefile")]
     if not force and all(os.path.exists(l) for l in libs):
         newest = max(os.path.getmtime(s) for s in src)
@@ -45,9 +45,10 @@ _STAGES = dict(means2D=(0, np.float32), depths=(1, np.float32), cov3D=(2, np.flo
                final_T=(13, np.float32), n_contrib=(14, np.uint32))
 
 
-def _load(omp: bool):
+def _load(omp):
+    """omp: False = the deterministic single-thread checker, True = its OpenMP build, "fma" = the contraction census build (Makefile: NOT a checker)"""
     build()
-    lib = C.CDLL(os.path.join(_HERE, "libgsr_oracle_omp.so" if omp else "libgsr_oracle.so"))
+    lib = C.CDLL(os.path.join(_HERE, "libgsr_oracle_fma.so" if omp == "fma" else "libgsr_oracle_omp.so" if omp else "libgsr_oracle.so"))
     lib.gsro_state_new.restype = C.c_void_p
     lib.gsro_state_free.argtypes = [C.c_void_p]
     lib.gsro_forward.restype = C.c_int
@@ -84,7 +85,7 @@ def _load(omp: bool):
 _LIBS: dict = {}
 
 
-def lib(omp: bool = False):
+def lib(omp=False):
     if omp not in _LIBS:
         _LIBS[omp] = _load(omp)
     return _LIBS[omp]
@@ -128,7 +129,7 @@ class Backward:
 class Oracle:
     """One forward (+ optional backward) of the restated reference pipeline."""
 
-    def __init__(self, omp: bool = False):
+    def __init__(self, omp=False):
         self.lib = lib(omp)
         self.state = C.c_void_p(self.lib.gsro_state_new())
         self._keep = None
@@ -241,7 +242,7 @@ class Oracle:
         return out
 
 
-def forward_scene(scene, omp: bool = False, copy_stages: bool = True):
+def forward_scene(scene, omp=False, copy_stages: bool = True):
     """Convenience: run a gsorb-slam_amd.synthetic.Scene through the oracle."""
     o = Oracle(omp)
     f = o.forward(copy_stages=copy_stages, means3D=scene.means3D, opacities=scene.opacities,
