@@ -49,6 +49,7 @@ def _hip():
     h.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
     h.hipEventSynchronize.argtypes = [C.c_void_p]
     h.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+    h.hipEventDestroy.argtypes = [C.c_void_p]
     return h
 
 
@@ -192,9 +193,55 @@ def quick_raster(gsr, dev, cam, arrays, grad_in, steps=50, prewarm=30, dual=Fals
             hip.hipEventElapsedTime(C.byref(v), e[i0], e[i1])
             tot += v.value
         return tot / max(len(ev), 1)
+    bwd_ms, fwd_ms = avg(0, 1), avg(2, 3)
+    # Outside the timed region: the library's per-stage event pairs on eight more steps (what the step's kernels take one by one: their sum against
+    # ms_per_step is the launch gaps a small frame pays), and the launches per step from the library's own counter.
+    L = gsr.capi.lib()
+    n0 = int(L.gsr_debug_launch_count())
+    step()
+    launches = int(L.gsr_debug_launch_count()) - n0
+    names = ["preprocess", "bin_count+colscan", "bin_fill", "tile_sort_cut", "blend_fwd", "bwd_clear", "blend_bwd", "splat_bwd"]
+    stage = np.zeros(8)
+    reps = 8
+    for _ in range(reps):
+        e = [C.c_void_p() for _ in range(16)]
+        for x in e:
+            hip.hipEventCreate(C.byref(x))
+        f = (C.c_void_p * 10)(*e[:10])
+        b = (C.c_void_p * 6)(*e[10:])
+        step(f, b)
+        torch.cuda.synchronize()
+        for k in range(8):
+            if k == 5:
+                continue                                  # (the clear stage does not run: one backward per forward)
+            v = C.c_float(0)
+            hip.hipEventElapsedTime(C.byref(v), e[2 * k], e[2 * k + 1])
+            stage[k] += v.value * 1e3 / reps
+        for x in e:
+            hip.hipEventDestroy(x)
     return {"splats": P, "width": W, "height": H, "visible": V, "tile_instances": R, "ms_per_step": ms,
-            "bwd_blend_ms": avg(0, 1), "fwd_blend_ms": avg(2, 3), "steps": steps, "prewarm_steps": prewarm,
-            "splats_pixels_per_s": P * W * H / (ms * 1e-3)}
+            "bwd_blend_ms": bwd_ms, "fwd_blend_ms": fwd_ms, "steps": steps, "prewarm_steps": prewarm,
+            "splats_pixels_per_s": P * W * H / (ms * 1e-3),
+            "launches_per_step": launches,
+            "stage_us": {n: round(float(stage[k]), 2) for k, n in enumerate(names) if k != 5},
+            "sum_kernel_us": round(float(stage.sum()), 1),
+            "roofline": step_roofline(P, V, R, W * H, ms, bwd_ms, dual)}
+
+
+def step_roofline(P, V, R, N, ms_step, bwd_blend_ms, dual=False):
+    """SURVEY.md section 8d's algorithmic bytes of one fwd+bwd with this run's R and V, against the step's time and the HBM peak; and the dominant
+    kernel (the backward blend: 40R + 20N + 36V) against its live HIP-event average. BASELINE config 5 asks for exactly this on the 2 M shape."""
+    total_ref = 152 * P + 340 * V + 128 * R + 44 * N
+    total = total_ref - 40 * V           # the two intermediates the timed call does not store (config.omitted_stores)
+    k_bytes = 40 * R + 20 * N + 36 * V
+    return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "formula": "152 P + 340 V + 128 R + 44 N (SURVEY.md 8d)" + (" — the plain render's bytes: the fused pair's two extra planes and its tenth sum are not in the survey's formula" if dual else ""),
+            "algorithmic_bytes": total, "algorithmic_bytes_with_reference_intermediates": total_ref,
+            "achieved": total / (ms_step * 1e-3) / 1e9, "frac": total / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "achieved_with_reference_intermediates": total_ref / (ms_step * 1e-3) / 1e9, "frac_with_reference_intermediates": total_ref / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "dominant_kernel": {"kernel": "K_blend_bwd", "algorithmic_bytes": k_bytes, "avg_launch_ms": bwd_blend_ms,
+                                "achieved": k_bytes / (bwd_blend_ms * 1e-3) / 1e9 if bwd_blend_ms > 0 else None,
+                                "frac": k_bytes / (bwd_blend_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if bwd_blend_ms > 0 else None}}
 
 
 def post_mapping_map(gsr, dev, P=300_000, iters=100):
@@ -265,6 +312,9 @@ def other_workloads(a, gsr, dev):
     synth("fat-x4", 1_000_000, "replica", "the headline scene with every splat 4x the single-pixel size (beyond the 5x5-patch reach word)", scale_mult=4.0, parity=True)
     synth("scale-x2", 1_000_000, "replica", "the headline scene with every splat 2x the single-pixel size (lists just over 1024 entries)", scale_mult=2.0)
     synth("two-walls", 1_000_000, "replica", "the headline scene with every splat on one of two thin depth slabs (the tile sort's crowded-bin case)", two_walls=True)
+    # the per-rank regime of BASELINE configs 4 and 5: a quarter of 1 M Gaussians at 1200x680, an eighth of 2 M at 640x480
+    out["rank-250k-1200x680"] = rank_regime(a, gsr, dev, 1_000_000, "replica", 4)
+    out["rank-250k-640x480"] = rank_regime(a, gsr, dev, 2_000_000, "scannet", 8)
     cam, arrays, g_in, info = post_mapping_map(gsr, dev)
     d = quick_raster(gsr, dev, cam, arrays, g_in, steps=a.other_steps)
     d["what"] = "a map AFTER mapping (BASELINE config 2's trained-map stand-in): see bench.py:post_mapping_map"
@@ -309,7 +359,7 @@ def cpp_loop_ms(a, gsr, dev, P=1_000_000, track_iters=20, map_iters=20):
             f.write(struct.pack("<6i2f", P, W, H, track_iters, map_iters, 3, camd["fx"], camd["fy"]))
             for arr in (xyz, col, sc.rotations, logit, np.log(sc.scales), rgb.cpu().numpy(), sur[0].cpu().numpy(), T_true.cpu().numpy(), T_init):
                 f.write(np.ascontiguousarray(arr, np.float32).tobytes())
-        r = subprocess.run([exe, path], capture_output=True, text=True, timeout=600)
+        r = subprocess.run([exe, path], capture_output=True, text=True, timeout=600, env=dict(os.environ, GSR_LOOP_WARMUP=str(a.loop_warmup)))
     if r.returncode != 0:
         return {"error": r.stderr[-500:]}
     o = {ln.split()[0]: [float(x) for x in ln.split()[1:]] for ln in r.stdout.splitlines() if ln.strip()}
@@ -325,7 +375,13 @@ def cpp_loop_ms(a, gsr, dev, P=1_000_000, track_iters=20, map_iters=20):
             "mapping": o.get("mapframe_ms_per_iter", o["map_ms_per_iter"])[0], "mapping_per_iteration_readback": o["map_ms_per_iter"][0],
             "tracking": o["track_ms_per_iter"][0], "raster_pair": pair["ms_per_step"],
             "raster_pair_bwd_blend_ms": pair["bwd_blend_ms"], "raster_pair_fwd_blend_ms": pair["fwd_blend_ms"],
-            "tracking_iterations_run": len(o.get("track", [])), "mapping_iterations_run": map_iters}
+            "tracking_iterations_run": len(o.get("track", [])), "mapping_iterations_run": map_iters, "warmup_iterations": a.loop_warmup,
+            "vs_shard_step_unsharded_same_scene": "loop_ms runs in a FRESH process (tests/cpp/slam_loop_main.bin) on the headline scene (seed 0, a damaged copy of the map against the "
+                                                  "true map's render); shard_step.unsharded_same_scene is the same SlamLoop class inside this process on shard_step's scene (seed 1234, "
+                                                  "the map against its own re-tinted render). Round 5's two figures (0.521 / 0.456 ms per tracking iteration) differed because the fresh "
+                                                  "process timed its 20 iterations after ~7 warm-up iterations (4 ms of GPU work: clocks still ramping) while shard_step warms up with 20 "
+                                                  "iterations behind the whole bench; with warmup_iterations more tracking + mapping iterations before its clock starts (GSR_LOOP_WARMUP) "
+                                                  "loop_ms is a steady-clock figure too"}
 
 
 def boundary_ms(gsr, sc, dev, steps=20):
@@ -359,6 +415,96 @@ def boundary_ms(gsr, sc, dev, steps=20):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+_ONE_RANK = {"group": None, "td": None, "error": None}
+
+
+def one_rank_group(dev):
+    """A process group of ONE rank with backend "nccl" (N = 1 runs): RCCL itself then executes the sharded loop's collectives on the loop's stream.
+    Created once per process, destroyed at the end of main()."""
+    if _ONE_RANK["group"] is None and _ONE_RANK["error"] is None:
+        try:
+            import socket
+            import torch.distributed as td1
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+            td1.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            _ONE_RANK.update(group=td1.group.WORLD, td=td1)
+        except Exception as e:                                   # (stated in the record, never silent)
+            _ONE_RANK["error"] = type(e).__name__
+    return _ONE_RANK["group"]
+
+
+def rank_regime(a, gsr, dev, total, camera, cells):
+    """What ONE rank of BASELINE configs 4-5 runs: `total` Gaussians cut into `cells` k-d cells (sharded.KdPartition), the rank holds one cell and
+    rasterizes it over the WHOLE frame. Every cell is timed through the plain fwd+bwd step (the slowest one is what a synchronous N-rank step waits for: reported),
+    and the slowest cell also through one sharded mapping / tracking iteration of the C++ loop at N = 1 with a one-rank RCCL group executing every collective."""
+    syn = gsr.synthetic
+    sharded = __import__("gsorb_slam_amd.sharded", fromlist=["x"])
+    sys.path.insert(0, os.path.join(ROOT, "gsorb-slam_amd"))
+    from diff_gaussian_rasterization import _C
+    camd = syn.CAMERAS[camera]
+    cam = syn.make_camera(**camd)
+    W, H = cam.width, cam.height
+    sc = syn.make_scene(total, cam, seed=1234)
+    t = lambda x: torch.tensor(x, dtype=torch.float32)
+    part = sharded.KdPartition.build(t(sc.means3D), cells)
+    owner = part.assign(t(sc.means3D)).numpy()
+    per_cell = []
+    for c in range(cells):
+        idx = np.nonzero(owner == c)[0]
+        arrays = dict(means3D=sc.means3D[idx], opacities=sc.opacities[idx], colors=sc.colors[idx], scales=sc.scales[idx], rotations=sc.rotations[idx])
+        d = quick_raster(gsr, dev, cam, arrays, sc.dL_dpix, steps=a.other_steps)
+        d["cell"] = c
+        per_cell.append(d)
+    worst = max(per_cell, key=lambda d: d["ms_per_step"])
+    out = dict(worst)
+    out["what"] = (f"one rank's share of {total} Gaussians cut into {cells} k-d cells, whole {W}x{H} frame: the plain fwd+bwd step of the SLOWEST cell "
+                   f"(ms_per_step; every cell in cells_ms_per_step), its kernels one by one (stage_us, sum_kernel_us), launches_per_step")
+    out["cells_ms_per_step"] = [round(d["ms_per_step"], 4) for d in per_cell]
+    out["cells_tile_instances"] = [d["tile_instances"] for d in per_cell]
+    out["splats_pixels_per_s_of_the_whole_map_if_every_rank_took_this_long"] = total * W * H / (worst["ms_per_step"] * 1e-3)
+    # the sharded loop's iterations on that cell, one rank, RCCL executing the collectives
+    group = one_rank_group(dev)
+    idx = np.nonzero(owner == worst["cell"])[0]
+    op = t(sc.opacities[idx]).reshape(-1, 1)
+    raw = [t(sc.means3D[idx]), t(sc.colors[idx]), t(sc.rotations[idx]), torch.log(op / (1 - op)), torch.log(t(sc.scales[idx]))]
+    L = gsr.capi.lib()
+    res = {}
+    for name, shard in (("sharded_one_rank_rccl", True), ("unsharded", False)):
+        loop = _C.SlamLoop(W, H, camd["fx"], camd["fy"], dev)
+        loop.set_map(*raw)
+        if shard:
+            loop.set_shard(group, 0, 1, torch.empty(0))
+        T = torch.eye(4, device=dev)
+        rgb, sur, _ = loop.render_composite(T)
+        rgb, depth = (rgb * 0.9 + 0.05).contiguous(), sur[0].contiguous()
+        T0 = T.clone(); T0[:3, 3] = torch.tensor([0.004, -0.003, 0.005], device=dev)
+        k = max(a.shard_steps, 20)
+
+        def timed(fn):
+            fn(k)
+            per = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                n0 = int(L.gsr_debug_launch_count())
+                t0 = time.perf_counter()
+                ran = fn(k)
+                torch.cuda.synchronize()
+                per.append(((time.perf_counter() - t0) / max(ran, 1) * 1e3, (int(L.gsr_debug_launch_count()) - n0) / max(ran, 1)))
+            return sorted(per)[1]
+        m_ms, m_l = timed(lambda n: len(loop.map_frame(rgb, depth, T, n)))
+        t_ms, t_l = timed(lambda n: len(loop.track(rgb, depth, T0, n)[0]))
+        res[name] = {"mapping_ms_per_iter": m_ms, "tracking_ms_per_iter": t_ms, "library_launches_per_mapping_iter": round(m_l, 2), "library_launches_per_tracking_iter": round(t_l, 2),
+                     "rccl_launches_per_iter": ({"mapping": 3, "tracking": 4} if shard and group is not None else 0), "transport": loop.shard_transport() if shard else None}
+        del loop
+    out["loop"] = res
+    out["loop"]["what"] = ("ORB_SLAM2::SlamLoop on the same cell: wall clock per mapping (MapFrame: one read-back per batch) / tracking iteration, median of three batches; "
+                           "library_launches = kernels the C ABI launched per iteration (gsr_debug_launch_count; includes the once-per-call preparation spread over the batch), "
+                           "rccl_launches = the collectives RCCL executes on the loop's stream")
+    if _ONE_RANK["error"]:
+        out["loop"]["one_rank_group_error"] = _ONE_RANK["error"]
+    return out
+
+
 def shard_step(a, gsr, td, rank, world, dev):
     """One sharded MAPPING iteration and one sharded TRACKING iteration of the C++ loop (torch_ext/DirectLoop.cpp: SlamLoop::SetShard) with
     every collective inside the timed region. --splats Gaussians in TOTAL, cut into `world` k-d cells (sharded.KdPartition: the partition
@@ -381,14 +527,11 @@ def shard_step(a, gsr, td, rank, world, dev):
     if world > 1:
         group, backend = td.group.WORLD, td.get_backend()
     else:
-        try:                                                     # one rank: RCCL itself still runs the loop's collectives
-            import socket
-            import torch.distributed as td1
-            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
-            td1.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
-            group, backend, own_group = td1.group.WORLD, "nccl (one rank)", True
-        except Exception as e:                                   # (stated in the record, never silent)
-            backend = f"none (single process: one-rank RCCL group failed: {type(e).__name__})"
+        group = one_rank_group(dev)                              # one rank: RCCL itself still runs the loop's collectives
+        if group is not None:
+            backend, own_group = "nccl (one rank)", True
+        else:                                                    # (stated in the record, never silent)
+            backend = f"none (single process: one-rank RCCL group failed: {_ONE_RANK['error']})"
     loop = _C.SlamLoop(W, H, camd["fx"], camd["fy"], dev)
     loop.set_map(*[x[idx] for x in raw])
     loop.set_shard(group, rank, world, part.nodes)
@@ -432,8 +575,6 @@ def shard_step(a, gsr, td, rank, world, dev):
         t_ms, _ = timed(lambda k: len(plain.track(rgb, depth, T0, k)[0]))
         same = {"mapping_ms_per_iter": m_ms, "tracking_ms_per_iter": t_ms}
         del plain
-    if own_group:
-        td1.destroy_process_group()
     plane = W * H * 4              # DirectLoop.cpp: all-gather (silhouette, surface depth), all-reduce of the 4 premultiplied planes, backward all-gather of 1 plane
     return {"what": "one sharded mapping iteration / one sharded tracking iteration of the C++ loop (ORB_SLAM2::SlamLoop with SetShard, torch_ext/DirectLoop.cpp): "
                     "fused rasterizer pair on the rank's k-d cell, gsr_shard_order, layer all-gather, gsr_composite_forward, all-reduce, the fused loss kernels on the "
@@ -528,6 +669,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-other", action="store_true", help="skip the other_workloads / loop_ms blocks (N = 1 only, after the headline)")
     ap.add_argument("--other-steps", type=int, default=50, help="timed steps of each entry of other_workloads")
+    ap.add_argument("--loop-warmup", type=int, default=60, help="loop_ms: untimed tracking + mapping iterations of the C++ loop driver before its clock starts (0: round 5's cold figure)")
     ap.add_argument("--depth-layout", choices=["uniform", "two-walls"], default="uniform",
                     help="experiment: 'two-walls' moves every splat along its pixel ray onto one of two thin depth slabs "
                          "(1.5 m and 4 m, 2 cm thick): every tile list has two depth clusters, the tile sort's hard case")
@@ -595,6 +737,8 @@ def main():
                    "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                    "config": {"workload": f"{a.splats} Gaussians in total, k-d cells over {world} rank(s), {ss['width']}x{ss['height']}"}}
         out["shard_step"] = ss
+    if _ONE_RANK["td"] is not None:
+        _ONE_RANK["td"].destroy_process_group()
     if rank == 0:
         C.CDLL(None).fflush(None)   # (RCCL prints a version banner through C stdio: out before the line, which must be the last one)
         print(json.dumps(out), flush=True)

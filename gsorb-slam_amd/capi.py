@@ -21,7 +21,8 @@ EXPORTS = ["gsr_forward", "gsr_forward_ws", "gsr_ws_status", "gsr_backward", "gs
            "gsr_adam_step", "gsr_pose_grad", "gsr_to_camera", "gsr_pose_from_quat", "gsr_pose_from_quat_backward",
            "gsr_pixel_loss", "gsr_pixel_loss_backward", "gsr_pixel_loss_backward_add", "gsr_track_loss", "gsr_scale_reg", "gsr_scale_reg_backward",
            "gsr_map_prepare", "gsr_map_update", "gsr_map_loss_total", "gsr_map_loss_forward", "gsr_map_loss_finish", "gsr_map_loss_backward", "gsr_pose_update", "gsr_pose_step", "gsr_pose_finish", "gsr_composite_forward", "gsr_composite_backward_local",
-           "gsr_composite_backward_occlusion", "gsr_shard_order", "gsr_reproj_loss", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version"]
+           "gsr_composite_backward_occlusion", "gsr_shard_order", "gsr_reproj_loss", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version",
+           "gsr_debug_launch_count"]
 
 
 def library_path() -> str:
@@ -196,6 +197,7 @@ def lib():
     L.gsr_error_string.argtypes = [C.c_int]
     L.gsr_last_hip_error.restype = C.c_char_p
     L.gsr_abi_version.restype = C.c_int
+    L.gsr_debug_launch_count.restype = C.c_ulonglong
     _LIB = L
     return L
 

@@ -21,6 +21,10 @@ inline bool hip_ok(hipError_t e)
 }
 #define GSR_HIP(x) do { if (!hip_ok(x)) return GSR_EHIP; } while (0)
 #define GSR_LAUNCHED() do { if (!hip_ok(hipGetLastError())) return GSR_EHIP; } while (0)
+// every kernel launch of the library goes through here: a process-wide statistics counter (gsr_debug_launch_count: bench.py states the launches per
+// step / per loop iteration from it), nothing reads it on any data path
+unsigned long long g_launches = 0;
+#define GSR_LAUNCH(...) do { __atomic_fetch_add(&g_launches, 1ull, __ATOMIC_RELAXED); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
 inline int blocks256(int n) { return (n + 255) / 256; }
 
@@ -106,25 +110,25 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     const StageTimer tm{a->profile_events, st};
     tm.begin(GSR_FWD_FILL);
     const BinGrid bg = bin_grid(P, T, GSR_FILL_WX, GSR_BIN_WINDOW);
-    hipLaunchKernelGGL(gsr::K_bin_fill, bg.grid, dim3(GSR_BINF_THREADS), (size_t)bg.twmax * 4, st, P, bg.per, T, f.grid_x, bg.wx, bg.nwin, gv,
+    GSR_LAUNCH(gsr::K_bin_fill, bg.grid, dim3(GSR_BINF_THREADS), (size_t)bg.twmax * 4, st, P, bg.per, T, f.grid_x, bg.wx, bg.nwin, gv,
                        iv.binmat, iv.tile_start, bv.pairs);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_FILL);
     tm.begin(GSR_FWD_SORT);
 #ifdef GSR_EXP_MIDSORT // timing experiment: the keys-only 16-keys-per-thread sort of the lists over 1024 entries, run beside the real one
-    hipLaunchKernelGGL(gsr::K_tile_sort<GSR_SORT_BLOCK>, dim3(T), dim3(256), 0, st, T, iv.ranges, gv.hdr, bv.pairs, bv.point_list);
+    GSR_LAUNCH(gsr::K_tile_sort<GSR_SORT_BLOCK>, dim3(T), dim3(256), 0, st, T, iv.ranges, gv.hdr, bv.pairs, bv.point_list);
 #endif
-    hipLaunchKernelGGL(gsr::K_tile_sort_cut, dim3(T), dim3(GSR_SORT_CUT_THREADS), 0, st, T, f.grid_x, iv.ranges, gv, bv.pairs, bv.point_list,
+    GSR_LAUNCH(gsr::K_tile_sort_cut, dim3(T), dim3(GSR_SORT_CUT_THREADS), 0, st, T, f.grid_x, iv.ranges, gv, bv.pairs, bv.point_list,
                        bv.qhits, iv.qcount);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SORT);
     tm.begin(GSR_FWD_BLEND);
     const int Tb = (f.band_y1 - f.band_y0) * f.grid_x; // tiles of the band
     if (Tb > 0 && a->out_ds)
-        hipLaunchKernelGGL((gsr::K_blend_fwd<GSR_ROWQ, true>), dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
+        GSR_LAUNCH((gsr::K_blend_fwd<GSR_ROWQ, true>), dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
                            f.grid_x, Tb, f.band_y0 * f.grid_x, a->out_color, a->out_depth, P, a->out_ds);
     else if (Tb > 0)
-        hipLaunchKernelGGL((gsr::K_blend_fwd<GSR_ROWQ, false>), dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
+        GSR_LAUNCH((gsr::K_blend_fwd<GSR_ROWQ, false>), dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
                            f.grid_x, Tb, f.band_y0 * f.grid_x, a->out_color, a->out_depth, P, (float*)nullptr);
     else // an empty band launches no blend kernel: clear the backward accumulators here
         GSR_HIP(hipMemsetAsync(gv.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
@@ -149,9 +153,9 @@ int forward_head(const gsr_forward_args* a, char* geom, char* image, hipStream_t
     tm.begin(GSR_FWD_PREPROCESS);
     if (a->raw) {
         in.opac_out = a->raw->opacities; in.scales_out = a->raw->scales; in.rots_out = a->raw->rotations; in.reg_limit = a->raw->reg_limit; in.reg_partial = a->raw->reg_partial;
-        hipLaunchKernelGGL(gsr::K_preprocess<true>, dim3((P + GSR_PRE_THREADS - 1) / GSR_PRE_THREADS), dim3(GSR_PRE_THREADS), 0, st, f, in, a->radii, *gv);
+        GSR_LAUNCH(gsr::K_preprocess<true>, dim3((P + GSR_PRE_THREADS - 1) / GSR_PRE_THREADS), dim3(GSR_PRE_THREADS), 0, st, f, in, a->radii, *gv);
     } else
-        hipLaunchKernelGGL(gsr::K_preprocess<false>, dim3((P + GSR_PRE_THREADS - 1) / GSR_PRE_THREADS), dim3(GSR_PRE_THREADS), 0, st, f, in, a->radii, *gv);
+        GSR_LAUNCH(gsr::K_preprocess<false>, dim3((P + GSR_PRE_THREADS - 1) / GSR_PRE_THREADS), dim3(GSR_PRE_THREADS), 0, st, f, in, a->radii, *gv);
     GSR_LAUNCHED();
     tm.end(GSR_FWD_PREPROCESS);
     tm.begin(GSR_FWD_SCAN);
@@ -160,12 +164,12 @@ int forward_head(const gsr_forward_args* a, char* geom, char* image, hipStream_t
         GSR_HIP(hipFuncSetAttribute((const void*)gsr::K_bin_count, hipFuncAttributeMaxDynamicSharedMemorySize, bg.twmax * 4));
         GSR_HIP(hipFuncSetAttribute((const void*)gsr::K_bin_fill, hipFuncAttributeMaxDynamicSharedMemorySize, bg.twmax * 4));
     }
-    hipLaunchKernelGGL(gsr::K_bin_count, bg.grid, dim3(GSR_BINC_THREADS), (size_t)bg.twmax * 4, st, P, bg.per, T, f.grid_x, bg.wx, bg.nwin, *gv, iv->binmat);
+    GSR_LAUNCH(gsr::K_bin_count, bg.grid, dim3(GSR_BINC_THREADS), (size_t)bg.twmax * 4, st, P, bg.per, T, f.grid_x, bg.wx, bg.nwin, *gv, iv->binmat);
 #ifdef GSR_SEPARATE_SCAN // (the two-launch form)
-    hipLaunchKernelGGL(gsr::K_bin_colscan, dim3((T + 31) / 32), dim3(1024), 0, st, bg.rows, T, iv->binmat, iv->tile_cnt, (uint32_t*)nullptr, (uint2*)nullptr, gv->hdr, capacity);
-    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, T, iv->tile_cnt, 1, iv->tile_start, 1, iv->ranges, gv->hdr, capacity);
+    GSR_LAUNCH(gsr::K_bin_colscan, dim3((T + 31) / 32), dim3(1024), 0, st, bg.rows, T, iv->binmat, iv->tile_cnt, (uint32_t*)nullptr, (uint2*)nullptr, gv->hdr, capacity);
+    GSR_LAUNCH(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, T, iv->tile_cnt, 1, iv->tile_start, 1, iv->ranges, gv->hdr, capacity);
 #else
-    hipLaunchKernelGGL(gsr::K_bin_colscan, dim3((T + 31) / 32), dim3(1024), 0, st, bg.rows, T, iv->binmat, iv->tile_cnt, iv->tile_start, iv->ranges, gv->hdr, capacity);
+    GSR_LAUNCH(gsr::K_bin_colscan, dim3((T + 31) / 32), dim3(1024), 0, st, bg.rows, T, iv->binmat, iv->tile_cnt, iv->tile_start, iv->ranges, gv->hdr, capacity);
 #endif
     GSR_LAUNCHED();
     tm.end(GSR_FWD_SCAN);
@@ -192,6 +196,7 @@ size_t gsr_geom_bytes(int P) { return geom_layout(nullptr, P, nullptr); }
 size_t gsr_image_bytes(int width, int height) { return image_layout(nullptr, width, height, nullptr); }
 size_t gsr_binning_bytes(size_t R) { return binning_layout(nullptr, R, nullptr); }
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+unsigned long long gsr_debug_launch_count(void) { return __atomic_load_n(&g_launches, __ATOMIC_RELAXED); }
 
 const char* gsr_error_string(int code)
 {
@@ -295,7 +300,7 @@ int gsr_forward(const gsr_forward_args* a, gsr_alloc_fn geom_alloc, void* geom_u
     if (R > guess) {
         binning = binning_alloc(binning_user, gsr_binning_bytes(R));
         if (!binning) return GSR_EALLOC;
-        hipLaunchKernelGGL(gsr::K_set_capacity, dim3(1), dim3(1), 0, st, gv.hdr, R);
+        GSR_LAUNCH(gsr::K_set_capacity, dim3(1), dim3(1), 0, st, gv.hdr, R);
         GSR_LAUNCHED();
         binning_layout(binning, R, &bv);
         rc = forward_tail(a, gv, iv, bv, f, st);
@@ -384,7 +389,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
     }
     if (a->P == 0) { // src/Rasterizer.cu:263. An empty map still owes the tracking loop its bookkeeping: loss history, best pose, the next Tcw
         if (a->fused_pose_step && !a->fused_pose_step->sums_only && ((a->stages ? a->stages : GSR_STAGE_SPLAT) & GSR_STAGE_SPLAT)) {
-            hipLaunchKernelGGL(gsr::K_pose_finish, dim3(1), dim3(64), 0, st, pu, const_cast<float*>(a->fused_pose_step->update->partial), (float*)nullptr);
+            GSR_LAUNCH(gsr::K_pose_finish, dim3(1), dim3(64), 0, st, pu, const_cast<float*>(a->fused_pose_step->update->partial), (float*)nullptr);
             GSR_LAUNCHED();
         }
         return GSR_OK;
@@ -417,7 +422,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
         // channel's colour is a constant): the fused pair's kernel without them (a tracking iteration)
         // (the fused map update steps the colours from those sums although it is handed no dL_dcolor buffer: ADVICE r4)
         const bool no_colour = (stages & GSR_STAGE_SPLAT) && !a->dL_dcolor && !a->dL_dsh && a->dL_dds && a->ds_detach_depth && !a->fused_map_update;
-#define GSR_BWD_DUAL(COL, SIL) hipLaunchKernelGGL((gsr::K_blend_bwd<GSR_ROWQ, true, COL, SIL>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, \
+#define GSR_BWD_DUAL(COL, SIL) GSR_LAUNCH((gsr::K_blend_bwd<GSR_ROWQ, true, COL, SIL>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, \
                                                   W, H, f.grid_x, Tb, f.band_y0 * f.grid_x, a->dL_dpix, a->dL_dds)
         if (no_colour && a->dds_depth_only) GSR_BWD_DUAL(false, false);
         else if (no_colour) GSR_BWD_DUAL(false, true);
@@ -425,7 +430,7 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
         else if (a->dL_dds) GSR_BWD_DUAL(true, true);
 #undef GSR_BWD_DUAL
         else
-            hipLaunchKernelGGL((gsr::K_blend_bwd<GSR_ROWQ, false>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, W, H, f.grid_x, Tb,
+            GSR_LAUNCH((gsr::K_blend_bwd<GSR_ROWQ, false>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, W, H, f.grid_x, Tb,
                                f.band_y0 * f.grid_x, a->dL_dpix, (const float*)nullptr);
         GSR_LAUNCHED();
         tm.end(GSR_BWD_BLEND);
@@ -439,19 +444,19 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
         o.dL_dsh = a->dL_dsh; o.dL_dscale = a->dL_dscale; o.dL_drot = a->dL_drot;
         tm.begin(GSR_BWD_SPLAT);
         if (a->fused_map_update) { // the per-splat stage takes the Adam step itself (include/gsr.h; arguments checked above, before the first launch)
-            if (stages & GSR_STAGE_REZERO) hipLaunchKernelGGL((gsr::K_splat_bwd<true, true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
-            else hipLaunchKernelGGL((gsr::K_splat_bwd<false, true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
+            if (stages & GSR_STAGE_REZERO) GSR_LAUNCH((gsr::K_splat_bwd<true, true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
+            else GSR_LAUNCH((gsr::K_splat_bwd<false, true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
         } else if (a->fused_pose_step) { // the per-splat stage forms the pose sums and its last workgroup takes the pose step (include/gsr.h)
             const gsr_pose_step_args* ps = a->fused_pose_step;
             static_assert(GSR_POSE_ACC_ROWS * 12 <= GSR_POSE_PARTIALS * 12, "gsr_pose_grad's scratch holds the accumulator rows");
             const gsr::PoseUpdate& u = pu;
             gsr::PoseStep k;
             k.X = ps->means_world; k.acc = const_cast<float*>(ps->update->partial); k.overflow_out = ps->sums_only ? ps->overflow_out : nullptr;
-            if (stages & GSR_STAGE_REZERO) hipLaunchKernelGGL((gsr::K_splat_bwd_pose<true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, k);
-            else hipLaunchKernelGGL((gsr::K_splat_bwd_pose<false>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, k);
-            if (!ps->sums_only) hipLaunchKernelGGL(gsr::K_pose_finish, dim3(1), dim3(64), 0, st, u, k.acc, (float*)nullptr);
-        } else if (stages & GSR_STAGE_REZERO) hipLaunchKernelGGL((gsr::K_splat_bwd<true, false>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
-        else hipLaunchKernelGGL((gsr::K_splat_bwd<false, false>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
+            if (stages & GSR_STAGE_REZERO) GSR_LAUNCH((gsr::K_splat_bwd_pose<true>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, k);
+            else GSR_LAUNCH((gsr::K_splat_bwd_pose<false>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, k);
+            if (!ps->sums_only) GSR_LAUNCH(gsr::K_pose_finish, dim3(1), dim3(64), 0, st, u, k.acc, (float*)nullptr);
+        } else if (stages & GSR_STAGE_REZERO) GSR_LAUNCH((gsr::K_splat_bwd<true, false>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
+        else GSR_LAUNCH((gsr::K_splat_bwd<false, false>), dim3(blocks256(P)), dim3(256), 0, st, f, in, gv, o, mu);
         GSR_LAUNCHED();
         tm.end(GSR_BWD_SPLAT);
     }
@@ -464,7 +469,7 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
     (void)projmatrix; // the reference's test only uses the view-space depth (auxiliary.h:154)
     if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) return GSR_EINVAL;
     if (P == 0) return GSR_OK;
-    hipLaunchKernelGGL(gsr::K_mark_visible, dim3(blocks256(P)), dim3(256), 0, (hipStream_t)stream, P, means3D, viewmatrix, present);
+    GSR_LAUNCH(gsr::K_mark_visible, dim3(blocks256(P)), dim3(256), 0, (hipStream_t)stream, P, means3D, viewmatrix, present);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -481,7 +486,7 @@ int gsr_visible_filter(int P, int width, int height, const float* means3D, const
     const FrameParams f = frame_params(P, 0, 0, width, height, tan_fovx, tan_fovy, scale_modifier);
     const gsr::SplatInputs in = splat_inputs(means3D, scales, rotations, nullptr, nullptr, nullptr, nullptr,
                                              viewmatrix, projmatrix, nullptr);
-    hipLaunchKernelGGL(gsr::K_filter_radii, dim3(blocks256(P)), dim3(256), 0, (hipStream_t)stream, f, in, radii);
+    GSR_LAUNCH(gsr::K_filter_radii, dim3(blocks256(P)), dim3(256), 0, (hipStream_t)stream, f, in, radii);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -509,23 +514,23 @@ int gsr_dist2(int P, const float* points, float* mean_dists, char* workspace, si
     const int bits = gsr::knn_bucket_bits(P), nb = 1 << bits, shift = 30 - bits;
     const int nbox = (P + GSR_KNN_BOX - 1) / GSR_KNN_BOX;
     GSR_HIP(hipMemsetAsync(k.buckets, 0, (size_t)nb * sizeof(gsr::BucketRec), st));
-    hipLaunchKernelGGL(gsr::K_knn_init, dim3(1), dim3(64), 0, st, k.bbox);
+    GSR_LAUNCH(gsr::K_knn_init, dim3(1), dim3(64), 0, st, k.bbox);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_knn_bbox, dim3(std::min(blocks256(P), 1024)), dim3(256), 0, st, P, points, k.bbox);
+    GSR_LAUNCH(gsr::K_knn_bbox, dim3(std::min(blocks256(P), 1024)), dim3(256), 0, st, P, points, k.bbox);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_knn_code, dim3(blocks256(P)), dim3(256), 0, st, P, shift, points, k.bbox, k.buckets, k.code, k.slot);
+    GSR_LAUNCH(gsr::K_knn_code, dim3(blocks256(P)), dim3(256), 0, st, P, shift, points, k.bbox, k.buckets, k.code, k.slot);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, nb, &k.buckets->cnt, 16, &k.buckets->start, 16, k.ranges, k.hdr, 0xFFFFFFFFu);
+    GSR_LAUNCH(gsr::K_scan_tiles, dim3(1), dim3(1024), 0, st, nb, &k.buckets->cnt, 16, &k.buckets->start, 16, k.ranges, k.hdr, 0xFFFFFFFFu);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_knn_fill, dim3(blocks256(P)), dim3(256), 0, st, P, shift, k.code, k.slot, k.buckets, k.pairs);
+    GSR_LAUNCH(gsr::K_knn_fill, dim3(blocks256(P)), dim3(256), 0, st, P, shift, k.code, k.slot, k.buckets, k.pairs);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_tile_sort<GSR_SORT_WAVE>, dim3(nb), dim3(GSR_SORT_SMALL_THREADS), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order);
+    GSR_LAUNCH(gsr::K_tile_sort<GSR_SORT_WAVE>, dim3(nb), dim3(GSR_SORT_SMALL_THREADS), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_tile_sort<GSR_SORT_BLOCK>, dim3(nb), dim3(256), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order);
+    GSR_LAUNCH(gsr::K_tile_sort<GSR_SORT_BLOCK>, dim3(nb), dim3(256), 0, st, nb, k.ranges, k.hdr, k.pairs, k.order);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_knn_boxes, dim3(nbox), dim3(256), 0, st, P, points, k.order, k.spts, k.boxes);
+    GSR_LAUNCH(gsr::K_knn_boxes, dim3(nbox), dim3(256), 0, st, P, points, k.order, k.spts, k.boxes);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_knn_search, dim3(blocks256(P)), dim3(256), 0, st, P, nbox, k.spts, k.boxes, mean_dists);
+    GSR_LAUNCH(gsr::K_knn_search, dim3(blocks256(P)), dim3(256), 0, st, P, nbox, k.spts, k.boxes, mean_dists);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -547,7 +552,7 @@ int gsr_ssim_forward(const float* img1, const float* img2, int C, int H, int W, 
     gsr::SsimTaps t;
     for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
     const gsr::SsimGrid sg = gsr::ssim_grid(C, H, W);
-    hipLaunchKernelGGL(gsr::K_ssim_fwd<false>, dim3((unsigned)gsr_ssim_partials(C, H, W)), dim3(64), 0, (hipStream_t)stream, img1, img2, C, H, W, t, sg, partial, dmaps,
+    GSR_LAUNCH(gsr::K_ssim_fwd<false>, dim3((unsigned)gsr_ssim_partials(C, H, W)), dim3(64), 0, (hipStream_t)stream, img1, img2, C, H, W, t, sg, partial, dmaps,
                        gsr::MapLossPlanes{});
     GSR_LAUNCHED();
     return GSR_OK;
@@ -560,7 +565,7 @@ int gsr_ssim_backward(const float* img1, const float* img2, const float* dmaps, 
     gsr::SsimTaps t;
     for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
     const gsr::SsimGrid sg = gsr::ssim_grid(C, H, W);
-    hipLaunchKernelGGL(gsr::K_ssim_bwd<false>, dim3((unsigned)gsr_ssim_partials(C, H, W)), dim3(64), 0, (hipStream_t)stream, img1, img2, dmaps, C, H, W, t, sg, dL_dmean,
+    GSR_LAUNCH(gsr::K_ssim_bwd<false>, dim3((unsigned)gsr_ssim_partials(C, H, W)), dim3(64), 0, (hipStream_t)stream, img1, img2, dmaps, C, H, W, t, sg, dL_dmean,
                        dL_dimg1, gsr::MapLossGrad{});
     GSR_LAUNCHED();
     return GSR_OK;
@@ -570,7 +575,7 @@ int gsr_to_camera(const float* means3D, size_t n, const float* Tcw, float* means
 {
     if (n == 0) return GSR_OK;
     if (!means3D || !Tcw || !means_cam || (n + 255) / 256 > 0x7FFFFFFFu) return GSR_EINVAL;
-    hipLaunchKernelGGL(gsr::K_to_camera, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, means3D, n, Tcw, means_cam);
+    GSR_LAUNCH(gsr::K_to_camera, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, means3D, n, Tcw, means_cam);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -580,7 +585,7 @@ int gsr_pose_grad(const float* means3D, const float* dL_dmeans_cam, size_t n, co
 {
     static_assert(GSR_POSE_PARTIALS == GSR_POSE_BLOCKS, "header and kernel agree on the number of partial rows");
     if ((!partial && !dL_dmeans3D) || !Tcw || (n > 0 && (!dL_dmeans_cam || (partial && !means3D)))) return GSR_EINVAL;
-    hipLaunchKernelGGL(gsr::K_pose_grad, dim3(GSR_POSE_BLOCKS), dim3(256), 0, (hipStream_t)stream, means3D, dL_dmeans_cam, n, Tcw, partial,
+    GSR_LAUNCH(gsr::K_pose_grad, dim3(GSR_POSE_BLOCKS), dim3(256), 0, (hipStream_t)stream, means3D, dL_dmeans_cam, n, Tcw, partial,
                        dL_dmeans3D);
     GSR_LAUNCHED();
     return GSR_OK;
@@ -589,7 +594,7 @@ int gsr_pose_grad(const float* means3D, const float* dL_dmeans_cam, size_t n, co
 int gsr_pose_from_quat(const float* quat, const float* trans, float* Tcw, void* stream)
 {
     if (!quat || !trans || !Tcw) return GSR_EINVAL;
-    hipLaunchKernelGGL(gsr::K_rt2T, dim3(1), dim3(64), 0, (hipStream_t)stream, quat, trans, Tcw);
+    GSR_LAUNCH(gsr::K_rt2T, dim3(1), dim3(64), 0, (hipStream_t)stream, quat, trans, Tcw);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -597,7 +602,7 @@ int gsr_pose_from_quat(const float* quat, const float* trans, float* Tcw, void* 
 int gsr_pose_from_quat_backward(const float* quat, const float* dL_dTcw, float* dL_dquat, float* dL_dtrans, void* stream)
 {
     if (!quat || !dL_dTcw || !dL_dquat || !dL_dtrans) return GSR_EINVAL;
-    hipLaunchKernelGGL(gsr::K_rt2T_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, quat, dL_dTcw, dL_dquat, dL_dtrans);
+    GSR_LAUNCH(gsr::K_rt2T_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, quat, dL_dTcw, dL_dquat, dL_dtrans);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -613,7 +618,7 @@ int gsr_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     const float step_size = (float)(lr / bc1), sqrt_bc2 = (float)std::sqrt(bc2);
     const size_t blocks = (n + 1023) / 1024;
     if (blocks > 0x7FFFFFFFu) return GSR_EINVAL;
-    hipLaunchKernelGGL(gsr::K_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1),
+    GSR_LAUNCH(gsr::K_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1),
                        (float)beta2, (float)(1.0 - beta2), (float)eps, step_size, sqrt_bc2);
     GSR_LAUNCHED();
     return GSR_OK;
@@ -629,9 +634,9 @@ int gsr_pixel_loss(const float* image, const float* depth, const float* sur, con
     const gsr::LossPlanes p{image, depth, sur, sil, frame_rgb, frame_depth};
     gsr::LossWeights w{{w3[0], w3[1], w3[2]}};
     const int nb = (int)std::min<size_t>(GSR_LOSS_BLOCKS, (N + 255) / 256);
-    hipLaunchKernelGGL(gsr::K_loss_sums, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, N, mode, sil_thr, partial);
+    GSR_LAUNCH(gsr::K_loss_sums, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, N, mode, sil_thr, partial);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_loss_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, partial, nb, mode, N, w, depth ? 0 : 1, sums);
+    GSR_LAUNCH(gsr::K_loss_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, partial, nb, mode, N, w, depth ? 0 : 1, sums);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -647,10 +652,10 @@ int gsr_track_loss(const float* image, const float* depth, const float* sur, con
     const int nb = (int)std::min<size_t>(GSR_LOSS_BLOCKS, (N + 255) / 256);
     static_assert(GSR_FINISH_THREADS == 256, "the last workgroup of K_track_loss runs the finish");
     static_assert(GSR_TICKET_WORDS == GSR_TICKET_WORDS_DEV, "header and kernels agree on the arrival counters");
-    hipLaunchKernelGGL(gsr::K_track_loss, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, N, sil_thr, w, partial, dL_dimage, dL_ddepth, ticket, depth ? 0 : 1, sums);
+    GSR_LAUNCH(gsr::K_track_loss, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, N, sil_thr, w, partial, dL_dimage, dL_ddepth, ticket, depth ? 0 : 1, sums);
     GSR_LAUNCHED();
     if (!ticket) {
-        hipLaunchKernelGGL(gsr::K_loss_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, partial, nb, 0, N, w, depth ? 0 : 1, sums);
+        GSR_LAUNCH(gsr::K_loss_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, partial, nb, 0, N, w, depth ? 0 : 1, sums);
         GSR_LAUNCHED();
     }
     return GSR_OK;
@@ -665,7 +670,7 @@ int gsr_pixel_loss_backward(const float* image, const float* depth, const float*
     if ((N + 255) / 256 > 0x7FFFFFFFu) return GSR_EINVAL;
     const gsr::LossPlanes p{image, depth, nullptr, sil, frame_rgb, frame_depth};
     gsr::LossWeights w{{w3[0], w3[1], w3[2]}};
-    hipLaunchKernelGGL(gsr::K_loss_grad, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, N, mode, sil_thr, w, sums, dL_dloss,
+    GSR_LAUNCH(gsr::K_loss_grad, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, N, mode, sil_thr, w, sums, dL_dloss,
                        dL_dimage, dL_ddepth, (const float*)nullptr);
     GSR_LAUNCHED();
     return GSR_OK;
@@ -680,7 +685,7 @@ int gsr_pixel_loss_backward_add(const float* image, const float* depth, const fl
     if ((N + 255) / 256 > 0x7FFFFFFFu) return GSR_EINVAL;
     const gsr::LossPlanes p{image, depth, nullptr, sil, frame_rgb, frame_depth};
     gsr::LossWeights w{{w3[0], w3[1], w3[2]}};
-    hipLaunchKernelGGL(gsr::K_loss_grad, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, N, mode, sil_thr, w, sums, dL_dloss,
+    GSR_LAUNCH(gsr::K_loss_grad, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, N, mode, sil_thr, w, sums, dL_dloss,
                        dL_dimage, dL_ddepth, add_image);
     GSR_LAUNCHED();
     return GSR_OK;
@@ -698,11 +703,11 @@ int gsr_map_prepare(size_t n, const float* xyz, const float* logit, const float*
         return GSR_EINVAL;
     const unsigned rows = (unsigned)((n + 255) / 256);
     if (n > 0 && !finish_only)
-        hipLaunchKernelGGL(gsr::K_map_prepare, dim3(rows), dim3(256), 0, (hipStream_t)stream, n, xyz, logit, log_scales, unnorm_quat, Tcw, means_cam,
+        GSR_LAUNCH(gsr::K_map_prepare, dim3(rows), dim3(256), 0, (hipStream_t)stream, n, xyz, logit, log_scales, unnorm_quat, Tcw, means_cam,
                            opacities, scales, rotations, reg_limit, reg_partial);
     GSR_LAUNCHED();
     if (reg_partial && reg_out) {
-        hipLaunchKernelGGL(gsr::K_scale_reg_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, reg_partial, (int)rows, w_long, w_scalar, reg_out);
+        GSR_LAUNCH(gsr::K_scale_reg_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, reg_partial, (int)rows, w_long, w_scalar, reg_out);
         GSR_LAUNCHED();
     }
     return GSR_OK;
@@ -715,8 +720,8 @@ int gsr_map_update(const gsr_map_update_args* a, void* stream)
     gsr::MapUpdate u;
     const int rc = make_map_update(a, true, &u);
     if (rc != GSR_OK) return rc;
-    if (a->n < (size_t)1 << 18) hipLaunchKernelGGL(gsr::K_map_update_small, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a->n, u);
-    else hipLaunchKernelGGL(gsr::K_map_update, dim3((unsigned)((a->n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, a->n, u); // four splats per thread
+    if (a->n < (size_t)1 << 18) GSR_LAUNCH(gsr::K_map_update_small, dim3((unsigned)((a->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a->n, u);
+    else GSR_LAUNCH(gsr::K_map_update, dim3((unsigned)((a->n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, a->n, u); // four splats per thread
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -725,7 +730,7 @@ int gsr_map_loss_total(const float* sums, const float* ssim_partial, int n_parti
                        const char* geom, float* loss, void* stream)
 {
     if (!sums || !loss || n_partial < 0 || (n_partial > 0 && (!ssim_partial || count == 0))) return GSR_EINVAL;
-    hipLaunchKernelGGL(gsr::K_map_loss_total, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, sums, ssim_partial, n_partial,
+    GSR_LAUNCH(gsr::K_map_loss_total, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, sums, ssim_partial, n_partial,
                        count ? 1.f / (float)count : 0.f, n_partial ? c_ssim : 0.f, reg_out, overflow_flag(geom), loss);
     GSR_LAUNCHED();
     return GSR_OK;
@@ -737,7 +742,7 @@ int gsr_composite_forward(int world, int rank, const long long* order, const flo
     if (world < 1 || rank < 0 || rank >= world || !order || !gathered || !layer4 || !contrib || !sil_total || H <= 0 || W <= 0) return GSR_EINVAL;
     if (gathered_planes < (has_sur ? 2 : 1)) return GSR_EINVAL;
     const size_t N = (size_t)H * W;
-    hipLaunchKernelGGL(gsr::K_composite_fwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, gathered, gathered_planes,
+    GSR_LAUNCH(gsr::K_composite_fwd, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, gathered, gathered_planes,
                        layer4, N, has_sur, contrib, sil_total, surf);
     GSR_LAUNCHED();
     return GSR_OK;
@@ -748,7 +753,7 @@ int gsr_composite_backward_local(int world, int rank, const long long* order, co
 {
     if (world < 1 || rank < 0 || rank >= world || !order || !gathered || !layer4 || !d_layer4 || !c_own || H <= 0 || W <= 0 || gathered_planes < 1) return GSR_EINVAL;
     const size_t N = (size_t)H * W;
-    hipLaunchKernelGGL(gsr::K_composite_bwd_local, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, gathered,
+    GSR_LAUNCH(gsr::K_composite_bwd_local, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, gathered,
                        gathered_planes, layer4, g4, N, d_layer4, c_own);
     GSR_LAUNCHED();
     return GSR_OK;
@@ -759,7 +764,7 @@ int gsr_composite_backward_occlusion(int world, int rank, const long long* order
 {
     if (world < 1 || rank < 0 || rank >= world || !order || !gathered || !c_all || !dS || H <= 0 || W <= 0 || gathered_planes < 1) return GSR_EINVAL;
     const size_t N = (size_t)H * W;
-    hipLaunchKernelGGL(gsr::K_composite_bwd_occlusion, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, gathered,
+    GSR_LAUNCH(gsr::K_composite_bwd_occlusion, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, gathered,
                        gathered_planes, c_all, g_sil, N, dS);
     GSR_LAUNCHED();
     return GSR_OK;
@@ -768,7 +773,7 @@ int gsr_composite_backward_occlusion(int world, int rank, const long long* order
 int gsr_shard_order(int world, const float* kd_nodes, const float* Tcw, long long* order, void* stream)
 {
     if (world < 1 || world > 32 || !order || (world > 1 && (!kd_nodes || !Tcw))) return GSR_EINVAL;
-    hipLaunchKernelGGL(gsr::K_shard_order, dim3(1), dim3(1), 0, (hipStream_t)stream, world, kd_nodes, Tcw, order);
+    GSR_LAUNCH(gsr::K_shard_order, dim3(1), dim3(1), 0, (hipStream_t)stream, world, kd_nodes, Tcw, order);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -781,7 +786,7 @@ int gsr_map_loss_forward(const float* image, const float* depth, const float* su
     for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
     const gsr::SsimGrid sg = gsr::ssim_grid(3, H, W);
     const gsr::MapLossPlanes ml{depth, sur, sil, frame_depth, sil_thr, partial6};
-    hipLaunchKernelGGL(gsr::K_ssim_fwd<true>, dim3(2u * (unsigned)gsr_ssim_partials(3, H, W)), dim3(64), 0, (hipStream_t)stream, image, frame_rgb, 3, H, W, t, sg, (float*)nullptr,
+    GSR_LAUNCH(gsr::K_ssim_fwd<true>, dim3(2u * (unsigned)gsr_ssim_partials(3, H, W)), dim3(64), 0, (hipStream_t)stream, image, frame_rgb, 3, H, W, t, sg, (float*)nullptr,
                        dmaps, ml);
     GSR_LAUNCHED();
     return GSR_OK;
@@ -797,7 +802,7 @@ int gsr_map_loss_finish(const float* partial6, const float* reg_partial, size_t 
     m.inv_pixels3 = 1.f / (3.f * (float)((size_t)H * W)); m.inv_count_ssim = 1.f / (float)((size_t)3 * H * W);
     m.w[0] = w3[0]; m.w[1] = w3[1]; m.w[2] = w3[2]; m.c_ssim = c_ssim; m.w_long = w_long; m.w_scalar = w_scalar;
     m.overflow = overflow_flag(geom); m.sums = sums; m.reg_out = reg_out; m.loss = loss;
-    hipLaunchKernelGGL(gsr::K_map_finish, dim3(1), dim3(GSR_MAP_FINISH_THREADS), 0, (hipStream_t)stream, m);
+    GSR_LAUNCH(gsr::K_map_finish, dim3(1), dim3(GSR_MAP_FINISH_THREADS), 0, (hipStream_t)stream, m);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -810,7 +815,7 @@ int gsr_map_loss_backward(const float* image, const float* depth, const float* f
     for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
     const gsr::SsimGrid sg = gsr::ssim_grid(3, H, W);
     const gsr::MapLossGrad mg{depth, frame_depth, sums, w3[0] / (3.f * (float)((size_t)H * W)), w3[1], dL_ddepth};
-    hipLaunchKernelGGL(gsr::K_ssim_bwd<true>, dim3((dL_ddepth ? 2u : 1u) * (unsigned)gsr_ssim_partials(3, H, W)), dim3(64), 0, (hipStream_t)stream, image, frame_rgb, dmaps, 3, H, W, t, sg, neg_c_ssim,
+    GSR_LAUNCH(gsr::K_ssim_bwd<true>, dim3((dL_ddepth ? 2u : 1u) * (unsigned)gsr_ssim_partials(3, H, W)), dim3(64), 0, (hipStream_t)stream, image, frame_rgb, dmaps, 3, H, W, t, sg, neg_c_ssim,
                        dL_dimage, mg);
     GSR_LAUNCHED();
     return GSR_OK;
@@ -836,7 +841,7 @@ int gsr_pose_update(const gsr_pose_update_args* a, void* stream)
     gsr::PoseUpdate u;
     const int rc = make_pose_update(a, &u);
     if (rc != GSR_OK) return rc;
-    hipLaunchKernelGGL(gsr::K_pose_update, dim3(1), dim3(64), 0, (hipStream_t)stream, u);
+    GSR_LAUNCH(gsr::K_pose_update, dim3(1), dim3(64), 0, (hipStream_t)stream, u);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -847,7 +852,7 @@ int gsr_pose_finish(const gsr_pose_update_args* a, float* acc_rows, float* sums_
     gsr::PoseUpdate u;
     const int rc = make_pose_update(a, &u);
     if (rc != GSR_OK) return rc;
-    hipLaunchKernelGGL(gsr::K_pose_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, u, acc_rows, sums_out);
+    GSR_LAUNCH(gsr::K_pose_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, u, acc_rows, sums_out);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -858,7 +863,7 @@ int gsr_reproj_loss(const float* obs, const float* Xw, const float* inv_sigma2, 
     if (M > 0x7FFFFFFFu || !Tcw || !pose_row || !loss || refresh_inliers < 0 || refresh_inliers > 2) return GSR_EINVAL;
     if (M > 0 && (!obs || !Xw || !inv_sigma2 || (refresh_inliers != 2 && !inliers))) return GSR_EINVAL;
     if (M == 0) return GSR_OK;
-    hipLaunchKernelGGL(gsr::K_reproj, dim3(1), dim3(256), 0, (hipStream_t)stream, obs, Xw, inv_sigma2, (int)M, Tcw, fx, fy, cx, cy, weight, weight * grad_scale,
+    GSR_LAUNCH(gsr::K_reproj, dim3(1), dim3(256), 0, (hipStream_t)stream, obs, Xw, inv_sigma2, (int)M, Tcw, fx, fy, cx, cy, weight, weight * grad_scale,
                        refresh_inliers, inliers, pose_row, loss);
     GSR_LAUNCHED();
     return GSR_OK;
@@ -870,7 +875,7 @@ int gsr_pose_step(const float* means3D, const float* dL_dmeans_cam, size_t n, co
     const int rc = make_pose_update(a, &u);
     if (rc != GSR_OK) return rc;
     if (!ticket || (n > 0 && (!means3D || !dL_dmeans_cam))) return GSR_EINVAL;
-    hipLaunchKernelGGL(gsr::K_pose_step, dim3(GSR_POSE_BLOCKS), dim3(256), 0, (hipStream_t)stream, means3D, dL_dmeans_cam, n, const_cast<float*>(a->partial), ticket, u);
+    GSR_LAUNCH(gsr::K_pose_step, dim3(GSR_POSE_BLOCKS), dim3(256), 0, (hipStream_t)stream, means3D, dL_dmeans_cam, n, const_cast<float*>(a->partial), ticket, u);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -879,9 +884,9 @@ int gsr_scale_reg(const float* log_scales, size_t n, float limit, float w_long, 
 {
     if (!partial || !out || (n > 0 && !log_scales)) return GSR_EINVAL;
     const int nb = (int)std::max<size_t>(1, std::min<size_t>(GSR_LOSS_BLOCKS, (n + 255) / 256));
-    hipLaunchKernelGGL(gsr::K_scale_reg, dim3(nb), dim3(256), 0, (hipStream_t)stream, log_scales, n, limit, partial);
+    GSR_LAUNCH(gsr::K_scale_reg, dim3(nb), dim3(256), 0, (hipStream_t)stream, log_scales, n, limit, partial);
     GSR_LAUNCHED();
-    hipLaunchKernelGGL(gsr::K_scale_reg_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, partial, nb, w_long, w_scalar, out);
+    GSR_LAUNCH(gsr::K_scale_reg_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, partial, nb, w_long, w_scalar, out);
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -891,7 +896,7 @@ int gsr_scale_reg_backward(const float* log_scales, size_t n, float limit, float
 {
     if (n == 0) return GSR_OK;
     if (!log_scales || !out || !dL_dvalue || !dL_dlog_scales || (n + 255) / 256 > 0x7FFFFFFFu) return GSR_EINVAL;
-    hipLaunchKernelGGL(gsr::K_scale_reg_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, log_scales, n, limit, w_long, w_scalar,
+    GSR_LAUNCH(gsr::K_scale_reg_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, log_scales, n, limit, w_long, w_scalar,
                        out, dL_dvalue, dL_dlog_scales);
     GSR_LAUNCHED();
     return GSR_OK;
@@ -908,7 +913,7 @@ int gsr_debug_export(int P, int width, int height, int R, const char* geom, cons
     const int gx = (width + GSR_TILE - 1) / GSR_TILE, gy = (height + GSR_TILE - 1) / GSR_TILE, T = gx * gy;
     const size_t N = (size_t)width * height;
     if (P > 0) {
-        hipLaunchKernelGGL(gsr::K_export_splats, dim3(blocks256(P)), dim3(256), 0, st, P, gx, gy, gv, out->means2D,
+        GSR_LAUNCH(gsr::K_export_splats, dim3(blocks256(P)), dim3(256), 0, st, P, gx, gy, gv, out->means2D,
                            out->depths, out->conic_opacity, out->rgb, out->tiles_touched);
         GSR_LAUNCHED();
     }
@@ -922,7 +927,7 @@ int gsr_debug_export(int P, int width, int height, int R, const char* geom, cons
         binning_layout(const_cast<char*>(binning), (size_t)h.capacity, &bv);
         if (out->point_list) GSR_HIP(hipMemcpyAsync(out->point_list, bv.point_list, (size_t)R * 4, hipMemcpyDeviceToDevice, st));
         if (out->point_list_keys) {
-            hipLaunchKernelGGL(gsr::K_export_keys, dim3(T), dim3(256), 0, st, T, iv.ranges, bv.point_list, gv, out->point_list_keys);
+            GSR_LAUNCH(gsr::K_export_keys, dim3(T), dim3(256), 0, st, T, iv.ranges, bv.point_list, gv, out->point_list_keys);
             GSR_LAUNCHED();
         }
     }

@@ -473,6 +473,10 @@ typedef struct gsr_debug_arrays {
 int gsr_debug_export(int P, int width, int height, int R, const char* geom, const char* binning,
                      const char* image, const gsr_debug_arrays* out, void* stream);
 
+/* Inspection: kernel launches this library has issued in this process so far, over all threads (a statistics counter, read by nothing on
+ * a data path; bench.py reports the launches per step / per loop iteration from it). hipMemsetAsync nodes are not counted. */
+unsigned long long gsr_debug_launch_count(void);
+
 /* Text for a GSR_E* code; the HIP error string of the last failing HIP call on this thread. */
 const char* gsr_error_string(int code);
 const char* gsr_last_hip_error(void);

@@ -82,6 +82,16 @@ for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), r
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         cnt[k][row["Counter_Name"]] += 1
 avg = {k: {c: v / cnt[k][c] for c, v in d.items()} for k, d in agg.items()}
+# durations of the kernels in the SAME pass that collected GRBM_GUI_ACTIVE (pmc_condense.py writes them): the clock and everything per SIMD derived from it
+pass_us = {}
+for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    if not any(r_["Counter_Name"] == "GRBM_GUI_ACTIVE" for r_ in csv.DictReader(open(f))):
+        continue
+    for g_ in glob.glob(os.path.join(os.path.dirname(f), "pass_kernel_durations.csv")):
+        tot, n_ = collections.defaultdict(float), collections.defaultdict(int)
+        for row in csv.DictReader(open(g_)):
+            k = short(row["Kernel_Name"]); tot[k] += float(row["AverageNs"]) * float(row["Launches"]); n_[k] += float(row["Launches"])
+        pass_us = {k: tot[k] / n_[k] / 1e3 for k in tot}
 order = ["K_preprocess", "K_bin_count", "K_bin_colscan", "K_scan_tiles", "K_bin_fill", "K_tile_sort_cut", "K_tile_sort_short", "K_tile_sort_long", "K_blend_fwd", "K_blend_bwd", "K_splat_bwd"]
 sq = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY",
       "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
@@ -94,7 +104,8 @@ with open(os.path.join(dst, tag + "_pmc.md"), "w") as o:
     for k in order:
         if k in avg:
             o.write("| %s | " % k + " | ".join("%.3g" % avg[k].get(c, float("nan")) for c in sq) + " |\n")
-    o.write("\nDerived (per launch; kernel time = the rocprofv3 --stats average of the same build):\n\n")
+    o.write("\nDerived (per launch). The clock and the per-SIMD figures divide this pass's GRBM_GUI_ACTIVE by the kernel's duration IN THE SAME PASS (counter passes serialise and slow "
+            "the launches; round 5 divided by the --stats pass's duration and printed up to 4.36 GHz on a 2.4 GHz part); 'us' is the rocprofv3 --stats average, 'us in the counter pass' what the clock uses:\n\n")
     o.write("| kernel | us | clock GHz (GUI_ACTIVE/8/us) | waves resident per SIMD (WAVE_CYCLES*4/cycles/1024) | VALU insts / us (chip, thousands) | cycles per VALU inst per wave | wave time: active / issue-stalled / waiting | LDS pipe busy (LDS_IDX_ACTIVE / BUSY_CU_CYCLES) |\n|---|---|---|---|---|---|---|---|\n")
     for k in order:
         if k in avg and k in stats_avg and "SQ_WAVE_CYCLES" in avg[k]:
@@ -102,8 +113,9 @@ with open(os.path.join(dst, tag + "_pmc.md"), "w") as o:
             us = stats_avg[k]
             cyc = a_.get("GRBM_GUI_ACTIVE", float("nan")) / 8
             wc = a_["SQ_WAVE_CYCLES"] * 4
-            o.write("| %s | %.1f | %.2f | %.2f | %.2f | %.1f | %.0f %% / %.0f %% / %.0f %% | %.2f |\n" % (
-                k, us, cyc / us / 1e3, wc / cyc / 1024 if cyc == cyc else float("nan"),
+            pus = pass_us.get(k, us)
+            o.write("| %s | %.1f (%.1f in the counter pass) | %.2f | %.2f | %.2f | %.1f | %.0f %% / %.0f %% / %.0f %% | %.2f |\n" % (
+                k, us, pus, cyc / pus / 1e3, wc / cyc / 1024 if cyc == cyc else float("nan"),
                 a_["SQ_INSTS_VALU"] / us / 1e3, wc / max(a_["SQ_INSTS_VALU"], 1),
                 100 * a_.get("SQ_ACTIVE_INST_ANY", float("nan")) / a_["SQ_WAVE_CYCLES"], 100 * a_["SQ_WAIT_INST_ANY"] / a_["SQ_WAVE_CYCLES"],
                 100 * a_["SQ_WAIT_ANY"] / a_["SQ_WAVE_CYCLES"],
@@ -131,8 +143,32 @@ with open(os.path.join(dst, tag + "_pmc.md"), "w") as o:
             if avg[k].get("SQ_BUSY_CU_CYCLES") and avg[k].get("SQ_LDS_IDX_ACTIVE"):
                 tj["kernels"][k]["lds_pipe_busy"] = avg[k]["SQ_LDS_IDX_ACTIVE"] / avg[k]["SQ_BUSY_CU_CYCLES"]
             if avg[k].get("GRBM_GUI_ACTIVE"):
-                tj["kernels"][k]["clock_ghz"] = avg[k]["GRBM_GUI_ACTIVE"] / 8 / stats_avg[k] / 1e3
+                tj["kernels"][k]["clock_ghz"] = avg[k]["GRBM_GUI_ACTIVE"] / 8 / pass_us.get(k, stats_avg[k]) / 1e3
             if avg[k].get("SQ_WAVE_CYCLES") and avg[k].get("GRBM_GUI_ACTIVE"):
                 tj["kernels"][k]["waves_per_simd"] = avg[k]["SQ_WAVE_CYCLES"] * 4 / (avg[k]["GRBM_GUI_ACTIVE"] / 8) / 1024
     json.dump(tj, open(os.path.join(dst, tag[:3] + "_traffic.json"), "w"), indent=1)
+
+# ---- per-kernel roofline table: algorithmic bytes (SURVEY.md 8d per stage, DESIGN.md section 4's table) / rocprof average / fraction of 8 TB/s / counter traffic
+c = bench["config"]
+P_, V_, R_, N_ = c["splats"], c["visible"], c["tile_instances"], c["width"] * c["height"]
+T_ = ((c["width"] + 15) // 16) * ((c["height"] + 15) // 16)
+rows_ = min(512, -(-P_ // 4096))
+alg = {"K_preprocess": ("20P + 72V", 20 * P_ + 72 * V_), "K_bin_count": ("16P (records read once) + 4 rows T (its row of the count matrix)", 16 * P_ + 4 * rows_ * T_),
+       "K_bin_colscan": ("8 rows T (count matrix in, offsets out) + 16T", 8 * rows_ * T_ + 16 * T_), "K_bin_fill": ("16P + 8R", 16 * P_ + 8 * R_),
+       "K_tile_sort_cut": ("12R (keys in, list out) + 8R (reach gather) + 8 x quad hits (~1.35 R)", int(20 * R_ + 8 * 1.35 * R_)),
+       "K_blend_fwd": ("44R + 24N", 44 * R_ + 24 * N_), "K_blend_bwd": ("40R + 20N + 36V", 40 * R_ + 20 * N_ + 36 * V_), "K_splat_bwd": ("8P + 208V", 8 * P_ + 208 * V_)}
+with open(os.path.join(dst, tag + "_kernel_stats.md"), "a") as o:
+    o.write("\n## Every kernel against the HBM roofline (8 TB/s): algorithmic bytes / rocprof average / fraction, and the counters' traffic beside it\n\n")
+    o.write("P = %d, V = %d, R = %d, N = %d pixels, T = %d tiles, %d splat ranges. Traffic = 2 x FETCH_SIZE + WRITE_SIZE of the PMC passes (profiles/%s_pmc.md).\n\n" % (P_, V_, R_, N_, T_, rows_, tag))
+    o.write("| kernel | algorithmic bytes (formula) | MB | avg us | GB/s | fraction of 8 TB/s | traffic MB | traffic / algorithmic |\n|---|---|---|---|---|---|---|---|\n")
+    tot_b = tot_us = 0.0
+    for k in order:
+        if k in alg and k in stats_avg:
+            fm, b_ = alg[k]
+            us = stats_avg[k]
+            tr = tj["kernels"].get(k, {}).get("traffic_bytes")
+            tot_b += b_; tot_us += us
+            o.write("| %s | %s | %.1f | %.1f | %.0f | %.3f | %s | %s |\n" % (k, fm, b_ / 1e6, us, b_ / us / 1e3, b_ / us / 1e3 / 8000.0,
+                                                                          "%.1f" % (tr / 1e6) if tr else "-", "%.2f" % (tr / b_) if tr else "-"))
+    o.write("| sum | | %.1f | %.1f | %.0f | %.3f | | |\n" % (tot_b / 1e6, tot_us, tot_b / tot_us / 1e3, tot_b / tot_us / 1e3 / 8000.0))
 print("written", tag)
