@@ -210,7 +210,7 @@ __device__ __forceinline__ void blend_bwd_rgb(ImageView im, char* __restrict__ b
 #ifdef GSR_EXP_TIMELINE
     TimelineMark mark(blockIdx.x);
 #endif
-    const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
+    const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles, 4u * GSR_XCD_TILES);
     const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u;
     const int tx = tile % grid_x, ty = tile / grid_x;
     const int lane = threadIdx.x, r = lane >> 4, l = lane & 15;
@@ -574,7 +574,7 @@ __device__ __forceinline__ void blend_bwd_lean(ImageView im, char* __restrict__ 
 #ifdef GSR_EXP_TIMELINE
     TimelineMark mark(blockIdx.x);
 #endif
-    const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
+    const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles, 4u * GSR_XCD_TILES);
     const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u;
     const int tx = tile % grid_x, ty = tile / grid_x;
     const int lane = threadIdx.x, r = lane >> 4, l = lane & 15;
@@ -978,7 +978,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
     // per-patch hit lists: BYTE OFFSETS of the entries (index * 16: shifts and integer mads are half-rate on gfx950,
     // LDS loads are not VALU work at all), 4 slots of slack behind the longest list for the software pipeline
     __shared__ uint16_t LIST[4 * (Q + 4)];
-    const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles);
+    const uint32_t w = xcd_remap(blockIdx.x, 4u * (uint32_t)ntiles, 4u * GSR_XCD_TILES);
     const uint32_t tile = (uint32_t)tile0 + (w >> 2), quad = w & 3u;
     const int tx = tile % grid_x, ty = tile / grid_x;
     const int lane = threadIdx.x, r = lane >> 4, l = lane & 15;

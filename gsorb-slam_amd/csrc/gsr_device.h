@@ -409,11 +409,31 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
-// XCD-aware block remap: consecutive block ids round-robin over the 8 XCDs, so give
-// XCD x the x-th contiguous band of tiles (neighbouring tiles share splats -> one L2).
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nblocks)
+// XCD-aware block remap: consecutive block ids round-robin over the 8 XCDs (block b runs on XCD b & 7). Neighbouring tiles share splats, so
+// neighbours should meet in one L2 — but the WORK must still reach all eight XCDs when it is concentrated in a part of the frame: one rank of a
+// sharded map renders a k-d cell that covers a quadrant of the image, and with XCD x owning the x-th contiguous band of tiles (rounds 1-5) a
+// quadrant's 3 225 blend jobs ran on four of the eight XCDs — 1 536 wave slots, two rounds: K_blend_bwd 127 us for a quarter of the
+// headline's work (218 us), K_blend_fwd 55 of 94 (profiles/r06_rank_regime.md). The jobs are therefore dealt out in GROUPS of `group`
+// consecutive jobs (GSR_XCD_TILES tiles), round-robin over the XCDs: every XCD samples the whole frame, a group's tiles (and the four quads of a
+// tile) still share an L2. The last, partial super-group of 8 * group jobs keeps the identity map (a bijection for any nblocks).
+#ifndef GSR_XCD_TILES
+#define GSR_XCD_TILES 16 // tiles per group of the BLEND kernels (0: the contiguous bands of rounds 1-5). Measured, whole bench line, two boxes (gpurun_out/ab_xcd*,
+                         // ms per step, bands -> 16-tile groups): headline 0.453 -> 0.449, one rank's quadrant of the 1 M map 0.260 -> 0.214, an eighth of the 2 M map at 640x480
+                         // 0.233 -> 0.208, 2 M frame 0.536 -> 0.538, fat x4 0.670 -> 0.668; groups of 1 / 2 / 4 tiles cost the long-list frames 5-15 % (fat x4 0.78 / 0.75 / 0.71)
+#endif
+#ifndef GSR_XCD_SORT_TILES
+#define GSR_XCD_SORT_TILES 0 // the tile sort keeps the contiguous bands: its keys were written by K_bin_fill's workgroup of the SAME tile window = XCD (sort in groups like the
+                             // blend kernels: 2 M frame 0.538 -> 0.543, fat x4 0.668 -> 0.676; the rank regime 0.214 -> 0.209: the sort's share of the imbalance is small)
+#endif
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nblocks, uint32_t group)
 {
-    const uint32_t xcd = b & 7u, q = nblocks >> 3, r = nblocks & 7u;
-    const uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + (b >> 3);
+    if (group == 0u) {
+        const uint32_t xcd = b & 7u, q = nblocks >> 3, r = nblocks & 7u;
+        const uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        return base + (b >> 3);
+    }
+    const uint32_t full = nblocks - nblocks % (8u * group); // jobs in whole super-groups
+    if (b >= full) return b;
+    const uint32_t xcd = b & 7u, slot = b >> 3;
+    return ((slot / group) * 8u + xcd) * group + slot % group;
 }

@@ -880,7 +880,7 @@ K_tile_sort(int ntiles, const uint2* __restrict__ ranges, const GeomHeader* __re
 {
     __shared__ SortShared<KIND> sh;
     if (hdr->overflow) return;
-    const uint2 r = ranges[xcd_remap(blockIdx.x, ntiles)];
+    const uint2 r = ranges[xcd_remap(blockIdx.x, ntiles, 0u)];
     const int n = (int)(r.y - r.x);
     if (n == 0 || (n <= GSR_SORT_SMALL) != (KIND == 0)) return;
     (void)sort_tile<KIND>(sh, pairs + r.x, n, point_list + r.x);
@@ -1174,7 +1174,7 @@ K_tile_sort_cut(int T, int grid_x, const uint2* __restrict__ ranges, GeomView g,
     __shared__ uint32_t counter, qcnt[4];
     __shared__ uint32_t chunk_first[GSR_PART_SLOTS];
     if (g.hdr->overflow) return;
-    const int tile = (int)xcd_remap(blockIdx.x, (uint32_t)T);
+    const int tile = (int)xcd_remap(blockIdx.x, (uint32_t)T, GSR_XCD_SORT_TILES);
     const uint2 r = ranges[tile];
     const int n = (int)(r.y - r.x);
     uint32_t* const qc4 = qcount + 4 * (size_t)tile;
