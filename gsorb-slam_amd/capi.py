@@ -22,7 +22,8 @@ EXPORTS = ["gsr_forward", "gsr_forward_ws", "gsr_ws_status", "gsr_backward", "gs
            "gsr_pixel_loss", "gsr_pixel_loss_backward", "gsr_pixel_loss_backward_add", "gsr_track_loss", "gsr_scale_reg", "gsr_scale_reg_backward",
            "gsr_map_prepare", "gsr_map_update", "gsr_map_loss_total", "gsr_map_loss_forward", "gsr_map_loss_finish", "gsr_map_loss_backward", "gsr_pose_update", "gsr_pose_step", "gsr_pose_finish", "gsr_composite_forward", "gsr_composite_backward_local",
            "gsr_composite_backward_occlusion", "gsr_shard_order", "gsr_reproj_loss", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version",
-           "gsr_debug_launch_count"]
+           "gsr_debug_launch_count", "gsr_band_composite_forward", "gsr_band_composite_backward", "gsr_shard_map_totals", "gsr_map_loss_partials_rows",
+           "gsr_map_loss_forward_rows", "gsr_map_loss_finish_rows", "gsr_map_loss_backward_rows", "gsr_track_loss_rows"]
 
 
 def library_path() -> str:
@@ -193,6 +194,23 @@ def lib():
     L.gsr_map_loss_backward.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)] + [C.c_void_p] * 5
     L.gsr_pose_update.restype = C.c_int
     L.gsr_pose_update.argtypes = [C.POINTER(PoseUpdateArgs), C.c_void_p]
+    # round 6: the band exchange's kernels and the loss kernels on a band of rows
+    L.gsr_band_composite_forward.restype = C.c_int
+    L.gsr_band_composite_forward.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4
+    L.gsr_band_composite_backward.restype = C.c_int
+    L.gsr_band_composite_backward.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3
+    L.gsr_shard_map_totals.restype = C.c_int
+    L.gsr_shard_map_totals.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 4
+    L.gsr_map_loss_partials_rows.restype = C.c_size_t
+    L.gsr_map_loss_partials_rows.argtypes = [C.c_int] * 4
+    L.gsr_map_loss_forward_rows.restype = C.c_int
+    L.gsr_map_loss_forward_rows.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.gsr_map_loss_finish_rows.restype = C.c_int
+    L.gsr_map_loss_finish_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]
+    L.gsr_map_loss_backward_rows.restype = C.c_int
+    L.gsr_map_loss_backward_rows.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]
+    L.gsr_track_loss_rows.restype = C.c_int
+    L.gsr_track_loss_rows.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float)] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p]
     L.gsr_error_string.restype = C.c_char_p
     L.gsr_error_string.argtypes = [C.c_int]
     L.gsr_last_hip_error.restype = C.c_char_p
@@ -662,6 +680,21 @@ def composite_backward_occlusion(world, rank, order, gathered, c_all, g_sil):
         _check(lib().gsr_composite_backward_occlusion(int(world), int(rank), _p(order), _p(gathered), int(gathered.shape[1]), _p(c_all),
                                                       _p(g_sil) if g_sil is not None else None, H, W, _p(dS), _stream()))
     return dS
+
+
+def band_composite_forward(world, rank, order, layers_all, own_layer, row_begin, row_end, halo, out_rgbd, out_sil, out_sur):
+    """gsr_band_composite_forward on device tensors: layers_all [world,6,H,W] (None with world 1), own_layer [6,H,W]; writes the band's rows of the outputs."""
+    H, W = int(own_layer.shape[-2]), int(own_layer.shape[-1])
+    with torch.cuda.device(own_layer.device):
+        _check(lib().gsr_band_composite_forward(int(world), int(rank), _p(order), _p(layers_all) if layers_all is not None else None, _p(own_layer), H, W,
+                                                int(row_begin), int(row_end), int(halo), _p(out_rgbd), _p(out_sil), _p(out_sur), _stream()))
+
+
+def band_composite_backward(world, rank, order, layers_all, own_layer, g4, row_begin, row_end, d_all, d_own):
+    H, W = int(own_layer.shape[-2]), int(own_layer.shape[-1])
+    with torch.cuda.device(own_layer.device):
+        _check(lib().gsr_band_composite_backward(int(world), int(rank), _p(order), _p(layers_all) if layers_all is not None else None, _p(own_layer), _p(g4), H, W,
+                                                 int(row_begin), int(row_end), _p(d_all) if d_all is not None else None, _p(d_own), _stream()))
 
 
 def reproj_loss(obs, Xw, inv_sigma2, Tcw, fx, fy, cx, cy, weight, pose_row, loss, inliers=None, refresh=2, grad_scale=1.0):

@@ -553,7 +553,7 @@ int gsr_ssim_forward(const float* img1, const float* img2, int C, int H, int W, 
     for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
     const gsr::SsimGrid sg = gsr::ssim_grid(C, H, W);
     GSR_LAUNCH(gsr::K_ssim_fwd<false>, dim3((unsigned)gsr_ssim_partials(C, H, W)), dim3(64), 0, (hipStream_t)stream, img1, img2, C, H, W, t, sg, partial, dmaps,
-                       gsr::MapLossPlanes{});
+                       gsr::MapLossPlanes{}, gsr::SsimRows{0, H, 0, H});
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -566,7 +566,7 @@ int gsr_ssim_backward(const float* img1, const float* img2, const float* dmaps, 
     for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
     const gsr::SsimGrid sg = gsr::ssim_grid(C, H, W);
     GSR_LAUNCH(gsr::K_ssim_bwd<false>, dim3((unsigned)gsr_ssim_partials(C, H, W)), dim3(64), 0, (hipStream_t)stream, img1, img2, dmaps, C, H, W, t, sg, dL_dmean,
-                       dL_dimg1, gsr::MapLossGrad{});
+                       dL_dimg1, gsr::MapLossGrad{}, gsr::SsimRows{0, H, 0, H});
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -645,14 +645,22 @@ int gsr_track_loss(const float* image, const float* depth, const float* sur, con
                    int H, int W, float sil_thr, const float* w3, float* partial, float* sums, float* dL_dimage, float* dL_ddepth, uint32_t* ticket,
                    void* stream)
 {
+    return gsr_track_loss_rows(image, depth, sur, sil, frame_rgb, frame_depth, H, W, sil_thr, w3, partial, sums, dL_dimage, dL_ddepth, ticket, 0, H, stream);
+}
+
+int gsr_track_loss_rows(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb, const float* frame_depth,
+                        int H, int W, float sil_thr, const float* w3, float* partial, float* sums, float* dL_dimage, float* dL_ddepth, uint32_t* ticket,
+                        int row_begin, int row_end, void* stream)
+{
     if (!image || !frame_rgb || !frame_depth || !w3 || !partial || !sums || !dL_dimage || H <= 0 || W <= 0 || (!depth && !sur)) return GSR_EINVAL;
-    const size_t N = (size_t)H * W;
+    if (row_begin < 0 || row_end > H || row_begin >= row_end) return GSR_EINVAL;
+    const size_t N = (size_t)H * W, i0 = (size_t)row_begin * W, i1 = (size_t)row_end * W;
     const gsr::LossPlanes p{image, depth, sur, sil, frame_rgb, frame_depth};
     gsr::LossWeights w{{w3[0], w3[1], w3[2]}};
-    const int nb = (int)std::min<size_t>(GSR_LOSS_BLOCKS, (N + 255) / 256);
+    const int nb = (int)std::min<size_t>(GSR_LOSS_BLOCKS, (i1 - i0 + 255) / 256);
     static_assert(GSR_FINISH_THREADS == 256, "the last workgroup of K_track_loss runs the finish");
     static_assert(GSR_TICKET_WORDS == GSR_TICKET_WORDS_DEV, "header and kernels agree on the arrival counters");
-    GSR_LAUNCH(gsr::K_track_loss, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, N, sil_thr, w, partial, dL_dimage, dL_ddepth, ticket, depth ? 0 : 1, sums);
+    GSR_LAUNCH(gsr::K_track_loss, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, N, sil_thr, w, partial, dL_dimage, dL_ddepth, ticket, depth ? 0 : 1, sums, i0, i1);
     GSR_LAUNCHED();
     if (!ticket) {
         GSR_LAUNCH(gsr::K_loss_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, partial, nb, 0, N, w, depth ? 0 : 1, sums);
@@ -770,6 +778,47 @@ int gsr_composite_backward_occlusion(int world, int rank, const long long* order
     return GSR_OK;
 }
 
+int gsr_band_composite_forward(int world, int rank, const long long* order, const float* layers_all, const float* own_layer, int H, int W, int row_begin, int row_end,
+                               int halo, float* out_rgbd, float* out_sil, float* out_sur, void* stream)
+{
+    if (world < 1 || world > 32 || rank < 0 || rank >= world || !order || !own_layer || (world > 1 && !layers_all) || !out_rgbd || !out_sil || !out_sur || H <= 0 || W <= 0) return GSR_EINVAL;
+    if (row_begin < 0 || row_end > H || row_begin >= row_end || halo < 0) return GSR_EINVAL;
+    const int e0 = std::max(0, row_begin - halo), e1 = std::min(H, row_end + halo);
+    const size_t n = (size_t)(e1 - e0) * W;
+    GSR_LAUNCH(gsr::K_band_composite_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, layers_all, own_layer, (size_t)H * W, W, e0, e1,
+               row_begin, row_end, out_rgbd, out_sil, out_sur);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_band_composite_backward(int world, int rank, const long long* order, const float* layers_all, const float* own_layer, const float* g4, int H, int W,
+                                int row_begin, int row_end, float* d_all, float* d_own, void* stream)
+{
+    if (world < 1 || world > 32 || rank < 0 || rank >= world || !order || !own_layer || (world > 1 && (!layers_all || !d_all)) || !g4 || !d_own || H <= 0 || W <= 0) return GSR_EINVAL;
+    if (row_begin < 0 || row_end > H || row_begin >= row_end) return GSR_EINVAL;
+    const size_t n = (size_t)(row_end - row_begin) * W;
+    if (world <= 8)
+        GSR_LAUNCH(gsr::K_band_composite_bwd<8>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, layers_all, own_layer, g4, (size_t)H * W, W,
+                   row_begin, row_end, d_all, d_own);
+    else
+        GSR_LAUNCH(gsr::K_band_composite_bwd<32>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, layers_all, own_layer, g4, (size_t)H * W, W,
+                   row_begin, row_end, d_all, d_own);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
+int gsr_shard_map_totals(int world, const float* rows, int H, int W, const float* w3, float c_ssim, float w_long, float w_scalar, float* sums, float* reg_out, float* loss,
+                         void* stream)
+{
+    if (world < 1 || !rows || !w3 || !sums || !loss || H <= 0 || W <= 0) return GSR_EINVAL;
+    gsr::ShardTotals t;
+    t.w[0] = w3[0]; t.w[1] = w3[1]; t.w[2] = w3[2]; t.c_ssim = c_ssim; t.w_long = w_long; t.w_scalar = w_scalar;
+    t.inv_pixels3 = 1.f / (3.f * (float)((size_t)H * W)); t.inv_count_ssim = 1.f / (float)((size_t)3 * H * W);
+    GSR_LAUNCH(gsr::K_shard_map_totals, dim3(1), dim3(64), 0, (hipStream_t)stream, world, rows, t, sums, reg_out, loss);
+    GSR_LAUNCHED();
+    return GSR_OK;
+}
+
 int gsr_shard_order(int world, const float* kd_nodes, const float* Tcw, long long* order, void* stream)
 {
     if (world < 1 || world > 32 || !order || (world > 1 && (!kd_nodes || !Tcw))) return GSR_EINVAL;
@@ -781,13 +830,39 @@ int gsr_shard_order(int world, const float* kd_nodes, const float* Tcw, long lon
 int gsr_map_loss_forward(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb, const float* frame_depth,
                          int H, int W, const float* taps11, float sil_thr, float* partial6, float* dmaps, void* stream)
 {
+    return gsr_map_loss_forward_rows(image, depth, sur, sil, frame_rgb, frame_depth, H, W, taps11, sil_thr, partial6, dmaps, 0, H, stream);
+}
+
+namespace {
+// the rows whose derivative maps a band's gradient needs: the band and the window's radius either side, inside the image
+inline void band_ext(int H, int row_begin, int row_end, int* e0, int* e1)
+{
+    *e0 = std::max(0, row_begin - GSR_SSIM_R);
+    *e1 = std::min(H, row_end + GSR_SSIM_R);
+}
+} // namespace
+
+size_t gsr_map_loss_partials_rows(int H, int W, int row_begin, int row_end)
+{
+    if (H <= 0 || W <= 0 || row_begin < 0 || row_end > H || row_begin >= row_end) return 0;
+    int e0, e1;
+    band_ext(H, row_begin, row_end, &e0, &e1);
+    return gsr_ssim_partials(3, e1 - e0, W);
+}
+
+int gsr_map_loss_forward_rows(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb, const float* frame_depth,
+                              int H, int W, const float* taps11, float sil_thr, float* partial6, float* dmaps, int row_begin, int row_end, void* stream)
+{
     if (!image || !frame_rgb || !frame_depth || !taps11 || !partial6 || !dmaps || !ssim_plane_ok(H, W)) return GSR_EINVAL;
+    if (row_begin < 0 || row_end > H || row_begin >= row_end) return GSR_EINVAL;
     gsr::SsimTaps t;
     for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
-    const gsr::SsimGrid sg = gsr::ssim_grid(3, H, W);
+    int e0, e1;
+    band_ext(H, row_begin, row_end, &e0, &e1);
+    const gsr::SsimGrid sg = gsr::ssim_grid(3, e1 - e0, W);
     const gsr::MapLossPlanes ml{depth, sur, sil, frame_depth, sil_thr, partial6};
-    GSR_LAUNCH(gsr::K_ssim_fwd<true>, dim3(2u * (unsigned)gsr_ssim_partials(3, H, W)), dim3(64), 0, (hipStream_t)stream, image, frame_rgb, 3, H, W, t, sg, (float*)nullptr,
-                       dmaps, ml);
+    GSR_LAUNCH(gsr::K_ssim_fwd<true>, dim3(2u * (unsigned)gsr_ssim_partials(3, e1 - e0, W)), dim3(64), 0, (hipStream_t)stream, image, frame_rgb, 3, H, W, t, sg, (float*)nullptr,
+                       dmaps, ml, gsr::SsimRows{e0, e1, row_begin, row_end});
     GSR_LAUNCHED();
     return GSR_OK;
 }
@@ -796,8 +871,16 @@ int gsr_map_loss_finish(const float* partial6, const float* reg_partial, size_t 
                         float w_scalar, const char* geom, float* sums, float* reg_out, float* loss, void* stream)
 {
     if (!partial6 || !w3 || !sums || !loss || H <= 0 || W <= 0 || (reg_partial && !reg_out)) return GSR_EINVAL;
+    return gsr_map_loss_finish_rows(partial6, reg_partial, n_gaussians, H, W, w3, c_ssim, w_long, w_scalar, geom, sums, reg_out, loss, 0, H, stream);
+}
+
+int gsr_map_loss_finish_rows(const float* partial6, const float* reg_partial, size_t n_gaussians, int H, int W, const float* w3, float c_ssim, float w_long,
+                             float w_scalar, const char* geom, float* sums, float* reg_out, float* loss, int row_begin, int row_end, void* stream)
+{
+    if (!partial6 || !w3 || !sums || !loss || H <= 0 || W <= 0 || (reg_partial && !reg_out)) return GSR_EINVAL;
+    if (row_begin < 0 || row_end > H || row_begin >= row_end) return GSR_EINVAL;
     gsr::MapFinish m;
-    m.partial6 = partial6; m.n6 = (int)gsr_ssim_partials(3, H, W);
+    m.partial6 = partial6; m.n6 = (int)gsr_map_loss_partials_rows(H, W, row_begin, row_end);
     m.reg_partial = reg_partial; m.n_reg = reg_partial ? (int)((n_gaussians + 255) / 256) : 0;
     m.inv_pixels3 = 1.f / (3.f * (float)((size_t)H * W)); m.inv_count_ssim = 1.f / (float)((size_t)3 * H * W);
     m.w[0] = w3[0]; m.w[1] = w3[1]; m.w[2] = w3[2]; m.c_ssim = c_ssim; m.w_long = w_long; m.w_scalar = w_scalar;
@@ -810,13 +893,21 @@ int gsr_map_loss_finish(const float* partial6, const float* reg_partial, size_t 
 int gsr_map_loss_backward(const float* image, const float* depth, const float* frame_rgb, const float* frame_depth, const float* dmaps, int H, int W,
                           const float* taps11, const float* w3, const float* neg_c_ssim, const float* sums, float* dL_dimage, float* dL_ddepth, void* stream)
 {
+    return gsr_map_loss_backward_rows(image, depth, frame_rgb, frame_depth, dmaps, H, W, taps11, w3, neg_c_ssim, sums, dL_dimage, dL_ddepth, 0, H, stream);
+}
+
+int gsr_map_loss_backward_rows(const float* image, const float* depth, const float* frame_rgb, const float* frame_depth, const float* dmaps, int H, int W,
+                               const float* taps11, const float* w3, const float* neg_c_ssim, const float* sums, float* dL_dimage, float* dL_ddepth,
+                               int row_begin, int row_end, void* stream)
+{
     if (!image || !frame_rgb || !frame_depth || !dmaps || !taps11 || !w3 || !neg_c_ssim || !sums || !dL_dimage || !ssim_plane_ok(H, W)) return GSR_EINVAL;
+    if (row_begin < 0 || row_end > H || row_begin >= row_end) return GSR_EINVAL;
     gsr::SsimTaps t;
     for (int k = 0; k < 11; k++) t.g[k] = taps11[k];
-    const gsr::SsimGrid sg = gsr::ssim_grid(3, H, W);
+    const gsr::SsimGrid sg = gsr::ssim_grid(3, row_end - row_begin, W);
     const gsr::MapLossGrad mg{depth, frame_depth, sums, w3[0] / (3.f * (float)((size_t)H * W)), w3[1], dL_ddepth};
-    GSR_LAUNCH(gsr::K_ssim_bwd<true>, dim3((dL_ddepth ? 2u : 1u) * (unsigned)gsr_ssim_partials(3, H, W)), dim3(64), 0, (hipStream_t)stream, image, frame_rgb, dmaps, 3, H, W, t, sg, neg_c_ssim,
-                       dL_dimage, mg);
+    GSR_LAUNCH(gsr::K_ssim_bwd<true>, dim3((dL_ddepth ? 2u : 1u) * (unsigned)gsr_ssim_partials(3, row_end - row_begin, W)), dim3(64), 0, (hipStream_t)stream, image, frame_rgb, dmaps, 3, H, W, t,
+                       sg, neg_c_ssim, dL_dimage, mg, gsr::SsimRows{row_begin, row_end, row_begin, row_end});
     GSR_LAUNCHED();
     return GSR_OK;
 }

@@ -84,6 +84,106 @@ K_composite_bwd_occlusion(int world, int rank, const long long* __restrict__ ord
     dS[i] = (g_sil ? g_sil[i] * P_excl : 0.f) - acc;
 }
 
+// ---- round 6: the BAND exchange. Instead of every rank compositing and evaluating the loss on the whole frame behind an
+// all-gather + all-reduce, rank r receives every rank's layer for ITS band of pixel rows (one grouped point-to-point exchange), composites the band,
+// evaluates the loss there, takes the band's gradient back through the composite for EVERY rank's layer and returns each rank its rows (a second
+// exchange): all per-pixel work / world, two collectives instead of three, and at 8 ranks a third of the bytes.
+//   layers_all [world][6][H][W]  rank k's layer (rgb, depth, silhouette S, surface depth) in rank order; only the rows this rank needs are valid;
+//                                `own` [6][H][W] stands in for layers_all[rank] (the rank's own render: no copy)
+// K_band_composite_fwd: rows [e0, e1) (the band and, for the mapping loss's SSIM window, ten rows either side): rgb = sum_k P_k rgb_k; on the band's own
+// rows [b0, b1) also depth, the stack's silhouette and the surface depth (K_composite_fwd's rule).
+__global__ void __launch_bounds__(256)
+K_band_composite_fwd(int world, int rank, const long long* __restrict__ order, const float* __restrict__ layers_all, const float* __restrict__ own, size_t N, int W,
+                     int e0, int e1, int b0, int b1, float* __restrict__ out_rgbd, float* __restrict__ out_sil, float* __restrict__ out_sur)
+{
+    const size_t i = (size_t)e0 * W + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)e1 * W) return;
+    const bool band = i >= (size_t)b0 * W && i < (size_t)b1 * W;
+    float T = 1.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dp = 0.f, su = 0.f;
+    bool found = false;
+    for (int k = 0; k < world; k++) {
+        const int r = (int)order[k];
+        const float* const L = r == rank ? own : layers_all + (size_t)r * 6 * N;
+        const float S = L[4 * N + i];
+        c0 = fmaf(T, L[i], c0); c1 = fmaf(T, L[N + i], c1); c2 = fmaf(T, L[2 * N + i], c2);
+        const float T_after = T * (1.f - S);
+        if (band) {
+            dp = fmaf(T, L[3 * N + i], dp);
+            const float SU = L[5 * N + i];
+            const bool has = SU > 0.f;
+            if (!found && has) su = SU;
+            found = found || (has && T_after <= 0.5f);
+        }
+        T = T_after;
+    }
+    out_rgbd[i] = c0; out_rgbd[N + i] = c1; out_rgbd[2 * N + i] = c2;
+    if (band) { out_rgbd[3 * N + i] = dp; out_sil[i] = 1.f - T; out_sur[i] = su; }
+}
+// K_band_composite_bwd: rows [b0, b1): from the loss's gradient g4 (rgb, depth) on the composite to EVERY rank's layer gradient on those rows:
+// d_all[k] = {P_k g4 (4 planes), dS_k}, dS_k = -P_k B_k with B_k = c_(k+1) + (1 - S_(k+1)) B_(k+1) over the front-to-back order (c_j = g4 . layer_j):
+// the occlusion term of K_composite_bwd_occlusion without a division by 1 - S. d_own [5][H][W] receives this rank's (no copy), d_all [world][5][H][W] the others'.
+template <int MAXW>
+__global__ void __launch_bounds__(256)
+K_band_composite_bwd(int world, int rank, const long long* __restrict__ order, const float* __restrict__ layers_all, const float* __restrict__ own,
+                     const float* __restrict__ g4, size_t N, int W, int b0, int b1, float* __restrict__ d_all, float* __restrict__ d_own)
+{
+    const size_t i = (size_t)b0 * W + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)b1 * W) return;
+    const float g0 = g4[i], g1 = g4[N + i], g2 = g4[2 * N + i], g3 = g4[3 * N + i];
+    float S[MAXW], c[MAXW];
+#pragma unroll
+    for (int k = 0; k < MAXW; k++) {
+        S[k] = 0.f; c[k] = 0.f;
+        if (k < world) {
+            const int r = (int)order[k];
+            const float* const L = r == rank ? own : layers_all + (size_t)r * 6 * N;
+            S[k] = L[4 * N + i];
+            c[k] = fmaf(g3, L[3 * N + i], fmaf(g2, L[2 * N + i], fmaf(g1, L[N + i], g0 * L[i])));
+        }
+    }
+    float B[MAXW]; // B_k: what the layers behind k contribute through k's transmittance
+    float acc = 0.f;
+#pragma unroll
+    for (int k = MAXW - 1; k >= 0; k--) {
+        B[k] = acc;
+        if (k < world) acc = fmaf(1.f - S[k], acc, c[k]);
+    }
+    float P = 1.f;
+#pragma unroll
+    for (int k = 0; k < MAXW; k++) {
+        if (k < world) {
+            const int r = (int)order[k];
+            float* const D = r == rank ? d_own : d_all + (size_t)r * 5 * N;
+            D[i] = P * g0; D[N + i] = P * g1; D[2 * N + i] = P * g2; D[3 * N + i] = P * g3;
+            D[4 * N + i] = -P * B[k];
+            P *= 1.f - S[k];
+        }
+    }
+}
+// The mapping loss's totals from every rank's row (gsr_map_loss_finish_rows on the rank's band: rows [world][16] = {sums[8] | reg_out[4] | the rank's loss slot:
+// NaN = its forward overflowed | 3 unused}): sums[8] as gsr_pixel_loss of the WHOLE frame, reg_out[4] of the whole map, the iteration's loss (NaN if any rank's is).
+struct ShardTotals {
+    float w[3], c_ssim, w_long, w_scalar, inv_pixels3, inv_count_ssim;
+};
+__global__ void __launch_bounds__(64)
+K_shard_map_totals(int world, const float* __restrict__ rows, ShardTotals t, float* __restrict__ sums, float* __restrict__ reg_out, float* __restrict__ loss)
+{
+    if (threadIdx.x != 0) return;
+    float a[12] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bool bad = false;
+    for (int r = 0; r < world; r++) {
+#pragma unroll
+        for (int q = 0; q < 12; q++) a[q] += rows[r * 16 + q];
+        const float l = rows[r * 16 + 12];
+        bad = bad || l != l;
+    }
+    const float pix = t.w[0] * (a[0] * t.inv_pixels3) + t.w[1] * (a[1] / fmaxf(a[2], 1.f)) + t.w[2] * (a[3] / fmaxf(a[4], 1.f));
+    const float reg = t.w_long * (a[8] > 0.f ? a[10] / a[8] : 0.f) + t.w_scalar * a[9];
+    sums[0] = a[0]; sums[1] = a[1]; sums[2] = a[2]; sums[3] = a[3]; sums[4] = a[4]; sums[5] = pix; sums[6] = a[6]; sums[7] = 0.f;
+    if (reg_out) { reg_out[0] = a[8]; reg_out[1] = a[9]; reg_out[2] = a[10]; reg_out[3] = reg; }
+    loss[0] = bad ? __builtin_nanf("") : pix + t.c_ssim * (1.f - a[6] * t.inv_count_ssim) + reg;
+}
+
 // Front-to-back order of the cells of a k-d partition of the map for the camera of Tcw (row-major 4x4, world -> camera): the leaves of
 // a BSP are ordered exactly by visiting, at every split, the side that holds the camera centre first. nodes [world - 1][4] =
 // {axis, split, left, right}; a child >= 0 is a node, a child < 0 the leaf (rank) -1 - child. One thread: world <= a few dozen.

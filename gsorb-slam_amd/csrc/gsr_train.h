@@ -43,6 +43,13 @@ __host__ __device__ inline SsimGrid ssim_grid(int C, int H, int W)
     g.nsy = (H + g.rows - 1) / g.rows;
     return g;
 }
+// Which rows of the image a launch of the SSIM kernels works on (round 6: a rank of the sharded loop evaluates the loss on its band of pixel rows only).
+// Outputs (the forward's derivative maps, the backward's gradient) are produced for rows [ybeg, yend) — the grid's segments cut THAT range —, the
+// forward's sums take the rows [sbeg, send) only (the band; the maps of the five rows either side are what the band's gradient needs). Zero padding
+// still happens at the image's own border (H). The whole image: {0, H, 0, H}.
+struct SsimRows {
+    int ybeg, yend, sbeg, send;
+};
 // sum over the wave in eight DPP adds (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, row_bcast15 / row_bcast31 across them): the total is in
 // lane 63. (__shfl_xor is six ds_bpermute round trips through the LDS pipe.)
 template <int CTRL, int ROWS>
@@ -122,7 +129,7 @@ __device__ __forceinline__ void st_off(float* base, const uint32_t off, const fl
 template <bool MAPLOSS>
 __global__ void __launch_bounds__(64)
 K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int C, int H, int W, SsimTaps taps, SsimGrid sg,
-           float* __restrict__ partial, float* __restrict__ dmaps, MapLossPlanes ml)
+           float* __restrict__ partial, float* __restrict__ dmaps, MapLossPlanes ml, SsimRows rw)
 {
     constexpr int R = GSR_SSIM_R, NT = 2 * R + 1;
     __shared__ v2f row[2][64 + 2 * R + 2]; // (image 1, image 2) of the current row at [lane + R]; the pads stay zero
@@ -130,14 +137,14 @@ K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int C
     const int nss = C * sg.nsx * sg.nsy;
     const size_t plane = (size_t)H * W, N = (size_t)C * plane;
     if (MAPLOSS && (int)blockIdx.x >= nss) {
-        const size_t first = ((size_t)blockIdx.x - nss) * 64 + lane, stride = ((size_t)gridDim.x - nss) * 64;
+        const size_t first = (size_t)rw.sbeg * W + ((size_t)blockIdx.x - nss) * 64 + lane, stride = ((size_t)gridDim.x - nss) * 64, pend = (size_t)rw.send * W;
         float l1 = 0.f, l2 = 0.f, l3 = 0.f, l4 = 0.f, l5 = 0.f;
         const bool has_d = ml.depth != nullptr, has_s = ml.sur != nullptr, has_m = ml.sil != nullptr;
         const float* const pd = has_d ? ml.depth : ml.fdepth; // (always valid addresses: what comes back is not used)
         const float* const ps = has_s ? ml.sur : ml.fdepth;
         const float* const pm = has_m ? ml.sil : ml.fdepth;
 #pragma unroll 2
-        for (size_t p = first; p < plane; p += stride) {
+        for (size_t p = first; p < pend; p += stride) {
             const float a0 = img1[p], a1 = img1[plane + p], a2 = img1[2 * plane + p], b0 = img2[p], b1 = img2[plane + p], b2 = img2[2 * plane + p];
             const float fd = ml.fdepth[p], dp = pd[p], su = ps[p], si = has_m ? pm[p] : 1.0e30f;
             l1 += (fabsf(a0 - b0) + fabsf(a1 - b1)) + fabsf(a2 - b2);
@@ -157,8 +164,8 @@ K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int C
     // (integer division runs on the vector pipe: without the readfirstlane the quotients, and every address and condition made from them, stay there)
     const int sx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % sg.nsx)), sy = __builtin_amdgcn_readfirstlane((int)((blockIdx.x / sg.nsx) % sg.nsy)),
               c = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / (sg.nsx * sg.nsy)));
-    const int gx = sx * GSR_SSIM_COLS - R + lane, y0 = sy * sg.rows;
-    const int nrows = min(sg.rows, H - y0);
+    const int gx = sx * GSR_SSIM_COLS - R + lane, y0 = rw.ybeg + sy * sg.rows;
+    const int nrows = min(sg.rows, rw.yend - y0);
     const bool col_in = gx >= 0 && gx < W, col_out = lane >= R && lane < 64 - R && gx < W;
     const float* __restrict__ p1 = img1 + c * plane;
     const float* __restrict__ p2 = img2 + c * plane;
@@ -240,7 +247,7 @@ K_ssim_fwd(const float* __restrict__ img1, const float* __restrict__ img2, int C
                 st_off(o, off, d0); st_off(o + N, off, d1); st_off(o + 2 * N, off, d2);
             }
         }
-        lsum += ok ? m : 0.f;
+        lsum += (ok && y0 + orow >= rw.sbeg && y0 + orow < rw.send) ? m : 0.f;
     };
     // whole groups of eleven steps (the loop's trip count is the only thing that varies): the first fills the ring and puts out one row
 #pragma unroll
@@ -270,7 +277,7 @@ struct MapLossGrad {
 template <bool MAPLOSS>
 __global__ void __launch_bounds__(64)
 K_ssim_bwd(const float* __restrict__ img1, const float* __restrict__ img2, const float* __restrict__ dmaps, int C, int H, int W,
-           SsimTaps taps, SsimGrid sg, const float* __restrict__ dL_dmean, float* __restrict__ dL_dimg1, MapLossGrad mg)
+           SsimTaps taps, SsimGrid sg, const float* __restrict__ dL_dmean, float* __restrict__ dL_dimg1, MapLossGrad mg, SsimRows rw)
 {
     // the forward's streaming scheme on the three derivative maps (transposed window: the taps run backwards); the images' own pixels of the
     // OUTPUT row travel in the queue with the input row that completes its window. MAPLOSS: the depth plane's gradient is elementwise — the
@@ -283,11 +290,11 @@ K_ssim_bwd(const float* __restrict__ img1, const float* __restrict__ img2, const
     const size_t plane = (size_t)H * W, N = (size_t)C * plane;
     if (MAPLOSS && (int)blockIdx.x >= nss) {
         if (!mg.ddepth) return;
-        const size_t first = ((size_t)blockIdx.x - nss) * 64 + lane, stride = ((size_t)gridDim.x - nss) * 64;
+        const size_t first = (size_t)rw.ybeg * W + ((size_t)blockIdx.x - nss) * 64 + lane, stride = ((size_t)gridDim.x - nss) * 64, pend = (size_t)rw.yend * W;
         const float k = mg.w_depth / fmaxf(mg.sums[2], 1.f);
         const float* const pd = mg.depth ? mg.depth : mg.fdepth;
 #pragma unroll 4
-        for (size_t p = first; p < plane; p += stride) {
+        for (size_t p = first; p < pend; p += stride) {
             const float fd = mg.fdepth[p], dd = mg.depth ? pd[p] - fd : 0.f;
             mg.ddepth[p] = fd > 0.f ? k * ((float)(dd > 0.f) - (float)(dd < 0.f)) : 0.f;
         }
@@ -295,8 +302,8 @@ K_ssim_bwd(const float* __restrict__ img1, const float* __restrict__ img2, const
     }
     const int sx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % sg.nsx)), sy = __builtin_amdgcn_readfirstlane((int)((blockIdx.x / sg.nsx) % sg.nsy)),
               c = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / (sg.nsx * sg.nsy)));
-    const int gx = sx * GSR_SSIM_COLS - R + lane, y0 = sy * sg.rows;
-    const int nrows = min(sg.rows, H - y0);
+    const int gx = sx * GSR_SSIM_COLS - R + lane, y0 = rw.ybeg + sy * sg.rows;
+    const int nrows = min(sg.rows, rw.yend - y0);
     const bool col_in = gx >= 0 && gx < W, col_out = lane >= R && lane < 64 - R && gx < W;
     {
         v2f z; z.x = 0.f; z.y = 0.f;
@@ -705,12 +712,13 @@ K_loss_finish(const float* __restrict__ partial, int nblocks, int mode, size_t N
 // (one launch and 30 MB of reads less per iteration). Same expressions, same order of a thread's additions as the two kernels.
 __global__ void __launch_bounds__(256)
 K_track_loss(LossPlanes p, size_t N, float thr, LossWeights w, float* partial, float* __restrict__ dimage, float* __restrict__ ddepth,
-             uint32_t* ticket, int depth_from_sur, float* __restrict__ sums)
+             uint32_t* ticket, int depth_from_sur, float* __restrict__ sums, size_t i_begin, size_t i_end)
 {
+    // (N = H W is the planes' stride; the pixels [i_begin, i_end) are this launch's — the whole image, or one rank's band of rows in the sharded loop)
     __shared__ float ws[4][5];
     __shared__ uint32_t s_ticket;
     float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (size_t)gridDim.x * 256) {
+    for (size_t i = i_begin + (size_t)blockIdx.x * 256 + threadIdx.x; i < i_end; i += (size_t)gridDim.x * 256) {
         const float fd = p.fdepth[i];
         const float sl = p.sil ? p.sil[i] : 0.f;
         const float i0 = p.image[i], i1 = p.image[N + i], i2 = p.image[2 * N + i], f0 = p.frgb[i], f1 = p.frgb[N + i], f2 = p.frgb[2 * N + i];

@@ -442,6 +442,40 @@ int gsr_composite_backward_local(int world, int rank, const long long* order, co
                                  int W, float* d_layer4, float* c_own, void* stream);
 int gsr_composite_backward_occlusion(int world, int rank, const long long* order, const float* gathered, int gathered_planes, const float* c_all, const float* g_sil,
                                      int H, int W, float* dS, void* stream);
+/* ---- round 6 (ABI 9): the BAND exchange of the sharded loop. Rank r composites, evaluates the loss and differentiates the composite on ITS band of pixel
+ * rows only, for every rank's layer: all per-pixel work / world. Rows are image rows; [row_begin, row_end) is the rank's band.
+ *   layers_all [world][6][H][W]  every rank's layer (rgb, depth, silhouette, surface depth) in RANK order, valid on the rows this rank received; own_layer [6][H][W]
+ *                                stands in for layers_all[rank] (NULL layers_all with world 1)
+ * gsr_band_composite_forward: rows [row_begin - halo, row_end + halo) inside the image: out_rgbd planes 0..2 = sum_k P_k rgb_k; on the band itself also plane 3
+ *   (depth), out_sil = 1 - prod (1 - S), out_sur = gsr_composite_forward's surface depth. out_rgbd [4][H][W], out_sil, out_sur [H][W]: only those rows are written.
+ * gsr_band_composite_backward: g4 [4][H][W] (d/d rgb, depth of the composite; band rows) -> for every rank k its layer's gradient on the band rows:
+ *   d_all [world][5][H][W] = {P_k g4, dS_k} (this rank's own goes to d_own [5][H][W]); dS_k is gsr_composite_backward_occlusion's term (no silhouette upstream gradient).
+ * gsr_shard_map_totals: rows [world][16] = every rank's {sums[8], reg_out[4], loss slot (NaN: that rank's forward overflowed), 3 unused} from
+ *   gsr_map_loss_finish_rows on its band -> sums [8] / reg_out [4] (NULL: none) of the whole frame / map and the iteration's loss. */
+int gsr_band_composite_forward(int world, int rank, const long long* order, const float* layers_all, const float* own_layer, int H, int W, int row_begin, int row_end,
+                               int halo, float* out_rgbd, float* out_sil, float* out_sur, void* stream);
+int gsr_band_composite_backward(int world, int rank, const long long* order, const float* layers_all, const float* own_layer, const float* g4, int H, int W,
+                                int row_begin, int row_end, float* d_all, float* d_own, void* stream);
+int gsr_shard_map_totals(int world, const float* rows, int H, int W, const float* w3 /* host */, float c_ssim, float w_long, float w_scalar, float* sums, float* reg_out,
+                         float* loss, void* stream);
+/* The loss kernels on a band of rows (the whole image: 0, H — what gsr_map_loss_forward / _finish / _backward / gsr_track_loss are). Planes keep their full
+ * [.,H,W] layout; only the band's rows are read (the SSIM window reaches ten rows beyond: the caller provides `image` there) and written.
+ *   gsr_map_loss_forward_rows   sums over the band's rows; derivative maps for the band and five rows either side; partial6 [6][gsr_map_loss_partials_rows(...)]
+ *   gsr_map_loss_finish_rows    the band's raw sums (sums[5], the pixel terms' value, divides by the BAND's counts: combine the ranks' rows with gsr_shard_map_totals)
+ *   gsr_map_loss_backward_rows  gradient planes on the band's rows; sums[2] must be the WHOLE frame's count of valid depth pixels
+ *   gsr_track_loss_rows         masked L1 sums and gradient planes on the band's rows */
+size_t gsr_map_loss_partials_rows(int H, int W, int row_begin, int row_end);
+int gsr_map_loss_forward_rows(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb, const float* frame_depth,
+                              int H, int W, const float* taps11 /* host */, float sil_thr, float* partial6, float* dmaps, int row_begin, int row_end, void* stream);
+int gsr_map_loss_finish_rows(const float* partial6, const float* reg_partial, size_t n_gaussians, int H, int W, const float* w3 /* host */, float c_ssim,
+                             float w_long, float w_scalar, const char* geom, float* sums, float* reg_out, float* loss, int row_begin, int row_end, void* stream);
+int gsr_map_loss_backward_rows(const float* image, const float* depth, const float* frame_rgb, const float* frame_depth, const float* dmaps, int H, int W,
+                               const float* taps11 /* host */, const float* w3 /* host */, const float* neg_c_ssim, const float* sums, float* dL_dimage,
+                               float* dL_ddepth, int row_begin, int row_end, void* stream);
+int gsr_track_loss_rows(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb, const float* frame_depth,
+                        int H, int W, float sil_thr, const float* w3 /* host */, float* partial, float* sums, float* dL_dimage, float* dL_ddepth,
+                        uint32_t* ticket, int row_begin, int row_end, void* stream);
+
 /* Front-to-back order of the cells of a k-d partition of the map (gsorb-slam_amd/sharded.py: KdPartition; one cell per rank) for the camera of
  * Tcw (DEVICE, row-major 4x4 world -> camera): order [world] (DEVICE int64) = the ranks, nearest cell first. The leaves of a BSP are ordered
  * exactly by visiting the side of every split that holds the camera centre first — for ANY view, unlike an order by nearest depth.
