@@ -92,6 +92,13 @@ struct SlamLoop::Direct {
     torch::Tensor kd_nodes, order;                                       // [world - 1, 4] the partition (gsr_shard_order), [world] int64 the ranks front to back
     torch::Tensor gathered, comp, D, c_own, c_all, reg_tot;              // [world,2,H,W]; [6,H,W] composite rgb, depth, silhouette, surface depth;
                                                                          // [5,H,W] d/d own layer (4) and d/d own silhouette; [H,W]; [world,H,W]; [4]
+    // the BAND exchange (LoopConfig::band_exchange): this rank's band of pixel rows [b0, b1), every rank's layer on it, every rank's layer gradient on it
+    struct Msg { int peer; float* send; float* recv; size_t n; };         // one contiguous block of rows of one plane: to a peer (send) OR from it (recv)
+    bool band = false;
+    int b0 = 0, b1 = 0;
+    torch::Tensor L_all, D_all, rows_all, frame_sums;                    // [world,6,H,W]; [world,5,H,W]; [world,16] {sums[8], reg_out[4], loss slot, 3 unused}; [8] (word 2: the frame's valid depth pixels)
+    std::vector<Msg> fwd_map, fwd_track, bwd_map, bwd_track;             // the exchanges' messages (built with the workspace: pointers and counts only)
+    void p2p(const std::vector<Msg>& ms);                                // one grouped exchange on the loop's stream
     ~Direct();
     bool sharded() const { return world > 1 || pg; }
     void all_gather(torch::Tensor out, const torch::Tensor& in);         // out [world, ...] <- every rank's `in`
@@ -107,6 +114,10 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     static const Rccl& get()
     {
@@ -119,6 +130,8 @@ struct Rccl {
             x.GetUniqueId = (decltype(x.GetUniqueId))sym("ncclGetUniqueId"); x.CommInitRank = (decltype(x.CommInitRank))sym("ncclCommInitRank");
             x.CommDestroy = (decltype(x.CommDestroy))sym("ncclCommDestroy"); x.AllGather = (decltype(x.AllGather))sym("ncclAllGather");
             x.AllReduce = (decltype(x.AllReduce))sym("ncclAllReduce"); x.GetErrorString = (decltype(x.GetErrorString))sym("ncclGetErrorString");
+            x.Send = (decltype(x.Send))sym("ncclSend"); x.Recv = (decltype(x.Recv))sym("ncclRecv");
+            x.GroupStart = (decltype(x.GroupStart))sym("ncclGroupStart"); x.GroupEnd = (decltype(x.GroupEnd))sym("ncclGroupEnd");
             return x;
         }();
         return r;
@@ -197,6 +210,39 @@ void SlamLoop::Direct::all_reduce(torch::Tensor t)
     }
     std::vector<torch::Tensor> v{t};
     pg->allreduce(v)->wait();
+}
+
+// One grouped point-to-point exchange: every message is a contiguous block of floats to one peer and one from it. RCCL: ncclSend / ncclRecv inside one
+// group = one launch on the loop's stream, no packing. Any other transport (the process group's own collectives; gloo staged through the host): the
+// blocks of a peer are packed in message order and travel through alltoall_base — both ends enumerate a pair's blocks in the same order.
+void SlamLoop::Direct::p2p(const std::vector<Msg>& ms)
+{
+    if (!pg || ms.empty()) return;
+    if (comm) {
+        const auto& r = Rccl::get();
+        nccl_chk(r.GroupStart(), "ncclGroupStart");
+        for (const auto& m : ms) {
+            if (m.send) nccl_chk(r.Send(m.send, m.n, ncclFloat, m.peer, comm, stream), "ncclSend");
+            else nccl_chk(r.Recv(m.recv, m.n, ncclFloat, m.peer, comm, stream), "ncclRecv");
+        }
+        nccl_chk(r.GroupEnd(), "ncclGroupEnd");
+        return;
+    }
+    std::vector<int64_t> s_split(world, 0), r_split(world, 0), s_off(world, 0), r_off(world, 0);
+    for (const auto& m : ms) (m.send ? s_split : r_split)[m.peer] += (int64_t)m.n;
+    int64_t s_tot = 0, r_tot = 0;
+    for (int k = 0; k < world; k++) { s_off[k] = s_tot; s_tot += s_split[k]; r_off[k] = r_tot; r_tot += r_split[k]; }
+    const auto fo = torch::TensorOptions().device(rows_all.device()).dtype(torch::kFloat32);
+    auto view = [&](float* p, size_t n) { return torch::from_blob(p, {(int64_t)n}, fo); };
+    auto in = torch::empty({s_tot}, fo), out = torch::empty({r_tot}, fo);
+    for (const auto& m : ms) if (m.send) { in.narrow(0, s_off[m.peer], (int64_t)m.n).copy_(view(m.send, m.n)); s_off[m.peer] += (int64_t)m.n; }
+    if (staged) {
+        auto hin = in.to(torch::kCPU), hout = torch::empty({r_tot}, hin.options());
+        pg->alltoall_base(hout, hin, r_split, s_split)->wait();
+        out.copy_(hout);
+    } else
+        pg->alltoall_base(out, in, r_split, s_split)->wait();
+    for (const auto& m : ms) if (!m.send) { view(m.recv, m.n).copy_(out.narrow(0, r_off[m.peer], (int64_t)m.n)); r_off[m.peer] += (int64_t)m.n; }
 }
 
 void SlamLoop::SetShard(c10::intrusive_ptr<c10d::ProcessGroup> pg, int rank, int world, const torch::Tensor& kd_nodes)
@@ -301,7 +347,8 @@ void SlamLoop::ensure_direct_(int64_t history_len)
         d.proj = rasterizer_.raster_settings_.projmatrix.to(dev_, torch::kFloat32).contiguous();
         d.pose = torch::zeros({7}, fo); d.pose_moments = torch::zeros({14}, fo); d.best = torch::zeros({8}, fo);
         d.tickets = torch::zeros({2 * GSR_TICKET_WORDS}, fo.dtype(torch::kInt32));
-        d.pose_acc = torch::zeros({64 * 12 + 4}, fo); d.last_sums = torch::zeros({12}, fo);
+        d.pose_acc = torch::zeros({64 * 12 + 16}, fo); d.last_sums = torch::zeros({12}, fo); // (word 768: the overflow flag; words 776..783: the band exchange's tracking-loss sums — they travel in the rows' all-reduce)
+        d.frame_sums = torch::zeros({8}, fo);
     }
     if (d.n != n) { // per map size
         d.n = n;
@@ -337,6 +384,41 @@ void SlamLoop::ensure_direct_(int64_t history_len)
         d.gathered = torch::empty({d.world, 2, H_, W_}, fo); d.comp = torch::zeros({6 * HW + 4}, fo); d.D = torch::empty({5, H_, W_}, fo);
         d.reg_tot = d.comp.slice(0, 4 * HW, 4 * HW + 4);
         d.c_own = torch::empty({1, H_, W_}, fo); d.c_all = torch::empty({d.world, 1, H_, W_}, fo);
+        // the band exchange: this rank's band, the buffers and the two exchanges' messages (forward: the rows of MY layer every peer's band needs — with
+        // ten rows either side of the colour and silhouette planes for the mapping loss's SSIM window —, backward: every peer's layer gradient on my band)
+        const int hb = (H_ + d.world - 1) / d.world;
+        auto band_of = [&](int k, int halo, int& lo, int& hi) { lo = std::max(0, std::min(H_, k * hb) - halo); hi = std::min(H_, std::min(H_, (k + 1) * hb) + halo); if (k * hb >= H_) lo = hi = 0; };
+        band_of(d.rank, 0, d.b0, d.b1);
+        d.band = cfg_.band_exchange && cfg_.fused_loss && cfg_.fused_update && (d.world - 1) * hb < H_; // (every rank a non-empty band: more ranks than rows keep the replicated composite)
+        d.fwd_map.clear(); d.fwd_track.clear(); d.bwd_map.clear(); d.bwd_track.clear();
+        d.rows_all = torch::zeros({d.world, 16}, fo);
+        if (d.band && d.world > 1) {
+            const size_t HW = (size_t)H_ * W_;
+            d.L_all = torch::zeros({d.world, 6, H_, W_}, fo); d.D_all = torch::zeros({d.world, 5, H_, W_}, fo);
+            for (int k = 0; k < d.world; k++) {
+                if (k == d.rank) continue;
+                for (int halo : {10, 0}) {
+                    auto& fwd = halo ? d.fwd_map : d.fwd_track;
+                    for (int pl : {0, 1, 2, 4, 3, 5}) {
+                        const int h = (pl == 3 || pl == 5) ? 0 : halo; // (depth and surface depth: the band itself)
+                        int s0, s1, r0, r1;
+                        band_of(k, h, s0, s1); band_of(d.rank, h, r0, r1);
+                        // what I send is rows [s0, s1) of my layer (peer k's band); what I receive is rows [r0, r1) of k's layer (my band).
+                        // (a message is a send OR a receive: the two bands of a pair may differ in height)
+                        if (s1 > s0) fwd.push_back(Direct::Msg{k, f(d.layers) + pl * HW + (size_t)s0 * W_, nullptr, (size_t)(s1 - s0) * W_});
+                        if (r1 > r0) fwd.push_back(Direct::Msg{k, nullptr, f(d.L_all) + ((size_t)k * 6 + pl) * HW + (size_t)r0 * W_, (size_t)(r1 - r0) * W_});
+                    }
+                }
+                int k0, k1;
+                band_of(k, 0, k0, k1);
+                for (int pl = 0; pl < 5; pl++) {
+                    if (d.b1 > d.b0) { Direct::Msg m{k, f(d.D_all) + ((size_t)k * 5 + pl) * HW + (size_t)d.b0 * W_, nullptr, (size_t)(d.b1 - d.b0) * W_}; d.bwd_map.push_back(m); d.bwd_track.push_back(m); }
+                    if (k1 > k0) { Direct::Msg m{k, nullptr, f(d.D) + pl * HW + (size_t)k0 * W_, (size_t)(k1 - k0) * W_}; d.bwd_map.push_back(m); d.bwd_track.push_back(m); }
+                }
+                d.bwd_map.push_back(Direct::Msg{k, f(d.rows_all) + (size_t)d.rank * 16, nullptr, 16});
+                d.bwd_map.push_back(Direct::Msg{k, nullptr, f(d.rows_all) + (size_t)k * 16, 16});
+            }
+        }
     }
 }
 
@@ -369,6 +451,37 @@ void SlamLoop::shard_composite_backward_()
     d.all_gather(d.c_all, d.c_own);
     chk(gsr_composite_backward_occlusion(d.world, d.rank, order, f(d.gathered), 2, f(d.c_all), nullptr, H_, W_, f(d.D) + (size_t)4 * H_ * W_, st),
         "gsr_composite_backward_occlusion");
+}
+
+// ---- the BAND exchange (LoopConfig::band_exchange): what replaces the two functions above in the loops' iterations
+bool SlamLoop::band_() const { return shard_ && d_ && d_->band; }
+
+// Every rank's layer on this rank's band of rows (one grouped exchange), then the composite of the band: comp = {rgb, depth, silhouette, surface depth} on
+// rows [b0, b1) — the mapping loss's SSIM window reads the colour planes ten rows beyond, so those rows travel and are composited too.
+void SlamLoop::band_forward_(bool pose_moved, bool tracking)
+{
+    Direct& d = *d_;
+    void* const st = stream_();
+    d.stream = (hipStream_t)st;
+    const size_t HW = (size_t)H_ * W_;
+    if (pose_moved && d.kd_nodes.defined()) chk(gsr_shard_order(d.world, f(d.kd_nodes), f(d.Tcw), (long long*)d.order.data_ptr<int64_t>(), st), "gsr_shard_order");
+    d.p2p(tracking ? d.fwd_track : d.fwd_map);
+    if (d.b1 > d.b0)
+        chk(gsr_band_composite_forward(d.world, d.rank, (const long long*)d.order.data_ptr<int64_t>(), d.L_all.defined() ? f(d.L_all) : nullptr, f(d.layers), H_, W_, d.b0, d.b1,
+                                       tracking ? 0 : 10, f(d.comp), f(d.comp) + 4 * HW + 4, f(d.comp) + 5 * HW + 4, st), "gsr_band_composite_forward");
+}
+
+// From the loss's gradient on the band (G: rgb, depth) to EVERY rank's layer gradient on the band, and each rank's rows back to it (the second exchange;
+// a mapping iteration's sixteen loss / regulariser words per rank ride in it): D = d/d own layer (rgb, depth, silhouette) on the whole frame.
+void SlamLoop::band_backward_(bool tracking)
+{
+    Direct& d = *d_;
+    void* const st = stream_();
+    d.stream = (hipStream_t)st;
+    if (d.b1 > d.b0)
+        chk(gsr_band_composite_backward(d.world, d.rank, (const long long*)d.order.data_ptr<int64_t>(), d.L_all.defined() ? f(d.L_all) : nullptr, f(d.layers), f(d.G), H_, W_, d.b0, d.b1,
+                                        d.D_all.defined() ? f(d.D_all) : nullptr, f(d.D), st), "gsr_band_composite_backward");
+    d.p2p(tracking ? d.bwd_track : d.bwd_map);
 }
 
 void SlamLoop::grow_binning_(size_t capacity)
@@ -458,7 +571,9 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
     // (sharded: the cell's three regulariser sums go into the all-reduce behind the composite's planes — the finish of the rows the projection kernel wrote)
     if (in_projection && shard_)
         chk(gsr_map_prepare(n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, limit, wl, wsc, f(d.reg_partial), f(d.reg_tot), st), "gsr_map_prepare (finish)");
-    if (shard_) { shard_composite_forward_(d.order_stale, true); d.order_stale = false; }
+    const bool band = band_();
+    if (band) { band_forward_(d.order_stale, false); d.order_stale = false; }
+    else if (shard_) { shard_composite_forward_(d.order_stale, true); d.order_stale = false; }
     // Render.cc:436-471: lam * L1 + (1 - lam) * (1 - SSIM), masked depth L1, masked surface-depth L1 (no gradient), the regularisers
     const float w3[3] = {(float)(cfg_.im_weight_mapping * cfg_.lam), (float)cfg_.depth_weight_mapping, (float)cfg_.sur_depth_weight_mapping};
     const float c_ssim = (float)(cfg_.im_weight_mapping * (1 - cfg_.lam));
@@ -466,7 +581,17 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
     const float* const im0 = shard_ ? f(d.comp) : f(d.layers); // (both blocks: rgb, depth, silhouette, surface depth; comp keeps four floats between depth and silhouette)
     const size_t gap = shard_ ? 4 : 0;
     const float *img = im0, *dep = im0 + 3 * HW, *sil = im0 + 4 * HW + gap, *sur = im0 + 5 * HW + gap;
-    if (cfg_.fused_loss) { // two passes over the image and one single-workgroup kernel between them
+    if (band) {
+        // the loss on this rank's band of rows: its raw sums (and the cell's regulariser sums, and the loss slot that says whether this rank's forward
+        // overflowed) go out with the gradient's exchange; the gradient planes need one total only — the frame's count of valid depth pixels, a constant of the frame
+        float* const row = f(d.rows_all) + (size_t)d.rank * 16;
+        chk(gsr_map_loss_forward_rows(img, dep, sur, sil, f(fr.rgb), f(fr.depth), H_, W_, taps_host_.data(), 0.99f, f(d.partial6), f(d.dmaps), d.b0, d.b1, st), "gsr_map_loss_forward_rows");
+        chk(gsr_map_loss_finish_rows(f(d.partial6), f(d.reg_tot), 1, H_, W_, w3, c_ssim, wl, wsc, b(d.geom), row, row + 8, row + 12, d.b0, d.b1, st), "gsr_map_loss_finish_rows");
+        chk(gsr_map_loss_backward_rows(img, dep, f(fr.rgb), f(fr.depth), f(d.dmaps), H_, W_, taps_host_.data(), w3, f(d.neg_c), f(d.frame_sums), f(d.g_image), f(d.g_ds), d.b0, d.b1, st),
+            "gsr_map_loss_backward_rows");
+        band_backward_(false);
+        chk(gsr_shard_map_totals(d.world, f(d.rows_all), H_, W_, w3, c_ssim, wl, wsc, f(d.sums), f(d.reg_out), loss_slot, st), "gsr_shard_map_totals");
+    } else if (cfg_.fused_loss) { // two passes over the image and one single-workgroup kernel between them
         chk(gsr_map_loss_forward(img, dep, sur, sil, f(fr.rgb), f(fr.depth), H_, W_, taps_host_.data(), 0.99f, f(d.partial6), f(d.dmaps), st), "gsr_map_loss_forward");
         // (sharded: the regulariser sums of the whole map stand in as ONE row)
         chk(gsr_map_loss_finish(f(d.partial6), shard_ ? f(d.reg_tot) : f(d.reg_partial), shard_ ? 1 : n, H_, W_, w3, c_ssim, wl, wsc, b(d.geom), f(d.sums), f(d.reg_out),
@@ -492,7 +617,7 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
     u.opacities = f(d.opac); u.scales = f(d.scales); u.Tcw = f(d.Tcw);
     u.reg_out = f(d.reg_out); u.reg_limit = limit; u.w_long = wl; u.w_scalar = wsc;
     u.geom = b(d.geom); u.beta1 = 0.9; u.beta2 = 0.999; u.eps = fopt_->eps();
-    if (shard_) shard_composite_backward_();
+    if (shard_ && !band) shard_composite_backward_();
     if (n == 0) return;
     if (cfg_.fused_update) {
         direct_backward_(false, false, &u, nullptr); // backward and update in the same per-splat pass (gsr_backward_args.fused_map_update)
@@ -516,6 +641,10 @@ std::vector<double> SlamLoop::MapFrame(const LoopFrame& fr, int iters)
     Direct& d = *d_;
     const LoopFrame frame{fr.rgb.to(dev_, torch::kFloat32).contiguous(), fr.depth.to(dev_, torch::kFloat32).contiguous(), fr.Tcw};
     d.Tcw.copy_(fr.Tcw.to(torch::kFloat32).reshape({4, 4}));
+    if (band_()) { // the frame's count of valid depth pixels: the one total the band's depth gradient divides by (a constant of the frame)
+        d.frame_sums.zero_();
+        d.frame_sums.slice(0, 2, 3).copy_((frame.depth > 0).sum().to(torch::kFloat32).reshape({1}));
+    }
     if (shard_) { shard_preflight_(); d.order_stale = true; }
     else if (d.fresh) shard_preflight_(); // (unsharded too — ADVICE r4: inside a batch nobody looks; an iteration that overflowed is still retaken below,
                                           // but the iterations behind it ran with Adam step numbers one too high: size the workspace BEFORE the batch instead)
@@ -586,21 +715,31 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
     }
     const int feature_clear = (int)(iters / 2.0);                                                       // Render.cc:1051
     // (a sharded run sums the ranks' pose rows: a term every rank holds in full enters each rank's row with weight 1 / world)
+    // (the band exchange sums the ranks' loss words with the pose rows: the term's VALUE is added on rank 0 only, the other ranks add it to a word nobody reads)
+    const bool band = band_();
+    float* const band_sums = f(d.pose_acc) + 64 * 12 + 8; // [8] this rank's tracking-loss sums: words 776..783 of the all-reduced block
+    float* const loss_word = band ? (d.rank == 0 ? band_sums + 5 : f(d.frame_sums) + 7) : f(d.sums) + 5;
     auto reproj = [&](int it, float* row) {
         if (!m_obs.defined()) return;
         chk(gsr_reproj_loss(f(m_obs), f(m_X), f(m_s2), (size_t)m_obs.size(0), f(d.Tcw), fx_, fy_, m_cx, m_cy, (float)cfg_.feature_weight_tracking,
                             shard_ ? 1.f / (float)d.world : 1.f, it < feature_clear ? 2 : it == feature_clear ? 1 : 0, m_inl.data_ptr<uint8_t>(), row,
-                            f(d.sums) + 5, st), "gsr_reproj_loss");
+                            loss_word, st), "gsr_reproj_loss");
     };
     std::vector<double> history;
     double last_loss = 0.0;
     int step = 0;
     for (int it = 0; it < iters; it++) {
         direct_forward_(true); // (the camera transform of Render.cc:750-752 rides in the projection kernel)
-        if (shard_) shard_composite_forward_(true, false);
-        // Render.cc:1088-1105: the masked L1 sums and their gradient planes, one pass over the render
-        chk(gsr_track_loss(img, dep, sur, sil, f(frame.rgb), f(frame.depth), H_, W_, 0.99f, w3, f(d.loss_partial), f(d.sums), f(d.g_image), f(d.g_ds),
-                           reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()), st), "gsr_track_loss");
+        if (band) band_forward_(true, true);
+        else if (shard_) shard_composite_forward_(true, false);
+        // Render.cc:1088-1105: the masked L1 sums and their gradient planes, one pass over the render (band exchange: over this rank's band of rows; its
+        // sums are added up over the ranks by the pose rows' all-reduce)
+        if (band)
+            chk(gsr_track_loss_rows(img, dep, sur, sil, f(frame.rgb), f(frame.depth), H_, W_, 0.99f, w3, f(d.loss_partial), band_sums, f(d.g_image), f(d.g_ds),
+                                    reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()), d.b0, d.b1, st), "gsr_track_loss_rows");
+        else
+            chk(gsr_track_loss(img, dep, sur, sil, f(frame.rgb), f(frame.depth), H_, W_, 0.99f, w3, f(d.loss_partial), f(d.sums), f(d.g_image), f(d.g_ds),
+                               reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()), st), "gsr_track_loss");
         gsr_pose_update_args u{};
         u.quat_trans = f(d.pose); u.moments = f(d.pose_moments); u.best = f(d.best); u.history = d.posted_dev + it; u.Tcw = f(d.Tcw);
         u.partial = f(d.pose_partial); u.loss = f(d.sums) + 5; u.geom = b(d.geom);
@@ -608,7 +747,8 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
         u.lr = cfg_.lr_cam_quat; u.beta1 = 0.9; u.beta2 = 0.999; u.eps = 1e-15; u.step = ++step;
         uint32_t* const tickets = reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()) + GSR_TICKET_WORDS;
         if (shard_ && cfg_.fused_update) { // the shard's pose sums come out of the backward's per-splat stage (accumulator rows), are summed over the ranks, and a one-wave kernel takes the (replicated) step
-            shard_composite_backward_();
+            if (band) { band_backward_(true); u.loss = band_sums + 5; } // (the loss the step records is the all-reduced word behind the rows)
+            else shard_composite_backward_();
             u.partial = f(d.pose_acc);
             //  whether this iteration counts is decided by ALL ranks: the per-splat stage leaves the rank's overflow flag behind the rows, the
             // all-reduce sums it with them, and every rank's step kernel skips + posts NaN on the total — so every rank then enters shard_any_ below

@@ -45,6 +45,10 @@ struct LoopConfig {
                               // false: gsr_pixel_loss, gsr_ssim_*, gsr_pixel_loss_backward_add, gsr_map_loss_total as six launches
     bool fused_update = true; // (direct) the backward's per-splat stage takes the Adam step itself (gsr_backward_args.fused_map_update);
                               // false: gsr_backward writes the gradients, gsr_map_update reads them
+    bool band_exchange = true; // (sharded, with fused_loss and fused_update) the BAND exchange of round 6: every rank receives all ranks' layers for its band of pixel rows
+                               // (one grouped point-to-point exchange), composites, evaluates the loss and differentiates the composite there — for every rank's layer —
+                               // and returns each rank its rows (a second exchange): all per-pixel work / world, two collectives per mapping iteration instead of three,
+                               // a third of the bytes at 8 ranks. false: round 5's replicated composite (all-gather, all-reduce, all-gather; every rank the whole frame)
 };
 
 struct LoopFrame {
@@ -143,6 +147,9 @@ private:
     bool shard_ = false;
     void shard_composite_forward_(bool pose_moved, bool with_reg);
     void shard_composite_backward_();
+    bool band_() const;
+    void band_forward_(bool pose_moved, bool tracking);
+    void band_backward_(bool tracking);
     void shard_preflight_();
     bool shard_any_(bool mine);
     torch::Tensor shard_cells_(const torch::Tensor& pts) const;

@@ -61,7 +61,7 @@ ORB_SLAM2::LoopConfig loop_config(const py::dict& kw)
         GSR_F(lr_opacities, double) GSR_F(lr_scales, double) GSR_F(lr_cam_quat, double) GSR_F(im_weight_tracking, double) GSR_F(depth_weight_tracking, double) GSR_F(feature_weight_tracking, double)
         GSR_F(scale_modifier, double) GSR_F(scene_radius, double) GSR_F(prune_opacities, double) GSR_F(median_mul, double) GSR_F(init_scalar_method, int)
         GSR_F(use_sur_depth, bool) GSR_F(fused_pair, bool) GSR_F(fused_ops, bool) GSR_F(direct, bool) GSR_F(binning_capacity, int64_t) GSR_F(fused_loss, bool)
-        GSR_F(fused_update, bool)
+        GSR_F(fused_update, bool) GSR_F(band_exchange, bool)
 #undef GSR_F
         throw std::invalid_argument("SlamLoop: unknown configuration field " + k);
     }

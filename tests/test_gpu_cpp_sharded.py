@@ -307,6 +307,110 @@ def test_an_empty_cell_takes_part_in_the_sharded_loop():
     np.testing.assert_allclose(got[1]["rows"], got[0]["rows"], rtol=1e-6)       # (the all-reduced pose rows: the empty rank added zeros)
 
 
+def _band_worker(rank, world, port, backend, q):
+    """the same cell through the sharded loop twice: the band exchange of round 6 and round 5's replicated composite"""
+    gsr, _C, sharded = _setup()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = rank if backend == "nccl" and world > 1 else 0
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        sc, raw = _scene(gsr)
+        part = sharded.KdPartition.build(raw[0], world)
+        idx = torch.nonzero(part.assign(raw[0]) == rank).squeeze(-1)
+        frame = _frame(_C, raw, dev)
+        rgb, depth, T = frame
+        obs, Xw, s2, cx, cy = _matches(_poses()[0])
+        m = (obs.to(T.device), Xw.to(T.device), s2.to(T.device), cx, cy)
+        res = {}
+        for name, band in (("band", True), ("replicated", False)):
+            loop = _loop(_C, [x[idx] for x in raw], dev, fused_update=True, band_exchange=band)
+            loop.set_shard(dist.group.WORLD if world > 1 or backend == "nccl" else None, rank, world, part.nodes)
+            r = {"map": loop.map_frame(rgb, depth, T, 8)}
+            hist, best = loop.track(rgb, depth, _poses()[1].cuda(dev), 1, *m)
+            r["pose_sums"], r["track1"] = loop.last_pose_sums().cpu().numpy(), hist[0]
+            hist, best = loop.track(rgb, depth, _poses()[1].cuda(dev), 8, *m)
+            r["track"], r["pose"] = hist, best.cpu().numpy()
+            r["xyz"] = loop.params()[0].double().sum().item()
+            r["transport"] = loop.shard_transport()
+            res[name] = r
+            del loop
+        torch.cuda.synchronize()
+        q.put((rank, res))
+    except Exception:
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()}))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_band(backend, world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_band_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    got, t0 = {}, time.time()
+    while len(got) < world:
+        try:
+            r, res = q.get(timeout=2)
+            assert "error" not in res, "rank %d failed:\n%s" % (r, res.get("error"))
+            got[r] = res
+        except queue.Empty:
+            if [p.exitcode for p in procs if p.exitcode not in (None, 0)] or time.time() - t0 > 400:
+                for p in procs:
+                    p.kill()
+                raise AssertionError("ranks died or hung: exit codes %s" % [p.exitcode for p in procs])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rel = lambda a, b: float(np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-30))
+    for r in range(world):
+        a, b = got[r]["band"], got[r]["replicated"]
+        n = min(len(a["track"]), len(b["track"]))
+        e = (rel(a["map"], b["map"]), rel(a["pose_sums"], b["pose_sums"]), rel(a["track"][:n], b["track"][:n]), float(np.abs(a["pose"] - b["pose"]).max()))
+        if r == 0:
+            print("\n  %s world %d, band exchange vs replicated composite: mapping loss curve %.1e, pose sums %.1e, tracking loss curve %.1e over %d iterations, tracked pose %.1e"
+                  % (backend, world, *e[:3], n, e[3]))
+        # the same render, loss and gradients — summed front to back instead of by an all-reduce, float atomics in both backward passes
+        assert len(a["map"]) == 8 and n >= 3
+        assert e[0] < 1e-5 and e[3] < 1e-5, e
+        assert abs(a["track1"] - b["track1"]) <= 1e-5 * abs(b["track1"])   # the tracking loss of the same pose
+        # (over the iterations the two runs' poses drift apart by ~1e-6 — float atomics in both — and the tracking loss is a masked SUM: a pixel whose
+        # silhouette crosses 0.99 enters or leaves it whole)
+        assert e[2] < 3e-4, e
+        assert e[1] < 1e-3, e                                              # (sums of ~1e4 signed terms that cancel: 1e-5 of the terms' own scale)
+        assert abs(a["xyz"] - b["xyz"]) <= 1e-7 * abs(b["xyz"])            # the maps after eight Adam steps
+        for rr in range(1, world):                                         # replicas: every rank records the same losses
+            np.testing.assert_allclose(got[rr]["band"]["map"], got[0]["band"]["map"], rtol=1e-6)
+            np.testing.assert_allclose(got[rr]["band"]["track"], got[0]["band"]["track"], rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_band_exchange_equals_the_replicated_composite_gloo(world):
+    """LoopConfig::band_exchange (round 6: every rank composites, evaluates the loss and differentiates the composite on its band of pixel rows only, two grouped
+    point-to-point exchanges per mapping iteration) against round 5's replicated composite (all-gather, all-reduce, all-gather; every rank the whole frame), same cells,
+    same frames: 2 and 4 processes on the test box's one GPU over gloo (the exchange staged through alltoall_base)."""
+    _run_band("gloo", world)
+
+
+@pytest.mark.gpu
+def test_band_exchange_one_rank_rccl():
+    _run_band("nccl", 1)
+
+
+@pytest.mark.gpu
+def test_band_exchange_two_gpus_rccl():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run_band("nccl", 2)
+
+
 def _matches(T, n=60, seed=9):
     """feature matches: world points in front of the camera of T and their (noisy) pixel observations"""
     g = torch.Generator().manual_seed(seed)
