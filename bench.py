@@ -532,7 +532,8 @@ def shard_step(a, gsr, td, rank, world, dev):
             backend, own_group = "nccl (one rank)", True
         else:                                                    # (stated in the record, never silent)
             backend = f"none (single process: one-rank RCCL group failed: {_ONE_RANK['error']})"
-    loop = _C.SlamLoop(W, H, camd["fx"], camd["fy"], dev)
+    band = os.environ.get("GSR_BENCH_BAND", "1") != "0"     # (A/B hook: 0 = round 5's replicated composite)
+    loop = _C.SlamLoop(W, H, camd["fx"], camd["fy"], dev, band_exchange=band)
     loop.set_map(*[x[idx] for x in raw])
     loop.set_shard(group, rank, world, part.nodes)
     transport = loop.shard_transport()   # "rccl": the loop's own communicator on its stream; "c10d": the group's collectives (fallback); "local": no group

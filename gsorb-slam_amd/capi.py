@@ -198,7 +198,7 @@ def lib():
     L.gsr_band_composite_forward.restype = C.c_int
     L.gsr_band_composite_forward.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4
     L.gsr_band_composite_backward.restype = C.c_int
-    L.gsr_band_composite_backward.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3
+    L.gsr_band_composite_backward.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 3
     L.gsr_shard_map_totals.restype = C.c_int
     L.gsr_shard_map_totals.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 4
     L.gsr_map_loss_partials_rows.restype = C.c_size_t
@@ -690,10 +690,11 @@ def band_composite_forward(world, rank, order, layers_all, own_layer, row_begin,
                                                 int(row_begin), int(row_end), int(halo), _p(out_rgbd), _p(out_sil), _p(out_sur), _stream()))
 
 
-def band_composite_backward(world, rank, order, layers_all, own_layer, g4, row_begin, row_end, d_all, d_own):
+def band_composite_backward(world, rank, order, layers_all, own_layer, g4, row_begin, row_end, d_all, d_own, g_sil=None):
     H, W = int(own_layer.shape[-2]), int(own_layer.shape[-1])
     with torch.cuda.device(own_layer.device):
-        _check(lib().gsr_band_composite_backward(int(world), int(rank), _p(order), _p(layers_all) if layers_all is not None else None, _p(own_layer), _p(g4), H, W,
+        _check(lib().gsr_band_composite_backward(int(world), int(rank), _p(order), _p(layers_all) if layers_all is not None else None, _p(own_layer), _p(g4),
+                                                 _p(g_sil) if g_sil is not None else None, H, W,
                                                  int(row_begin), int(row_end), _p(d_all) if d_all is not None else None, _p(d_own), _stream()))
 
 

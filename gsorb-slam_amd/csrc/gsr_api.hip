@@ -791,17 +791,17 @@ int gsr_band_composite_forward(int world, int rank, const long long* order, cons
     return GSR_OK;
 }
 
-int gsr_band_composite_backward(int world, int rank, const long long* order, const float* layers_all, const float* own_layer, const float* g4, int H, int W,
+int gsr_band_composite_backward(int world, int rank, const long long* order, const float* layers_all, const float* own_layer, const float* g4, const float* g_sil, int H, int W,
                                 int row_begin, int row_end, float* d_all, float* d_own, void* stream)
 {
     if (world < 1 || world > 32 || rank < 0 || rank >= world || !order || !own_layer || (world > 1 && (!layers_all || !d_all)) || !g4 || !d_own || H <= 0 || W <= 0) return GSR_EINVAL;
     if (row_begin < 0 || row_end > H || row_begin >= row_end) return GSR_EINVAL;
     const size_t n = (size_t)(row_end - row_begin) * W;
     if (world <= 8)
-        GSR_LAUNCH(gsr::K_band_composite_bwd<8>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, layers_all, own_layer, g4, (size_t)H * W, W,
+        GSR_LAUNCH(gsr::K_band_composite_bwd<8>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, layers_all, own_layer, g4, g_sil, (size_t)H * W, W,
                    row_begin, row_end, d_all, d_own);
     else
-        GSR_LAUNCH(gsr::K_band_composite_bwd<32>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, layers_all, own_layer, g4, (size_t)H * W, W,
+        GSR_LAUNCH(gsr::K_band_composite_bwd<32>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, world, rank, order, layers_all, own_layer, g4, g_sil, (size_t)H * W, W,
                    row_begin, row_end, d_all, d_own);
     GSR_LAUNCHED();
     return GSR_OK;

@@ -121,15 +121,15 @@ K_band_composite_fwd(int world, int rank, const long long* __restrict__ order, c
 }
 // K_band_composite_bwd: rows [b0, b1): from the loss's gradient g4 (rgb, depth) on the composite to EVERY rank's layer gradient on those rows:
 // d_all[k] = {P_k g4 (4 planes), dS_k}, dS_k = -P_k B_k with B_k = c_(k+1) + (1 - S_(k+1)) B_(k+1) over the front-to-back order (c_j = g4 . layer_j):
-// the occlusion term of K_composite_bwd_occlusion without a division by 1 - S. d_own [5][H][W] receives this rank's (no copy), d_all [world][5][H][W] the others'.
+// the occlusion term of K_composite_bwd_occlusion without a division by 1 - S; g_sil (nullptr: none), the stack's silhouette's upstream gradient, adds g_sil P_k Q_k. d_own [5][H][W] receives this rank's (no copy), d_all [world][5][H][W] the others'.
 template <int MAXW>
 __global__ void __launch_bounds__(256)
 K_band_composite_bwd(int world, int rank, const long long* __restrict__ order, const float* __restrict__ layers_all, const float* __restrict__ own,
-                     const float* __restrict__ g4, size_t N, int W, int b0, int b1, float* __restrict__ d_all, float* __restrict__ d_own)
+                     const float* __restrict__ g4, const float* __restrict__ g_sil, size_t N, int W, int b0, int b1, float* __restrict__ d_all, float* __restrict__ d_own)
 {
     const size_t i = (size_t)b0 * W + (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)b1 * W) return;
-    const float g0 = g4[i], g1 = g4[N + i], g2 = g4[2 * N + i], g3 = g4[3 * N + i];
+    const float g0 = g4[i], g1 = g4[N + i], g2 = g4[2 * N + i], g3 = g4[3 * N + i], gs = g_sil ? g_sil[i] : 0.f;
     float S[MAXW], c[MAXW];
 #pragma unroll
     for (int k = 0; k < MAXW; k++) {
@@ -141,12 +141,12 @@ K_band_composite_bwd(int world, int rank, const long long* __restrict__ order, c
             c[k] = fmaf(g3, L[3 * N + i], fmaf(g2, L[2 * N + i], fmaf(g1, L[N + i], g0 * L[i])));
         }
     }
-    float B[MAXW]; // B_k: what the layers behind k contribute through k's transmittance
-    float acc = 0.f;
+    float B[MAXW]; // B_k: what the layers behind k contribute through k's transmittance, minus the silhouette's upstream gradient through the layers behind k
+    float acc = 0.f, Q = 1.f; // Q: prod_{h behind k} (1 - S_h) — d(1 - prod (1 - S)) / dS_k = P_k Q_k
 #pragma unroll
     for (int k = MAXW - 1; k >= 0; k--) {
-        B[k] = acc;
-        if (k < world) acc = fmaf(1.f - S[k], acc, c[k]);
+        B[k] = fmaf(-gs, Q, acc);
+        if (k < world) { acc = fmaf(1.f - S[k], acc, c[k]); Q *= 1.f - S[k]; }
     }
     float P = 1.f;
 #pragma unroll

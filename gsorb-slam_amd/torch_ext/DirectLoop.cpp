@@ -473,14 +473,14 @@ void SlamLoop::band_forward_(bool pose_moved, bool tracking)
 
 // From the loss's gradient on the band (G: rgb, depth) to EVERY rank's layer gradient on the band, and each rank's rows back to it (the second exchange;
 // a mapping iteration's sixteen loss / regulariser words per rank ride in it): D = d/d own layer (rgb, depth, silhouette) on the whole frame.
-void SlamLoop::band_backward_(bool tracking)
+void SlamLoop::band_backward_(bool tracking, const float* g_sil)
 {
     Direct& d = *d_;
     void* const st = stream_();
     d.stream = (hipStream_t)st;
     if (d.b1 > d.b0)
-        chk(gsr_band_composite_backward(d.world, d.rank, (const long long*)d.order.data_ptr<int64_t>(), d.L_all.defined() ? f(d.L_all) : nullptr, f(d.layers), f(d.G), H_, W_, d.b0, d.b1,
-                                        d.D_all.defined() ? f(d.D_all) : nullptr, f(d.D), st), "gsr_band_composite_backward");
+        chk(gsr_band_composite_backward(d.world, d.rank, (const long long*)d.order.data_ptr<int64_t>(), d.L_all.defined() ? f(d.L_all) : nullptr, f(d.layers), f(d.G), g_sil, H_, W_,
+                                        d.b0, d.b1, d.D_all.defined() ? f(d.D_all) : nullptr, f(d.D), st), "gsr_band_composite_backward");
     d.p2p(tracking ? d.bwd_track : d.bwd_map);
 }
 
@@ -880,6 +880,18 @@ torch::Tensor SlamLoop::ShardRenderStep(const torch::Tensor& Tcw, const torch::T
         chk(gsr_map_prepare((size_t)d.n, f(xyz), f(logit_opacities), f(log_scales), f(unnorm_quat), f(d.Tcw), f(d.mc), f(d.opac), f(d.scales), f(d.rots), 0.f, 0.f, 0.f,
                             nullptr, nullptr, st), "gsr_map_prepare");
     direct_forward_();
+    if (band_()) { // the band exchange: the caller's gradient of the composite taken back on this rank's band of rows, for every rank's layer
+        band_forward_(true, true);
+        const torch::Tensor keep = d.G;
+        d.G = G;
+        band_backward_(true, f(G) + (size_t)4 * H_ * W_);
+        d.G = keep;
+        direct_backward_(false, false, nullptr, nullptr);
+        if (d.n > 0) chk(gsr_pose_grad(f(xyz), f(d.d_mc), (size_t)d.n, f(d.Tcw), f(d.pose_partial), nullptr, st), "gsr_pose_grad");
+        else d.pose_partial.zero_();
+        d.all_reduce(d.pose_partial);
+        return d.pose_partial;
+    }
     shard_composite_forward_(true, false);
     // the compositor's backward reads the loss's gradient from d.G: hand it the caller's (the silhouette's upstream gradient rides in plane 4)
     const torch::Tensor keepG = d.G;

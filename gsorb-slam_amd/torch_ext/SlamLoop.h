@@ -149,7 +149,7 @@ private:
     void shard_composite_backward_();
     bool band_() const;
     void band_forward_(bool pose_moved, bool tracking);
-    void band_backward_(bool tracking);
+    void band_backward_(bool tracking, const float* g_sil = nullptr);
     void shard_preflight_();
     bool shard_any_(bool mine);
     torch::Tensor shard_cells_(const torch::Tensor& pts) const;

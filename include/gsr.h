@@ -449,13 +449,14 @@ int gsr_composite_backward_occlusion(int world, int rank, const long long* order
  * gsr_band_composite_forward: rows [row_begin - halo, row_end + halo) inside the image: out_rgbd planes 0..2 = sum_k P_k rgb_k; on the band itself also plane 3
  *   (depth), out_sil = 1 - prod (1 - S), out_sur = gsr_composite_forward's surface depth. out_rgbd [4][H][W], out_sil, out_sur [H][W]: only those rows are written.
  * gsr_band_composite_backward: g4 [4][H][W] (d/d rgb, depth of the composite; band rows) -> for every rank k its layer's gradient on the band rows:
- *   d_all [world][5][H][W] = {P_k g4, dS_k} (this rank's own goes to d_own [5][H][W]); dS_k is gsr_composite_backward_occlusion's term (no silhouette upstream gradient).
+ *   d_all [world][5][H][W] = {P_k g4, dS_k} (this rank's own goes to d_own [5][H][W]); dS_k is gsr_composite_backward_occlusion's term; g_sil [H][W] (NULL: none) is the
+ *   upstream gradient of the stack's silhouette.
  * gsr_shard_map_totals: rows [world][16] = every rank's {sums[8], reg_out[4], loss slot (NaN: that rank's forward overflowed), 3 unused} from
  *   gsr_map_loss_finish_rows on its band -> sums [8] / reg_out [4] (NULL: none) of the whole frame / map and the iteration's loss. */
 int gsr_band_composite_forward(int world, int rank, const long long* order, const float* layers_all, const float* own_layer, int H, int W, int row_begin, int row_end,
                                int halo, float* out_rgbd, float* out_sil, float* out_sur, void* stream);
-int gsr_band_composite_backward(int world, int rank, const long long* order, const float* layers_all, const float* own_layer, const float* g4, int H, int W,
-                                int row_begin, int row_end, float* d_all, float* d_own, void* stream);
+int gsr_band_composite_backward(int world, int rank, const long long* order, const float* layers_all, const float* own_layer, const float* g4, const float* g_sil, int H,
+                                int W, int row_begin, int row_end, float* d_all, float* d_own, void* stream);
 int gsr_shard_map_totals(int world, const float* rows, int H, int W, const float* w3 /* host */, float c_ssim, float w_long, float w_scalar, float* sums, float* reg_out,
                          float* loss, void* stream);
 /* The loss kernels on a band of rows (the whole image: 0, H — what gsr_map_loss_forward / _finish / _backward / gsr_track_loss are). Planes keep their full

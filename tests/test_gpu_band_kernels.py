@@ -35,7 +35,7 @@ def test_band_compositor_equals_the_dense_composite_and_the_round4_kernels(gsr, 
     L[:, 5] = torch.where(torch.rand((world, H, W), generator=g) < 0.7, 0.5 + 3 * L[:, 5], torch.zeros(1))
     keys = torch.rand((world,), generator=g)
     order = torch.argsort(keys.double(), stable=True)
-    G4 = torch.randn((4, H, W), generator=g)
+    G4 = torch.randn((4, H, W), generator=g); Gs = torch.randn((H, W), generator=g)
     # dense float64 reference
     Ld = L[:, :4].double().requires_grad_(True); Sd = L[:, 4:5].double().requires_grad_(True)
     T = torch.ones((1, H, W), dtype=torch.float64); out = torch.zeros((4, H, W), dtype=torch.float64)
@@ -46,10 +46,8 @@ def test_band_compositor_equals_the_dense_composite_and_the_round4_kernels(gsr, 
         has = L[k, 5:6] > 0
         surf_ref = torch.where(~found & has, L[k, 5:6], surf_ref)
         found = found | (has & (T.detach() <= 0.5))
-    (out * G4.double()).sum().backward()
-    if Sd.grad is None:                      # (one layer: nothing lies behind it)
-        Sd.grad = torch.zeros_like(Sd)
-    Ld_c, order_d, G4d = L.cuda().contiguous(), order.cuda(), G4.cuda().contiguous()
+    ((out * G4.double()).sum() + ((1 - T[0]) * Gs.double()).sum()).backward()
+    Ld_c, order_d, G4d, Gsd = L.cuda().contiguous(), order.cuda(), G4.cuda().contiguous(), Gs.cuda().contiguous()
     comp = torch.full((4, H, W), float("nan"), device="cuda"); sil = torch.full((H, W), float("nan"), device="cuda"); sur = torch.full((H, W), float("nan"), device="cuda")
     d_from = [torch.zeros((world, 5, H, W), device="cuda") for _ in range(world)]     # d_from[r][k]: what rank r computed for rank k's layer (its band's rows)
     for r, (b0, b1) in enumerate(_bands(H, world)):
@@ -64,7 +62,7 @@ def test_band_compositor_equals_the_dense_composite_and_the_round4_kernels(gsr, 
         assert torch.isnan(c_r[3, :b0]).all() and torch.isnan(c_r[3, b1:]).all()
         comp[:, b0:b1] = c_r[:, b0:b1]; sil[b0:b1] = s_r[b0:b1]; sur[b0:b1] = u_r[b0:b1]
         d_own = torch.zeros((5, H, W), device="cuda")
-        gsr.capi.band_composite_backward(world, r, order_d, Ld_c if world > 1 else None, own, G4d, b0, b1, d_from[r] if world > 1 else None, d_own)
+        gsr.capi.band_composite_backward(world, r, order_d, Ld_c if world > 1 else None, own, G4d, b0, b1, d_from[r] if world > 1 else None, d_own, g_sil=Gsd)
         d_from[r][r] = d_own
     assert (comp.cpu().double() - out.detach()).abs().max() < 5e-6
     assert (sil.cpu().double() - (1 - T.detach()[0])).abs().max() < 2e-6
@@ -80,7 +78,7 @@ def test_band_compositor_equals_the_dense_composite_and_the_round4_kernels(gsr, 
     c_all = torch.stack([c for _, c in locs]).contiguous()
     for k in range(world):
         assert (d_layer[k, :4] - locs[k][0]).abs().max() <= 1e-6
-        dS = gsr.capi.composite_backward_occlusion(world, k, order_d, gathered, c_all, None)
+        dS = gsr.capi.composite_backward_occlusion(world, k, order_d, gathered, c_all, Gsd.reshape(1, H, W))
         assert (d_layer[k, 4] - dS[0]).abs().max() <= 1e-5 * max(1.0, float(dS.abs().max()))
 
 
