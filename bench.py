@@ -505,6 +505,18 @@ def rank_regime(a, gsr, dev, total, camera, cells):
     return out
 
 
+def band_exchange_bytes(W, H, world, rank):
+    """Bytes one rank SENDS per iteration in the band exchange (DirectLoop.cpp: ensure_direct_): forward = the rows of its layer every peer's band needs (colour and
+    silhouette planes with ten rows either side for the mapping loss's SSIM window, depth and surface depth on the band), backward = every peer's layer gradient
+    (five planes) on its own band."""
+    hb = -(-H // world)
+    band = lambda k, halo: (max(0, min(H, k * hb) - halo), min(H, min(H, (k + 1) * hb) + halo))
+    rows = lambda k, halo: max(0, band(k, halo)[1] - band(k, halo)[0])
+    peers = [k for k in range(world) if k != rank]
+    return {"map_fwd": sum(4 * rows(k, 10) + 2 * rows(k, 0) for k in peers) * W * 4, "track_fwd": sum(6 * rows(k, 0) for k in peers) * W * 4,
+            "bwd": 5 * rows(rank, 0) * W * 4 * len(peers)}
+
+
 def shard_step(a, gsr, td, rank, world, dev):
     """One sharded MAPPING iteration and one sharded TRACKING iteration of the C++ loop (torch_ext/DirectLoop.cpp: SlamLoop::SetShard) with
     every collective inside the timed region. --splats Gaussians in TOTAL, cut into `world` k-d cells (sharded.KdPartition: the partition
@@ -576,18 +588,25 @@ def shard_step(a, gsr, td, rank, world, dev):
         t_ms, _ = timed(lambda k: len(plain.track(rgb, depth, T0, k)[0]))
         same = {"mapping_ms_per_iter": m_ms, "tracking_ms_per_iter": t_ms}
         del plain
-    plane = W * H * 4              # DirectLoop.cpp: all-gather (silhouette, surface depth), all-reduce of the 4 premultiplied planes, backward all-gather of 1 plane
-    return {"what": "one sharded mapping iteration / one sharded tracking iteration of the C++ loop (ORB_SLAM2::SlamLoop with SetShard, torch_ext/DirectLoop.cpp): "
-                    "fused rasterizer pair on the rank's k-d cell, gsr_shard_order, layer all-gather, gsr_composite_forward, all-reduce, the fused loss kernels on the "
-                    "composite, gsr_composite_backward_* around an all-gather, backward with the Adam step fused (mapping: + all-reduce of three regulariser "
-                    "sums) or gsr_pose_grad + all-reduce of the pose rows + gsr_pose_update (tracking) — collectives INSIDE the timed region",
+    plane = W * H * 4
+    ex = band_exchange_bytes(W, H, world, rank)
+    return {"what": "one sharded mapping iteration / one sharded tracking iteration of the C++ loop (ORB_SLAM2::SlamLoop with SetShard, torch_ext/DirectLoop.cpp) — round 6, the BAND "
+                    "exchange: fused rasterizer pair on the rank's k-d cell, gsr_shard_order, one grouped point-to-point exchange (every rank's layer on this rank's band of pixel "
+                    "rows), gsr_band_composite_forward, the fused loss kernels on the band, gsr_band_composite_backward (every rank's layer gradient on the band), the second "
+                    "exchange (each rank's rows back; the mapping loss's sums ride in it), backward with the Adam step fused (mapping) or the pose sums out of the backward's "
+                    "per-splat stage + all-reduce of 784 floats + gsr_pose_finish (tracking) — collectives INSIDE the timed region" if band else
+                    "round 5's replicated composite (GSR_BENCH_BAND=0): layer all-gather, gsr_composite_forward, all-reduce, the fused loss kernels on the whole frame, "
+                    "gsr_composite_backward_* around an all-gather, backward",
+            "exchange": "band (LoopConfig::band_exchange)" if band else "replicated composite",
             "scaling": "strong", "total_splats": a.splats, "splats_per_rank": int(idx.numel()), "width": W, "height": H,
             "partition": f"k-d cells x{world} (sharded.KdPartition)", "backend": backend, "rccl_ranks": (td.get_world_size() if world > 1 else (1 if own_group else 0)),
             "mapping_ms_per_iter": map_ms, "tracking_ms_per_iter": track_ms, "tracking_iterations_run": ran,
             "unsharded_same_scene": same, "warmup_iters": max(a.shard_steps, 20), "transport": transport, "batches_ms": batches,
             "mapping_splats_pixels_per_s": 2 * a.splats * W * H / (map_ms * 1e-3),
-            "collectives_per_mapping_iter": {"all_gather_bytes_sent_per_rank": 3 * plane, "all_reduce_bytes": 4 * plane, "all_reduce_floats": 3},
-            "collectives_per_tracking_iter": {"all_gather_bytes_sent_per_rank": 3 * plane, "all_reduce_bytes": 4 * plane, "all_reduce_floats": 512 * 12},
+            "collectives_per_mapping_iter": ({"grouped_p2p_exchanges": 2, "bytes_sent_per_rank": ex["map_fwd"] + ex["bwd"] + 64 * (world - 1), "all_reduce_floats": 0} if band else
+                                             {"all_gather_bytes_sent_per_rank": 3 * plane * (world - 1), "all_reduce_bytes": 4 * plane, "all_reduce_floats": 3}),
+            "collectives_per_tracking_iter": ({"grouped_p2p_exchanges": 2, "bytes_sent_per_rank": ex["track_fwd"] + ex["bwd"], "all_reduce_floats": 784} if band else
+                                              {"all_gather_bytes_sent_per_rank": 3 * plane * (world - 1), "all_reduce_bytes": 4 * plane, "all_reduce_floats": 512 * 12}),
             "timed_iters": n}
 
 
@@ -642,14 +661,16 @@ def shard_render(a, gsr, td, rank, world, dev, weak=False):
         dt = float(tt.item())
     ms = dt / max(a.steps, 1) * 1e3
     plane = W * H * 4
+    ex = band_exchange_bytes(W, H, world, rank)
     return {"what": "sharded fwd+bwd rasterize with its exchange through the C++ loop (SlamLoop::ShardRenderStep): fused colour + depth/silhouette pass of the rank's cell, "
-                    "layer compositing (three HIP kernels), backward through both, pose-row all-reduce; collectives (RCCL on the loop's stream) INSIDE the timed region",
+                    "the band exchange (every rank's layer on this rank's band of rows; gsr_band_composite_forward / _backward; each rank's gradient rows back), backward, "
+                    "pose-row all-reduce; collectives (RCCL on the loop's stream) INSIDE the timed region",
             "scaling": "weak" if weak else "strong", "partition": how, "total_splats": total, "splats_per_rank": int(idx.numel()), "width": W, "height": H, "ms_per_step": ms,
             "value": total * W * H / (ms * 1e-3), "unit": "splats*pixels/s",
             "backend": (td.get_backend() if world > 1 else "none (single process)"), "ranks": (td.get_world_size() if world > 1 else 1),
             "transport": loop.shard_transport(),
-            "collective_bytes_per_rank_per_step": {"all_gather_fwd": 2 * plane * (world - 1) if world > 1 else 0, "all_reduce_fwd": 4 * plane if world > 1 else 0,
-                                                   "all_gather_bwd": plane * (world - 1) if world > 1 else 0, "all_reduce_pose": 512 * 12 * 4 if world > 1 else 0}}
+            "collective_bytes_per_rank_per_step": {"p2p_forward_sent": ex["track_fwd"], "p2p_backward_sent": ex["bwd"], "all_reduce_pose": 512 * 12 * 4 if world > 1 else 0,
+                                                   "round5_replicated_composite_sent": (3 * plane * (world - 1) + 2 * 4 * plane * (world - 1) // max(world, 1)) if world > 1 else 0}}
 
 
 def main():

@@ -229,7 +229,7 @@ def test_two_gpus_rccl_drive_the_hip_backends():
 def test_bench_runs_its_multi_rank_branch_with_two_ranks():
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process), here with both ranks on
     whatever GPUs exist and gloo instead of RCCL (GSR_BENCH_BACKEND): rendezvous, barriers, the max-over-ranks timing, the
-    strong-scaling `shard_render` headline (depth slabs, layer compositing collectives, pose-gradient all-reduce), the
+    strong-scaling `shard_render` headline (k-d cells, the band exchange, pose-gradient all-reduce), the
     collective-free replica figure beside it, and `shard_step` all execute; one JSON line from rank 0."""
     import json
     import socket
@@ -252,7 +252,8 @@ def test_bench_runs_its_multi_rank_branch_with_two_ranks():
     assert "x2" in d["config"]["parallelism"] and "cpu_baseline" not in d and "parity" not in d
     sr = d["shard_render"]
     assert sr["splats_per_rank"] == 20000 and sr["total_splats"] == 40000 and d["value"] == sr["value"] and d["ms_per_step"] == sr["ms_per_step"]
-    assert sr["collective_bytes_per_rank_per_step"]["all_reduce_fwd"] == 4 * 640 * 480 * 4
+    # (round 6, the band exchange: rank 0 sends the peer's band — 240 rows — of its six layer planes, and the peer's five gradient planes on its own band)
+    assert sr["collective_bytes_per_rank_per_step"]["p2p_forward_sent"] == 6 * 240 * 640 * 4 and sr["collective_bytes_per_rank_per_step"]["p2p_backward_sent"] == 5 * 240 * 640 * 4
     assert d["replica_rasterize"]["scaling"] == "weak" and d["replica_rasterize"]["value"] > 0
     wk = d["shard_render_weak"]   # the weak-scaling scheme-B figure beside the strong headline: --splats per rank, the map grows with the ranks
     assert wk["scaling"] == "weak" and wk["splats_per_rank"] == 40000 and wk["total_splats"] == 80000 and wk["ranks"] == 2 and wk["value"] > 0
