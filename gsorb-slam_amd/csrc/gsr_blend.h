@@ -231,6 +231,23 @@ __device__ __forceinline__ void blend_bwd_rgb(ImageView im, char* __restrict__ b
     const uint2* __restrict__ qh = bn.qhits + (ovf ? (size_t)0 : 4 * (size_t)range.x + (size_t)quad * (size_t)n);
     const size_t pix = (size_t)py * W + px, HW = (size_t)H * W;
 
+#ifdef GSR_EXP_PROLOGUE2 // experiment (round 6): a second, serialised copy of the job's dependent trips to memory (tile range -> quad-hit record -> splat record) in front
+                         // of the real ones: what the kernel's time rises by is what a prologue hidden behind the previous job's last round could return at most
+    {
+        uint32_t t2 = tile;
+        asm volatile("" : "+v"(t2));
+        const uint2 r2 = im.ranges[t2];
+        const uint32_t c2 = im.qdone[4 * t2 + quad];
+        const uint2* q2 = bn.qhits + 4 * (size_t)r2.x + (size_t)quad * (size_t)(r2.y - r2.x);
+        const uint2 e2 = q2[max((int)c2 - 1 - lane, 0)];
+#if GSR_EXP_PROLOGUE2 >= 3
+        const float4 z2 = g.g0[e2.y & GSR_ID_MASK];
+        asm volatile("" ::"v"(z2.x));
+#else
+        asm volatile("" ::"v"(e2.x));
+#endif
+    }
+#endif
     uint2 rec_c = qh[max(cq - 1 - lane, 0)];
     uint2 rec_n = qh[max(cq - 1 - (lane + Q), 0)];
     const float T_final = inside ? im.final_T[pix] : 0.f;
