@@ -917,7 +917,7 @@ def rasterize(a, gsr, td, rank, world, dev):
                     return n
             return None
         try:
-            quoted["traffic"], quoted["valu_mix"] = newest(["r05_traffic.json", "r04_traffic.json"]), newest(["r05_valu_mix.json", "r03_valu_mix.json"])
+            quoted["traffic"], quoted["valu_mix"] = newest(["r06_traffic.json", "r05_traffic.json", "r04_traffic.json"]), newest(["r06_valu_mix.json", "r05_valu_mix.json", "r03_valu_mix.json"])
             tj = json.load(open(os.path.join(ROOT, "profiles", quoted["traffic"])))
             mix = json.load(open(os.path.join(ROOT, "profiles", quoted["valu_mix"])))["kernels"]
             if P == 1_000_000 and a.camera == "replica" and a.scale_mult == 1.0:

@@ -114,8 +114,14 @@ with open(os.path.join(dst, tag + "_pmc.md"), "w") as o:
             cyc = a_.get("GRBM_GUI_ACTIVE", float("nan")) / 8
             wc = a_["SQ_WAVE_CYCLES"] * 4
             pus = pass_us.get(k, us)
-            o.write("| %s | %.1f (%.1f in the counter pass) | %.2f | %.2f | %.2f | %.1f | %.0f %% / %.0f %% / %.0f %% | %.2f |\n" % (
-                k, us, pus, cyc / pus / 1e3, wc / cyc / 1024 if cyc == cyc else float("nan"),
+            # GRBM_GUI_ACTIVE spans the dispatch and the drain of a launch as well: for a kernel of a few tens of microseconds it is 1.2-1.8 x the kernel's own
+            # cycles (K_bin_colscan: 17 us of "GUI active" around a 9.9 us kernel) — as a clock that reads 2.8-4.2 GHz on a 2.4 GHz part. The cycles a kernel
+            # can have had are capped at its duration x 2.4 GHz; the clock column says which kernels the cap applied to.
+            capped = cyc > pus * 2400.0
+            cyc = min(cyc, pus * 2400.0)
+            o.write("| %s | %.1f (%.1f in the counter pass) | %s | %.2f | %.2f | %.1f | %.0f %% / %.0f %% / %.0f %% | %.2f |\n" % (
+                k, us, pus, ("2.40 (cap: GUI_ACTIVE window %.1fx the kernel)" % (a_.get("GRBM_GUI_ACTIVE", 0) / 8 / (pus * 2400.0))) if capped else "%.2f" % (cyc / pus / 1e3),
+                wc / cyc / 1024 if cyc == cyc else float("nan"),
                 a_["SQ_INSTS_VALU"] / us / 1e3, wc / max(a_["SQ_INSTS_VALU"], 1),
                 100 * a_.get("SQ_ACTIVE_INST_ANY", float("nan")) / a_["SQ_WAVE_CYCLES"], 100 * a_["SQ_WAIT_INST_ANY"] / a_["SQ_WAVE_CYCLES"],
                 100 * a_["SQ_WAIT_ANY"] / a_["SQ_WAVE_CYCLES"],
@@ -143,9 +149,9 @@ with open(os.path.join(dst, tag + "_pmc.md"), "w") as o:
             if avg[k].get("SQ_BUSY_CU_CYCLES") and avg[k].get("SQ_LDS_IDX_ACTIVE"):
                 tj["kernels"][k]["lds_pipe_busy"] = avg[k]["SQ_LDS_IDX_ACTIVE"] / avg[k]["SQ_BUSY_CU_CYCLES"]
             if avg[k].get("GRBM_GUI_ACTIVE"):
-                tj["kernels"][k]["clock_ghz"] = avg[k]["GRBM_GUI_ACTIVE"] / 8 / pass_us.get(k, stats_avg[k]) / 1e3
+                tj["kernels"][k]["clock_ghz"] = min(2.4, avg[k]["GRBM_GUI_ACTIVE"] / 8 / pass_us.get(k, stats_avg[k]) / 1e3)
             if avg[k].get("SQ_WAVE_CYCLES") and avg[k].get("GRBM_GUI_ACTIVE"):
-                tj["kernels"][k]["waves_per_simd"] = avg[k]["SQ_WAVE_CYCLES"] * 4 / (avg[k]["GRBM_GUI_ACTIVE"] / 8) / 1024
+                tj["kernels"][k]["waves_per_simd"] = avg[k]["SQ_WAVE_CYCLES"] * 4 / min(avg[k]["GRBM_GUI_ACTIVE"] / 8, pass_us.get(k, stats_avg[k]) * 2400.0) / 1024
     json.dump(tj, open(os.path.join(dst, tag[:3] + "_traffic.json"), "w"), indent=1)
 
 # ---- per-kernel roofline table: algorithmic bytes (SURVEY.md 8d per stage, DESIGN.md section 4's table) / rocprof average / fraction of 8 TB/s / counter traffic
