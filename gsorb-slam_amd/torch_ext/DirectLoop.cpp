@@ -569,9 +569,10 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
                             f(d.reg_partial), shard_ ? f(d.reg_tot) : cfg_.fused_loss ? nullptr : f(d.reg_out), st), "gsr_map_prepare");
     direct_forward_(in_projection, in_projection, limit);
     // (sharded: the cell's three regulariser sums go into the all-reduce behind the composite's planes — the finish of the rows the projection kernel wrote)
-    if (in_projection && shard_)
-        chk(gsr_map_prepare(n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, limit, wl, wsc, f(d.reg_partial), f(d.reg_tot), st), "gsr_map_prepare (finish)");
+    // (band exchange: nobody all-reduces them — the band's finish kernel adds the rows up itself, like the unsharded loop's: one single-workgroup launch less)
     const bool band = band_();
+    if (in_projection && shard_ && !band)
+        chk(gsr_map_prepare(n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, limit, wl, wsc, f(d.reg_partial), f(d.reg_tot), st), "gsr_map_prepare (finish)");
     if (band) { band_forward_(d.order_stale, false); d.order_stale = false; }
     else if (shard_) { shard_composite_forward_(d.order_stale, true); d.order_stale = false; }
     // Render.cc:436-471: lam * L1 + (1 - lam) * (1 - SSIM), masked depth L1, masked surface-depth L1 (no gradient), the regularisers
@@ -586,7 +587,9 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
         // overflowed) go out with the gradient's exchange; the gradient planes need one total only — the frame's count of valid depth pixels, a constant of the frame
         float* const row = f(d.rows_all) + (size_t)d.rank * 16;
         chk(gsr_map_loss_forward_rows(img, dep, sur, sil, f(fr.rgb), f(fr.depth), H_, W_, taps_host_.data(), 0.99f, f(d.partial6), f(d.dmaps), d.b0, d.b1, st), "gsr_map_loss_forward_rows");
-        chk(gsr_map_loss_finish_rows(f(d.partial6), f(d.reg_tot), 1, H_, W_, w3, c_ssim, wl, wsc, b(d.geom), row, row + 8, row + 12, d.b0, d.b1, st), "gsr_map_loss_finish_rows");
+        // (an empty cell has no rows: its regulariser sums are the zeros d.reg_tot holds)
+        chk(gsr_map_loss_finish_rows(f(d.partial6), n > 0 ? f(d.reg_partial) : f(d.reg_tot), n > 0 ? n : 1, H_, W_, w3, c_ssim, wl, wsc, b(d.geom), row, row + 8, row + 12, d.b0, d.b1, st),
+            "gsr_map_loss_finish_rows");
         chk(gsr_map_loss_backward_rows(img, dep, f(fr.rgb), f(fr.depth), f(d.dmaps), H_, W_, taps_host_.data(), w3, f(d.neg_c), f(d.frame_sums), f(d.g_image), f(d.g_ds), d.b0, d.b1, st),
             "gsr_map_loss_backward_rows");
         band_backward_(false);
