@@ -138,8 +138,11 @@ def _worker(rank, world, port, q, depth_cells=False):
         frames = _frames(hz, sc, OracleRasterizer, poses)
         # depth_cells: the cells are stacked along z — in front of each other for every keyframe (the order and the splats that straddle
         # a boundary in depth are what is tested); otherwise the k-d split picks the axes of largest extent (x here: cells side by side)
-        squash = torch.tensor([1e-3, 1e-3, 1.0]) if depth_cells else torch.ones(3)
-        part = sharded.KdPartition.build(torch.tensor(sc.means3D) * squash, world)
+        # (round 6: the product's own way to get them — KdPartition.view_weights of the keyframe poses: the split axes weighted by where the cameras look)
+        weights = sharded.KdPartition.view_weights(poses) if depth_cells else None
+        part = sharded.KdPartition.build(torch.tensor(sc.means3D), world, weights=weights)
+        if depth_cells:
+            assert set(part.nodes[:, 0].tolist()) == {2.0}, part.nodes
         owner = part.assign(torch.tensor(sc.means3D))
         idx = torch.nonzero(owner == rank).squeeze(-1).numpy()
         m = sharded.make_sharded_mapper(hz)(_fill(hz, sc, idx), W, H, partition=part, rasterizer_cls=OracleRasterizer)
