@@ -75,6 +75,9 @@ def test_struct_layout_matches_header(gsr):
     assert fields("gsr_forward_args") == [n for n, _ in gsr.capi.ForwardArgs._fields_]
     assert fields("gsr_backward_args") == [n for n, _ in gsr.capi.BackwardArgs._fields_]
     assert fields("gsr_debug_arrays") == [n for n, _ in gsr.capi.DebugArrays._fields_]
+    # (ABI 9 appended one field to each of these)
+    assert fields("gsr_pose_update_args") == [n for n, _ in gsr.capi.PoseUpdateArgs._fields_]
+    assert fields("gsr_pose_step_args") == [n for n, _ in gsr.capi.PoseStepArgs._fields_]
 
 
 def test_no_cpu_fallback_when_library_is_missing(gsr, monkeypatch):
