@@ -391,11 +391,12 @@ def _run_band(backend, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 7])
 def test_band_exchange_equals_the_replicated_composite_gloo(world):
     """LoopConfig::band_exchange (round 6: every rank composites, evaluates the loss and differentiates the composite on its band of pixel rows only, two grouped
     point-to-point exchanges per mapping iteration) against round 5's replicated composite (all-gather, all-reduce, all-gather; every rank the whole frame), same cells,
-    same frames: 2 and 4 processes on the test box's one GPU over gloo (the exchange staged through alltoall_base)."""
+    same frames: 2, 4 and 7 processes on the test box's one GPU over gloo (the exchange staged through alltoall_base; seven ranks cut the 240 rows into bands of
+    35 and a last one of 30: messages of unequal sizes between the pairs)."""
     _run_band("gloo", world)
 
 
