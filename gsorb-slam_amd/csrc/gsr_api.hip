@@ -421,7 +421,11 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
         // nobody consumes the colour sums (this call also runs the per-splat stage, which is handed no colour / SH output, and the fused depth
         // channel's colour is a constant): the fused pair's kernel without them (a tracking iteration)
         // (the fused map update steps the colours from those sums although it is handed no dL_dcolor buffer: ADVICE r4)
-        const bool no_colour = (stages & GSR_STAGE_SPLAT) && !a->dL_dcolor && !a->dL_dsh && a->dL_dds && a->ds_detach_depth && !a->fused_map_update;
+        const bool colour_unused = (stages & GSR_STAGE_SPLAT) && !a->dL_dcolor && !a->dL_dsh && !a->fused_map_update;
+        const bool no_colour = colour_unused && a->dL_dds && a->ds_detach_depth;
+        // (round 6) the plain render without the colour sums: a tracking iteration whose depth term is the surface (median) depth passes no gradient through the
+        // fused channels at all (dL_dds = NULL) — the lean body without DUAL's depth recursion: four waves per SIMD
+        const bool no_colour_plain = colour_unused && !a->dL_dds;
 #define GSR_BWD_DUAL(COL, SIL) GSR_LAUNCH((gsr::K_blend_bwd<GSR_ROWQ, true, COL, SIL>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, \
                                                   W, H, f.grid_x, Tb, f.band_y0 * f.grid_x, a->dL_dpix, a->dL_dds)
         if (no_colour && a->dds_depth_only) GSR_BWD_DUAL(false, false);
@@ -429,6 +433,9 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
         else if (a->dL_dds && a->dds_depth_only) GSR_BWD_DUAL(true, false);
         else if (a->dL_dds) GSR_BWD_DUAL(true, true);
 #undef GSR_BWD_DUAL
+        else if (no_colour_plain)
+            GSR_LAUNCH((gsr::K_blend_bwd<GSR_ROWQ, false, false, false>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, W, H, f.grid_x, Tb,
+                       f.band_y0 * f.grid_x, a->dL_dpix, (const float*)nullptr);
         else
             GSR_LAUNCH((gsr::K_blend_bwd<GSR_ROWQ, false>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, W, H, f.grid_x, Tb,
                                f.band_y0 * f.grid_x, a->dL_dpix, (const float*)nullptr);

@@ -969,7 +969,7 @@ __attribute__((amdgpu_waves_per_eu(GSR_BWD_WAVES, GSR_BWD_WAVES))) __global__ vo
 K_blend_bwd(ImageView im, char* __restrict__ binning, GeomView g, const float* __restrict__ bg, int W, int H,
                  int grid_x, int ntiles, int tile0, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dds)
 {
-    if constexpr (DUAL || GSR_BWD_LEAN_ALWAYS) blend_bwd_lean<Q, DUAL, COLORS, SIL>(im, binning, g, bg, W, H, grid_x, ntiles, tile0, dL_dpix, dL_dds);
+    if constexpr (DUAL || !COLORS || GSR_BWD_LEAN_ALWAYS) blend_bwd_lean<Q, DUAL, COLORS, SIL>(im, binning, g, bg, W, H, grid_x, ntiles, tile0, dL_dpix, dL_dds);
     else blend_bwd_rgb<Q>(im, binning, g, bg, W, H, grid_x, ntiles, tile0, dL_dpix);
 }
 

@@ -531,6 +531,11 @@ void SlamLoop::direct_backward_(bool detach_depth_colour, bool means_only, const
     a.dds_depth_only = 1; // (the silhouette is a detached mask in both losses: plane 1 of g_ds would be zeros)
     if (shard_) { // the own layer's gradient comes from the compositor, and the own silhouette has one: what the layer occludes
         a.dL_dpix = f(d.D); a.dL_dds = f(d.D) + (size_t)3 * H_ * W_; a.dds_depth_only = 0;
+    } else if (means_only && cfg_.use_sur_depth) {
+        // (round 6) a tracking iteration on the surface (median) depth: the loss has no gradient through the blended depth and the silhouette is a detached mask —
+        // nothing arrives through the fused channels (gsr_track_loss wrote zeros): the backward blend runs its plain form without DUAL's depth recursion and without
+        // the colour sums (118 registers, four waves per SIMD)
+        a.dL_dds = nullptr; a.dds_depth_only = 0;
     }
     a.fused_map_update = fused; // (the per-splat stage then takes the Adam step itself and writes no gradient)
     a.fused_pose_step = pose_step; // (tracking: the per-splat stage forms the pose sums and its last workgroup takes the pose step: no gradient tensor)

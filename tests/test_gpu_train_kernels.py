@@ -613,6 +613,30 @@ def test_fused_mapping_loss_equals_its_separate_kernels(gsr, hz, shape):
     assert (gd - depth.grad).abs().max() <= 2e-6 * float(depth.grad.abs().max())
 
 
+def test_backward_without_colour_outputs_takes_the_lean_plain_kernel(gsr):
+    """gsr_backward on a plain render with no colour / SH gradient buffer and no fused channels (round 6: an unsharded tracking iteration on the surface depth) runs the
+    backward blend WITHOUT the colour sums (K_blend_bwd<64, false, false, false>: the lean body at four waves per SIMD). Every other gradient must equal the full call's
+    (to the order of the float atomics), and the accumulators are left clean."""
+    syn = gsr.synthetic
+    cam = syn.make_camera(320, 240, 260.0, 258.0, bg=(0.2, 0.1, 0.3))
+    sc = syn.make_scene(30000, cam, seed=8, scale_mult=2.0)
+    s = gsr.capi.Settings.from_camera(cam)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    g = t(sc.dL_dpix)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    full = gsr.backward(st, g)
+    lean = gsr.capi.alloc_grads(sc.P, 0, "cuda", intermediates=False)
+    lean.dL_dcolors = None
+    lean.dL_dsh = None
+    out = gsr.backward(st, g, grads=lean)
+    assert float(gsr.capi.acc_view(st).abs().max()) == 0.0
+    for n in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dscales", "dL_drotations"):
+        a, b = getattr(out, n), getattr(full, n)
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), n
+    again = gsr.backward(st, g)                                       # the state is reusable: a full backward afterwards gives the full gradients
+    assert float((again.dL_dcolors - full.dL_dcolors).abs().max()) <= 2e-6 * float(full.dL_dcolors.abs().max())
+
+
 @pytest.mark.parametrize("M", [1, 37, 700])
 def test_reprojection_term_adds_its_pose_sums_and_its_value(gsr, hz, M):
     """gsr_reproj_loss (the ORB matches' term of the tracking loss, src/Render.cc:1031-1096) against float64 autograd through the reference's
