@@ -437,7 +437,7 @@ def backward(st: ForwardState, dL_dpix, grads: Grads | None = None, events=None,
                      _p(out.dL_dscales) if has_sr else None, _p(out.dL_drotations) if has_sr else None, events,
                      int(st.band[0]), int(st.band[1]), int(stages), _p(gds), int(bool(detach_depth_color)),
                      C.c_void_p(C.addressof(fused_map_update)) if fused_map_update is not None else None,   # (a MapUpdateArgs: map_update_args())
-                     int(bool(dds_depth_only)),
+                     int(dds_depth_only),                                                                     # (False / True / 2: include/gsr.h)
                      C.c_void_p(C.addressof(fused_pose_step)) if fused_pose_step is not None else None)       # (a PoseStepArgs)
     if stages & 4:
         st.dirty = not (stages & 8)

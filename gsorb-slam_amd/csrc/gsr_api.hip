@@ -375,6 +375,10 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
     // The fused steps are validated BEFORE anything is launched: an EINVAL must leave the accumulators as the forward left them (a retried
     // backward would otherwise count the blend stage twice).
     if (a->fused_map_update && a->fused_pose_step) return GSR_EINVAL; // one or the other (include/gsr.h)
+    // dds_depth_only == 2 (dL_dds = the silhouette's plane alone) exists only in the form without colour sums and with the depth channel's colour detached
+    if (a->dL_dds && a->dds_depth_only == 2 &&
+        (a->dL_dcolor || a->dL_dsh || a->fused_map_update || !a->ds_detach_depth || !((a->stages ? a->stages : GSR_STAGE_SPLAT) & GSR_STAGE_SPLAT))) return GSR_EINVAL;
+    if (a->dds_depth_only < 0 || a->dds_depth_only > 2) return GSR_EINVAL;
     gsr::MapUpdate mu{};
     gsr::PoseUpdate pu{};
     if (a->fused_map_update) {
@@ -422,13 +426,17 @@ int gsr_backward(const gsr_backward_args* a, void* stream)
         // channel's colour is a constant): the fused pair's kernel without them (a tracking iteration)
         // (the fused map update steps the colours from those sums although it is handed no dL_dcolor buffer: ADVICE r4)
         const bool colour_unused = (stages & GSR_STAGE_SPLAT) && !a->dL_dcolor && !a->dL_dsh && !a->fused_map_update;
-        const bool no_colour = colour_unused && a->dL_dds && a->ds_detach_depth;
+        const bool sil_only = a->dL_dds && a->dds_depth_only == 2; // dL_dds = ONE plane, the silhouette's upstream gradient (the depth channel's is zero)
+        const bool no_colour = colour_unused && a->dL_dds && a->ds_detach_depth && !sil_only;
         // (round 6) the plain render without the colour sums: a tracking iteration whose depth term is the surface (median) depth passes no gradient through the
         // fused channels at all (dL_dds = NULL) — the lean body without DUAL's depth recursion: four waves per SIMD
         const bool no_colour_plain = colour_unused && !a->dL_dds;
 #define GSR_BWD_DUAL(COL, SIL) GSR_LAUNCH((gsr::K_blend_bwd<GSR_ROWQ, true, COL, SIL>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, \
                                                   W, H, f.grid_x, Tb, f.band_y0 * f.grid_x, a->dL_dpix, a->dL_dds)
-        if (no_colour && a->dds_depth_only) GSR_BWD_DUAL(false, false);
+        if (sil_only)
+            GSR_LAUNCH((gsr::K_blend_bwd<GSR_ROWQ, false, false, true>), dim3(4 * Tb), dim3(64), 0, st, iv, a->binning_buffer, gv, a->background, W, H, f.grid_x, Tb,
+                       f.band_y0 * f.grid_x, a->dL_dpix, a->dL_dds);
+        else if (no_colour && a->dds_depth_only) GSR_BWD_DUAL(false, false);
         else if (no_colour) GSR_BWD_DUAL(false, true);
         else if (a->dL_dds && a->dds_depth_only) GSR_BWD_DUAL(true, false);
         else if (a->dL_dds) GSR_BWD_DUAL(true, true);

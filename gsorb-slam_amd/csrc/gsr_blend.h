@@ -619,7 +619,8 @@ __device__ __forceinline__ void blend_bwd_lean(ImageView im, char* __restrict__ 
     const uint32_t last = inside ? im.n_contrib[pix] : 0u;
     const float g0 = inside ? dL_dpix[pix] : 0.f, g1 = inside ? dL_dpix[HW + pix] : 0.f,
                 g2 = inside ? dL_dpix[2 * HW + pix] : 0.f;
-    const float g3 = DUAL && inside ? dL_dds[pix] : 0.f, g4 = DUAL && SIL && inside ? dL_dds[HW + pix] : 0.f; // (their background is 0)
+    // (their background is 0; without DUAL but with SIL, dL_dds IS the silhouette's plane: a sharded tracking iteration on the surface depth, round 6)
+    const float g3 = DUAL && inside ? dL_dds[pix] : 0.f, g4 = SIL && inside ? dL_dds[DUAL ? HW + pix : pix] : 0.f;
     const float bg_dot = bg[0] * g0 + bg[1] * g1 + bg[2] * g2;
     // The silhouette channel (colour 1 on every splat) needs no recursion of its own: what it accumulates is 1 - T_final, so its share of
     // dL/dalpha_i, g4 T_i (1 - accum_rec_i) = g4 T_final / (1 - alpha_i), has the background term's form with colour -1 and rides in its factor.

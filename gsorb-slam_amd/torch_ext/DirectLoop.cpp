@@ -35,6 +35,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -531,7 +532,9 @@ void SlamLoop::direct_backward_(bool detach_depth_colour, bool means_only, const
     a.dds_depth_only = 1; // (the silhouette is a detached mask in both losses: plane 1 of g_ds would be zeros)
     if (shard_) { // the own layer's gradient comes from the compositor, and the own silhouette has one: what the layer occludes
         a.dL_dpix = f(d.D); a.dL_dds = f(d.D) + (size_t)3 * H_ * W_; a.dds_depth_only = 0;
-    } else if (means_only && cfg_.use_sur_depth) {
+        // (round 6) tracking on the surface depth: the composite's depth plane carries no gradient, so the layer's is zero too — only the silhouette's plane goes in
+        if (means_only && cfg_.use_sur_depth && pose_step && !std::getenv("GSR_EXP_TRACK_DUAL_BWD")) { a.dL_dds = f(d.D) + (size_t)4 * H_ * W_; a.dds_depth_only = 2; }
+    } else if (means_only && cfg_.use_sur_depth && !std::getenv("GSR_EXP_TRACK_DUAL_BWD")) { // (A/B hook: the fused pair's no-colour kernel, as in round 5)
         // (round 6) a tracking iteration on the surface (median) depth: the loss has no gradient through the blended depth and the silhouette is a detached mask —
         // nothing arrives through the fused channels (gsr_track_loss wrote zeros): the backward blend runs its plain form without DUAL's depth recursion and without
         // the colour sums (118 registers, four waves per SIMD)

@@ -202,8 +202,11 @@ typedef struct gsr_backward_args {
      * Needs scales + rotations, no SH, and a call that runs the per-splat stage. 112 bytes of traffic per Gaussian and one launch less
      * than gsr_backward followed by gsr_map_update. */
     const struct gsr_map_update_args* fused_map_update;
-    /* non-zero: dL_dds holds ONE plane [1,H,W], the depth channel's upstream gradient; the silhouette's is zero (GSORB-SLAM's losses use the
-     * silhouette only as a detached mask, src/Render.cc:436-471, :1088-1090): its recursion leaves the blend kernel's loop */
+    /* 1: dL_dds holds ONE plane [1,H,W], the depth channel's upstream gradient; the silhouette's is zero (GSORB-SLAM's losses use the
+     * silhouette only as a detached mask, src/Render.cc:436-471, :1088-1090): its recursion leaves the blend kernel's loop.
+     * 2 (round 6): dL_dds holds ONE plane, the SILHOUETTE's upstream gradient; the depth channel's is zero — a sharded tracking iteration on the surface depth,
+     * whose layer receives only what it occludes. Only without colour outputs (dL_dcolor = dL_dsh = NULL), with ds_detach_depth, and in a call that runs the
+     * per-splat stage (GSR_EINVAL otherwise): the blend kernel then drops the depth channel's recursion and the colour sums. */
     int dds_depth_only;
     /* Optional (NULL: off; not together with fused_map_update). A tracking iteration's backward (the pose is the only parameter; means3D = gsr_to_camera's
      * means_cam with an identity view matrix): the per-splat stage also forms the pose sums of dL/dmeans_cam against the world-frame means (gsr_pose_grad)

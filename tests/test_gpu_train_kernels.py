@@ -637,6 +637,33 @@ def test_backward_without_colour_outputs_takes_the_lean_plain_kernel(gsr):
     assert float((again.dL_dcolors - full.dL_dcolors).abs().max()) <= 2e-6 * float(full.dL_dcolors.abs().max())
 
 
+def test_silhouette_only_backward_equals_the_fused_pair_with_a_zero_depth_gradient(gsr):
+    """gsr_backward_args.dds_depth_only = 2 (round 6: a sharded tracking iteration on the surface depth — the layer receives a colour gradient and what it occludes,
+    nothing through the blended depth): the plain no-colour kernel with the silhouette's plane folded into the background factor must give what the fused pair's
+    no-colour kernel gives for dL_dds = [0, g_sil]; the combination with colour outputs is refused before anything is launched."""
+    syn = gsr.synthetic
+    cam = syn.make_camera(320, 240, 260.0, 258.0, bg=(0.0, 0.0, 0.0))
+    sc = syn.make_scene(30000, cam, seed=9, scale_mult=2.0)
+    s = gsr.capi.Settings.from_camera(cam)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    g = t(sc.dL_dpix)
+    gs = torch.randn((1, cam.height, cam.width), generator=torch.Generator().manual_seed(4)).cuda()
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations, dual=True)
+    def nocol():
+        gr = gsr.capi.alloc_grads(sc.P, 0, "cuda", intermediates=False)
+        gr.dL_dcolors = None; gr.dL_dsh = None
+        return gr
+    ref = gsr.backward(st, g, grads=nocol(), dL_dds=torch.cat([torch.zeros_like(gs), gs]).contiguous(), detach_depth_color=True)
+    out = gsr.backward(st, g, grads=nocol(), dL_dds=gs.contiguous(), detach_depth_color=True, dds_depth_only=2)
+    for n in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dscales", "dL_drotations"):
+        a, b = getattr(out, n), getattr(ref, n)
+        assert float((a - b).abs().max()) <= 3e-6 * float(b.abs().max()), n
+    assert float(gsr.capi.acc_view(st).abs().max()) == 0.0
+    with pytest.raises(gsr.capi.GsrError):                            # colour outputs asked for: the silhouette-only form does not exist
+        gsr.backward(st, g, dL_dds=gs.contiguous(), detach_depth_color=True, dds_depth_only=2)
+    assert float(gsr.capi.acc_view(st).abs().max()) == 0.0            # (refused before the first launch: the accumulators are as the forward left them)
+
+
 @pytest.mark.parametrize("M", [1, 37, 700])
 def test_reprojection_term_adds_its_pose_sums_and_its_value(gsr, hz, M):
     """gsr_reproj_loss (the ORB matches' term of the tracking loss, src/Render.cc:1031-1096) against float64 autograd through the reference's
