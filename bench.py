@@ -10,16 +10,19 @@ synthetic scene whose inputs are already resident in HBM, through the C ABI
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1, headline line: STRONG scaling of the rasterize path with its exchange (shard_render): the same --splats scene
-split into depth slabs over the ranks, every rank renders its slab, the layers are composited and the pose gradient
-all-reduced inside the timed region. The collective-free replica figure (every rank its own scene) is kept as
-`replica_rasterize`.
+cut into k-d cells over the ranks, every rank renders its cell, the layers travel by pixel-row band (the band exchange,
+DESIGN.md section 7), the composite's gradient is taken back to every rank's layer and the pose gradient all-reduced inside
+the timed region. The collective-free replica figure (every rank its own scene) is kept as `replica_rasterize`.
 
 `shard_step` (same JSON line, --mode all | shard-step): the step that DOES exchange data — one sharded mapping
 iteration and one sharded tracking iteration of the C++ loop (torch_ext/DirectLoop.cpp: ORB_SLAM2::SlamLoop with SetShard;
 src/Render.cc:420-483, :1054-1126 with the map cut into k-d cells over the ranks; BASELINE.json config 4: --splats Gaussians in
-TOTAL, strong scaling). Its timed region contains the fused rasterizer pair of the rank's cell forwards and backwards, the layer
-compositing (all-gather of 2 floats/pixel/rank, all-reduce of 4 channels, backward all-gather of 1), the fused losses, the
-regulariser / pose-row all-reduce and the Adam step, over RCCL ("nccl"; a one-rank RCCL group when N = 1).
+TOTAL, strong scaling). Its timed region contains the fused rasterizer pair of the rank's cell forwards and backwards, the two
+grouped point-to-point exchanges of the band exchange around the band's compositor and loss kernels, tracking's all-reduce of
+the pose rows and the Adam / pose step, over RCCL ("nccl"; a one-rank RCCL group when N = 1).
+
+`other_workloads`: the other frame shapes of BASELINE.json's configs, each with its kernels one by one and a roofline block —
+among them what ONE RANK of configs 4 and 5 runs (`rank-250k-*`: a k-d cell of the map over the whole frame).
 
 The JSON line also carries
   roofline     : the dominant kernel (backward blend) against the HBM roofline, timed live
