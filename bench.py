@@ -381,7 +381,8 @@ def cpp_loop_ms(a, gsr, dev, P=1_000_000, track_iters=20, map_iters=20):
                     "sequences of C-ABI launches on a persistent workspace (torch_ext/DirectLoop.cpp: fused pair, fused loss / SSIM kernels, "
                     "gsr_map_prepare / gsr_map_update / gsr_pose_update). mapping = SlamLoop::MapFrame (Render::RenderForFrame's loop: the losses "
                     "are read back once, after the last iteration, like the reference's loop, which never looks at one); mapping_per_iteration_readback "
-                    "= MappingIteration in a loop (one loss read-back and synchronisation per iteration); tracking reads its loss every iteration "
+                    "= MappingIteration in a loop (the caller looks at every loss: posted by the finish kernel into host-mapped memory, like tracking's — round 5 read it back "
+                    "behind a stream synchronisation: 0.66 ms); tracking reads its loss every iteration "
                     "(Render.cc:1107); raster_pair = fwd+bwd of the fused colour + depth/silhouette pass alone",
             "mapping": o.get("mapframe_ms_per_iter", o["map_ms_per_iter"])[0], "mapping_per_iteration_readback": o["map_ms_per_iter"][0],
             "tracking": o["track_ms_per_iter"][0], "raster_pair": pair["ms_per_step"],

@@ -660,6 +660,19 @@ std::vector<double> SlamLoop::MapFrame(const LoopFrame& fr, int iters)
     else if (d.fresh) shard_preflight_(); // (unsharded too — ADVICE r4: inside a batch nobody looks; an iteration that overflowed is still retaken below,
                                           // but the iterations behind it ran with Adam step numbers one too high: size the workspace BEFORE the batch instead)
     d.fresh = false;
+    // ONE iteration per call (MappingIteration in a caller's own loop): the loss is POSTED into host-mapped memory by the finish kernel — in the middle of the
+    // iteration, before the backward — and the host spins on the word (the tracking loop's mechanism): no copy kernel, no stream synchronisation, the next call's
+    // launches queue up behind this one's backward. Only a NaN (an overflowed forward posts one) takes the blocking look at the workspace. (round 6)
+    if (iters == 1 && !shard_) {
+        for (int attempt = 0; attempt < 4; attempt++) {
+            __atomic_store_n(reinterpret_cast<uint32_t*>(d.posted), kNotPosted, __ATOMIC_RELEASE);
+            direct_map_iteration_(frame, d.posted_dev);
+            const double v = wait_posted(d.posted, (hipStream_t)stream_());
+            if (!std::isnan(v) || !direct_overflowed_()) { losses.push_back(v); return losses; }
+            for (int g = 0; g < 5; g++) fopt_->retract_step(g); // the step was skipped on the device: taken again on the grown workspace
+        }
+        throw std::runtime_error("direct loop: the binning workspace keeps overflowing");
+    }
     int done = 0;
     while (done < iters) {
         const int batch = iters - done;
