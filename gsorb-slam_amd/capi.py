@@ -23,7 +23,7 @@ EXPORTS = ["gsr_forward", "gsr_forward_ws", "gsr_ws_status", "gsr_backward", "gs
            "gsr_map_prepare", "gsr_map_update", "gsr_map_loss_total", "gsr_map_loss_forward", "gsr_map_loss_finish", "gsr_map_loss_backward", "gsr_pose_update", "gsr_pose_step", "gsr_pose_finish", "gsr_composite_forward", "gsr_composite_backward_local",
            "gsr_composite_backward_occlusion", "gsr_shard_order", "gsr_reproj_loss", "gsr_error_string", "gsr_last_hip_error", "gsr_abi_version",
            "gsr_debug_launch_count", "gsr_band_composite_forward", "gsr_band_composite_backward", "gsr_shard_map_totals", "gsr_map_loss_partials_rows",
-           "gsr_map_loss_forward_rows", "gsr_map_loss_finish_rows", "gsr_map_loss_backward_rows", "gsr_track_loss_rows"]
+           "gsr_map_loss_forward_rows", "gsr_map_loss_finish_rows", "gsr_map_loss_backward_rows", "gsr_track_loss_rows", "gsr_transmittance_view"]
 
 
 def library_path() -> str:
@@ -210,7 +210,9 @@ def lib():
     L.gsr_map_loss_backward_rows.restype = C.c_int
     L.gsr_map_loss_backward_rows.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]
     L.gsr_track_loss_rows.restype = C.c_int
-    L.gsr_track_loss_rows.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float)] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_void_p]
+    L.gsr_track_loss_rows.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_float, C.POINTER(C.c_float)] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.gsr_transmittance_view.restype = C.c_int
+    L.gsr_transmittance_view.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.gsr_error_string.restype = C.c_char_p
     L.gsr_error_string.argtypes = [C.c_int]
     L.gsr_last_hip_error.restype = C.c_char_p
@@ -872,3 +874,13 @@ def acc_view(st: ForwardState) -> torch.Tensor:
     _check(lib().gsr_acc_view(_p(st.geom), st.P, C.byref(ptr), C.byref(n)))
     off = ptr.value - st.geom.data_ptr()
     return st.geom[off:off + n.value * 4].view(torch.float32)
+
+
+def transmittance_view(st: ForwardState) -> torch.Tensor:
+    """The final transmittance [H,W] the forward left in its image blob (forward.cu's final_T; include/gsr.h:
+    gsr_transmittance_view): 1 - T is the silhouette the plain forward does not render."""
+    ptr = C.c_void_p()
+    H, W = st.settings.image_height, st.settings.image_width
+    _check(lib().gsr_transmittance_view(_p(st.image), W, H, C.byref(ptr)))
+    off = ptr.value - st.image.data_ptr()
+    return st.image[off:off + H * W * 4].view(torch.float32).view(H, W)

@@ -516,6 +516,15 @@ int gsr_acc_view(char* geom, int P, float** acc, size_t* count)
     return GSR_OK;
 }
 
+int gsr_transmittance_view(char* image, int width, int height, float** final_T)
+{
+    if (!image || width <= 0 || height <= 0 || !final_T) return GSR_EINVAL;
+    ImageView iv;
+    image_layout(image, width, height, &iv);
+    *final_T = iv.final_T;
+    return GSR_OK;
+}
+
 size_t gsr_knn_bytes(int P) { return gsr::knn_layout(nullptr, P, nullptr); }
 
 int gsr_dist2(int P, const float* points, float* mean_dists, char* workspace, size_t workspace_bytes, void* stream)
@@ -660,12 +669,12 @@ int gsr_track_loss(const float* image, const float* depth, const float* sur, con
                    int H, int W, float sil_thr, const float* w3, float* partial, float* sums, float* dL_dimage, float* dL_ddepth, uint32_t* ticket,
                    void* stream)
 {
-    return gsr_track_loss_rows(image, depth, sur, sil, frame_rgb, frame_depth, H, W, sil_thr, w3, partial, sums, dL_dimage, dL_ddepth, ticket, 0, H, stream);
+    return gsr_track_loss_rows(image, depth, sur, sil, frame_rgb, frame_depth, H, W, sil_thr, w3, partial, sums, dL_dimage, dL_ddepth, ticket, 0, H, 0, stream);
 }
 
 int gsr_track_loss_rows(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb, const float* frame_depth,
                         int H, int W, float sil_thr, const float* w3, float* partial, float* sums, float* dL_dimage, float* dL_ddepth, uint32_t* ticket,
-                        int row_begin, int row_end, void* stream)
+                        int row_begin, int row_end, int sil_is_transmittance, void* stream)
 {
     if (!image || !frame_rgb || !frame_depth || !w3 || !partial || !sums || !dL_dimage || H <= 0 || W <= 0 || (!depth && !sur)) return GSR_EINVAL;
     if (row_begin < 0 || row_end > H || row_begin >= row_end) return GSR_EINVAL;
@@ -675,7 +684,7 @@ int gsr_track_loss_rows(const float* image, const float* depth, const float* sur
     const int nb = (int)std::min<size_t>(GSR_LOSS_BLOCKS, (i1 - i0 + 255) / 256);
     static_assert(GSR_FINISH_THREADS == 256, "the last workgroup of K_track_loss runs the finish");
     static_assert(GSR_TICKET_WORDS == GSR_TICKET_WORDS_DEV, "header and kernels agree on the arrival counters");
-    GSR_LAUNCH(gsr::K_track_loss, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, N, sil_thr, w, partial, dL_dimage, dL_ddepth, ticket, depth ? 0 : 1, sums, i0, i1);
+    GSR_LAUNCH(gsr::K_track_loss, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, N, sil_thr, w, partial, dL_dimage, dL_ddepth, ticket, depth ? 0 : 1, sums, i0, i1, sil_is_transmittance ? 1 : 0);
     GSR_LAUNCHED();
     if (!ticket) {
         GSR_LAUNCH(gsr::K_loss_finish, dim3(1), dim3(GSR_FINISH_THREADS), 0, (hipStream_t)stream, partial, nb, 0, N, w, depth ? 0 : 1, sums);

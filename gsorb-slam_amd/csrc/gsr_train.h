@@ -712,8 +712,10 @@ K_loss_finish(const float* __restrict__ partial, int nblocks, int mode, size_t N
 // (one launch and 30 MB of reads less per iteration). Same expressions, same order of a thread's additions as the two kernels.
 __global__ void __launch_bounds__(256)
 K_track_loss(LossPlanes p, size_t N, float thr, LossWeights w, float* partial, float* __restrict__ dimage, float* __restrict__ ddepth,
-             uint32_t* ticket, int depth_from_sur, float* __restrict__ sums, size_t i_begin, size_t i_end)
+             uint32_t* ticket, int depth_from_sur, float* __restrict__ sums, size_t i_begin, size_t i_end, int sil_is_T)
 {
+    // (sil_is_T: the `sil` plane holds the render's final transmittance T — what the plain forward keeps per pixel anyway — and the silhouette is 1 - T:
+    // a tracking iteration on the surface depth needs nothing else of the fused pair's channels, round 6)
     // (N = H W is the planes' stride; the pixels [i_begin, i_end) are this launch's — the whole image, or one rank's band of rows in the sharded loop)
     __shared__ float ws[4][5];
     __shared__ uint32_t s_ticket;
@@ -723,7 +725,7 @@ K_track_loss(LossPlanes p, size_t N, float thr, LossWeights w, float* partial, f
         const float sl = p.sil ? p.sil[i] : 0.f;
         const float i0 = p.image[i], i1 = p.image[N + i], i2 = p.image[2 * N + i], f0 = p.frgb[i], f1 = p.frgb[N + i], f2 = p.frgb[2 * N + i];
         const float dp = p.depth ? p.depth[i] : 0.f, sr = p.sur ? p.sur[i] : 0.f;
-        const bool solid = !p.sil || sl > thr;
+        const bool solid = !p.sil || (sil_is_T ? 1.f - sl : sl) > thr;
         const bool in = solid && fd == fd; // the tracking mask: colour and depth terms alike
         if (in) {
             a[0] += (fabsf(i0 - f0) + fabsf(i1 - f1)) + fabsf(i2 - f2);

@@ -495,7 +495,7 @@ void SlamLoop::grow_binning_(size_t capacity)
 }
 
 // the fused colour + depth / silhouette pass on the workspace (sync-free), and its backward
-void SlamLoop::direct_forward_(bool from_world, bool raw, float reg_limit)
+void SlamLoop::direct_forward_(bool from_world, bool raw, float reg_limit, bool plain)
 {
     Direct& d = *d_;
     if (d.n == 0) { d.layers.zero_(); return; } // (an empty shard still takes part in the exchange: its layer is nothing)
@@ -512,7 +512,7 @@ void SlamLoop::direct_forward_(bool from_world, bool raw, float reg_limit)
     a.colors_precomp = f(rgb); a.opacities = raw ? f(logit_opacities) : f(d.opac); a.scales = raw ? f(log_scales) : f(d.scales); a.scale_modifier = s.scale_modifier;
     a.rotations = raw ? f(unnorm_quat) : f(d.rots); a.raw = raw ? &ro : nullptr; a.viewmatrix = f(d.view); a.projmatrix = f(d.proj); a.cam_pos = f(d.campos);
     a.tan_fovx = s.tanfovx; a.tan_fovy = s.tanfovy; a.prefiltered = 0;
-    a.out_color = f(d.out_color); a.out_depth = f(d.out_sur); a.radii = d.radii.data_ptr<int>(); a.out_ds = f(d.out_ds);
+    a.out_color = f(d.out_color); a.out_depth = f(d.out_sur); a.radii = d.radii.data_ptr<int>(); a.out_ds = plain ? nullptr : f(d.out_ds); // (plain: the three colour channels only — a tracking iteration on the surface depth)
     chk(gsr_forward_ws(&a, b(d.geom), b(d.binning), d.binning_bytes, b(d.image), stream_()), "gsr_forward_ws");
 }
 
@@ -741,6 +741,11 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
     // (a sharded run sums the ranks' pose rows: a term every rank holds in full enters each rank's row with weight 1 / world)
     // (the band exchange sums the ranks' loss words with the pose rows: the term's VALUE is added on rank 0 only, the other ranks add it to a word nobody reads)
     const bool band = band_();
+    // (round 6) unsharded, on the surface depth: the loss needs the colours, the median depth and a silhouette MASK — the plain forward renders the first two and
+    // keeps the final transmittance per pixel (1 - T is the silhouette): no fused depth / silhouette channels, neither forwards nor backwards
+    const bool plain_track = !shard_ && cfg_.use_sur_depth && !std::getenv("GSR_EXP_TRACK_DUAL_BWD");
+    float* final_T = nullptr;
+    if (plain_track) chk(gsr_transmittance_view(b(d.image), W_, H_, &final_T), "gsr_transmittance_view");
     float* const band_sums = f(d.pose_acc) + 64 * 12 + 8; // [8] this rank's tracking-loss sums: words 776..783 of the all-reduced block
     float* const loss_word = band ? (d.rank == 0 ? band_sums + 5 : f(d.frame_sums) + 7) : f(d.sums) + 5;
     auto reproj = [&](int it, float* row) {
@@ -753,14 +758,17 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
     double last_loss = 0.0;
     int step = 0;
     for (int it = 0; it < iters; it++) {
-        direct_forward_(true); // (the camera transform of Render.cc:750-752 rides in the projection kernel)
+        direct_forward_(true, false, 0.f, plain_track); // (the camera transform of Render.cc:750-752 rides in the projection kernel)
         if (band) band_forward_(true, true);
         else if (shard_) shard_composite_forward_(true, false);
         // Render.cc:1088-1105: the masked L1 sums and their gradient planes, one pass over the render (band exchange: over this rank's band of rows; its
         // sums are added up over the ranks by the pose rows' all-reduce)
         if (band)
             chk(gsr_track_loss_rows(img, dep, sur, sil, f(frame.rgb), f(frame.depth), H_, W_, 0.99f, w3, f(d.loss_partial), band_sums, f(d.g_image), f(d.g_ds),
-                                    reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()), d.b0, d.b1, st), "gsr_track_loss_rows");
+                                    reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()), d.b0, d.b1, 0, st), "gsr_track_loss_rows");
+        else if (plain_track)
+            chk(gsr_track_loss_rows(img, dep, sur, final_T, f(frame.rgb), f(frame.depth), H_, W_, 0.99f, w3, f(d.loss_partial), f(d.sums), f(d.g_image), f(d.g_ds),
+                                    reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()), 0, H_, 1, st), "gsr_track_loss_rows (transmittance)");
         else
             chk(gsr_track_loss(img, dep, sur, sil, f(frame.rgb), f(frame.depth), H_, W_, 0.99f, w3, f(d.loss_partial), f(d.sums), f(d.g_image), f(d.g_ds),
                                reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()), st), "gsr_track_loss");

@@ -478,7 +478,11 @@ int gsr_map_loss_backward_rows(const float* image, const float* depth, const flo
                                float* dL_ddepth, int row_begin, int row_end, void* stream);
 int gsr_track_loss_rows(const float* image, const float* depth, const float* sur, const float* sil, const float* frame_rgb, const float* frame_depth,
                         int H, int W, float sil_thr, const float* w3 /* host */, float* partial, float* sums, float* dL_dimage, float* dL_ddepth,
-                        uint32_t* ticket, int row_begin, int row_end, void* stream);
+                        uint32_t* ticket, int row_begin, int row_end,
+                        int sil_is_transmittance /* non-zero: `sil` holds the render's final transmittance T (gsr_transmittance_view), the silhouette is 1 - T */, void* stream);
+/* The per-pixel final transmittance [H,W] the last forward on `image` left in the image blob (forward.cu's accum_alpha / final_T): 1 - T is the silhouette the
+ * fused pair's second channel accumulates — a tracking iteration that needs nothing else of the pair renders the plain 3 channels and masks with this. */
+int gsr_transmittance_view(char* image, int width, int height, float** final_T);
 
 /* Front-to-back order of the cells of a k-d partition of the map (gsorb-slam_amd/sharded.py: KdPartition; one cell per rank) for the camera of
  * Tcw (DEVICE, row-major 4x4 world -> camera): order [world] (DEVICE int64) = the ranks, nearest cell first. The leaves of a BSP are ordered

@@ -141,7 +141,7 @@ def test_losses_band_by_band_equal_the_whole_image(gsr, hz, shape, world):
         if b0 >= b1:
             continue
         s_r = torch.empty((8,), device="cuda")
-        chk(L.gsr_track_loss_rows(p(image), p(depth), None, p(sil), p(frgb), p(fd), H, W, 0.99, wt, p(part_t), p(s_r), p(di_b), p(dd_b), p(tick) if r % 2 else None, b0, b1, None))
+        chk(L.gsr_track_loss_rows(p(image), p(depth), None, p(sil), p(frgb), p(fd), H, W, 0.99, wt, p(part_t), p(s_r), p(di_b), p(dd_b), p(tick) if r % 2 else None, b0, b1, 0, None))
         acc += s_r
     assert torch.equal(di_b, di) and torch.equal(dd_b, dd)
     assert (acc[:6] - s_full[:6]).abs().max() <= 3e-6 * float(s_full[:6].abs().max())

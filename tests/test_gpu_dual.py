@@ -110,3 +110,41 @@ def test_pose_only_backward_without_the_colour_sums_gives_the_same_mean_gradient
             for n in ("dL_dcolors", "dL_dopacity", "dL_dscales", "dL_drotations"):
                 a, b = getattr(out, n), getattr(full, n)
                 assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), n
+
+
+@pytest.mark.parametrize("name", ["tum-10k", "odd-pose-fat"])
+def test_silhouette_from_the_plain_forwards_transmittance(gsr, syn, name):
+    """Round 6: tracking on the surface depth renders the 3 colour channels only; its loss masks with 1 - final_T, which the plain forward keeps per pixel
+    anyway (forward.cu:455 final_T; include/gsr.h: gsr_transmittance_view, gsr_track_loss_rows' sil_is_transmittance). Pinned: 1 - T is the silhouette
+    channel of the fused pair to rounding (the channel is the sum of alpha * T the same pass accumulates, Render.cc:963-975 renders it as colour 1), and
+    the tracking loss on T equals the tracking loss on the silhouette wherever no pixel sits within that rounding of the 0.99 threshold."""
+    import ctypes as C
+    kw = dict(P=10000, cam=syn.TUM1, mult=2.0) if name == "tum-10k" else dict(P=3000, cam=dict(width=203, height=149, fx=150.0, fy=152.0), mult=4.0, Tcw=pose())
+    cam = syn.make_camera(**kw["cam"], Tcw=kw.get("Tcw"))
+    sc = syn.make_scene(kw["P"], cam, seed=9, scale_mult=kw["mult"])
+    H, W = cam.height, cam.width
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations, dual=True)
+    plain = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    T = gsr.capi.transmittance_view(plain)
+    sil = st.ds[1]
+    assert T.shape == (H, W) and float(T.min()) >= 0.0 and float(T.max()) <= 1.0
+    assert ((1.0 - T) - sil).abs().max() <= 2e-6
+    assert torch.equal(gsr.capi.transmittance_view(st), T)                       # the fused pair keeps the same plane
+    # the tracking loss, masked by either plane
+    g = torch.Generator().manual_seed(3)
+    frgb = torch.rand((3, H, W), generator=g).cuda(); fd = (0.5 + 3 * torch.rand((H, W), generator=g)); fd[::5, ::3] = 0.0; fd = fd.cuda()
+    L = gsr.lib(); p = lambda t: C.c_void_p(t.data_ptr()); chk = gsr.capi._check
+    wt = (C.c_float * 3)(0.7, 1.0, 0.0)
+    near = ((sil - 0.99).abs() <= 4e-6)
+    res = []
+    for plane, flag in ((sil.contiguous(), 0), (T, 1)):
+        part = torch.empty((1024 * 5,), device="cuda"); sums = torch.empty((8,), device="cuda")
+        di = torch.empty((3, H, W), device="cuda"); dd = torch.empty((H, W), device="cuda")
+        chk(L.gsr_track_loss_rows(p(plain.color), p(st.ds[0].contiguous()), None, p(plane), p(frgb), p(fd), H, W, 0.99, wt, p(part), p(sums), p(di), p(dd), None, 0, H, flag, None))
+        res.append((sums.clone(), di, dd))
+    keep = ~near
+    assert torch.equal(res[0][1][:, keep], res[1][1][:, keep]) and torch.equal(res[0][2][keep], res[1][2][keep])
+    if not bool(near.any()):
+        assert (res[0][0][:6] - res[1][0][:6]).abs().max() <= 1e-6 * float(res[0][0][:6].abs().max())
+    assert int(keep.sum()) > 0.99 * H * W
