@@ -743,7 +743,7 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
     const bool band = band_();
     // (round 6) unsharded, on the surface depth: the loss needs the colours, the median depth and a silhouette MASK — the plain forward renders the first two and
     // keeps the final transmittance per pixel (1 - T is the silhouette): no fused depth / silhouette channels, neither forwards nor backwards
-    const bool plain_track = !shard_ && cfg_.use_sur_depth && !std::getenv("GSR_EXP_TRACK_DUAL_BWD");
+    const bool plain_track = !shard_ && cfg_.use_sur_depth && d.n > 0 && !std::getenv("GSR_EXP_TRACK_DUAL_BWD"); // (an empty map renders nothing: no transmittance plane either — the zeroed layers then mask every pixel out)
     float* final_T = nullptr;
     if (plain_track) chk(gsr_transmittance_view(b(d.image), W_, H_, &final_T), "gsr_transmittance_view");
     float* const band_sums = f(d.pose_acc) + 64 * 12 + 8; // [8] this rank's tracking-loss sums: words 776..783 of the all-reduced block
