@@ -520,13 +520,14 @@ def rank_regime(a, gsr, dev, total, camera, cells):
 def band_exchange_bytes(W, H, world, rank):
     """Bytes one rank SENDS per iteration in the band exchange (DirectLoop.cpp: ensure_direct_): forward = the rows of its layer every peer's band needs (colour and
     silhouette planes with ten rows either side for the mapping loss's SSIM window, depth and surface depth on the band), backward = every peer's layer gradient
-    (five planes) on its own band."""
+    (five planes; tracking on the surface depth: four) on its own band."""
     hb = -(-H // world)
     band = lambda k, halo: (max(0, min(H, k * hb) - halo), min(H, min(H, (k + 1) * hb) + halo))
     rows = lambda k, halo: max(0, band(k, halo)[1] - band(k, halo)[0])
     peers = [k for k in range(world) if k != rank]
-    return {"map_fwd": sum(4 * rows(k, 10) + 2 * rows(k, 0) for k in peers) * W * 4, "track_fwd": sum(6 * rows(k, 0) for k in peers) * W * 4,
-            "bwd": 5 * rows(rank, 0) * W * 4 * len(peers)}
+    # (a tracking iteration on the surface depth — LoopConfig::use_sur_depth, the default — leaves the blended-depth plane at home, both ways; ShardRenderStep ships every plane)
+    return {"map_fwd": sum(4 * rows(k, 10) + 2 * rows(k, 0) for k in peers) * W * 4, "track_fwd": sum(5 * rows(k, 0) for k in peers) * W * 4,
+            "render_fwd": sum(6 * rows(k, 0) for k in peers) * W * 4, "bwd": 5 * rows(rank, 0) * W * 4 * len(peers), "track_bwd": 4 * rows(rank, 0) * W * 4 * len(peers)}
 
 
 def shard_step(a, gsr, td, rank, world, dev):
@@ -617,7 +618,7 @@ def shard_step(a, gsr, td, rank, world, dev):
             "mapping_splats_pixels_per_s": 2 * a.splats * W * H / (map_ms * 1e-3),
             "collectives_per_mapping_iter": ({"grouped_p2p_exchanges": 2, "bytes_sent_per_rank": ex["map_fwd"] + ex["bwd"] + 64 * (world - 1), "all_reduce_floats": 0} if band else
                                              {"all_gather_bytes_sent_per_rank": 3 * plane * (world - 1), "all_reduce_bytes": 4 * plane, "all_reduce_floats": 3}),
-            "collectives_per_tracking_iter": ({"grouped_p2p_exchanges": 2, "bytes_sent_per_rank": ex["track_fwd"] + ex["bwd"], "all_reduce_floats": 784} if band else
+            "collectives_per_tracking_iter": ({"grouped_p2p_exchanges": 2, "bytes_sent_per_rank": ex["track_fwd"] + ex["track_bwd"], "all_reduce_floats": 784} if band else
                                               {"all_gather_bytes_sent_per_rank": 3 * plane * (world - 1), "all_reduce_bytes": 4 * plane, "all_reduce_floats": 512 * 12}),
             "timed_iters": n}
 
@@ -681,7 +682,7 @@ def shard_render(a, gsr, td, rank, world, dev, weak=False):
             "value": total * W * H / (ms * 1e-3), "unit": "splats*pixels/s",
             "backend": (td.get_backend() if world > 1 else "none (single process)"), "ranks": (td.get_world_size() if world > 1 else 1),
             "transport": loop.shard_transport(),
-            "collective_bytes_per_rank_per_step": {"p2p_forward_sent": ex["track_fwd"], "p2p_backward_sent": ex["bwd"], "all_reduce_pose": 512 * 12 * 4 if world > 1 else 0,
+            "collective_bytes_per_rank_per_step": {"p2p_forward_sent": ex["render_fwd"], "p2p_backward_sent": ex["bwd"], "all_reduce_pose": 512 * 12 * 4 if world > 1 else 0,
                                                    "round5_replicated_composite_sent": (3 * plane * (world - 1) + 2 * 4 * plane * (world - 1) // max(world, 1)) if world > 1 else 0}}
 
 

@@ -98,7 +98,7 @@ struct SlamLoop::Direct {
     bool band = false;
     int b0 = 0, b1 = 0;
     torch::Tensor L_all, D_all, rows_all, frame_sums;                    // [world,6,H,W]; [world,5,H,W]; [world,16] {sums[8], reg_out[4], loss slot, 3 unused}; [8] (word 2: the frame's valid depth pixels)
-    std::vector<Msg> fwd_map, fwd_track, bwd_map, bwd_track;             // the exchanges' messages (built with the workspace: pointers and counts only)
+    std::vector<Msg> fwd_map, fwd_track, fwd_render, bwd_map, bwd_track, bwd_render; // the exchanges' messages (built with the workspace: pointers and counts only)
     void p2p(const std::vector<Msg>& ms);                                // one grouped exchange on the loop's stream
     ~Direct();
     bool sharded() const { return world > 1 || pg; }
@@ -391,7 +391,7 @@ void SlamLoop::ensure_direct_(int64_t history_len)
         auto band_of = [&](int k, int halo, int& lo, int& hi) { lo = std::max(0, std::min(H_, k * hb) - halo); hi = std::min(H_, std::min(H_, (k + 1) * hb) + halo); if (k * hb >= H_) lo = hi = 0; };
         band_of(d.rank, 0, d.b0, d.b1);
         d.band = cfg_.band_exchange && cfg_.fused_loss && cfg_.fused_update && (d.world - 1) * hb < H_; // (every rank a non-empty band: more ranks than rows keep the replicated composite)
-        d.fwd_map.clear(); d.fwd_track.clear(); d.bwd_map.clear(); d.bwd_track.clear();
+        d.fwd_map.clear(); d.fwd_track.clear(); d.fwd_render.clear(); d.bwd_map.clear(); d.bwd_track.clear(); d.bwd_render.clear();
         d.rows_all = torch::zeros({d.world, 16}, fo);
         if (d.band && d.world > 1) {
             const size_t HW = (size_t)H_ * W_;
@@ -399,22 +399,27 @@ void SlamLoop::ensure_direct_(int64_t history_len)
             for (int k = 0; k < d.world; k++) {
                 if (k == d.rank) continue;
                 for (int halo : {10, 0}) {
-                    auto& fwd = halo ? d.fwd_map : d.fwd_track;
                     for (int pl : {0, 1, 2, 4, 3, 5}) {
                         const int h = (pl == 3 || pl == 5) ? 0 : halo; // (depth and surface depth: the band itself)
                         int s0, s1, r0, r1;
                         band_of(k, h, s0, s1); band_of(d.rank, h, r0, r1);
                         // what I send is rows [s0, s1) of my layer (peer k's band); what I receive is rows [r0, r1) of k's layer (my band).
                         // (a message is a send OR a receive: the two bands of a pair may differ in height)
-                        if (s1 > s0) fwd.push_back(Direct::Msg{k, f(d.layers) + pl * HW + (size_t)s0 * W_, nullptr, (size_t)(s1 - s0) * W_});
-                        if (r1 > r0) fwd.push_back(Direct::Msg{k, nullptr, f(d.L_all) + ((size_t)k * 6 + pl) * HW + (size_t)r0 * W_, (size_t)(r1 - r0) * W_});
+                        // (a tracking iteration on the surface depth reads nothing of the blended depth: plane 3 stays at home, forwards and backwards — the same
+                        // LoopConfig on every rank, like everything else of the exchange; ShardRenderStep's gradient has all five planes)
+                        const bool track_too = !(pl == 3 && cfg_.use_sur_depth);
+                        auto put = [&](const Direct::Msg& m) { if (halo) d.fwd_map.push_back(m); else { d.fwd_render.push_back(m); if (track_too) d.fwd_track.push_back(m); } };
+                        if (s1 > s0) put(Direct::Msg{k, f(d.layers) + pl * HW + (size_t)s0 * W_, nullptr, (size_t)(s1 - s0) * W_});
+                        if (r1 > r0) put(Direct::Msg{k, nullptr, f(d.L_all) + ((size_t)k * 6 + pl) * HW + (size_t)r0 * W_, (size_t)(r1 - r0) * W_});
                     }
                 }
                 int k0, k1;
                 band_of(k, 0, k0, k1);
                 for (int pl = 0; pl < 5; pl++) {
-                    if (d.b1 > d.b0) { Direct::Msg m{k, f(d.D_all) + ((size_t)k * 5 + pl) * HW + (size_t)d.b0 * W_, nullptr, (size_t)(d.b1 - d.b0) * W_}; d.bwd_map.push_back(m); d.bwd_track.push_back(m); }
-                    if (k1 > k0) { Direct::Msg m{k, nullptr, f(d.D) + pl * HW + (size_t)k0 * W_, (size_t)(k1 - k0) * W_}; d.bwd_map.push_back(m); d.bwd_track.push_back(m); }
+                    const bool track_too = !(pl == 3 && cfg_.use_sur_depth);
+                    auto put = [&](const Direct::Msg& m) { d.bwd_map.push_back(m); d.bwd_render.push_back(m); if (track_too) d.bwd_track.push_back(m); };
+                    if (d.b1 > d.b0) put(Direct::Msg{k, f(d.D_all) + ((size_t)k * 5 + pl) * HW + (size_t)d.b0 * W_, nullptr, (size_t)(d.b1 - d.b0) * W_});
+                    if (k1 > k0) put(Direct::Msg{k, nullptr, f(d.D) + pl * HW + (size_t)k0 * W_, (size_t)(k1 - k0) * W_});
                 }
                 d.bwd_map.push_back(Direct::Msg{k, f(d.rows_all) + (size_t)d.rank * 16, nullptr, 16});
                 d.bwd_map.push_back(Direct::Msg{k, nullptr, f(d.rows_all) + (size_t)k * 16, 16});
@@ -459,14 +464,15 @@ bool SlamLoop::band_() const { return shard_ && d_ && d_->band; }
 
 // Every rank's layer on this rank's band of rows (one grouped exchange), then the composite of the band: comp = {rgb, depth, silhouette, surface depth} on
 // rows [b0, b1) — the mapping loss's SSIM window reads the colour planes ten rows beyond, so those rows travel and are composited too.
-void SlamLoop::band_forward_(bool pose_moved, bool tracking)
+void SlamLoop::band_forward_(bool pose_moved, int kind)
 {
     Direct& d = *d_;
     void* const st = stream_();
     d.stream = (hipStream_t)st;
     const size_t HW = (size_t)H_ * W_;
     if (pose_moved && d.kd_nodes.defined()) chk(gsr_shard_order(d.world, f(d.kd_nodes), f(d.Tcw), (long long*)d.order.data_ptr<int64_t>(), st), "gsr_shard_order");
-    d.p2p(tracking ? d.fwd_track : d.fwd_map);
+    const bool tracking = kind != kBandMap;
+    d.p2p(kind == kBandMap ? d.fwd_map : kind == kBandTrack ? d.fwd_track : d.fwd_render);
     if (d.b1 > d.b0)
         chk(gsr_band_composite_forward(d.world, d.rank, (const long long*)d.order.data_ptr<int64_t>(), d.L_all.defined() ? f(d.L_all) : nullptr, f(d.layers), H_, W_, d.b0, d.b1,
                                        tracking ? 0 : 10, f(d.comp), f(d.comp) + 4 * HW + 4, f(d.comp) + 5 * HW + 4, st), "gsr_band_composite_forward");
@@ -474,7 +480,7 @@ void SlamLoop::band_forward_(bool pose_moved, bool tracking)
 
 // From the loss's gradient on the band (G: rgb, depth) to EVERY rank's layer gradient on the band, and each rank's rows back to it (the second exchange;
 // a mapping iteration's sixteen loss / regulariser words per rank ride in it): D = d/d own layer (rgb, depth, silhouette) on the whole frame.
-void SlamLoop::band_backward_(bool tracking, const float* g_sil)
+void SlamLoop::band_backward_(int kind, const float* g_sil)
 {
     Direct& d = *d_;
     void* const st = stream_();
@@ -482,7 +488,7 @@ void SlamLoop::band_backward_(bool tracking, const float* g_sil)
     if (d.b1 > d.b0)
         chk(gsr_band_composite_backward(d.world, d.rank, (const long long*)d.order.data_ptr<int64_t>(), d.L_all.defined() ? f(d.L_all) : nullptr, f(d.layers), f(d.G), g_sil, H_, W_,
                                         d.b0, d.b1, d.D_all.defined() ? f(d.D_all) : nullptr, f(d.D), st), "gsr_band_composite_backward");
-    d.p2p(tracking ? d.bwd_track : d.bwd_map);
+    d.p2p(kind == kBandMap ? d.bwd_map : kind == kBandTrack ? d.bwd_track : d.bwd_render);
 }
 
 void SlamLoop::grow_binning_(size_t capacity)
@@ -581,7 +587,7 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
     const bool band = band_();
     if (in_projection && shard_ && !band)
         chk(gsr_map_prepare(n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, limit, wl, wsc, f(d.reg_partial), f(d.reg_tot), st), "gsr_map_prepare (finish)");
-    if (band) { band_forward_(d.order_stale, false); d.order_stale = false; }
+    if (band) { band_forward_(d.order_stale, kBandMap); d.order_stale = false; }
     else if (shard_) { shard_composite_forward_(d.order_stale, true); d.order_stale = false; }
     // Render.cc:436-471: lam * L1 + (1 - lam) * (1 - SSIM), masked depth L1, masked surface-depth L1 (no gradient), the regularisers
     const float w3[3] = {(float)(cfg_.im_weight_mapping * cfg_.lam), (float)cfg_.depth_weight_mapping, (float)cfg_.sur_depth_weight_mapping};
@@ -600,7 +606,7 @@ void SlamLoop::direct_map_iteration_(const LoopFrame& fr, float* loss_slot)
             "gsr_map_loss_finish_rows");
         chk(gsr_map_loss_backward_rows(img, dep, f(fr.rgb), f(fr.depth), f(d.dmaps), H_, W_, taps_host_.data(), w3, f(d.neg_c), f(d.frame_sums), f(d.g_image), f(d.g_ds), d.b0, d.b1, st),
             "gsr_map_loss_backward_rows");
-        band_backward_(false);
+        band_backward_(kBandMap);
         chk(gsr_shard_map_totals(d.world, f(d.rows_all), H_, W_, w3, c_ssim, wl, wsc, f(d.sums), f(d.reg_out), loss_slot, st), "gsr_shard_map_totals");
     } else if (cfg_.fused_loss) { // two passes over the image and one single-workgroup kernel between them
         chk(gsr_map_loss_forward(img, dep, sur, sil, f(fr.rgb), f(fr.depth), H_, W_, taps_host_.data(), 0.99f, f(d.partial6), f(d.dmaps), st), "gsr_map_loss_forward");
@@ -759,7 +765,7 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
     int step = 0;
     for (int it = 0; it < iters; it++) {
         direct_forward_(true, false, 0.f, plain_track); // (the camera transform of Render.cc:750-752 rides in the projection kernel)
-        if (band) band_forward_(true, true);
+        if (band) band_forward_(true, kBandTrack);
         else if (shard_) shard_composite_forward_(true, false);
         // Render.cc:1088-1105: the masked L1 sums and their gradient planes, one pass over the render (band exchange: over this rank's band of rows; its
         // sums are added up over the ranks by the pose rows' all-reduce)
@@ -779,7 +785,7 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
         u.lr = cfg_.lr_cam_quat; u.beta1 = 0.9; u.beta2 = 0.999; u.eps = 1e-15; u.step = ++step;
         uint32_t* const tickets = reinterpret_cast<uint32_t*>(d.tickets.data_ptr<int>()) + GSR_TICKET_WORDS;
         if (shard_ && cfg_.fused_update) { // the shard's pose sums come out of the backward's per-splat stage (accumulator rows), are summed over the ranks, and a one-wave kernel takes the (replicated) step
-            if (band) { band_backward_(true); u.loss = band_sums + 5; } // (the loss the step records is the all-reduced word behind the rows)
+            if (band) { band_backward_(kBandTrack); u.loss = band_sums + 5; } // (the loss the step records is the all-reduced word behind the rows)
             else shard_composite_backward_();
             u.partial = f(d.pose_acc);
             //  whether this iteration counts is decided by ALL ranks: the per-splat stage leaves the rank's overflow flag behind the rows, the
@@ -913,10 +919,10 @@ torch::Tensor SlamLoop::ShardRenderStep(const torch::Tensor& Tcw, const torch::T
                             nullptr, nullptr, st), "gsr_map_prepare");
     direct_forward_();
     if (band_()) { // the band exchange: the caller's gradient of the composite taken back on this rank's band of rows, for every rank's layer
-        band_forward_(true, true);
+        band_forward_(true, kBandRender);
         const torch::Tensor keep = d.G;
         d.G = G;
-        band_backward_(true, f(G) + (size_t)4 * H_ * W_);
+        band_backward_(kBandRender, f(G) + (size_t)4 * H_ * W_);
         d.G = keep;
         direct_backward_(false, false, nullptr, nullptr);
         if (d.n > 0) chk(gsr_pose_grad(f(xyz), f(d.d_mc), (size_t)d.n, f(d.Tcw), f(d.pose_partial), nullptr, st), "gsr_pose_grad");

@@ -148,8 +148,9 @@ private:
     void shard_composite_forward_(bool pose_moved, bool with_reg);
     void shard_composite_backward_();
     bool band_() const;
-    void band_forward_(bool pose_moved, bool tracking);
-    void band_backward_(bool tracking, const float* g_sil = nullptr);
+    enum { kBandMap = 0, kBandTrack = 1, kBandRender = 2 }; // which exchange: a mapping iteration (ten halo rows), a tracking iteration (no blended depth on the surface depth), ShardRenderStep (every plane)
+    void band_forward_(bool pose_moved, int kind);
+    void band_backward_(int kind, const float* g_sil = nullptr);
     void shard_preflight_();
     bool shard_any_(bool mine);
     torch::Tensor shard_cells_(const torch::Tensor& pts) const;
