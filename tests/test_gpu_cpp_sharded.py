@@ -307,7 +307,7 @@ def test_an_empty_cell_takes_part_in_the_sharded_loop():
     np.testing.assert_allclose(got[1]["rows"], got[0]["rows"], rtol=1e-6)       # (the all-reduced pose rows: the empty rank added zeros)
 
 
-def _band_worker(rank, world, port, backend, q):
+def _band_worker(rank, world, port, backend, q, extra=None):
     """the same cell through the sharded loop twice: the band exchange of round 6 and round 5's replicated composite"""
     gsr, _C, sharded = _setup()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -324,7 +324,7 @@ def _band_worker(rank, world, port, backend, q):
         m = (obs.to(T.device), Xw.to(T.device), s2.to(T.device), cx, cy)
         res = {}
         for name, band in (("band", True), ("replicated", False)):
-            loop = _loop(_C, [x[idx] for x in raw], dev, fused_update=True, band_exchange=band)
+            loop = _loop(_C, [x[idx] for x in raw], dev, fused_update=True, band_exchange=band, **(extra or {}))
             loop.set_shard(dist.group.WORLD if world > 1 or backend == "nccl" else None, rank, world, part.nodes)
             r = {"map": loop.map_frame(rgb, depth, T, 8)}
             hist, best = loop.track(rgb, depth, _poses()[1].cuda(dev), 1, *m)
@@ -345,11 +345,11 @@ def _band_worker(rank, world, port, backend, q):
         dist.destroy_process_group()
 
 
-def _run_band(backend, world):
+def _run_band(backend, world, extra=None):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_band_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    procs = [ctx.Process(target=_band_worker, args=(r, world, port, backend, q, extra)) for r in range(world)]
     for p in procs:
         p.start()
     import queue
@@ -401,6 +401,13 @@ def test_band_exchange_equals_the_replicated_composite_gloo(world):
 
 
 @pytest.mark.gpu
+def test_band_exchange_with_tracking_on_the_blended_depth_gloo():
+    """Tracking.use_sur_depth = false: the tracking exchange then ships every plane (on the surface depth the blended-depth plane stays at home, both ways)
+    and the rank's backward takes the depth and silhouette planes of its layer's gradient; three ranks."""
+    _run_band("gloo", 3, dict(use_sur_depth=False))
+
+
+@pytest.mark.gpu
 def test_band_exchange_one_rank_rccl():
     _run_band("nccl", 1)
 
@@ -424,8 +431,10 @@ def _matches(T, n=60, seed=9):
 
 
 @pytest.mark.gpu
-def test_cpp_track_with_feature_matches_follows_the_python_harness():
-    """SlamLoop::Track with the ORB matches' reprojection term (Render.cc:1031-1096; gsr_reproj_loss inside the direct loop, fused pose step and
+@pytest.mark.parametrize("sur", [True, False])
+def test_cpp_track_with_feature_matches_follows_the_python_harness(sur):
+    """(sur: Tracking.use_sur_depth — the depth term on the surface (median) depth, the reference's default and the C++ loop's plain three-channel forward with
+    the mask from the final transmittance, or on the alpha-blended depth through the fused pair.) SlamLoop::Track with the ORB matches' reprojection term (Render.cc:1031-1096; gsr_reproj_loss inside the direct loop, fused pose step and
     two-launch form; the tensor expressions on the autograd path) against the Python harness's track() with the same matches on the same map:
     loss curves, the pose, and the term really pulls (without it the curve differs)."""
     gsr, _C, sharded = _setup()
@@ -441,12 +450,13 @@ def test_cpp_track_with_feature_matches_follows_the_python_harness():
     with torch.no_grad():
         g.unnorm_quat.copy_(raw[2].cuda()); g.logit_opacities.copy_(raw[3].cuda()); g.log_scales.copy_(raw[4].cuda())
     g.cfg.feature_weight_tracking = FW
+    g.cfg.use_sur_depth = sur
     r = hz.SlamRenderer(g, W, H)
     mt = (torch.cat([obs, torch.ones(len(obs), 1)], 1).reshape(-1, 3, 1).cuda(), torch.cat([Xw, torch.ones(len(Xw), 1)], 1).reshape(-1, 4, 1).cuda(), s2.reshape(-1, 1).cuda())
     T_ref, h_ref = r.track(hz.Frame(frame[0], frame[1], frame[2]), T0.cuda(), iters=iters, matches=mt, K=K)
     out = {}
     for name, cfg in (("fused", dict()), ("two-launch", dict(fused_update=False)), ("autograd", dict(direct=False)), ("no-matches", dict())):
-        loop = _loop(_C, raw, feature_weight_tracking=FW, **cfg)
+        loop = _loop(_C, raw, feature_weight_tracking=FW, use_sur_depth=sur, **cfg)
         args = () if name == "no-matches" else (obs.cuda(), Xw.cuda(), s2.cuda(), cx, cy)
         h, best = loop.track(frame[0], frame[1], T0.cuda(), iters, *args)
         out[name] = (np.array(h), best.cpu().numpy())
