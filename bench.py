@@ -93,6 +93,20 @@ def cpu_baseline(sc, P, W, H, budget_s=20.0):
     P1 = int(len(sc.means3D[sub]))
     out["single_thread"] = {"value": P1 * W * H / t1, "unit": "splats*pixels/s", "cores": 1,
                             "sample": f"one fwd+bwd of every 8th splat of the scene ({P1} splats, {W}x{H}), oracle/libgsr_oracle.so, {t1 * 1e3:.0f} ms"}
+    # Beside the CPU figure, when oracle/_ref is built: the REFERENCE's own kernels on this GPU (oracle/build_ref.sh: the reference's .cu files translated by
+    # hipify-perl and compiled by hipcc with its default contraction, i.e. what a user of the reference gets on this hardware without this library) —
+    # a baseline like the CPU one, never the product.
+    try:
+        from oracle import ref
+        if ref.available():
+            rt = ref.time_scene(sc, iters=5)
+            tt = (rt["forward_ms"] + rt["backward_ms"]) * 1e-3
+            out["reference_kernels_on_this_gpu"] = {
+                "value": P * W * H / tt, "unit": "splats*pixels/s", "forward_ms": rt["forward_ms"], "backward_ms": rt["backward_ms"], "kind": "reference",
+                "sample": f"5 fwd+bwd of the same scene after one warm-up, inputs resident, HIP events; CudaRasterizer::Rasterizer::forward / backward "
+                          f"(hipified at build time, oracle/_ref/libgsr_ref_fma.so): hipcub radix sort + scan, 16x16-thread tiles, per-pixel atomics — as the reference wrote them"}
+    except Exception as e:                                   # (a baseline: its absence never fails the bench)
+        out["reference_kernels_on_this_gpu"] = {"error": repr(e)}
     return out
 
 

@@ -120,3 +120,18 @@ def test_argument_validation_rejects_inconsistent_sh_degree_before_any_gpu_work(
         L.gsr_forward_ws.restype = C.c_int
         return L.gsr_forward_ws(C.byref(a), dummy, dummy, C.c_size_t(1 << 20), dummy, None)
     assert fwd(3, 9) == EINVAL and fwd(1, 3) == EINVAL
+
+
+def test_reference_build_loads_and_exports_its_entry_points():
+    """oracle/_ref (test infrastructure: the reference's own rasterizer for this GPU, oracle/build_ref.sh) — no compute here; the -m gpu tests call it"""
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref is not built (needs /root/reference)")
+    for fma in (False, True):
+        lib = ref.lib(fma)
+        for name in ("gsref_state_new", "gsref_state_free", "gsref_forward", "gsref_backward", "gsref_stage", "gsref_time", "gsref_mark_visible"):
+            assert hasattr(lib, name), name
+    # the recipe leaves no text of the reference behind
+    assert sorted(os.listdir(os.path.join(ROOT, "oracle", "_ref"))) == ["libgsr_ref.so", "libgsr_ref_fma.so"]

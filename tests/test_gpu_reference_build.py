@@ -1,0 +1,188 @@
+"""GPU (-m gpu): the REFERENCE's own rasterizer run on this GPU — oracle/_ref/libgsr_ref.so, built by oracle/build_ref.sh from the reference's
+sources where they lie (Thirdparty/diff_gaussian_rasterization/cuda_rasterizer/*.cu, *.h translated by ROCm's hipify-perl at build time and compiled by hipcc
+with -ffp-contract=off; oracle/ref_shim.hip only moves arrays) — against (A) the CPU oracle and (B) the HIP library, on the same seeded inputs.
+
+(A) is what pins the oracle: its restatement of preprocessCUDA / computeCov2D / duplicateWithKeys / the radix sort / identifyTileRanges / renderCUDA and the
+whole backward (forward.cu:74-401, backward.cu:144-557, rasterizer_impl.cu:71-345) is held to values the reference's own kernels computed — radii,
+tiles_touched, offsets, sorted keys, point_list, ranges and the projected geometry BIT-EXACT, images and gradients inside the 1e-4 bars (observed: colour
+4e-7, gradients 4e-7). (B) holds the shipped library to the same values directly. What this does NOT pin: nvcc's own code generation (its contraction
+choices, CUDA's expf against ROCm's) — test_contracted_reference_build_census counts what hipcc's default contraction moves, the nearest thing to it that
+can be run here.
+
+The bars are test_gpu_parity.py's; the knife-edge pixels (a blend branch within 1e-5 of its threshold: exp() differs between glibc, CUDA and ROCm in the
+last bit) come from the oracle's margins, as there."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle, ref
+from test_gpu_parity import BIG, CASE_NAMES, EPS_MARGIN, ODD, SMALL, TOL, _build, _cases
+from util import mixed_err, rel_err
+
+pytestmark = pytest.mark.gpu
+
+GRADS = ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+INT_STAGES = ("tiles_touched", "point_offsets", "keys_unsorted", "values_unsorted", "keys_sorted", "point_list", "ranges")
+GEOM_STAGES = ("means2D", "depths", "conic_opacity", "cov3D")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _needs_the_reference_build():
+    if not ref.available():
+        pytest.skip("oracle/_ref/libgsr_ref.so is not built (oracle/build_ref.sh needs /root/reference: __graft_entry__.build() runs it where the reference is present)")
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint8).reshape(a.shape[0], -1) if a.ndim else a
+
+
+def _compare_forward(name, what, got_stages, got_radii, got_R, got_color, got_depth, fr, ok_c, ok_d, H, W, sh):
+    """`got` (the oracle, or the HIP library re-expressed by gsr_debug_export) against the reference's forward `fr`"""
+    assert got_R == fr.num_rendered, (name, what)
+    np.testing.assert_array_equal(got_radii, fr.radii, err_msg="%s %s radii" % (name, what))
+    vis = fr.radii > 0
+    for k in INT_STAGES:
+        if k in got_stages:
+            np.testing.assert_array_equal(got_stages[k], fr.stages[k], err_msg="%s %s %s" % (name, what, k))
+    for k in GEOM_STAGES:       # (a culled splat's entries are never written by the reference: forward.cu:196-200 returns early)
+        if k in got_stages:
+            a, b = got_stages[k].reshape(len(vis), -1)[vis], fr.stages[k].reshape(len(vis), -1)[vis]
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "%s %s %s: %d of %d values differ" % (name, what, k, int((a.view(np.uint32) != b.view(np.uint32)).sum()), a.size)
+    if sh and "rgb" in got_stages:
+        np.testing.assert_allclose(got_stages["rgb"].reshape(-1, 3)[vis], fr.stages["rgb"].reshape(-1, 3)[vis], atol=2e-6)
+    scale = max(1.0, float(np.abs(fr.color).max()))
+    e_col = float(np.abs(got_color - fr.color)[:, ok_c].max())
+    assert e_col <= TOL * scale, (name, what, e_col)
+    assert np.array_equal(got_depth.reshape(H, W)[ok_d], fr.depth.reshape(H, W)[ok_d]), (name, what, "median depth")
+    e_T = float(np.abs(got_stages["final_T"].reshape(H, W) - fr.stages["final_T"].reshape(H, W))[ok_c].max())
+    assert e_T <= TOL, (name, what, e_T)
+    assert np.array_equal(got_stages["n_contrib"].reshape(H, W)[ok_c], fr.stages["n_contrib"].reshape(H, W)[ok_c]), (name, what, "n_contrib")
+    return e_col, e_T
+
+
+def _compare_grads(name, what, got, want, afloor):
+    worst = {}
+    for n in GRADS:
+        a, b = np.asarray(getattr(got, n)), np.asarray(getattr(want, n))
+        if b.size == 0:
+            continue
+        e, m = rel_err(a, b), mixed_err(a, b, afloor=afloor)
+        worst[n] = (e, m)
+        assert e <= TOL, (name, what, n, e)
+        assert m <= 1.0, (name, what, n, "element-wise bar exceeded by x%.2f" % m)
+    return worst
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_oracle_and_hip_library_against_the_reference_kernels(gsr, syn, name):
+    sc = _build(syn, **_cases(syn)[name])
+    H, W = sc.cam.height, sc.cam.width
+    r, fr = ref.forward_scene(sc)                                  # the reference's kernels
+    o, fo = oracle.forward_scene(sc, omp=name in BIG)              # the CPU restatement
+    mc, md = o.margins(fo)
+    ok_c, ok_d = mc >= EPS_MARGIN, md >= EPS_MARGIN
+    g_in = sc.dL_dpix * ok_c[None]
+    br = r.backward(g_in)
+    # both sides of (A) accumulate in float here (the reference's atomicAdd; the oracle's double accumulators are the parity tests' choice): the floor of the
+    # element-wise bar is test_gpu_parity's
+    afloor = 4e-5 if name == "deep-stack-depth" else 1e-6
+
+    # ---- (A) the oracle against the reference
+    ea = _compare_forward(name, "oracle", fo.stages, fo.radii, fo.num_rendered, fo.color, fo.depth, fr, ok_c, ok_d, H, W, sc.shs is not None)
+    wa = _compare_grads(name, "oracle", o.backward(g_in), br, afloor)
+
+    # ---- (B) the HIP library against the reference
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    d = gsr.debug_export(st)
+    stages = dict(d)
+    stages["keys_sorted"] = d["point_list_keys"]
+    eb = _compare_forward(name, "hip", stages, st.radii.cpu().numpy(), st.num_rendered, st.color.cpu().numpy(), st.depth.cpu().numpy(), fr, ok_c, ok_d, H, W,
+                          sc.shs is not None)
+    gr = gsr.backward(st, g_in)
+    torch.cuda.synchronize()
+
+    class _G:
+        pass
+    gg = _G()
+    for n in GRADS:
+        setattr(gg, n, getattr(gr, n).cpu().numpy())
+    wb = _compare_grads(name, "hip", gg, br, afloor)
+    print("\n%s against the reference's kernels: oracle colour %.1e final_T %.1e, worst gradient %.1e | HIP library colour %.1e final_T %.1e, worst gradient %.1e"
+          % (name, ea[0], ea[1], max(v[0] for v in wa.values()), eb[0], eb[1], max(v[0] for v in wb.values())))
+
+
+def test_reference_mark_visible_and_culled_scene(gsr, syn):
+    """markVisible (rasterizer_impl.cu:140-160) and a frame with splats behind the camera / off screen: the three implementations agree on who is visible."""
+    sc = _build(syn, 4000, SMALL, mult=2.0, frac_behind=0.3, frac_offscreen=0.3)
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    m_ref = ref.mark_visible(sc.means3D, sc.cam)
+    m_ora = oracle.mark_visible(sc.means3D, sc.cam)
+    m_hip = gsr.mark_visible(torch.tensor(sc.means3D, device="cuda"), s.viewmatrix, s.projmatrix).cpu().numpy()
+    assert 0 < int(m_ref.sum()) < len(m_ref)
+    assert np.array_equal(m_ref, m_ora) and np.array_equal(m_ref, m_hip)
+    _, fr = ref.forward_scene(sc)
+    _, fo = oracle.forward_scene(sc)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations)
+    assert int((fr.radii == 0).sum()) > 500
+    np.testing.assert_array_equal(fo.radii, fr.radii)
+    np.testing.assert_array_equal(st.radii.cpu().numpy(), fr.radii)
+
+
+def test_cov3d_precomp_path_against_the_reference(gsr, syn):
+    sc = _build(syn, 3000, ODD, mult=2.0, bg=(0.1, 0.1, 0.4))
+    _, f0 = ref.forward_scene(sc)
+    cov = f0.stages["cov3D"].reshape(-1, 6)                        # the reference's own computeCov3D
+    r = ref.Reference()
+    fr = r.forward(means3D=sc.means3D, opacities=sc.opacities, cam=sc.cam, colors=sc.colors, cov3D_precomp=cov)
+    o = oracle.Oracle()
+    fo = o.forward(means3D=sc.means3D, opacities=sc.opacities, cam=sc.cam, colors=sc.colors, cov3D_precomp=cov)
+    mc, _ = o.margins(fo)
+    g_in = sc.dL_dpix * (mc >= EPS_MARGIN)[None]
+    br, bo = r.backward(g_in), o.backward(g_in)
+    np.testing.assert_array_equal(fo.radii, fr.radii)
+    np.testing.assert_array_equal(fo.stages["point_list"], fr.stages["point_list"])
+    assert rel_err(bo.dL_dcov3D, br.dL_dcov3D) <= TOL and rel_err(bo.dL_dmeans3D, br.dL_dmeans3D) <= TOL
+    assert float(np.abs(br.dL_dscales).max()) == 0.0 and float(np.abs(br.dL_drotations).max()) == 0.0
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    st = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, cov3D_precomp=cov)
+    np.testing.assert_array_equal(st.radii.cpu().numpy(), fr.radii)
+    gr = gsr.backward(st, g_in)
+    assert rel_err(gr.dL_dcov3D.cpu().numpy(), br.dL_dcov3D) <= TOL and rel_err(gr.dL_dmeans3D.cpu().numpy(), br.dL_dmeans3D) <= TOL
+
+
+@pytest.mark.parametrize("name", ["replica-1M-rgb", "scannet-2M-rgb", "odd-sh3-pose-bg", "fat-clamped"])
+def test_contracted_reference_build_census(syn, name):
+    """What floating-point contraction moves in the reference's OWN kernels: libgsr_ref_fma.so (hipcc's default -ffp-contract=fast, the counterpart of nvcc's
+    default --fmad=true that the reference's CMake builds with) against libgsr_ref.so (-ffp-contract=off, the statement the oracle and the library hold). The
+    GPU-code counterpart of tests/test_oracle_fma_census.py (gcc's contractions of the C restatement). hipcc's choice of contractions is not nvcc's: the size of
+    the effect, not a prediction of which entries move. Asserted: the INDEX stages barely move (a radius needs a covariance eigenvalue within an ulp of an
+    integer boundary), images stay inside the 1e-4 bar."""
+    sc = _build(syn, **_cases(syn)[name])
+    _, a = ref.forward_scene(sc)
+    _, b = ref.forward_scene(sc, fma=True)
+    vis = a.radii > 0
+    P = len(vis)
+    out = {"scene": name, "P": P, "visible": int(vis.sum()), "num_rendered": [a.num_rendered, b.num_rendered],
+           "radii_differ": int((a.radii != b.radii).sum()), "tiles_touched_differ": int((a.stages["tiles_touched"] != b.stages["tiles_touched"]).sum())}
+    if a.num_rendered == b.num_rendered:
+        out["point_list_positions_that_differ"] = int((a.stages["point_list"] != b.stages["point_list"]).sum())
+        out["ranges_differ"] = int((a.stages["ranges"] != b.stages["ranges"]).any(1).sum())
+    for k in GEOM_STAGES:
+        x, y = a.stages[k].reshape(P, -1)[vis], b.stages[k].reshape(P, -1)[vis]
+        out[k + "_values_that_differ"] = int((x.view(np.uint32) != y.view(np.uint32)).sum())
+        out[k + "_max_rel"] = float((np.abs(x - y) / np.maximum(np.abs(x), 1e-30)).max()) if x.size else 0.0
+    out["color_max_abs_diff"] = float(np.abs(a.color - b.color).max())
+    out["color_pixels_beyond_1e-4"] = int((np.abs(a.color - b.color).max(0) > 1e-4).sum())
+    out["n_contrib_pixels_differ"] = int((a.stages["n_contrib"] != b.stages["n_contrib"]).sum())
+    print("\ncontraction census, the reference's kernels:", json.dumps(out))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "ref_fma_census_%s.json" % name), "w") as f:
+            json.dump(out, f, indent=1)
+    assert out["radii_differ"] <= max(2, P // 100000)
+    assert out["tiles_touched_differ"] <= max(2, P // 100000)
+    assert out["color_pixels_beyond_1e-4"] <= max(4, a.color[0].size // 20000)
