@@ -40,6 +40,10 @@ def lib(fma: bool = False):
         L.gsref_stage.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
         L.gsref_time.restype = C.c_int
         L.gsref_time.argtypes = [C.c_void_p, C.POINTER(_o._Scene), C.c_void_p, C.c_int, C.c_void_p]
+        L.gsref_visible_filter.restype = C.c_int
+        L.gsref_visible_filter.argtypes = [C.POINTER(_o._Scene), C.c_int, C.c_int, C.c_void_p]
+        L.gsref_dist2.restype = C.c_int
+        L.gsref_dist2.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.gsref_mark_visible.restype = C.c_int
         L.gsref_mark_visible.argtypes = [C.c_int] + [C.c_void_p] * 4
         _LIBS[fma] = L
@@ -128,3 +132,23 @@ def mark_visible(means3D, cam) -> np.ndarray:
     if lib().gsref_mark_visible(m.shape[0], _o._ptr(m), _o._ptr(v), _o._ptr(p), _o._ptr(out)) != 0:
         raise RuntimeError("the reference's markVisible failed")
     return out.astype(bool)
+
+
+def dist2(points, fma: bool = False) -> np.ndarray:
+    """SimpleKNN::knn (src/simple_knn.cu:185-220; distCUDA2): mean squared distance of every point to its three nearest neighbours"""
+    p = _o._f32(points)
+    out = np.zeros(p.shape[0], np.float32)
+    if lib(fma).gsref_dist2(p.shape[0], _o._ptr(p), _o._ptr(out)) != 0:
+        raise RuntimeError("the reference's k-NN failed")
+    return out
+
+
+def filter_radii(means3D, scales, rotations, cam, width=None, height=None) -> np.ndarray:
+    """Rasterizer::visible_filter (rasterizer_impl.cu:348-403; Render.cc:784-831 calls it on an enlarged image): the radii alone"""
+    r = Reference()
+    z = np.zeros((len(means3D), 1), np.float32)
+    s, P, M = r._scene(means3D=means3D, opacities=z, cam=cam, colors=np.zeros((len(means3D), 3), np.float32), scales=scales, rotations=rotations)
+    out = np.zeros(max(P, 1), np.int32)
+    if r.lib.gsref_visible_filter(C.byref(s), width or cam.width, height or cam.height, _o._ptr(out)) != 0:
+        raise RuntimeError("the reference's visible_filter failed")
+    return out[:P]

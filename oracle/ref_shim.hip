@@ -20,6 +20,7 @@
 
 #include "rasterizer.h"
 #include "rasterizer_impl.h"
+#include "simple_knn.h"
 
 namespace {
 
@@ -280,6 +281,46 @@ int gsref_mark_visible(int P, const float* means3D, const float* view, const flo
         return 0;
     } catch (const std::exception& e) {
         fprintf(stderr, "[gsref] markVisible: %s\n", e.what());
+        return -1;
+    }
+}
+
+// rasterizer_impl.cu (Rasterizer::visible_filter, what Render.cc:784-831 calls on a 1.2x enlarged image): radii [P], HOST arrays
+int gsref_visible_filter(const Scene* s, int width, int height, int* radii)
+{
+    try {
+        const size_t P = (size_t)s->P;
+        if (P == 0) return 0;
+        DevBuf geom, binning, image;
+        DevArr<float> m, sc, rt, v, p;
+        DevArr<int> r;
+        m.upload(s->means3D, 3 * P); sc.upload(s->scales, 3 * P); rt.upload(s->rotations, 4 * P); v.upload(s->viewmatrix, 16); p.upload(s->projmatrix, 16); r.zeros(P);
+        std::function<char*(size_t)> ga = [&](size_t n) { return geom.get(n); };
+        std::function<char*(size_t)> ba = [&](size_t n) { return binning.get(n); };
+        std::function<char*(size_t)> ia = [&](size_t n) { return image.get(n); };
+        CudaRasterizer::Rasterizer::visible_filter(ga, ba, ia, s->P, s->M, width, height, m.p, sc.p, s->scale_modifier, rt.p, v.p, p.p, s->tan_fovx, s->tan_fovy, false, r.p);
+        chk(hipDeviceSynchronize(), "reference visible_filter");
+        r.download(radii, P);
+        return 0;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "[gsref] visible_filter: %s\n", e.what());
+        return -1;
+    }
+}
+
+// src/simple_knn.cu:185-220 (SimpleKNN::knn, what distCUDA2 calls: src/spatial.cu:14-26): mean squared distance to the three nearest neighbours; HOST arrays
+int gsref_dist2(int P, const float* points, float* mean_dists)
+{
+    try {
+        if (P <= 0) return 0;
+        DevArr<float> pts, out;
+        pts.upload(points, (size_t)3 * P); out.zeros((size_t)P);
+        SimpleKNN::knn(P, reinterpret_cast<float3*>(pts.p), out.p);
+        chk(hipDeviceSynchronize(), "reference knn");
+        out.download(mean_dists, (size_t)P);
+        return 0;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "[gsref] knn: %s\n", e.what());
         return -1;
     }
 }

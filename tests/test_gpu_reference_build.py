@@ -132,6 +132,17 @@ def test_reference_mark_visible_and_culled_scene(gsr, syn):
     np.testing.assert_array_equal(st.radii.cpu().numpy(), fr.radii)
 
 
+def test_visible_filter_against_the_reference(gsr, syn):
+    """Rasterizer::visible_filter on the 1.2x enlarged image of Render.cc:784-831"""
+    sc = _build(syn, 6000, SMALL, mult=3.0, frac_behind=0.2, frac_offscreen=0.4)
+    s = gsr.capi.Settings.from_camera(sc.cam)
+    W2, H2 = int(sc.cam.width * 1.2), int(sc.cam.height * 1.2)
+    want = ref.filter_radii(sc.means3D, sc.scales, sc.rotations, sc.cam, W2, H2)
+    assert 0 < int((want > 0).sum()) < len(want)
+    np.testing.assert_array_equal(oracle.filter_radii(sc.means3D, sc.scales, sc.rotations, sc.cam, W2, H2), want)
+    np.testing.assert_array_equal(gsr.visible_filter(s, sc.means3D, sc.scales, sc.rotations, W2, H2).cpu().numpy(), want)
+
+
 def test_cov3d_precomp_path_against_the_reference(gsr, syn):
     sc = _build(syn, 3000, ODD, mult=2.0, bg=(0.1, 0.1, 0.4))
     _, f0 = ref.forward_scene(sc)

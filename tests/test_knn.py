@@ -146,3 +146,19 @@ def test_densification_at_config5_size_feeds_the_rasterizer(gsr, syn):
     g2 = gsr.backward(st2, gin)
     for n in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity", "dL_dcolors"):
         assert rel_err(getattr(g2, n).cpu().numpy(), getattr(b, n)) <= 1e-4, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,P", [("uniform", 20000), ("surface", 30000), ("dupes", 5000), ("uniform", 700), ("surface", 5), ("uniform", 300000)])
+def test_oracle_and_hip_dist2_against_the_reference_knn(gsr, kind, P):
+    """SimpleKNN::knn itself (src/simple_knn.cu, translated by hipify-perl at build time and compiled by hipcc: oracle/build_ref.sh) on this GPU: the oracle's
+    brute force and the library's grid search select the same three neighbours; the squared distances agree to the association freedom of three products."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref is not built")
+    pts = _cloud(kind, P, 2)
+    want = ref.dist2(pts)
+    with np.errstate(over="ignore"):
+        if P <= 30000:
+            np.testing.assert_allclose(oracle.dist2(pts), want, rtol=1e-6, atol=0)
+        np.testing.assert_allclose(gsr.dist2(pts).cpu().numpy(), want, rtol=1e-6, atol=0)
