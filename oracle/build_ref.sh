@@ -12,6 +12,7 @@
 #   2. hipcc compiles them with oracle/ref_shim.hip (host arrays in / out, the reference's own entry points and state layout) into
 #        libgsr_ref.so      -ffp-contract=off : the arithmetic as the source states it (what the CPU oracle and the HIP library hold)
 #        libgsr_ref_fma.so  hipcc's default contraction (fast): what a default nvcc build (--fmad=true, the reference's CMake) is like
+#        gsr_ref_C.so       the reference's Python-operator binding (rasterize_points.cu + ext.cpp, g++ against this image's libtorch) on the first build's objects
 #   3. the scratch directory is removed: no text of the reference stays in the tree; oracle/_ref/ is git-ignored, the .so files travel
 #      to the GPU box with the snapshot.
 # Needs /root/reference (this container); on the GPU box the prebuilt files are used.
@@ -21,7 +22,7 @@ REF=${GSR_REFERENCE:-/root/reference}/Thirdparty/diff_gaussian_rasterization
 SRC=$REF/cuda_rasterizer
 OUT=$HERE/_ref
 [ -d "$SRC" ] || { echo "build_ref.sh: $SRC not found (the prebuilt oracle/_ref/*.so are used as they are)"; exit 0; }
-if [ -f "$OUT/libgsr_ref.so" ] && [ -f "$OUT/libgsr_ref_fma.so" ] && [ "$OUT/libgsr_ref.so" -nt "$HERE/ref_shim.hip" ] && [ "$OUT/libgsr_ref.so" -nt "$HERE/build_ref.sh" ] && [ "$1" != "--force" ]; then exit 0; fi
+if [ -f "$OUT/libgsr_ref.so" ] && [ -f "$OUT/libgsr_ref_fma.so" ] && [ -f "$OUT/gsr_ref_C.so" ] && [ "$OUT/libgsr_ref.so" -nt "$HERE/ref_shim.hip" ] && [ "$OUT/libgsr_ref.so" -nt "$HERE/build_ref.sh" ] && [ "$1" != "--force" ]; then exit 0; fi
 TMP=$OUT/.scratch
 rm -rf "$TMP" && mkdir -p "$TMP"
 trap 'rm -rf "$TMP"' EXIT
@@ -36,9 +37,36 @@ for f in src/simple_knn.cu include/simple_knn.h; do
     /opt/rocm/bin/hipify-perl "${GSR_REFERENCE:-/root/reference}/$f" > "$TMP/$o" 2>/dev/null
     sed -i -e '/#include ""/d' -e '/cub\/device\/device_radix_sort.cuh/d' -e '/cooperative_groups\/reduce.h/d' -e 's/<< </<<</g' -e 's/>> >/>>>/g' "$TMP/$o"
 done
+# the Python operator's binding (rasterize_points.cu, rasterize_points.h, ext.cpp: host code on torch tensors, the `_C` module of the reference's
+# diff_gaussian_rasterization package) — for tests/test_gpu_reference_build.py's argument-for-argument comparison of the two `_C` modules
+for f in rasterize_points.cu rasterize_points.h ext.cpp; do
+    o=$f; case $f in *.cu) o=${f%.cu}.hip;; esac
+    /opt/rocm/bin/hipify-perl "$REF/$f" > "$TMP/$o" 2>/dev/null
+    sed -i -e '/#include ""/d' "$TMP/$o"
+done
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -w -D__trap=__builtin_trap -include cfloat -I$REF/third_party/glm -I$TMP"
-$HIPCC $COMMON -ffp-contract=off -o "$OUT/libgsr_ref.so" "$TMP/forward.hip" "$TMP/backward.hip" "$TMP/rasterizer_impl.hip" "$TMP/simple_knn.hip" "$HERE/ref_shim.hip" &
-$HIPCC $COMMON -o "$OUT/libgsr_ref_fma.so" "$TMP/forward.hip" "$TMP/backward.hip" "$TMP/rasterizer_impl.hip" "$TMP/simple_knn.hip" "$HERE/ref_shim.hip" &
+DEV="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -D__trap=__builtin_trap -include cfloat -I$REF/third_party/glm -I$TMP"
+build_variant() { # $1 = object suffix, $2 = extra flags: the reference's device code + the shim
+    for u in forward backward rasterizer_impl simple_knn; do $HIPCC $DEV $2 -c "$TMP/$u.hip" -o "$TMP/$u$1.o" || return 1; done
+    $HIPCC $DEV $2 -c "$HERE/ref_shim.hip" -o "$TMP/shim$1.o" || return 1
+}
+build_variant _off -ffp-contract=off &
+build_variant _fma "" &
+# (host-only: g++ against this image's libtorch; the module is named gsr_ref_C so that it cannot be mistaken for the library's _C)
+TORCH=$(python3 - <<'PY'
+import os, sysconfig, torch
+from torch.utils import cpp_extension as ce
+print(" ".join("-I" + i for i in ce.include_paths() + [sysconfig.get_paths()["include"]]), "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI))
+print(os.path.join(os.path.dirname(torch.__file__), "lib"))
+PY
+)
+TINC=$(echo "$TORCH" | head -1); TLIB=$(echo "$TORCH" | tail -1)
+HOST="-std=c++17 -O2 -fPIC -w -D__HIP_PLATFORM_AMD__=1 -DUSE_ROCM=1 -DTORCH_EXTENSION_NAME=gsr_ref_C -DTORCH_API_INCLUDE_EXTENSION_H $TINC -I/opt/rocm/include -I$REF -I$TMP"
+g++ $HOST -x c++ -c "$TMP/rasterize_points.hip" -o "$TMP/rp.o"
+g++ $HOST -c "$TMP/ext.cpp" -o "$TMP/ext.o"
 wait %1 && wait %2
-echo "built $OUT/libgsr_ref.so, libgsr_ref_fma.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgsr_ref.so" "$TMP"/{forward,backward,rasterizer_impl,simple_knn,shim}_off.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgsr_ref_fma.so" "$TMP"/{forward,backward,rasterizer_impl,simple_knn,shim}_fma.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/gsr_ref_C.so" "$TMP"/{forward,backward,rasterizer_impl}_off.o "$TMP/rp.o" "$TMP/ext.o" \
+    -L"$TLIB" -lc10 -lc10_hip -ltorch -ltorch_cpu -ltorch_hip -ltorch_python -Wl,-rpath,"$TLIB"
+echo "built $OUT/libgsr_ref.so, libgsr_ref_fma.so, gsr_ref_C.so"

@@ -197,3 +197,61 @@ def test_contracted_reference_build_census(syn, name):
     assert out["radii_differ"] <= max(2, P // 100000)
     assert out["tiles_touched_differ"] <= max(2, P // 100000)
     assert out["color_pixels_beyond_1e-4"] <= max(4, a.color[0].size // 20000)
+
+
+@pytest.mark.parametrize("mode", ["rgb", "sh"])
+def test_python_operator_binding_argument_for_argument(gsr, syn, mode):
+    """The `_C` module of the Python operator: the reference's own binding (Thirdparty/diff_gaussian_rasterization/ext.cpp:15-19, rasterize_points.cu — built
+    against this image's libtorch as oracle/_ref/gsr_ref_C.so) and the library's (`gsorb-slam_amd/diff_gaussian_rasterization/_C.so`) are called with the SAME
+    positional arguments — rasterize_gaussians (18 of them), rasterize_gaussians_backward (20), mark_visible (3) — and return tuples of the same arity, shapes and
+    dtypes with the same values: num_rendered, radii, the median depth equal; colour and the eight gradient tensors inside the 1e-4 bars. (The three state
+    buffers are each implementation's own layout: what crosses forward -> backward is passed back to the module that made it.)"""
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "oracle", "_ref"))
+    sys.path.insert(0, os.path.join(here, "gsorb-slam_amd"))
+    if not os.path.exists(os.path.join(here, "oracle", "_ref", "gsr_ref_C.so")):
+        pytest.skip("oracle/_ref/gsr_ref_C.so is not built")
+    import gsr_ref_C
+    from diff_gaussian_rasterization import _C
+    kw = dict(P=3000, cam=ODD, mode="sh", mult=3.0, bg=(0.3, 0.5, 0.7), frac_behind=0.1, frac_offscreen=0.3) if mode == "sh" else dict(P=10000, cam=syn.TUM1, mult=2.0)
+    sc = _build(syn, **kw)
+    o, fo = oracle.forward_scene(sc)
+    mc, _ = o.margins(fo)
+    ok = mc >= EPS_MARGIN
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device="cuda")
+    empty = torch.empty(0, device="cuda")
+    cam = sc.cam
+    sh = t(sc.shs) if sc.shs is not None else empty
+    colors = empty if sc.shs is not None else t(sc.colors)
+    fwd_args = (t(cam.bg), t(sc.means3D), colors, t(sc.opacities), t(sc.scales), t(sc.rotations), float(cam.scale_modifier), empty, t(cam.viewmatrix), t(cam.projmatrix),
+                float(cam.tanfovx), float(cam.tanfovy), int(cam.height), int(cam.width), sh, int(cam.sh_degree), t(cam.campos), False)
+    a, b = _C.rasterize_gaussians(*fwd_args), gsr_ref_C.rasterize_gaussians(*fwd_args)
+    torch.cuda.synchronize()
+    assert len(a) == len(b) == 7 and a[0] == b[0] == fo.num_rendered
+    for i in (1, 2, 6):                                           # colour [3,H,W], radii [P] int32, depth [1,H,W]
+        assert a[i].shape == b[i].shape and a[i].dtype == b[i].dtype and a[i].device == b[i].device, i
+    for i in (3, 4, 5):                                           # the three state buffers: byte tensors on the device
+        assert a[i].dtype == b[i].dtype == torch.uint8 and a[i].is_cuda and a[i].dim() == b[i].dim() == 1
+    assert torch.equal(a[2], b[2])
+    okt = torch.tensor(ok, device="cuda")
+    assert float((a[1] - b[1]).abs()[:, okt].max()) <= TOL * max(1.0, float(b[1].abs().max()))
+    assert torch.equal(a[6][0][okt], b[6][0][okt])
+    g = t(sc.dL_dpix * ok[None])
+    bwd = lambda out: (fwd_args[0], fwd_args[1], out[2], fwd_args[2], fwd_args[4], fwd_args[5], fwd_args[6], fwd_args[7], fwd_args[8], fwd_args[9], fwd_args[10],
+                       fwd_args[11], g, fwd_args[14], fwd_args[15], fwd_args[16], out[3], out[0], out[4], out[5])
+    ga, gb = _C.rasterize_gaussians_backward(*bwd(a)), gsr_ref_C.rasterize_gaussians_backward(*bwd(b))
+    torch.cuda.synchronize()
+    assert len(ga) == len(gb) == 8
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+    worst = {}
+    for n, x, y in zip(names, ga, gb):
+        assert x.shape == y.shape and x.dtype == y.dtype, (n, x.shape, y.shape)
+        if y.numel() == 0:
+            continue
+        e, m = rel_err(x.cpu().numpy(), y.cpu().numpy()), mixed_err(x.cpu().numpy(), y.cpu().numpy())
+        worst[n] = e
+        assert e <= TOL and m <= 1.0, (n, e, m)
+    va, vb = _C.mark_visible(fwd_args[1], fwd_args[8], fwd_args[9]), gsr_ref_C.mark_visible(fwd_args[1], fwd_args[8], fwd_args[9])
+    assert va.dtype == vb.dtype and torch.equal(va, vb)
+    print("\n_C against the reference's _C (%s): worst gradient %.1e" % (mode, max(worst.values())))
