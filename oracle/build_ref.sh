@@ -13,6 +13,7 @@
 #        libgsr_ref.so      -ffp-contract=off : the arithmetic as the source states it (what the CPU oracle and the HIP library hold)
 #        libgsr_ref_fma.so  hipcc's default contraction (fast): what a default nvcc build (--fmad=true, the reference's CMake) is like
 #        gsr_ref_C.so       the reference's Python-operator binding (rasterize_points.cu + ext.cpp, g++ against this image's libtorch) on the first build's objects
+#        dropin_ref.bin     the reference's C++ host layer (src/Rasterizer.cu, spatial.cu) under tests/cpp/dropin_main.cpp, a caller written against its API
 #   3. the scratch directory is removed: no text of the reference stays in the tree; oracle/_ref/ is git-ignored, the .so files travel
 #      to the GPU box with the snapshot.
 # Needs /root/reference (this container); on the GPU box the prebuilt files are used.
@@ -22,7 +23,7 @@ REF=${GSR_REFERENCE:-/root/reference}/Thirdparty/diff_gaussian_rasterization
 SRC=$REF/cuda_rasterizer
 OUT=$HERE/_ref
 [ -d "$SRC" ] || { echo "build_ref.sh: $SRC not found (the prebuilt oracle/_ref/*.so are used as they are)"; exit 0; }
-if [ -f "$OUT/libgsr_ref.so" ] && [ -f "$OUT/libgsr_ref_fma.so" ] && [ -f "$OUT/gsr_ref_C.so" ] && [ "$OUT/libgsr_ref.so" -nt "$HERE/ref_shim.hip" ] && [ "$OUT/libgsr_ref.so" -nt "$HERE/build_ref.sh" ] && [ "$1" != "--force" ]; then exit 0; fi
+if [ -f "$OUT/libgsr_ref.so" ] && [ -f "$OUT/libgsr_ref_fma.so" ] && [ -f "$OUT/gsr_ref_C.so" ] && [ -f "$OUT/dropin_ref.bin" ] && [ "$OUT/dropin_ref.bin" -nt "$HERE/../tests/cpp/dropin_main.cpp" ] && [ "$OUT/libgsr_ref.so" -nt "$HERE/ref_shim.hip" ] && [ "$OUT/libgsr_ref.so" -nt "$HERE/build_ref.sh" ] && [ "$1" != "--force" ]; then exit 0; fi
 TMP=$OUT/.scratch
 rm -rf "$TMP" && mkdir -p "$TMP"
 trap 'rm -rf "$TMP"' EXIT
@@ -64,9 +65,25 @@ TINC=$(echo "$TORCH" | head -1); TLIB=$(echo "$TORCH" | tail -1)
 HOST="-std=c++17 -O2 -fPIC -w -D__HIP_PLATFORM_AMD__=1 -DUSE_ROCM=1 -DTORCH_EXTENSION_NAME=gsr_ref_C -DTORCH_API_INCLUDE_EXTENSION_H $TINC -I/opt/rocm/include -I$REF -I$TMP"
 g++ $HOST -x c++ -c "$TMP/rasterize_points.hip" -o "$TMP/rp.o"
 g++ $HOST -c "$TMP/ext.cpp" -o "$TMP/ext.o"
+# the C++ host layer GSORB-SLAM's Render.cc calls (src/Rasterizer.cu, include/Rasterizer.cuh, src/spatial.cu, include/spatial.h: host code on torch tensors) and
+# ONE caller written against its API (tests/cpp/dropin_main.cpp, this repository's) -> dropin_ref.bin; the same caller compiled against this repository's host
+# layer is tests/cpp/dropin_hip.bin (tests/cpp/build.py)
+ROOTREF=${GSR_REFERENCE:-/root/reference}
+mkdir -p "$TMP/host"
+for f in src/Rasterizer.cu include/Rasterizer.cuh src/spatial.cu include/spatial.h; do
+    /opt/rocm/bin/hipify-perl "$ROOTREF/$f" > "$TMP/host/$(basename $f)" 2>/dev/null
+    sed -i -e '/#include ""/d' "$TMP/host/$(basename $f)"
+done
+HOST2="-std=c++17 -O1 -fPIC -w -D__HIP_PLATFORM_AMD__=1 -DUSE_ROCM=1 $TINC -I/opt/rocm/include -I$TMP/host -I$TMP -I$ROOTREF -I$REF"
+g++ $HOST2 -x c++ -c "$TMP/host/Rasterizer.cu" -o "$TMP/host/Rasterizer.o"
+g++ $HOST2 -x c++ -c "$TMP/host/spatial.cu" -o "$TMP/host/spatial.o"
+g++ $HOST2 '-DDROPIN_HEADER="Rasterizer.cuh"' -c "$HERE/../tests/cpp/dropin_main.cpp" -o "$TMP/host/dropin.o"
 wait %1 && wait %2
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgsr_ref.so" "$TMP"/{forward,backward,rasterizer_impl,simple_knn,shim}_off.o
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgsr_ref_fma.so" "$TMP"/{forward,backward,rasterizer_impl,simple_knn,shim}_fma.o
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/gsr_ref_C.so" "$TMP"/{forward,backward,rasterizer_impl}_off.o "$TMP/rp.o" "$TMP/ext.o" \
     -L"$TLIB" -lc10 -lc10_hip -ltorch -ltorch_cpu -ltorch_hip -ltorch_python -Wl,-rpath,"$TLIB"
-echo "built $OUT/libgsr_ref.so, libgsr_ref_fma.so, gsr_ref_C.so"
+$HIPCC --offload-arch=gfx950 -fPIC -o "$OUT/dropin_ref.bin" "$TMP"/{forward,backward,rasterizer_impl,simple_knn}_off.o "$TMP/host/Rasterizer.o" "$TMP/host/spatial.o" "$TMP/host/dropin.o" \
+    -L"$TLIB" -lc10 -lc10_hip -ltorch -ltorch_cpu -ltorch_python -Wl,--no-as-needed -ltorch_hip -Wl,--as-needed -Wl,-rpath,"$TLIB" $(python3-config --ldflags --embed)
+# (torch/extension.h, which the reference's header includes, brings pybind11 in: the executable links libpython)
+echo "built $OUT/libgsr_ref.so, libgsr_ref_fma.so, gsr_ref_C.so, dropin_ref.bin"

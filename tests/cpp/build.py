@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 EXT = os.path.join(ROOT, "gsorb-slam_amd", "torch_ext")
 OUT = os.path.join(HERE, "render_api_test.bin")
 LOOP_OUT = os.path.join(HERE, "slam_loop_main.bin")
+DROPIN_OUT = os.path.join(HERE, "dropin_hip.bin")
 
 
 def _ext():
@@ -20,7 +21,7 @@ def _ext():
     return m
 
 
-def _build(src, out, force):
+def _build(src, out, force, extra=()):
     be = _ext()
     lib = be.build_lib()
     deps = [src, lib] + be.HEADERS
@@ -28,7 +29,7 @@ def _build(src, out, force):
         return out
     tlib, cflags = be._flags()
     cflags = [f for f in cflags if f not in ("-O2", "-fPIC")] + ["-O1"]
-    subprocess.run(["g++", *cflags, src, "-o", out] + be.link_flags(tlib), check=True)
+    subprocess.run(["g++", *cflags, *extra, src, "-o", out] + be.link_flags(tlib), check=True)
     return out
 
 
@@ -40,6 +41,13 @@ def build_loop(force=False):
     return _build(os.path.join(HERE, "slam_loop_main.cpp"), LOOP_OUT, force)
 
 
+def build_dropin(force=False):
+    """the caller written against the reference's C++ API (dropin_main.cpp), compiled against THIS repository's host layer; oracle/build_ref.sh compiles
+    the same file against the reference's"""
+    return _build(os.path.join(HERE, "dropin_main.cpp"), DROPIN_OUT, force, ['-DDROPIN_HEADER="Rasterizer.h"', f"-I{EXT}"])
+
+
 if __name__ == "__main__":
     print(build("--force" in sys.argv))
     print(build_loop("--force" in sys.argv))
+    print(build_dropin("--force" in sys.argv))

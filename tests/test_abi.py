@@ -134,4 +134,4 @@ def test_reference_build_loads_and_exports_its_entry_points():
         for name in ("gsref_state_new", "gsref_state_free", "gsref_forward", "gsref_backward", "gsref_stage", "gsref_time", "gsref_mark_visible", "gsref_visible_filter", "gsref_dist2"):
             assert hasattr(lib, name), name
     # the recipe leaves no text of the reference behind
-    assert sorted(os.listdir(os.path.join(ROOT, "oracle", "_ref"))) == ["gsr_ref_C.so", "libgsr_ref.so", "libgsr_ref_fma.so"]
+    assert sorted(os.listdir(os.path.join(ROOT, "oracle", "_ref"))) == ["dropin_ref.bin", "gsr_ref_C.so", "libgsr_ref.so", "libgsr_ref_fma.so"]

@@ -255,3 +255,72 @@ def test_python_operator_binding_argument_for_argument(gsr, syn, mode):
     va, vb = _C.mark_visible(fwd_args[1], fwd_args[8], fwd_args[9]), gsr_ref_C.mark_visible(fwd_args[1], fwd_args[8], fwd_args[9])
     assert va.dtype == vb.dtype and torch.equal(va, vb)
     print("\n_C against the reference's _C (%s): worst gradient %.1e" % (mode, max(worst.values())))
+
+
+def _read_blocks(path):
+    import struct
+    out, b = {}, open(path, "rb").read()
+    i = 0
+    while i < len(b):
+        (ln,) = struct.unpack_from("<i", b, i); i += 4
+        name = b[i:i + ln].decode(); i += ln
+        kind, n = struct.unpack_from("<iq", b, i); i += 12
+        out[name] = np.frombuffer(b, dtype=np.float32 if kind == 0 else np.int32, count=n, offset=i).copy(); i += 4 * n
+    return out
+
+
+@pytest.mark.parametrize("mode", ["rgb", "sh"])
+def test_one_cpp_caller_against_both_host_layers(gsr, syn, tmp_path, mode):
+    """tests/cpp/dropin_main.cpp is written once against the reference's C++ API as src/Render.cc uses it (GaussianRasterizationSettings,
+    GaussianRasterizer::forward / mark_visible / Visable, autograd through the render, distCUDA2; include/Rasterizer.cuh:76-382) and compiled twice without an
+    #ifdef: against this repository's host layer (tests/cpp/dropin_hip.bin) and against the reference's own src/Rasterizer.cu + spatial.cu + rasterizer
+    (oracle/_ref/dropin_ref.bin). Same scene file in, the two output files compared: radii, median depth, visibility, filter radii equal; colour, the gradients
+    autograd hands back for every leaf (means3D, means2D, opacities, scales, rotations, colours or SH) and distCUDA2 inside the bars; the same
+    std::invalid_argument for the same bad argument combinations."""
+    import struct
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe_hip, exe_ref = os.path.join(here, "tests", "cpp", "dropin_hip.bin"), os.path.join(here, "oracle", "_ref", "dropin_ref.bin")
+    if not os.path.exists(exe_ref):
+        pytest.skip("oracle/_ref/dropin_ref.bin is not built")
+    assert os.path.exists(exe_hip), "tests/cpp/dropin_hip.bin is missing: run __graft_entry__.build()"
+    kw = dict(P=3000, cam=ODD, mode="sh", mult=3.0, Tcw=None, bg=(0.3, 0.5, 0.7), frac_behind=0.1, frac_offscreen=0.3) if mode == "sh" else dict(P=10000, cam=syn.TUM1, mult=2.0)
+    sc = _build(syn, **kw)
+    cam = sc.cam
+    o, fo = oracle.forward_scene(sc)
+    mc, md = o.margins(fo)
+    ok = mc >= EPS_MARGIN
+    G = (sc.dL_dpix * ok[None]).astype(np.float32)
+    P = len(sc.means3D)
+    M = 0 if sc.shs is None else sc.shs.shape[1]
+    scene = str(tmp_path / "scene.bin")
+    with open(scene, "wb") as f:
+        f.write(struct.pack("<5i3f", P, M, cam.width, cam.height, cam.sh_degree, cam.tanfovx, cam.tanfovy, cam.scale_modifier))
+        for a in (cam.bg, cam.viewmatrix, cam.projmatrix, cam.campos, sc.means3D, sc.opacities, sc.scales, sc.rotations, sc.colors if M == 0 else sc.shs, G, sc.means3D):
+            f.write(np.ascontiguousarray(a, np.float32).tobytes())
+    outs = {}
+    for name, exe in (("hip", exe_hip), ("ref", exe_ref)):
+        out = str(tmp_path / (name + ".out"))
+        r = subprocess.run([exe, scene, out], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (name, r.stdout[-500:], r.stderr[-2000:])
+        outs[name] = _read_blocks(out)
+    a, b = outs["hip"], outs["ref"]
+    assert set(a) == set(b)
+    for k in ("radii", "visible", "filter_radii", "invalid_argument_checks"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert int(b["invalid_argument_checks"][0]) == 7                       # all three bad combinations throw, on both sides
+    H, W = cam.height, cam.width
+    assert np.abs(a["color"] - b["color"]).reshape(3, H, W)[:, ok].max() <= TOL * max(1.0, float(np.abs(b["color"]).max()))
+    okd = md >= EPS_MARGIN
+    assert np.array_equal(a["depth"].reshape(H, W)[okd], b["depth"].reshape(H, W)[okd])
+    worst = {}
+    for k in sorted(a):
+        if k.startswith("d_") or k == "dist2":
+            assert a[k].shape == b[k].shape, k
+            with np.errstate(over="ignore", invalid="ignore"):
+                fin = np.isfinite(b[k])
+                assert np.array_equal(fin, np.isfinite(a[k])), k
+                e, m = rel_err(a[k][fin], b[k][fin]), mixed_err(a[k][fin], b[k][fin])
+            worst[k] = e
+            assert e <= TOL and m <= 1.0, (k, e, m)
+    print("\none C++ caller, two host layers (%s): %s" % (mode, {k: "%.1e" % v for k, v in worst.items()}))
