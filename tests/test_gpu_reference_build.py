@@ -324,3 +324,29 @@ def test_one_cpp_caller_against_both_host_layers(gsr, syn, tmp_path, mode):
             worst[k] = e
             assert e <= TOL and m <= 1.0, (k, e, m)
     print("\none C++ caller, two host layers (%s): %s" % (mode, {k: "%.1e" % v for k, v in worst.items()}))
+
+
+def test_random_frames_against_the_reference_kernels(gsr, syn):
+    """scripts/fuzz_ref.py as a test: 200 random frames (sizes, splat counts, scales, colour modes, poses, culling as tests/test_gpu_fuzz.py draws them; another
+    seed) through the HIP library and through the reference's own kernels, no CPU oracle in the loop. Index stages and projected geometry bit-exact in every
+    frame (asserted inside run_case); images within 1e-4 on the pixels where both renders took the same branches; gradients within 1e-4 — or, on the one
+    documented kind of ill-conditioned frame (depth colours at scale x16, lists of tens of thousands of entries: tests/test_gpu_fuzz.py), no further from the
+    EXACT value of the reference's formulas than the reference's own fp32 kernels are (x1.25) or than 1e-4. The 1 000-frame sweep of the same script:
+    profiles/r06_fuzz_ref_1000.json."""
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(here, "scripts"))
+    import fuzz_ref
+    seed, ill = 77, []
+    rows = [fuzz_ref.run_case(gsr, syn, c, seed) for c in fuzz_ref.configs(200, seed)]
+    for x in rows:
+        assert x["image"] <= TOL, x
+        assert x["depth_pixels_differ"] <= 2, x
+        assert x["branch_pixels"] <= 2e-3, x
+        if x["worst_grad"] > TOL:
+            c = x["ill_conditioned"]
+            assert c["hip_vs_exact"] <= max(TOL, 1.25 * c["reference_vs_exact"]), x
+            ill.append((x["it"], x["worst_grad"], c))
+    print("\n200 random frames against the reference's kernels: %d tile instances, image worst %.1e, gradient worst %.1e, ill-conditioned frames %s"
+          % (sum(x["R"] for x in rows), max(x["image"] for x in rows), max(x["worst_grad"] for x in rows), ill))
+    assert len(ill) <= 3
