@@ -27,7 +27,9 @@ among them what ONE RANK of configs 4 and 5 runs (`rank-250k-*`: a k-d cell of t
 The JSON line also carries
   roofline     : the dominant kernel (backward blend) against the HBM roofline, timed live
                  with HIP events recorded by the library on the launching stream
-  cpu_baseline : the CPU oracle ("port", OpenMP over all host cores) on a bounded sample
+  cpu_baseline : the CPU oracle ("port", OpenMP over all host cores) on a bounded sample; beside it, when oracle/_ref is built (oracle/build_ref.sh),
+                 `reference_kernels_on_this_gpu`: the reference's own CUDA kernels translated by hipify-perl and compiled by hipcc, timed on this GPU
+  parity       : the timed scene against the oracle and (`against_reference_kernels`) against those kernels — the metric's "PSNR vs ref"
 """
 import argparse
 import ctypes as C
@@ -145,7 +147,29 @@ def parity_block(gsr, sc, s, ws, ins, dev):
     for n in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dscales", "dL_drotations"):
         a, r = getattr(gr, n).cpu().numpy().astype(np.float64), np.asarray(getattr(b, n), np.float64)
         worst[n] = float(np.abs(a - r).max() / max(np.abs(r).max(), 1e-30))
-    return {"against": "oracle/libgsr_oracle_omp.so (CPU restatement of the reference path) on the timed scene",
+    vs_ref = None
+    try:     # the metric's "PSNR vs ref" against the REFERENCE's own kernels on this GPU, when oracle/_ref is built (oracle/build_ref.sh)
+        from oracle import ref
+        if ref.available():
+            rr, fr = ref.forward_scene(sc)
+            br = rr.backward(g_in)
+            vis = fr.radii > 0
+            geo = sum(int((d[k].reshape(len(vis), -1)[vis].view(np.uint32) != fr.stages[k].reshape(len(vis), -1)[vis].view(np.uint32)).sum()) for k in ("means2D", "depths", "conic_opacity"))
+            idx_r = int((st.radii.cpu().numpy() != fr.radii).sum()) + int((d["point_list"] != fr.stages["point_list"]).sum()) + int((d["ranges"] != fr.stages["ranges"]).sum()) \
+                + int((d["point_list_keys"] != fr.stages["keys_sorted"]).sum()) + int(R != fr.num_rendered)
+            wr = {n: float(np.abs(getattr(gr, n).cpu().numpy().astype(np.float64) - np.asarray(getattr(br, n), np.float64)).max() / max(np.abs(getattr(br, n)).max(), 1e-30))
+                  for n in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dscales", "dL_drotations")}
+            vs_ref = {"against": "oracle/_ref/libgsr_ref.so: CudaRasterizer::Rasterizer::forward / backward themselves (the reference's .cu files translated by hipify-perl at "
+                                 "build time, hipcc -ffp-contract=off) on the timed scene, on this GPU",
+                      "index_mismatches": idx_r, "indices_compared": "radii, ranges, sorted keys, sorted point_list, num_rendered",
+                      "projected_geometry_values_that_differ": geo, "geometry_compared": "means2D, depths, conic + opacity of every visible splat, bit for bit",
+                      "psnr_vs_ref_db": psnr(float((((col - fr.color) ** 2)[:, ok]).mean())), "psnr_vs_ref_db_all_pixels": psnr(float(((col - fr.color) ** 2).mean())),
+                      "max_abs_colour_err": float(np.abs(col - fr.color)[:, ok].max()), "max_grad_rel_err": max(wr.values()), "grad_rel_err": wr,
+                      "oracle_vs_ref_index_mismatches": int((f.radii != fr.radii).sum()) + int((f.stages["point_list"] != fr.stages["point_list"]).sum())}
+    except Exception as e:
+        vs_ref = {"error": repr(e)}
+    return {"against_reference_kernels": vs_ref,
+            "against": "oracle/libgsr_oracle_omp.so (CPU restatement of the reference path) on the timed scene",
             "bar": "the plain one: every gradient tensor within 1e-4 of the fp32 oracle (tensor scale), colours within 1e-4, integer stages bit-exact — "
                    "no appeal to the exact-state evaluation the randomised sweep allows its one ill-conditioned case (tests/test_gpu_fuzz.py, DESIGN.md section 2)",
             "passes_plain_1e-4_bar": bool(idx == 0 and max(worst.values()) <= 1e-4 and float(np.abs(col - f.color)[:, ok].max()) <= 1e-4),
