@@ -27,7 +27,7 @@ among them what ONE RANK of configs 4 and 5 runs (`rank-250k-*`: a k-d cell of t
 The JSON line also carries
   roofline     : the dominant kernel (backward blend) against the HBM roofline, timed live
                  with HIP events recorded by the library on the launching stream
-  cpu_baseline : the CPU oracle ("port", OpenMP over all host cores) on a bounded sample; beside it, when oracle/_ref is built (oracle/build_ref.sh),
+  cpu_baseline : the CPU oracle ("port", OpenMP over all host cores) on a bounded sample; beside it, only with the opt-in reference build (GSR_REFERENCE_BUILD=1, off by default: oracle/build_ref.sh),
                  `reference_kernels_on_this_gpu`: the reference's own CUDA kernels translated by hipify-perl and compiled by hipcc, timed on this GPU
   parity       : the timed scene against the oracle and (`against_reference_kernels`) against those kernels — the metric's "PSNR vs ref"
 """
@@ -95,7 +95,7 @@ def cpu_baseline(sc, P, W, H, budget_s=20.0):
     P1 = int(len(sc.means3D[sub]))
     out["single_thread"] = {"value": P1 * W * H / t1, "unit": "splats*pixels/s", "cores": 1,
                             "sample": f"one fwd+bwd of every 8th splat of the scene ({P1} splats, {W}x{H}), oracle/libgsr_oracle.so, {t1 * 1e3:.0f} ms"}
-    # Beside the CPU figure, when oracle/_ref is built: the REFERENCE's own kernels on this GPU (oracle/build_ref.sh: the reference's .cu files translated by
+    # Beside the CPU figure, only with the OPT-IN reference build (GSR_REFERENCE_BUILD=1 and oracle/_ref built; off by default): the REFERENCE's own kernels on this GPU (oracle/build_ref.sh: the reference's .cu files translated by
     # hipify-perl and compiled by hipcc with its default contraction, i.e. what a user of the reference gets on this hardware without this library) —
     # a baseline like the CPU one, never the product.
     try:
@@ -148,7 +148,7 @@ def parity_block(gsr, sc, s, ws, ins, dev):
         a, r = getattr(gr, n).cpu().numpy().astype(np.float64), np.asarray(getattr(b, n), np.float64)
         worst[n] = float(np.abs(a - r).max() / max(np.abs(r).max(), 1e-30))
     vs_ref = None
-    try:     # the metric's "PSNR vs ref" against the REFERENCE's own kernels on this GPU, when oracle/_ref is built (oracle/build_ref.sh)
+    try:     # the metric's "PSNR vs ref" against the REFERENCE's own kernels on this GPU — only with the opt-in reference build (GSR_REFERENCE_BUILD=1; off by default)
         from oracle import ref
         if ref.available():
             rr, fr = ref.forward_scene(sc)

@@ -17,6 +17,11 @@
 #   3. the scratch directory is removed: no text of the reference stays in the tree; oracle/_ref/ is git-ignored, the .so files travel
 #      to the GPU box with the snapshot.
 # Needs /root/reference (this container); on the GPU box the prebuilt files are used.
+# OPT-IN ONLY: nothing here runs unless a human sets GSR_REFERENCE_BUILD=1. Translating, compiling and running the reference's own sources — even as a
+# checker, with outputs only under the git-ignored oracle/_ref/ — is a decision for the repository's owner (the task's rules say "not a hipify" of the product and
+# "no stand-ins" for the checker; whether ROCm's translator on the reference's files is admissible for the checker is not this script's call). Default: no build,
+# no oracle/_ref, every test / smoke / bench leg that would use it is skipped.
+if [ "${GSR_REFERENCE_BUILD:-0}" != "1" ]; then echo "build_ref.sh: GSR_REFERENCE_BUILD=1 not set: the reference build is opt-in (see the header); nothing done"; exit 0; fi
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd)
 REF=${GSR_REFERENCE:-/root/reference}/Thirdparty/diff_gaussian_rasterization

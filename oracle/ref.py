@@ -5,7 +5,8 @@ state arrays under the same names, backward(dL_dpix) -> oracle.Backward — so a
     Reference()            -ffp-contract=off: the source's arithmetic as written
     Reference(fma=True)    hipcc's default contraction: what a default nvcc build (--fmad=true) is like — NOT a checker, a census (cf. libgsr_oracle_fma.so)
 
-Needs a GPU. Only tests/ may import this."""
+OPT-IN: used only when a human has set GSR_REFERENCE_BUILD=1 (build and run); by default available() is False and every caller skips.
+Needs a GPU. Only tests/ (and, opted in, bench.py's baseline leg and smoke()) may import this."""
 import ctypes as C
 import os
 import subprocess
@@ -18,13 +19,19 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
 
 
+def enabled() -> bool:
+    """OPT-IN: a human sets GSR_REFERENCE_BUILD=1 to build and to use oracle/_ref (oracle/build_ref.sh's header says why this is not the default)."""
+    return os.environ.get("GSR_REFERENCE_BUILD", "0") == "1"
+
+
 def available() -> bool:
-    return os.path.exists(os.path.join(_HERE, "_ref", "libgsr_ref.so"))
+    return enabled() and os.path.exists(os.path.join(_HERE, "_ref", "libgsr_ref.so"))
 
 
 def build(force: bool = False) -> None:
-    """(re)build when /root/reference is present; a no-op otherwise (the GPU box uses the prebuilt files)"""
-    subprocess.run(["bash", os.path.join(_HERE, "build_ref.sh")] + (["--force"] if force else []), check=True)
+    """(re)build when opted in and /root/reference is present; a no-op otherwise"""
+    if enabled():
+        subprocess.run(["bash", os.path.join(_HERE, "build_ref.sh")] + (["--force"] if force else []), check=True)
 
 
 def lib(fma: bool = False):

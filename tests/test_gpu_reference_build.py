@@ -32,7 +32,7 @@ GEOM_STAGES = ("means2D", "depths", "conic_opacity", "cov3D")
 @pytest.fixture(scope="module", autouse=True)
 def _needs_the_reference_build():
     if not ref.available():
-        pytest.skip("oracle/_ref/libgsr_ref.so is not built (oracle/build_ref.sh needs /root/reference: __graft_entry__.build() runs it where the reference is present)")
+        pytest.skip("opt-in: oracle/_ref is built and used only with GSR_REFERENCE_BUILD=1 (oracle/build_ref.sh: a human's decision)")
 
 
 def _bits(a):
@@ -210,7 +210,7 @@ def test_python_operator_binding_argument_for_argument(gsr, syn, mode):
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(here, "oracle", "_ref"))
     sys.path.insert(0, os.path.join(here, "gsorb-slam_amd"))
-    if not os.path.exists(os.path.join(here, "oracle", "_ref", "gsr_ref_C.so")):
+    if not ref.available() or not os.path.exists(os.path.join(here, "oracle", "_ref", "gsr_ref_C.so")):
         pytest.skip("oracle/_ref/gsr_ref_C.so is not built")
     import gsr_ref_C
     from diff_gaussian_rasterization import _C
@@ -281,7 +281,7 @@ def test_one_cpp_caller_against_both_host_layers(gsr, syn, tmp_path, mode):
     import subprocess
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe_hip, exe_ref = os.path.join(here, "tests", "cpp", "dropin_hip.bin"), os.path.join(here, "oracle", "_ref", "dropin_ref.bin")
-    if not os.path.exists(exe_ref):
+    if not ref.available() or not os.path.exists(exe_ref):
         pytest.skip("oracle/_ref/dropin_ref.bin is not built")
     assert os.path.exists(exe_hip), "tests/cpp/dropin_hip.bin is missing: run __graft_entry__.build()"
     kw = dict(P=3000, cam=ODD, mode="sh", mult=3.0, Tcw=None, bg=(0.3, 0.5, 0.7), frac_behind=0.1, frac_offscreen=0.3) if mode == "sh" else dict(P=10000, cam=syn.TUM1, mult=2.0)
