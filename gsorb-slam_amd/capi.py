@@ -46,7 +46,7 @@ class ForwardArgs(C.Structure):
                 ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int),
                 ("out_color", C.c_void_p), ("out_depth", C.c_void_p), ("radii", C.c_void_p),
                 ("profile_events", C.POINTER(C.c_void_p)), ("band_y0", C.c_int), ("band_y1", C.c_int),
-                ("out_ds", C.c_void_p), ("pre_Tcw", C.c_void_p), ("means_cam_out", C.c_void_p), ("raw", C.c_void_p)]
+                ("out_ds", C.c_void_p), ("pre_Tcw", C.c_void_p), ("means_cam_out", C.c_void_p), ("raw", C.c_void_p), ("out_sil", C.c_void_p)]
 
 
 class RawOutputs(C.Structure):
@@ -316,9 +316,10 @@ def _prep(s: Settings, means3D, opacities, colors, shs, scales, rotations, cov3D
 
 
 def forward(s: Settings, means3D, opacities, colors=None, shs=None, scales=None, rotations=None,
-            cov3D_precomp=None, band=(0, 0), out=None, dual: bool = False) -> ForwardState:
+            cov3D_precomp=None, band=(0, 0), out=None, dual: bool = False, out_sil=None) -> ForwardState:
     """gsr_forward with torch-owned blobs (the reference's resizeFunctional, src/Rasterizer.cu:127-134).
-    dual: also blend the depth / silhouette channels in the same pass (state.ds [2,H,W]; include/gsr.h: out_ds)."""
+    dual: also blend the depth / silhouette channels in the same pass (state.ds [2,H,W]; include/gsr.h: out_ds).
+    out_sil [H,W]: the plain forward also stores the silhouette 1 - final T there (include/gsr.h: out_sil; not with dual)."""
     L = lib()
     dev, ins = _prep(s, means3D, opacities, colors, shs, scales, rotations, cov3D_precomp)
     H, W = s.image_height, s.image_width
@@ -339,6 +340,8 @@ def forward(s: Settings, means3D, opacities, colors=None, shs=None, scales=None,
     cbs = [mk("geom"), mk("binning"), mk("image")]
     a, P, M = _fwd_args(s, ins["means3D"], ins["opacities"], ins["colors"], ins["shs"], ins["scales"],
                         ins["rotations"], ins["cov3D"], color, depth, radii, None, band, ds)
+    if out_sil is not None:
+        a.out_sil = _p(out_sil)
     with torch.cuda.device(dev):
         R = _check(L.gsr_forward(C.byref(a), cbs[0], None, cbs[1], None, cbs[2], None, _stream()))
     return ForwardState(s, P, M, R, ins, color, depth, radii[:P], blobs["geom"], blobs["binning"],

@@ -65,6 +65,7 @@ int check_forward(const gsr_forward_args* a)
     if (has_sh && (a->M <= 0 || a->D < 0 || a->D > 3 || (a->D + 1) * (a->D + 1) > a->M || !a->cam_pos)) return GSR_EINVAL;
     const bool has_sr = a->scales != nullptr && a->rotations != nullptr, has_cov = a->cov3D_precomp != nullptr;
     if (has_sr == has_cov) return GSR_EINVAL; // exactly one (:313-316)
+    if (a->out_sil && a->out_ds) return GSR_EINVAL; // (the fused pair renders the silhouette itself: out_ds[1])
     if (a->pre_Tcw && !a->means_cam_out) return GSR_EINVAL; // (the camera-frame means must go somewhere: the backward takes them)
     if (a->raw && (!has_sr || !a->raw->opacities || !a->raw->scales || !a->raw->rotations)) return GSR_EINVAL;
     return GSR_OK;
@@ -126,10 +127,10 @@ int forward_tail(const gsr_forward_args* a, const GeomView& gv, const ImageView&
     const int Tb = (f.band_y1 - f.band_y0) * f.grid_x; // tiles of the band
     if (Tb > 0 && a->out_ds)
         GSR_LAUNCH((gsr::K_blend_fwd<GSR_ROWQ, true>), dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
-                           f.grid_x, Tb, f.band_y0 * f.grid_x, a->out_color, a->out_depth, P, a->out_ds);
+                           f.grid_x, Tb, f.band_y0 * f.grid_x, a->out_color, a->out_depth, P, a->out_ds, (float*)nullptr);
     else if (Tb > 0)
         GSR_LAUNCH((gsr::K_blend_fwd<GSR_ROWQ, false>), dim3(4 * Tb), dim3(64), 0, st, iv, bv, gv, a->background, a->width, a->height,
-                           f.grid_x, Tb, f.band_y0 * f.grid_x, a->out_color, a->out_depth, P, (float*)nullptr);
+                           f.grid_x, Tb, f.band_y0 * f.grid_x, a->out_color, a->out_depth, P, (float*)nullptr, a->out_sil);
     else // an empty band launches no blend kernel: clear the backward accumulators here
         GSR_HIP(hipMemsetAsync(gv.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
     GSR_LAUNCHED();
@@ -184,6 +185,7 @@ int forward_empty(const gsr_forward_args* a, char* geom, hipStream_t st)
     GSR_HIP(hipMemsetAsync(a->out_color, 0, N * 3 * sizeof(float), st));
     GSR_HIP(hipMemsetAsync(a->out_depth, 0, N * sizeof(float), st));
     if (a->out_ds) GSR_HIP(hipMemsetAsync(a->out_ds, 0, N * 2 * sizeof(float), st));
+    if (a->out_sil) GSR_HIP(hipMemsetAsync(a->out_sil, 0, N * sizeof(float), st));
     if (geom) GSR_HIP(hipMemsetAsync(geom, 0, sizeof(GeomHeader), st));
     return GSR_OK;
 }

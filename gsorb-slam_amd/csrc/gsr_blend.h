@@ -987,7 +987,7 @@ template <int Q, bool DUAL>
 __global__ void __launch_bounds__(64)
 K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, int W, int H,
                  int grid_x, int ntiles, int tile0, float* __restrict__ out_color, float* __restrict__ out_depth, int P,
-                 float* __restrict__ out_ds)
+                 float* __restrict__ out_ds, float* __restrict__ out_sil)
 {
     static_assert(Q == 64, "one parked entry per lane");
     // parked entries; slot Q is a dummy that no pixel can see (opacity 0, far away): the per-patch lists are padded with
@@ -1150,6 +1150,7 @@ K_blend_fwd(ImageView im, BinView bn, GeomView g, const float* __restrict__ bg, 
         out_color[2 * HW + pix] = C2 + T * bg[2];
         out_depth[pix] = Dp;
         if (DUAL) { out_ds[pix] = C3; out_ds[HW + pix] = C4; }
+        else if (out_sil) out_sil[pix] = 1.f - T; // (gsr_forward_args.out_sil: sum alpha T of this walk)
     }
     { // The backward accumulators (64 bytes per splat) must be zero when the forward is done. Clearing them is
       // pure memory traffic and this kernel is pure VALU work, so every block clears its share here for free

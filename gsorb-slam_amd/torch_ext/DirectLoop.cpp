@@ -501,7 +501,7 @@ void SlamLoop::grow_binning_(size_t capacity)
 }
 
 // the fused colour + depth / silhouette pass on the workspace (sync-free), and its backward
-void SlamLoop::direct_forward_(bool from_world, bool raw, float reg_limit, bool plain)
+void SlamLoop::direct_forward_(bool from_world, bool raw, float reg_limit, bool plain, bool plain_sil)
 {
     Direct& d = *d_;
     if (d.n == 0) { d.layers.zero_(); return; } // (an empty shard still takes part in the exchange: its layer is nothing)
@@ -519,6 +519,7 @@ void SlamLoop::direct_forward_(bool from_world, bool raw, float reg_limit, bool 
     a.rotations = raw ? f(unnorm_quat) : f(d.rots); a.raw = raw ? &ro : nullptr; a.viewmatrix = f(d.view); a.projmatrix = f(d.proj); a.cam_pos = f(d.campos);
     a.tan_fovx = s.tanfovx; a.tan_fovy = s.tanfovy; a.prefiltered = 0;
     a.out_color = f(d.out_color); a.out_depth = f(d.out_sur); a.radii = d.radii.data_ptr<int>(); a.out_ds = plain ? nullptr : f(d.out_ds); // (plain: the three colour channels only — a tracking iteration on the surface depth)
+    if (plain && plain_sil) a.out_sil = f(d.out_ds) + (size_t)H_ * W_; // (... and the silhouette 1 - T into its plane of the layer: what the sharded compositor needs of the pair)
     chk(gsr_forward_ws(&a, b(d.geom), b(d.binning), d.binning_bytes, b(d.image), stream_()), "gsr_forward_ws");
 }
 
@@ -749,6 +750,10 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
     const bool band = band_();
     // (round 6) unsharded, on the surface depth: the loss needs the colours, the median depth and a silhouette MASK — the plain forward renders the first two and
     // keeps the final transmittance per pixel (1 - T is the silhouette): no fused depth / silhouette channels, neither forwards nor backwards
+    // (sharded, on the surface depth: the compositor needs every layer's colours, silhouette and surface depth — the plain forward with gsr_forward_args.out_sil
+    // renders exactly those; the blended-depth plane of the layer is not written and not exchanged, zeroed once so that the compositor's unused depth channel stays finite)
+    const bool shard_plain = shard_ && band_() && cfg_.use_sur_depth && cfg_.fused_update && !std::getenv("GSR_EXP_TRACK_DUAL_BWD");
+    if (shard_plain) d.layers.slice(0, 3, 4).zero_();
     const bool plain_track = !shard_ && cfg_.use_sur_depth && d.n > 0 && !std::getenv("GSR_EXP_TRACK_DUAL_BWD"); // (an empty map renders nothing: no transmittance plane either — the zeroed layers then mask every pixel out)
     float* final_T = nullptr;
     if (plain_track) chk(gsr_transmittance_view(b(d.image), W_, H_, &final_T), "gsr_transmittance_view");
@@ -764,7 +769,7 @@ std::vector<double> SlamLoop::direct_track_(const LoopFrame& fr, const torch::Te
     double last_loss = 0.0;
     int step = 0;
     for (int it = 0; it < iters; it++) {
-        direct_forward_(true, false, 0.f, plain_track); // (the camera transform of Render.cc:750-752 rides in the projection kernel)
+        direct_forward_(true, false, 0.f, plain_track || shard_plain, shard_plain); // (the camera transform of Render.cc:750-752 rides in the projection kernel)
         if (band) band_forward_(true, kBandTrack);
         else if (shard_) shard_composite_forward_(true, false);
         // Render.cc:1088-1105: the masked L1 sums and their gradient planes, one pass over the render (band exchange: over this rank's band of rows; its

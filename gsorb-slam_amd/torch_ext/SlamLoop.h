@@ -158,7 +158,7 @@ private:
     void* stream_() const;
     void ensure_direct_(int64_t history_len);
     void grow_binning_(size_t capacity);
-    void direct_forward_(bool from_world = false, bool raw = false, float reg_limit = 0.f, bool plain = false);
+    void direct_forward_(bool from_world = false, bool raw = false, float reg_limit = 0.f, bool plain = false, bool plain_sil = false);
     void direct_backward_(bool detach_depth_colour, bool means_only, const ::gsr_map_update_args* fused, const ::gsr_pose_step_args* pose_step);
     bool direct_overflowed_();
     void direct_map_iteration_(const LoopFrame& frame, float* loss_slot);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 9 /* 9: gsr_pose_update_args.skip and gsr_pose_step_args.overflow_out appended (the sharded loop's overflow decision rides in its pose all-reduce); 8: gsr_forward_args.pre_Tcw / means_cam_out / raw appended (the camera transform and the map's activations inside the projection kernel), gsr_pose_step_args.sums_only and gsr_pose_finish added; 7: gsr_composite_* take the plane count of the gathered buffer, gsr_shard_order and gsr_reproj_loss added; 6: gsr_track_loss, gsr_pose_step, gsr_backward_args.fused_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
+#define GSR_ABI_VERSION 10 /* 10: gsr_forward_args.out_sil appended (the plain 3-channel forward also stores the silhouette 1 - final T), gsr_track_loss_rows takes sil_is_transmittance, gsr_transmittance_view added; 9: gsr_pose_update_args.skip and gsr_pose_step_args.overflow_out appended (the sharded loop's overflow decision rides in its pose all-reduce); 8: gsr_forward_args.pre_Tcw / means_cam_out / raw appended (the camera transform and the map's activations inside the projection kernel), gsr_pose_step_args.sums_only and gsr_pose_finish added; 7: gsr_composite_* take the plane count of the gathered buffer, gsr_shard_order and gsr_reproj_loss added; 6: gsr_track_loss, gsr_pose_step, gsr_backward_args.fused_pose_step added; 3: out_ds / dL_dds (fused depth + silhouette channels) appended to the argument structs; 4: gsr_pixel_loss*, gsr_scale_reg* added;
                            * 5: gsr_map_prepare / gsr_map_update / gsr_map_loss_total / gsr_pose_update / gsr_pixel_loss_backward_add / gsr_composite_* added, GSR_LOSS_PARTIALS 256 -> 1024 */
 
 #define GSR_OK 0
@@ -102,6 +102,11 @@ typedef struct gsr_forward_args {
      * stores the activated values where gsr_backward will read them, and — reg_partial != NULL — writes gsr_map_prepare's rows of the scale
      * regularisers' three sums ([3 * ceil(P / 256)], the layout gsr_map_loss_finish takes). Needs scales + rotations (not cov3D_precomp). */
     const struct gsr_raw_outputs* raw;
+    /* The silhouette out of the PLAIN 3-channel forward (new capability; NULL = not wanted; only without out_ds). The silhouette GSORB-SLAM renders as colour
+     * 1 of its second pass (src/Render.cc:963-975) is sum alpha_i T_i = 1 - final T of the very walk the colour pass does: with out_sil [H,W] the plain forward
+     * stores 1 - T per pixel next to the colours (equal to the fused pair's out_ds[1] to rounding). A sharded tracking iteration on the surface depth needs the
+     * layer's colours, surface depth and silhouette and nothing of the blended depth: it renders this way instead of the fused pair. */
+    float* out_sil;
 } gsr_forward_args;
 
 /* forward stages, in launch order */

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(gsr):
     for name in _declared():
         assert hasattr(lib, name), f"{name} declared in include/gsr.h but not exported"
     assert set(gsr.capi.EXPORTS) == set(_declared())
-    assert gsr.lib().gsr_abi_version() == 9
+    assert gsr.lib().gsr_abi_version() == 10
 
 
 def test_workspace_sizes_are_sane(gsr):

@@ -131,6 +131,25 @@ def test_silhouette_from_the_plain_forwards_transmittance(gsr, syn, name):
     assert T.shape == (H, W) and float(T.min()) >= 0.0 and float(T.max()) <= 1.0
     assert ((1.0 - T) - sil).abs().max() <= 2e-6
     assert torch.equal(gsr.capi.transmittance_view(st), T)                       # the fused pair keeps the same plane
+    # gsr_forward_args.out_sil (ABI 10): the plain forward stores 1 - T itself; same colours, same radii; refused together with the pair
+    sil_out = torch.full((H, W), float("nan"), device="cuda")
+    plain2 = gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations, out_sil=sil_out)
+    assert torch.equal(plain2.color, plain.color) and torch.equal(plain2.radii, plain.radii)
+    assert torch.equal(sil_out, 1.0 - gsr.capi.transmittance_view(plain2))
+    with pytest.raises(gsr.GsrError):
+        gsr.forward(s, sc.means3D, sc.opacities, colors=sc.colors, scales=sc.scales, rotations=sc.rotations, dual=True, out_sil=sil_out)
+    # ... and the silhouette-only backward (dds_depth_only = 2) gives the same gradients behind either forward
+    gS = torch.rand((H, W), generator=torch.Generator().manual_seed(5)).cuda()
+    gpix = torch.tensor(sc.dL_dpix, device="cuda")
+    def nocol():                                                              # (the form exists without colour sums only: a tracking iteration)
+        gr = gsr.capi.alloc_grads(sc.P, 0, "cuda", intermediates=False)
+        gr.dL_dcolors = None; gr.dL_dsh = None
+        return gr
+    ga = gsr.backward(st, gpix, grads=nocol(), dL_dds=gS.reshape(1, H, W).contiguous(), detach_depth_color=True, dds_depth_only=2)
+    gb = gsr.backward(plain2, gpix, grads=nocol(), dL_dds=gS.reshape(1, H, W).contiguous(), detach_depth_color=True, dds_depth_only=2)
+    torch.cuda.synchronize()
+    for n in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations"):
+        assert rel_err(getattr(gb, n).cpu().numpy(), getattr(ga, n).cpu().numpy()) <= 2e-6, n
     # the tracking loss, masked by either plane
     g = torch.Generator().manual_seed(3)
     frgb = torch.rand((3, H, W), generator=g).cuda(); fd = (0.5 + 3 * torch.rand((H, W), generator=g)); fd[::5, ::3] = 0.0; fd = fd.cuda()
