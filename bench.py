@@ -544,7 +544,7 @@ def rank_regime(a, gsr, dev, total, camera, cells):
         m_ms, m_l = timed(lambda n: len(loop.map_frame(rgb, depth, T, n)))
         t_ms, t_l = timed(lambda n: len(loop.track(rgb, depth, T0, n)[0]))
         res[name] = {"mapping_ms_per_iter": m_ms, "tracking_ms_per_iter": t_ms, "library_launches_per_mapping_iter": round(m_l, 2), "library_launches_per_tracking_iter": round(t_l, 2),
-                     "rccl_launches_per_iter": ({"mapping": 3, "tracking": 4} if shard and group is not None else 0), "transport": loop.shard_transport() if shard else None}
+                     "collectives_per_iter": ({"mapping": 2, "tracking": 3, "what": "the band exchange: two grouped point-to-point exchanges (+ the pose rows' all-reduce while tracking); at ONE rank the exchanges have no peer and launch nothing"} if shard and group is not None else 0), "transport": loop.shard_transport() if shard else None}
         del loop
     out["loop"] = res
     out["loop"]["what"] = ("ORB_SLAM2::SlamLoop on the same cell: wall clock per mapping (MapFrame: one read-back per batch) / tracking iteration, median of three batches; "
